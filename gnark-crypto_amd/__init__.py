@@ -1,0 +1,7 @@
+"""MI355X-native multi-scalar multiplication for gnark-crypto's ecc/<curve>.MultiExp path.
+
+Import with importlib (the directory name carries a hyphen):
+    gm = importlib.import_module("gnark-crypto_amd")
+"""
+from .curves import BLS12_381, BN254, BW6_761, CURVES  # noqa: F401
+from .multiexp import G1Affine, G1Jac, G2Affine, G2Jac, MultiExpConfig  # noqa: F401

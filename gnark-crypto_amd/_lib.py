@@ -1,0 +1,99 @@
+"""ctypes binding of libgmsm.so (C ABI declared in include/gmsm.h).
+
+The library is built in-tree by `make -C gnark-crypto_amd/csrc` (see __graft_entry__.build()).  Loading fails loudly
+when it is missing; there is no Python/CPU fallback for any compute entry.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libgmsm.so")
+
+GMSM_OK, GMSM_ERR_LEN, GMSM_ERR_CONFIG, GMSM_ERR_DEVICE, GMSM_ERR_ARG = 0, 1, 2, 3, 4
+
+GROUP_IDS = {
+    ("bn254", "g1"): 0, ("bn254", "g2"): 1,
+    ("bls12_381", "g1"): 2, ("bls12_381", "g2"): 3,
+    ("bw6_761", "g1"): 4, ("bw6_761", "g2"): 5,
+}
+
+# every symbol include/gmsm.h declares (tests/test_abi.py checks the built library exports all of them)
+ABI_SYMBOLS = [
+    "gmsm_bn254_g1_multiexp", "gmsm_bn254_g2_multiexp", "gmsm_bls12_381_g1_multiexp", "gmsm_bls12_381_g2_multiexp",
+    "gmsm_bw6_761_g1_multiexp", "gmsm_bw6_761_g2_multiexp", "gmsm_multiexp", "gmsm_multiexp_affine",
+    "gmsm_multiexp_device", "gmsm_default_window_bits", "gmsm_num_windows", "gmsm_window_sums_device",
+    "gmsm_fold_windows", "gmsm_jac_to_affine", "gmsm_affine_limbs", "gmsm_scalar_limbs", "gmsm_debug_decompose",
+    "gmsm_debug_field_op", "gmsm_debug_group_op", "gmsm_device_count", "gmsm_set_device", "gmsm_last_error",
+    "gmsm_version",
+]
+
+_lib = None
+
+
+def build(jobs=None):
+    """Compile libgmsm.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    jobs = jobs or os.cpu_count() or 4
+    subprocess.check_call(["make", "-C", CSRC, f"-j{jobs}", "libgmsm.so"])
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `make -C gnark-crypto_amd/csrc` (or __graft_entry__.build()); "
+                           "there is no fallback implementation")
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1. Two HSA runtimes in one process
+    # cannot both own the GPU, so when torch is going to share the process (device tensors, torch.distributed/RCCL) it
+    # must be loaded first; libgmsm.so then binds to the already-loaded runtime by SONAME.
+    if os.environ.get("GMSM_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+    L = ctypes.CDLL(LIB_PATH)
+    vp, sz, u64p = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p
+    for name in ABI_SYMBOLS[:6]:
+        f = getattr(L, name)
+        f.restype = ctypes.c_int
+        f.argtypes = [u64p, sz, u64p, sz, ctypes.c_int, u64p]
+    L.gmsm_multiexp.restype = ctypes.c_int
+    L.gmsm_multiexp.argtypes = [ctypes.c_int, u64p, sz, u64p, sz, ctypes.c_int, u64p]
+    L.gmsm_multiexp_affine.restype = ctypes.c_int
+    L.gmsm_multiexp_affine.argtypes = [ctypes.c_int, u64p, sz, u64p, sz, ctypes.c_int, u64p]
+    L.gmsm_multiexp_device.restype = ctypes.c_int
+    L.gmsm_multiexp_device.argtypes = [ctypes.c_int, vp, vp, sz, vp, u64p]
+    L.gmsm_default_window_bits.restype = ctypes.c_uint
+    L.gmsm_default_window_bits.argtypes = [ctypes.c_int, sz]
+    L.gmsm_num_windows.restype = ctypes.c_uint
+    L.gmsm_num_windows.argtypes = [ctypes.c_int, ctypes.c_uint]
+    L.gmsm_window_sums_device.restype = ctypes.c_int
+    L.gmsm_window_sums_device.argtypes = [ctypes.c_int, vp, vp, sz, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, vp, u64p]
+    L.gmsm_fold_windows.restype = ctypes.c_int
+    L.gmsm_fold_windows.argtypes = [ctypes.c_int, ctypes.c_uint, u64p, u64p]
+    L.gmsm_jac_to_affine.restype = ctypes.c_int
+    L.gmsm_jac_to_affine.argtypes = [ctypes.c_int, u64p, u64p]
+    L.gmsm_affine_limbs.restype = sz
+    L.gmsm_affine_limbs.argtypes = [ctypes.c_int]
+    L.gmsm_scalar_limbs.restype = sz
+    L.gmsm_scalar_limbs.argtypes = [ctypes.c_int]
+    L.gmsm_debug_decompose.restype = ctypes.c_int
+    L.gmsm_debug_decompose.argtypes = [ctypes.c_int, u64p, sz, ctypes.c_uint, vp]
+    L.gmsm_debug_field_op.restype = ctypes.c_int
+    L.gmsm_debug_field_op.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, u64p, u64p, sz, u64p]
+    L.gmsm_debug_group_op.restype = ctypes.c_int
+    L.gmsm_debug_group_op.argtypes = [ctypes.c_int, ctypes.c_int, u64p, u64p, sz, u64p]
+    L.gmsm_device_count.restype = ctypes.c_int
+    L.gmsm_set_device.restype = ctypes.c_int
+    L.gmsm_set_device.argtypes = [ctypes.c_int]
+    L.gmsm_last_error.restype = ctypes.c_char_p
+    L.gmsm_version.restype = ctypes.c_char_p
+    _lib = L
+    return L
+
+
+def last_error():
+    return load().gmsm_last_error().decode()

@@ -1,0 +1,112 @@
+// Per-device context, workspace buffers and error plumbing shared by the engine (C ABI) and the per-group
+// translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/gmsm.h"
+
+namespace gmsm {
+
+int fail(int code, const std::string &msg);  // records the thread-local error text, returns code
+
+#define HIP_TRY(expr)                                                                                        \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return ::gmsm::fail(GMSM_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + \
+                                                     std::to_string(__LINE__) + ")");                        \
+    } while (0)
+
+// ------------------------------------------------------------------ per-device context
+struct DeviceBuffer {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return GMSM_OK;
+        if (ptr) HIP_TRY(hipFree(ptr));
+        ptr = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8;  // grow-only with slack
+        HIP_TRY(hipMalloc(&ptr, want));
+        cap = want;
+        return GMSM_OK;
+    }
+};
+
+struct Context {
+    std::mutex mu;
+    int device = -1;
+    hipStream_t stream = nullptr;  // used when the caller passes no stream
+    DeviceBuffer points, scalars;  // staging for the host-pointer entry
+    DeviceBuffer digits, sorted, blockhist, counts, starts, buckets, partials, totals;
+    void *pinned = nullptr;  // pinned host buffer for the window totals
+    size_t pinned_cap = 0;
+    int init(int dev) {
+        device = dev;
+        HIP_TRY(hipSetDevice(dev));
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        return GMSM_OK;
+    }
+    int ensure_pinned(size_t bytes) {
+        if (bytes <= pinned_cap) return GMSM_OK;
+        if (pinned) HIP_TRY(hipHostFree(pinned));
+        pinned = nullptr;
+        HIP_TRY(hipHostMalloc(&pinned, bytes, hipHostMallocDefault));
+        pinned_cap = bytes;
+        return GMSM_OK;
+    }
+};
+
+int get_context(Context **out);  // context of the calling thread's device (gmsm_set_device), created on first use
+
+
+// ------------------------------------------------------------------ window geometry
+static inline unsigned num_windows(unsigned fr_bits, unsigned c) { return (fr_bits + c - 1) / c; }  // multiexp.go:681
+static inline unsigned last_c(unsigned fr_bits, unsigned c) {                                         // multiexp.go:690
+    unsigned avail = num_windows(fr_bits, c) * c - fr_bits;
+    return c + 1 - avail;
+}
+
+static inline unsigned env_uint(const char *name, unsigned dflt) {
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    return (unsigned)strtoul(v, nullptr, 10);
+}
+
+// Window width. The affine result does not depend on it (the reference asserts exactly that for c in 2..16,
+// multiexp_test.go:95-126), so it is purely a cost choice: n*nwin mixed adds in k_accumulate against
+// 2*nbuckets*nwin full adds (with a serial depth) in k_reduce.  GMSM_C overrides for experiments.
+static inline unsigned choose_c(unsigned fr_bits, size_t n) {
+    unsigned forced = env_uint("GMSM_C", 0);
+    if (forced >= 2 && forced <= 24) return forced;
+    (void)fr_bits;
+    unsigned lg = 0;
+    while (((size_t)1 << (lg + 1)) <= n) ++lg;
+    int c = (int)lg - 4;
+    if (c < 4) c = 4;
+    if (c > 16) c = 16;
+    return (unsigned)c;
+}
+
+struct GroupVTable {
+    unsigned fr_bits;
+    size_t aff_bytes, scalar_bytes, jac_bytes, xyzz_bytes;
+    int (*multiexp_host)(const uint64_t *points, size_t n_points, const uint64_t *scalars, size_t n_scalars, int nb_tasks,
+                         uint64_t *out_jac);
+    int (*multiexp_device)(Context &ctx, const void *d_points, const void *d_scalars, size_t n, hipStream_t stream,
+                           uint64_t *out_jac);
+    int (*window_sums)(Context &ctx, const void *d_points, const void *d_scalars, size_t n, unsigned c, unsigned win_first,
+                       unsigned win_stride, hipStream_t stream, uint64_t *out_xyzz);
+    void (*fold)(const uint64_t *xyzz_windows, unsigned c, uint64_t *out_jac);
+    void (*jac_to_affine)(const uint64_t *jac, uint64_t *out_affine);
+    int (*debug_decompose)(const uint64_t *scalars, size_t n, unsigned c, uint32_t *out_digits);
+    int (*debug_field_op)(int field, int op, const uint64_t *a, const uint64_t *b, size_t count, uint64_t *out);
+    int (*debug_group_op)(int op, const uint64_t *acc, const uint64_t *other, size_t count, uint64_t *out);
+};
+
+}  // namespace gmsm

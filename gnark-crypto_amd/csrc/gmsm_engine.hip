@@ -1,0 +1,190 @@
+// libgmsm.so -- C ABI (include/gmsm.h), per-device contexts and dispatch to the per-group pipelines (gmsm_group.h).
+// There is no CPU fallback: every compute entry needs a usable gfx950 device and fails loudly otherwise.
+#include "gmsm_context.h"
+
+namespace gmsm {
+
+static thread_local std::string g_last_error;
+static thread_local int g_device = 0;
+
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+static std::mutex g_ctx_mu;
+static std::vector<Context *> g_ctx;
+
+int get_context(Context **out) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(GMSM_ERR_DEVICE, std::string("no usable HIP device (hipGetDeviceCount: ") + hipGetErrorString(e) +
+                                         "); libgmsm has no CPU fallback");
+    if (g_device < 0 || g_device >= ndev) return fail(GMSM_ERR_DEVICE, "gmsm_set_device: device index out of range");
+    if ((int)g_ctx.size() < ndev) g_ctx.resize(ndev, nullptr);
+    if (!g_ctx[g_device]) {
+        Context *c = new Context();
+        int rc = c->init(g_device);
+        if (rc != GMSM_OK) {
+            delete c;
+            return rc;
+        }
+        g_ctx[g_device] = c;
+    }
+    *out = g_ctx[g_device];
+    return GMSM_OK;
+}
+
+const GroupVTable *gmsm_vtable_bn254_g1();
+const GroupVTable *gmsm_vtable_bn254_g2();
+const GroupVTable *gmsm_vtable_bls12_381_g1();
+const GroupVTable *gmsm_vtable_bls12_381_g2();
+const GroupVTable *gmsm_vtable_bw6_761_g1();
+const GroupVTable *gmsm_vtable_bw6_761_g2();
+
+static const GroupVTable *vtable(int group) {
+    switch (group) {
+        case GMSM_BN254_G1: return gmsm_vtable_bn254_g1();
+        case GMSM_BN254_G2: return gmsm_vtable_bn254_g2();
+        case GMSM_BLS12_381_G1: return gmsm_vtable_bls12_381_g1();
+        case GMSM_BLS12_381_G2: return gmsm_vtable_bls12_381_g2();
+        case GMSM_BW6_761_G1: return gmsm_vtable_bw6_761_g1();
+        case GMSM_BW6_761_G2: return gmsm_vtable_bw6_761_g2();
+        default: return nullptr;
+    }
+}
+
+}  // namespace gmsm
+
+using namespace gmsm;
+
+#define GMSM_EXPORT __attribute__((visibility("default")))
+#define VT_OR_FAIL(group)                          \
+    const GroupVTable *vt = vtable(group);         \
+    if (!vt) return fail(GMSM_ERR_ARG, "unknown group id")
+
+extern "C" {
+
+GMSM_EXPORT int gmsm_multiexp(int group, const uint64_t *points, size_t n_points, const uint64_t *scalars,
+                              size_t n_scalars, int nb_tasks, uint64_t *out_jac) {
+    VT_OR_FAIL(group);
+    return vt->multiexp_host(points, n_points, scalars, n_scalars, nb_tasks, out_jac);
+}
+
+#define GMSM_DROPIN(name, id)                                                                                \
+    GMSM_EXPORT int gmsm_##name##_multiexp(const uint64_t *points, size_t n_points, const uint64_t *scalars, \
+                                           size_t n_scalars, int nb_tasks, uint64_t *out_jac) {              \
+        return gmsm_multiexp(id, points, n_points, scalars, n_scalars, nb_tasks, out_jac);                   \
+    }
+GMSM_DROPIN(bn254_g1, GMSM_BN254_G1)
+GMSM_DROPIN(bn254_g2, GMSM_BN254_G2)
+GMSM_DROPIN(bls12_381_g1, GMSM_BLS12_381_G1)
+GMSM_DROPIN(bls12_381_g2, GMSM_BLS12_381_G2)
+GMSM_DROPIN(bw6_761_g1, GMSM_BW6_761_G1)
+GMSM_DROPIN(bw6_761_g2, GMSM_BW6_761_G2)
+
+GMSM_EXPORT int gmsm_multiexp_affine(int group, const uint64_t *points, size_t n_points, const uint64_t *scalars,
+                                     size_t n_scalars, int nb_tasks, uint64_t *out_affine) {
+    VT_OR_FAIL(group);
+    std::vector<uint64_t> jac(vt->jac_bytes / 8);
+    int rc = vt->multiexp_host(points, n_points, scalars, n_scalars, nb_tasks, jac.data());
+    if (rc) return rc;
+    vt->jac_to_affine(jac.data(), out_affine);
+    return GMSM_OK;
+}
+
+GMSM_EXPORT int gmsm_multiexp_device(int group, const void *d_points, const void *d_scalars, size_t n, void *hip_stream,
+                                     uint64_t *out_jac) {
+    VT_OR_FAIL(group);
+    Context *ctx;
+    int rc = get_context(&ctx);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return vt->multiexp_device(*ctx, d_points, d_scalars, n, hip_stream ? (hipStream_t)hip_stream : ctx->stream, out_jac);
+}
+
+GMSM_EXPORT unsigned gmsm_default_window_bits(int group, size_t n) {
+    const GroupVTable *vt = vtable(group);
+    return vt ? choose_c(vt->fr_bits, n) : 0;
+}
+
+GMSM_EXPORT unsigned gmsm_num_windows(int group, unsigned c) {
+    const GroupVTable *vt = vtable(group);
+    return (vt && c) ? num_windows(vt->fr_bits, c) : 0;
+}
+
+GMSM_EXPORT int gmsm_window_sums_device(int group, const void *d_points, const void *d_scalars, size_t n, unsigned c,
+                                        unsigned win_first, unsigned win_stride, void *hip_stream, uint64_t *out_xyzz) {
+    VT_OR_FAIL(group);
+    if (c < 2 || c > 16) return fail(GMSM_ERR_ARG, "c out of range (2..16)");
+    Context *ctx;
+    int rc = get_context(&ctx);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return vt->window_sums(*ctx, d_points, d_scalars, n, c, win_first, win_stride,
+                           hip_stream ? (hipStream_t)hip_stream : ctx->stream, out_xyzz);
+}
+
+GMSM_EXPORT int gmsm_fold_windows(int group, unsigned c, const uint64_t *xyzz_windows, uint64_t *out_jac) {
+    VT_OR_FAIL(group);
+    if (c < 2 || c > 24) return fail(GMSM_ERR_ARG, "c out of range");
+    vt->fold(xyzz_windows, c, out_jac);
+    return GMSM_OK;
+}
+
+GMSM_EXPORT int gmsm_jac_to_affine(int group, const uint64_t *jac, uint64_t *out_affine) {
+    VT_OR_FAIL(group);
+    vt->jac_to_affine(jac, out_affine);
+    return GMSM_OK;
+}
+
+GMSM_EXPORT size_t gmsm_affine_limbs(int group) {
+    const GroupVTable *vt = vtable(group);
+    return vt ? vt->aff_bytes / 8 : 0;
+}
+
+GMSM_EXPORT size_t gmsm_scalar_limbs(int group) {
+    const GroupVTable *vt = vtable(group);
+    return vt ? vt->scalar_bytes / 8 : 0;
+}
+
+GMSM_EXPORT int gmsm_debug_decompose(int group, const uint64_t *scalars, size_t n, unsigned c, uint32_t *out_digits) {
+    VT_OR_FAIL(group);
+    return vt->debug_decompose(scalars, n, c, out_digits);
+}
+
+GMSM_EXPORT int gmsm_debug_field_op(int group, int field, int op, const uint64_t *a, const uint64_t *b, size_t count,
+                                    uint64_t *out) {
+    VT_OR_FAIL(group);
+    if (count == 0) return GMSM_OK;
+    return vt->debug_field_op(field, op, a, b, count, out);
+}
+
+GMSM_EXPORT int gmsm_debug_group_op(int group, int op, const uint64_t *acc, const uint64_t *other, size_t count,
+                                    uint64_t *out) {
+    VT_OR_FAIL(group);
+    if (count == 0) return GMSM_OK;
+    return vt->debug_group_op(op, acc, other, count, out);
+}
+
+GMSM_EXPORT int gmsm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+GMSM_EXPORT int gmsm_set_device(int device) {
+    int n = gmsm_device_count();
+    if (device < 0 || device >= n) return fail(GMSM_ERR_DEVICE, "gmsm_set_device: no such device");
+    g_device = device;
+    return GMSM_OK;
+}
+
+GMSM_EXPORT const char *gmsm_last_error(void) { return g_last_error.c_str(); }
+GMSM_EXPORT const char *gmsm_version(void) { return "gmsm 0.1 (gfx950)"; }
+
+}  // extern "C"

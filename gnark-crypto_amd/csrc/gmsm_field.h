@@ -1,0 +1,255 @@
+// Prime-field and Fp2 arithmetic for the MSM kernels (gfx950) and for the host-side fold.
+//
+// Representation: N 32-bit limbs, little-endian, Montgomery form with R = 2^(32N) -- bit-identical in memory to
+// the reference's `fp.Element [N/2]uint64` (ecc/bn254/fp/element.go:24-36), so Go slices are consumed as-is.
+// Every result is fully reduced into [0,q), like the reference, so limb values are canonical.
+//
+// What each op replaces in the reference:
+//   add/dbl/sub/neg   ecc/bn254/fp/element.go:386-454
+//   mul/sqr           ecc/bn254/fp/element_purego.go:46 (no-carry CIOS, "Algorithm 2" of El Housni-Botrel) -- the
+//                     amd64 build runs field/asm/element_4w_amd64.s:208-304 instead; here it is a 32-bit-limb CIOS
+//                     whose inner step is one v_mad_u64_u32 (32x32+64 -> 64, measured 4 cycles / wave64 / SIMD)
+//   from_mont         ecc/bn254/fp/element.go:593-642
+//   Fp2               ecc/bn254/internal/fptower/e2_bn254.go:28-50, e2_fallback.go:10-28 (u^2 = -1)
+// The no-carry variant needs the modulus' top word to leave a spare bit (field_config.go:200-206); true for all
+// six fields in scope.
+#pragma once
+#include <stdint.h>
+#include "gmsm_params32.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GMSM_HD __host__ __device__ __forceinline__
+// The Montgomery product is the one big straight-line body (2N^2+N multiply-adds, fully unrolled so that limbs stay in
+// VGPRs). It is a real function call on the device unless GMSM_INLINE_MUL is set: one copy in the instruction cache
+// instead of ten per mixed add, and compile time that stays in seconds for the 24-limb field.
+#if defined(GMSM_INLINE_MUL)
+#define GMSM_MUL_HD __host__ __device__ __forceinline__
+#else
+#define GMSM_MUL_HD __host__ __device__ __noinline__
+#endif
+#else
+#define GMSM_HD inline
+#define GMSM_MUL_HD inline
+#endif
+
+namespace gmsm {
+
+template <class P>
+struct Fp {
+    static constexpr int N = P::N;
+    using Params = P;
+    uint32_t l[N];
+
+    GMSM_HD static Fp zero() {
+        Fp z;
+#pragma unroll
+        for (int i = 0; i < N; ++i) z.l[i] = 0;
+        return z;
+    }
+    GMSM_HD static Fp one() {
+        Fp z;
+#pragma unroll
+        for (int i = 0; i < N; ++i) z.l[i] = P::ONE[i];
+        return z;
+    }
+    GMSM_HD bool is_zero() const {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc |= l[i];
+        return acc == 0;
+    }
+    GMSM_HD bool operator==(const Fp &o) const {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc |= l[i] ^ o.l[i];
+        return acc == 0;
+    }
+};
+
+// z = (t >= q) ? t - q : t      (t < 2q)
+template <class P>
+GMSM_HD void fp_reduce_once(Fp<P> &t) {
+    constexpr int N = P::N;
+    uint32_t d[N];
+    uint32_t b = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) d[i] = __builtin_subc(t.l[i], P::Q[i], b, &b);
+    // b == 1  <=>  t < q  -> keep t
+#pragma unroll
+    for (int i = 0; i < N; ++i) t.l[i] = b ? t.l[i] : d[i];
+}
+
+template <class P>
+GMSM_HD Fp<P> fp_add(const Fp<P> &x, const Fp<P> &y) {
+    constexpr int N = P::N;
+    Fp<P> z;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) z.l[i] = __builtin_addc(x.l[i], y.l[i], c, &c);
+    fp_reduce_once(z);  // top word of q leaves a spare bit: no carry out of limb N-1
+    return z;
+}
+
+template <class P>
+GMSM_HD Fp<P> fp_dbl(const Fp<P> &x) {
+    return fp_add(x, x);
+}
+
+template <class P>
+GMSM_HD Fp<P> fp_sub(const Fp<P> &x, const Fp<P> &y) {
+    constexpr int N = P::N;
+    Fp<P> z;
+    uint32_t b = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) z.l[i] = __builtin_subc(x.l[i], y.l[i], b, &b);
+    // if borrow: z += q
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) z.l[i] = __builtin_addc(z.l[i], b ? P::Q[i] : 0u, c, &c);
+    return z;
+}
+
+template <class P>
+GMSM_HD Fp<P> fp_neg(const Fp<P> &x) {
+    constexpr int N = P::N;
+    Fp<P> z;
+    uint32_t b = 0;
+    const bool zero = x.is_zero();
+#pragma unroll
+    for (int i = 0; i < N; ++i) z.l[i] = __builtin_subc(P::Q[i], x.l[i], b, &b);
+#pragma unroll
+    for (int i = 0; i < N; ++i) z.l[i] = zero ? 0u : z.l[i];
+    return z;
+}
+
+// Montgomery product x*y*R^-1 mod q. Two interleaved carry chains per outer iteration (A for x*y_i, C for m*q),
+// each inner step is a 32x32 multiply plus two 32-bit addends, which never overflows 64 bits.
+template <class P>
+GMSM_MUL_HD Fp<P> fp_mul(const Fp<P> x, const Fp<P> y) {
+    constexpr int N = P::N;
+    uint32_t t[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t yi = y.l[i];
+        uint64_t a = (uint64_t)x.l[0] * yi + t[0];
+        uint32_t A = (uint32_t)(a >> 32);
+        const uint32_t m = (uint32_t)a * P::QINV;
+        uint64_t c = (uint64_t)m * P::Q[0] + (uint32_t)a;
+        uint32_t C = (uint32_t)(c >> 32);
+#pragma unroll
+        for (int j = 1; j < N; ++j) {
+            a = (uint64_t)x.l[j] * yi + t[j] + A;
+            A = (uint32_t)(a >> 32);
+            c = (uint64_t)m * P::Q[j] + (uint32_t)a + C;
+            C = (uint32_t)(c >> 32);
+            t[j - 1] = (uint32_t)c;
+        }
+        t[N - 1] = A + C;  // no-carry condition: cannot overflow
+    }
+    Fp<P> z;
+#pragma unroll
+    for (int i = 0; i < N; ++i) z.l[i] = t[i];
+    fp_reduce_once(z);
+    return z;
+}
+
+template <class P>
+GMSM_HD Fp<P> fp_sqr(const Fp<P> &x) {
+    return fp_mul(x, x);
+}
+
+// x * R^-1 mod q: N rounds of (z + m q) / 2^32
+template <class P>
+GMSM_HD Fp<P> fp_from_mont(const Fp<P> &x) {
+    constexpr int N = P::N;
+    Fp<P> z = x;
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        const uint32_t m = z.l[0] * P::QINV;
+        uint64_t c = (uint64_t)m * P::Q[0] + z.l[0];
+        uint32_t C = (uint32_t)(c >> 32);
+#pragma unroll
+        for (int j = 1; j < N; ++j) {
+            c = (uint64_t)m * P::Q[j] + z.l[j] + C;
+            C = (uint32_t)(c >> 32);
+            z.l[j - 1] = (uint32_t)c;
+        }
+        z.l[N - 1] = C;
+    }
+    fp_reduce_once(z);
+    return z;
+}
+
+// x^-1 = x^(q-2) (value-identical to the reference's bingcd Inverse; 0 -> 0). Host-side use only (final
+// FromJacobian, ecc/bn254/g1.go:150-166); not on the device hot path.
+template <class P>
+GMSM_HD Fp<P> fp_inv(const Fp<P> &x) {
+    constexpr int N = P::N;
+    if (x.is_zero()) return x;
+    uint32_t e[N];
+    uint32_t b = 2;
+    for (int i = 0; i < N; ++i) {
+        uint32_t old = P::Q[i];
+        e[i] = old - b;
+        b = old < b ? 1u : 0u;
+    }
+    int top = N * 32 - 1;
+    while (!((e[top / 32] >> (top % 32)) & 1)) --top;
+    Fp<P> acc = x;
+    for (int i = top - 1; i >= 0; --i) {
+        acc = fp_sqr(acc);
+        if ((e[i / 32] >> (i % 32)) & 1) acc = fp_mul(acc, x);
+    }
+    return acc;
+}
+
+// ------------------------------------------------------------------ Fp2 = Fp[u]/(u^2+1)
+template <class P>
+struct Fp2 {
+    using Params = P;
+    static constexpr int N = 2 * P::N;  // 32-bit words per element
+    Fp<P> a0, a1;
+    GMSM_HD static Fp2 zero() { return Fp2{Fp<P>::zero(), Fp<P>::zero()}; }
+    GMSM_HD static Fp2 one() { return Fp2{Fp<P>::one(), Fp<P>::zero()}; }
+    GMSM_HD bool is_zero() const { return a0.is_zero() && a1.is_zero(); }
+    GMSM_HD bool operator==(const Fp2 &o) const { return a0 == o.a0 && a1 == o.a1; }
+};
+
+template <class P> GMSM_HD Fp2<P> fp_add(const Fp2<P> &x, const Fp2<P> &y) { return Fp2<P>{fp_add(x.a0, y.a0), fp_add(x.a1, y.a1)}; }
+template <class P> GMSM_HD Fp2<P> fp_sub(const Fp2<P> &x, const Fp2<P> &y) { return Fp2<P>{fp_sub(x.a0, y.a0), fp_sub(x.a1, y.a1)}; }
+template <class P> GMSM_HD Fp2<P> fp_dbl(const Fp2<P> &x) { return Fp2<P>{fp_dbl(x.a0), fp_dbl(x.a1)}; }
+template <class P> GMSM_HD Fp2<P> fp_neg(const Fp2<P> &x) { return Fp2<P>{fp_neg(x.a0), fp_neg(x.a1)}; }
+
+template <class P>
+GMSM_HD Fp2<P> fp_mul(const Fp2<P> &x, const Fp2<P> &y) {  // Karatsuba, 3 base muls
+    Fp<P> a = fp_add(x.a0, x.a1);
+    Fp<P> b = fp_add(y.a0, y.a1);
+    a = fp_mul(a, b);
+    b = fp_mul(x.a0, y.a0);
+    Fp<P> c = fp_mul(x.a1, y.a1);
+    Fp2<P> z;
+    z.a1 = fp_sub(fp_sub(a, b), c);
+    z.a0 = fp_sub(b, c);
+    return z;
+}
+
+template <class P>
+GMSM_HD Fp2<P> fp_sqr(const Fp2<P> &x) {  // 2 base muls
+    Fp<P> a = fp_add(x.a0, x.a1);
+    Fp<P> b = fp_sub(x.a0, x.a1);
+    a = fp_mul(a, b);
+    b = fp_dbl(fp_mul(x.a0, x.a1));
+    return Fp2<P>{a, b};
+}
+
+template <class P>
+GMSM_HD Fp2<P> fp_inv(const Fp2<P> &x) {
+    Fp<P> t0 = fp_add(fp_sqr(x.a0), fp_sqr(x.a1));
+    Fp<P> t1 = fp_inv(t0);
+    return Fp2<P>{fp_mul(x.a0, t1), fp_neg(fp_mul(x.a1, t1))};
+}
+
+}  // namespace gmsm

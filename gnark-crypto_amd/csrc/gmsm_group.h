@@ -1,0 +1,344 @@
+// One (curve, group) instance of the engine: pipeline driver, host fold, test hooks, and the function table the C ABI
+// dispatches through. Instantiated once per group in gmsm_group_inst.hip (one translation unit per group so the six
+// groups compile in parallel).
+#pragma once
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "gmsm_context.h"
+#include "gmsm_kernels.h"
+
+namespace gmsm {
+
+// ------------------------------------------------------------------ one (curve, group)
+template <class F_, class FrP_>
+struct Group {
+    using F = F_;
+    using FrP = FrP_;
+    using Aff = Affine<F>;
+    using Ext = XYZZ<F>;
+    using J = Jac<F>;
+    static constexpr unsigned FR_BITS = FrP::BITS;
+    static constexpr size_t AFF_BYTES = sizeof(Aff);
+    static constexpr size_t SCALAR_BYTES = sizeof(Fp<FrP>);
+    static constexpr int RED_TPB = 256;
+    static constexpr int RED2_TPB = 64;
+
+    static WindowPlan make_plan(unsigned c, unsigned win_first, unsigned win_stride) {
+        WindowPlan p;
+        p.c = c;
+        p.nwin_total = num_windows(FR_BITS, c);
+        unsigned lc = last_c(FR_BITS, c);
+        p.nbuckets = 1u << (std::max(c, lc) - 1);
+        p.win_first = win_first;
+        p.win_stride = win_stride ? win_stride : 1;
+        p.nwin_local = win_first < p.nwin_total ? (p.nwin_total - win_first + p.win_stride - 1) / p.win_stride : 0;
+        return p;
+    }
+
+    // Runs the device pipeline for the windows of `plan`; host_xyzz receives plan.nwin_local window totals.
+    static int window_sums(Context &ctx, const void *d_points, const void *d_scalars, size_t n, const WindowPlan &plan,
+                           hipStream_t stream, Ext *host_xyzz) {
+        const uint32_t nw = plan.nwin_local;
+        if (nw == 0) return GMSM_OK;
+        if (n == 0) {
+            for (uint32_t k = 0; k < nw; ++k) host_xyzz[k] = Ext::infinity();
+            return GMSM_OK;
+        }
+        if (n >= ((size_t)1 << 31)) return fail(GMSM_ERR_ARG, "n must be < 2^31");
+        const uint32_t NB = plan.nbuckets;
+        // chunks: ~256 (window, chunk) blocks in flight, each at least 4096 digits
+        uint32_t nchunks = std::max<uint32_t>(1, 512 / nw);
+        nchunks = (uint32_t)std::min<size_t>(nchunks, (n + 4095) / 4096);
+        const size_t chunk_len = (n + nchunks - 1) / nchunks;
+        // reduction geometry
+        uint32_t log2L = 3;
+        while ((((size_t)NB + ((size_t)RED_TPB << log2L) - 1) / ((size_t)RED_TPB << log2L)) > (size_t)RED2_TPB) ++log2L;
+        const uint32_t nblocks1 = (uint32_t)(((size_t)NB + ((size_t)RED_TPB << log2L) - 1) / ((size_t)RED_TPB << log2L));
+        uint32_t log2span = log2L;
+        for (int t = RED_TPB; t > 1; t >>= 1) ++log2span;
+
+        int rc;
+        if ((rc = ctx.digits.ensure((size_t)nw * n * 4))) return rc;
+        if ((rc = ctx.sorted.ensure((size_t)nw * n * 4))) return rc;
+        if ((rc = ctx.blockhist.ensure((size_t)nw * nchunks * NB * 4))) return rc;
+        if ((rc = ctx.counts.ensure((size_t)nw * NB * 4))) return rc;
+        if ((rc = ctx.starts.ensure((size_t)nw * (NB + 1) * 4))) return rc;
+        if ((rc = ctx.buckets.ensure((size_t)nw * NB * sizeof(Ext)))) return rc;
+        if ((rc = ctx.partials.ensure((size_t)nw * nblocks1 * 2 * sizeof(Ext)))) return rc;
+        if ((rc = ctx.totals.ensure((size_t)nw * sizeof(Ext)))) return rc;
+        if ((rc = ctx.ensure_pinned((size_t)nw * sizeof(Ext)))) return rc;
+
+        uint32_t *digits = (uint32_t *)ctx.digits.ptr, *sorted = (uint32_t *)ctx.sorted.ptr;
+        uint32_t *blockhist = (uint32_t *)ctx.blockhist.ptr, *counts = (uint32_t *)ctx.counts.ptr;
+        uint32_t *starts = (uint32_t *)ctx.starts.ptr;
+
+        // 1. signed-digit decomposition
+        hipLaunchKernelGGL((k_decompose<FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                           (const uint32_t *)d_scalars, n, plan, digits);
+        // 2. group point references by bucket (counting sort per window)
+        const size_t hist_lds = (size_t)NB * 4;
+        if (hist_lds > 160 * 1024) return fail(GMSM_ERR_ARG, "window too wide for the LDS histogram (c <= 16)");
+        static bool attr_done = false;
+        if (!attr_done) {
+            HIP_TRY(hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(k_hist, dim3(nchunks, nw), dim3(1024), hist_lds, stream, digits, n, NB, chunk_len, blockhist);
+        hipLaunchKernelGGL(k_colscan, dim3((NB + 255) / 256, nw), dim3(256), 0, stream, blockhist, nchunks, NB, counts);
+        hipLaunchKernelGGL(k_rowscan, dim3(nw), dim3(1024), 0, stream, counts, NB, starts);
+        hipLaunchKernelGGL(k_scatter, dim3(nchunks, nw), dim3(1024), hist_lds, stream, digits, n, NB, chunk_len,
+                           blockhist, starts, sorted);
+        // 3. bucket accumulation
+        hipLaunchKernelGGL((k_accumulate<F>), dim3((NB + 255) / 256, nw), dim3(256), 0, stream, d_points, n, NB, starts,
+                           sorted, ctx.buckets.ptr);
+        // 4. bucket reduction -> window totals
+        static bool red_attr_done = false;
+        if (!red_attr_done) {
+            HIP_TRY(hipFuncSetAttribute((const void *)k_reduce1<F, RED_TPB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(RED_TPB * sizeof(Ext))));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_reduce2<F, RED2_TPB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(RED2_TPB * sizeof(Ext))));
+            red_attr_done = true;
+        }
+        hipLaunchKernelGGL((k_reduce1<F, RED_TPB>), dim3(nblocks1, nw), dim3(RED_TPB), RED_TPB * sizeof(Ext), stream,
+                           ctx.buckets.ptr, NB, log2L, ctx.partials.ptr);
+        hipLaunchKernelGGL((k_reduce2<F, RED2_TPB>), dim3(nw), dim3(RED2_TPB), RED2_TPB * sizeof(Ext), stream,
+                           ctx.partials.ptr, nblocks1, log2span, ctx.totals.ptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(ctx.pinned, ctx.totals.ptr, (size_t)nw * sizeof(Ext), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        memcpy(host_xyzz, ctx.pinned, (size_t)nw * sizeof(Ext));
+        return GMSM_OK;
+    }
+
+    // msmReduceChunk (multiexp.go:302-315): Horner from the top window down, then XYZZ -> Jacobian.
+    static J fold(const Ext *totals, unsigned c) {
+        const unsigned nwin = num_windows(FR_BITS, c);
+        Ext acc = totals[nwin - 1];
+        for (int j = (int)nwin - 2; j >= 0; --j) {
+            for (unsigned l = 0; l < c; ++l) acc = xyzz_double(acc);
+            xyzz_add(acc, totals[j]);
+        }
+        return jac_from_xyzz(acc);
+    }
+
+    static int multiexp_device(Context &ctx, const void *d_points, const void *d_scalars, size_t n, hipStream_t stream,
+                               J *out) {
+        const unsigned c = choose_c(FR_BITS, n);
+        WindowPlan plan = make_plan(c, 0, 1);
+        std::vector<Ext> totals(plan.nwin_total);
+        int rc = window_sums(ctx, d_points, d_scalars, n, plan, stream, totals.data());
+        if (rc) return rc;
+        *out = fold(totals.data(), c);
+        return GMSM_OK;
+    }
+
+    static int multiexp_host(const uint64_t *points, size_t n_points, const uint64_t *scalars, size_t n_scalars,
+                             int nb_tasks, J *out) {
+        // argument checks of (*G1Jac).MultiExp, multiexp.go:61-71
+        if (n_points != n_scalars) return fail(GMSM_ERR_LEN, "len(points) != len(scalars)");
+        if (nb_tasks > 1024) return fail(GMSM_ERR_CONFIG, "invalid config: config.NbTasks > 1024");
+        Context *ctx;
+        int rc = get_context(&ctx);
+        if (rc) return rc;
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        HIP_TRY(hipSetDevice(ctx->device));
+        const size_t n = n_points;
+        if (n == 0) {
+            *out = J{F::one(), F::one(), F::zero()};
+            return GMSM_OK;
+        }
+        if ((rc = ctx->points.ensure(n * AFF_BYTES))) return rc;
+        if ((rc = ctx->scalars.ensure(n * SCALAR_BYTES))) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->points.ptr, points, n * AFF_BYTES, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->scalars.ptr, scalars, n * SCALAR_BYTES, hipMemcpyHostToDevice, ctx->stream));
+        return multiexp_device(*ctx, ctx->points.ptr, ctx->scalars.ptr, n, ctx->stream, out);
+    }
+};
+
+// ------------------------------------------------------------------ debug / test kernels
+template <class FT>
+__global__ void k_field_op(int op, const FT *a, const FT *b, size_t count, FT *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    FT x = a[i], y = b ? b[i] : a[i], z;
+    switch (op) {
+        case 0: z = fp_mul(x, y); break;
+        case 1: z = fp_add(x, y); break;
+        case 2: z = fp_sub(x, y); break;
+        case 3: z = fp_neg(x); break;
+        case 4: z = fp_dbl(x); break;
+        default: z = fp_sqr(x); break;
+    }
+    out[i] = z;
+}
+
+template <class P>
+__global__ void k_from_mont(const Fp<P> *a, size_t count, Fp<P> *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = fp_from_mont(a[i]);
+}
+
+template <class F>
+__global__ void k_group_op(int op, const XYZZ<F> *acc, const void *other, size_t count, XYZZ<F> *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    XYZZ<F> p = acc[i];
+    if (op == 0 || op == 1) {
+        Affine<F> a = reinterpret_cast<const Affine<F> *>(other)[i];
+        xyzz_add_mixed(p, a, op == 1);
+    } else if (op == 2) {
+        XYZZ<F> q = reinterpret_cast<const XYZZ<F> *>(other)[i];
+        xyzz_add(p, q);
+    } else {
+        p = xyzz_double(p);
+    }
+    out[i] = p;
+}
+
+template <class FT, class Launch>
+static int run_elementwise(size_t in_bytes_a, const void *a, size_t in_bytes_b, const void *b, size_t out_bytes, void *out,
+                           Launch launch) {
+    Context *ctx;
+    int rc = get_context(&ctx);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    void *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc(&da, in_bytes_a));
+    HIP_TRY(hipMemcpy(da, a, in_bytes_a, hipMemcpyHostToDevice));
+    if (b) {
+        HIP_TRY(hipMalloc(&db, in_bytes_b));
+        HIP_TRY(hipMemcpy(db, b, in_bytes_b, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMalloc(&dout, out_bytes));
+    launch(da, db, dout, ctx->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(out, dout, out_bytes, hipMemcpyDeviceToHost));
+    hipFree(da);
+    if (db) hipFree(db);
+    hipFree(dout);
+    return GMSM_OK;
+}
+
+template <class FT>
+static int debug_field(int op, const uint64_t *a, const uint64_t *b, size_t count, uint64_t *out) {
+    return run_elementwise<FT>(count * sizeof(FT), a, b ? count * sizeof(FT) : 0, b, count * sizeof(FT), out,
+                               [&](void *da, void *db, void *dout, hipStream_t s) {
+                                   hipLaunchKernelGGL((k_field_op<FT>), dim3((unsigned)((count + 127) / 128)), dim3(128), 0,
+                                                      s, op, (const FT *)da, (const FT *)db, count, (FT *)dout);
+                               });
+}
+
+template <class P>
+static int debug_from_mont(const uint64_t *a, size_t count, uint64_t *out) {
+    return run_elementwise<Fp<P>>(count * sizeof(Fp<P>), a, 0, nullptr, count * sizeof(Fp<P>), out,
+                                  [&](void *da, void *, void *dout, hipStream_t s) {
+                                      hipLaunchKernelGGL((k_from_mont<P>), dim3((unsigned)((count + 127) / 128)),
+                                                         dim3(128), 0, s, (const Fp<P> *)da, count, (Fp<P> *)dout);
+                                  });
+}
+
+template <class G>
+static int debug_group(int op, const uint64_t *acc, const uint64_t *other, size_t count, uint64_t *out) {
+    using F = typename G::F;
+    const size_t ob = (op == 0 || op == 1) ? sizeof(Affine<F>) : sizeof(XYZZ<F>);
+    return run_elementwise<F>(count * sizeof(XYZZ<F>), acc, other ? count * ob : 0, other, count * sizeof(XYZZ<F>), out,
+                              [&](void *da, void *db, void *dout, hipStream_t s) {
+                                  hipLaunchKernelGGL((k_group_op<F>), dim3((unsigned)((count + 63) / 64)), dim3(64), 0, s,
+                                                     op, (const XYZZ<F> *)da, (const void *)db, count, (XYZZ<F> *)dout);
+                              });
+}
+
+template <class G>
+static int debug_decompose_impl(const uint64_t *scalars, size_t n, unsigned c, uint32_t *out_digits) {
+    if (c < 2 || c > 24) return fail(GMSM_ERR_ARG, "c out of range");
+    Context *ctx;
+    int rc = get_context(&ctx);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    WindowPlan plan = G::make_plan(c, 0, 1);
+    if (n == 0) return GMSM_OK;
+    if ((rc = ctx->scalars.ensure(n * G::SCALAR_BYTES))) return rc;
+    if ((rc = ctx->digits.ensure((size_t)plan.nwin_total * n * 4))) return rc;
+    HIP_TRY(hipMemcpy(ctx->scalars.ptr, scalars, n * G::SCALAR_BYTES, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL((k_decompose<typename G::FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const uint32_t *)ctx->scalars.ptr, n, plan, (uint32_t *)ctx->digits.ptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(out_digits, ctx->digits.ptr, (size_t)plan.nwin_total * n * 4, hipMemcpyDeviceToHost));
+    return GMSM_OK;
+}
+
+
+// ------------------------------------------------------------------ function table
+
+template <class G>
+struct VTableOf {
+    static int multiexp_host(const uint64_t *points, size_t n_points, const uint64_t *scalars, size_t n_scalars,
+                             int nb_tasks, uint64_t *out_jac) {
+        typename G::J j;
+        int rc = G::multiexp_host(points, n_points, scalars, n_scalars, nb_tasks, &j);
+        if (rc) return rc;
+        memcpy(out_jac, &j, sizeof j);
+        return GMSM_OK;
+    }
+    static int multiexp_device(Context &ctx, const void *d_points, const void *d_scalars, size_t n, hipStream_t stream,
+                               uint64_t *out_jac) {
+        typename G::J j;
+        if (n == 0) j = typename G::J{G::F::one(), G::F::one(), G::F::zero()};
+        else {
+            int rc = G::multiexp_device(ctx, d_points, d_scalars, n, stream, &j);
+            if (rc) return rc;
+        }
+        memcpy(out_jac, &j, sizeof j);
+        return GMSM_OK;
+    }
+    static int window_sums(Context &ctx, const void *d_points, const void *d_scalars, size_t n, unsigned c,
+                           unsigned win_first, unsigned win_stride, hipStream_t stream, uint64_t *out_xyzz) {
+        WindowPlan plan = G::make_plan(c, win_first, win_stride);
+        return G::window_sums(ctx, d_points, d_scalars, n, plan, stream, reinterpret_cast<typename G::Ext *>(out_xyzz));
+    }
+    static void fold(const uint64_t *xyzz_windows, unsigned c, uint64_t *out_jac) {
+        typename G::J j = G::fold(reinterpret_cast<const typename G::Ext *>(xyzz_windows), c);
+        memcpy(out_jac, &j, sizeof j);
+    }
+    static void jac_to_affine(const uint64_t *jac, uint64_t *out_affine) {
+        typename G::J j;
+        memcpy(&j, jac, sizeof j);
+        typename G::Aff a = affine_from_jac(j);
+        memcpy(out_affine, &a, sizeof a);
+    }
+    static int debug_decompose(const uint64_t *scalars, size_t n, unsigned c, uint32_t *out_digits) {
+        return debug_decompose_impl<G>(scalars, n, c, out_digits);
+    }
+    static int debug_field_op(int field, int op, const uint64_t *a, const uint64_t *b, size_t count, uint64_t *out) {
+        using BaseP = typename G::F::Params;
+        if (field == 0) {
+            if (op == 6) return debug_from_mont<BaseP>(a, count, out);
+            return debug_field<Fp<BaseP>>(op, a, b, count, out);
+        } else if (field == 1) {
+            if (op == 6) return debug_from_mont<typename G::FrP>(a, count, out);
+            return debug_field<Fp<typename G::FrP>>(op, a, b, count, out);
+        }
+        if (op == 6) return fail(GMSM_ERR_ARG, "from_mont is defined on prime fields only");
+        return debug_field<typename G::F>(op, a, b, count, out);
+    }
+    static int debug_group_op(int op, const uint64_t *acc, const uint64_t *other, size_t count, uint64_t *out) {
+        return debug_group<G>(op, acc, other, count, out);
+    }
+    static const GroupVTable *get() {
+        static const GroupVTable vt = {G::FR_BITS,      G::AFF_BYTES,   G::SCALAR_BYTES, sizeof(typename G::J),
+                                       sizeof(typename G::Ext), &multiexp_host, &multiexp_device, &window_sums,
+                                       &fold,           &jac_to_affine, &debug_decompose, &debug_field_op,
+                                       &debug_group_op};
+        return &vt;
+    }
+};
+
+}  // namespace gmsm

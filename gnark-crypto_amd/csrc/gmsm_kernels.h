@@ -1,0 +1,312 @@
+// HIP kernels of the Pippenger pipeline (gfx950). One template per stage, instantiated per (curve, group) in
+// gmsm_engine.hip. Stage -> reference function it replaces:
+//
+//   k_decompose        partitionScalars                    ecc/bn254/multiexp.go:709-803 (+ fr.Bits/fromMont, fr/element.go:855)
+//   k_hist/k_colscan/k_rowscan/k_scatter
+//                      (no reference twin) group each window's point references by bucket, so that
+//                      every bucket is owned by exactly one accumulation thread -- replaces the reference's
+//                      "one goroutine walks all n digits of a window" (multiexp_jacobian.go:26-39)
+//   k_accumulate       bucket accumulation loop             multiexp_jacobian.go:26-39 (addMixed / subMixed)
+//   k_reduce           running-sum bucket reduction         multiexp_jacobian.go:44-52
+//   (host) fold        msmReduceChunkG1Affine               multiexp.go:302-315
+//
+// Digit code (same as the reference's uint16 digits, widened to 32 bit so c may exceed 16):
+//   0 = skip, d > 0 -> 2d, d < 0 -> 2(-d-1)+1;  bucket = (code>>1) - ((code&1)^1), negate = code&1.
+// Sorted entry: (point_index << 1) | negate.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gmsm_curve.h"
+
+namespace gmsm {
+
+// Window geometry shared by host and device.
+struct WindowPlan {
+    uint32_t c;          // window width in bits
+    uint32_t nwin_total; // number of windows of the full scalar (= computeNbChunks(c), multiexp.go:681)
+    uint32_t nbuckets;   // buckets allocated per window: 2^(max(c,lastC)-1)
+    uint32_t win_first;  // this launch handles windows win_first + k*win_stride, k < nwin_local (window sharding)
+    uint32_t win_stride;
+    uint32_t nwin_local;
+};
+
+template <class T>
+__device__ __forceinline__ T load_struct(const void *base, size_t index) {
+    // sizeof(T) is a multiple of 16 for every element type in scope (32..384 B): 16-byte vector loads
+    static_assert(sizeof(T) % 16 == 0, "element size");
+    T r;
+    const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(base) + index * sizeof(T));
+    uint4 *dst = reinterpret_cast<uint4 *>(&r);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 16); ++i) dst[i] = src[i];
+    return r;
+}
+
+template <class T>
+__device__ __forceinline__ void store_struct(void *base, size_t index, const T &v) {
+    static_assert(sizeof(T) % 16 == 0, "element size");
+    uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(base) + index * sizeof(T));
+    const uint4 *src = reinterpret_cast<const uint4 *>(&v);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 16); ++i) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------ scalar decomposition
+// One thread per scalar. digits is [nwin_local][n] (window-major, coalesced stores).
+template <class FrP>
+__global__ void __launch_bounds__(256) k_decompose(const uint32_t *__restrict__ scalars, size_t n, WindowPlan plan,
+                                                   uint32_t *__restrict__ digits) {
+    constexpr int NR = FrP::N;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp<FrP> s;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(scalars + i * NR);
+        uint4 *dst = reinterpret_cast<uint4 *>(s.l);
+#pragma unroll
+        for (int k = 0; k < NR / 4; ++k) dst[k] = src[k];
+    }
+    const bool zero = s.is_zero();  // multiexp.go:743
+    s = fp_from_mont(s);
+    const uint32_t c = plan.c;
+    const uint32_t mask = (1u << c) - 1u;
+    const int max = (1 << (c - 1)) - 1;
+    int carry = 0;
+    uint32_t next_local = 0;  // next local window slot expected
+    for (uint32_t w = 0; w < plan.nwin_total; ++w) {
+        const uint32_t bit = w * c, idx = bit >> 5, sh = bit & 31;
+        // up to 3 words can contribute when c > 32-sh ... c <= 24 is enforced on the host: 2 words suffice
+        // for c+sh <= 64
+        uint64_t lo = s.l[idx];
+        uint64_t hi = (idx + 1 < (uint32_t)NR) ? s.l[idx + 1] : 0u;
+        uint64_t v = ((hi << 32) | lo) >> sh;
+        int digit = carry + (int)((uint32_t)v & mask);
+        uint32_t code;
+        if (w + 1 < plan.nwin_total) {
+            carry = 0;
+            if (digit > max) {
+                digit -= 1 << c;
+                carry = 1;
+            }
+            code = digit == 0 ? 0u : (digit > 0 ? ((uint32_t)digit << 1) : ((((uint32_t)(-digit) - 1u) << 1) | 1u));
+        } else {
+            code = (uint32_t)digit << 1;  // top window: no borrow (multiexp.go:788-800)
+        }
+        if (w >= plan.win_first && (w - plan.win_first) % plan.win_stride == 0) {
+            const uint32_t k = (w - plan.win_first) / plan.win_stride;
+            if (k < plan.nwin_local) digits[(size_t)k * n + i] = zero ? 0u : code;
+            (void)next_local;
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t code_bucket(uint32_t code) { return (code >> 1) - ((code & 1u) ^ 1u); }
+
+// ------------------------------------------------------------------ counting sort by bucket
+// grid = (nchunks, nwin_local). LDS histogram of one (window, chunk); dynamic LDS = nbuckets * 4 B.
+static __global__ void __launch_bounds__(1024) k_hist(const uint32_t *__restrict__ digits, size_t n, uint32_t nbuckets,
+                                               size_t chunk_len, uint32_t *__restrict__ blockhist) {
+    extern __shared__ uint32_t lds_hist[];
+    const uint32_t chunk = blockIdx.x, k = blockIdx.y, nchunks = gridDim.x;
+    for (uint32_t b = threadIdx.x; b < nbuckets; b += blockDim.x) lds_hist[b] = 0;
+    __syncthreads();
+    const size_t lo = (size_t)chunk * chunk_len;
+    const size_t hi = lo + chunk_len < n ? lo + chunk_len : n;
+    const uint32_t *d = digits + (size_t)k * n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t code = d[i];
+        if (code) atomicAdd(&lds_hist[code_bucket(code)], 1u);
+    }
+    __syncthreads();
+    uint32_t *out = blockhist + ((size_t)k * nchunks + chunk) * nbuckets;
+    for (uint32_t b = threadIdx.x; b < nbuckets; b += blockDim.x) out[b] = lds_hist[b];
+}
+
+// One thread per (window, bucket): turn the per-chunk counts into exclusive prefixes over chunks and emit the
+// bucket total.
+static __global__ void __launch_bounds__(256) k_colscan(uint32_t *__restrict__ blockhist, uint32_t nchunks, uint32_t nbuckets,
+                                                 uint32_t *__restrict__ counts) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (b >= nbuckets) return;
+    uint32_t run = 0;
+    for (uint32_t ch = 0; ch < nchunks; ++ch) {
+        uint32_t *p = blockhist + ((size_t)k * nchunks + ch) * nbuckets + b;
+        const uint32_t v = *p;
+        *p = run;
+        run += v;
+    }
+    counts[(size_t)k * nbuckets + b] = run;
+}
+
+// One block per window: exclusive scan of counts over buckets -> starts[k][0..nbuckets] (last = window total).
+static __global__ void __launch_bounds__(1024) k_rowscan(const uint32_t *__restrict__ counts, uint32_t nbuckets,
+                                                  uint32_t *__restrict__ starts) {
+    __shared__ uint32_t part[1024];
+    const uint32_t k = blockIdx.x, t = threadIdx.x, T = blockDim.x;
+    const uint32_t per = (nbuckets + T - 1) / T;
+    const uint32_t lo = t * per, hi = lo + per < nbuckets ? lo + per : nbuckets;
+    const uint32_t *c = counts + (size_t)k * nbuckets;
+    uint32_t s = 0;
+    for (uint32_t b = lo; b < hi; ++b) s += c[b];
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < T; d <<= 1) {  // Hillis-Steele inclusive scan
+        uint32_t v = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - s;  // exclusive
+    uint32_t *o = starts + (size_t)k * (nbuckets + 1);
+    for (uint32_t b = lo; b < hi; ++b) {
+        o[b] = run;
+        run += c[b];
+    }
+    if (t == T - 1) o[nbuckets] = part[T - 1];
+}
+
+// grid = (nchunks, nwin_local). LDS cursors = starts + chunk prefix; each digit takes the next slot of its bucket.
+static __global__ void __launch_bounds__(1024) k_scatter(const uint32_t *__restrict__ digits, size_t n, uint32_t nbuckets,
+                                                  size_t chunk_len, const uint32_t *__restrict__ blockhist,
+                                                  const uint32_t *__restrict__ starts, uint32_t *__restrict__ sorted) {
+    extern __shared__ uint32_t lds_cur[];
+    const uint32_t chunk = blockIdx.x, k = blockIdx.y, nchunks = gridDim.x;
+    const uint32_t *pre = blockhist + ((size_t)k * nchunks + chunk) * nbuckets;
+    const uint32_t *st = starts + (size_t)k * (nbuckets + 1);
+    for (uint32_t b = threadIdx.x; b < nbuckets; b += blockDim.x) lds_cur[b] = st[b] + pre[b];
+    __syncthreads();
+    const size_t lo = (size_t)chunk * chunk_len;
+    const size_t hi = lo + chunk_len < n ? lo + chunk_len : n;
+    const uint32_t *d = digits + (size_t)k * n;
+    uint32_t *out = sorted + (size_t)k * n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t code = d[i];
+        if (code) {
+            const uint32_t pos = atomicAdd(&lds_cur[code_bucket(code)], 1u);
+            out[pos] = ((uint32_t)i << 1) | (code & 1u);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ bucket accumulation (the hot loop)
+// One thread per (window, bucket): walks its sorted run, gathers the affine points, mixed-adds them into an XYZZ
+// accumulator held in VGPRs, stores the bucket.
+template <class F>
+__global__ void __launch_bounds__(256) k_accumulate(const void *__restrict__ points, size_t n, uint32_t nbuckets,
+                                                    const uint32_t *__restrict__ starts,
+                                                    const uint32_t *__restrict__ sorted, void *__restrict__ buckets) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (b >= nbuckets) return;
+    const uint32_t *st = starts + (size_t)k * (nbuckets + 1);
+    const uint32_t lo = st[b], hi = st[b + 1];
+    const uint32_t *ent = sorted + (size_t)k * n;
+    XYZZ<F> acc = XYZZ<F>::infinity();
+    for (uint32_t e = lo; e < hi; ++e) {
+        const uint32_t v = ent[e];
+        Affine<F> p = load_struct<Affine<F>>(points, v >> 1);
+        xyzz_add_mixed(acc, p, (v & 1u) != 0);
+    }
+    store_struct(buckets, (size_t)k * nbuckets + b, acc);
+}
+
+// ------------------------------------------------------------------ bucket reduction
+// Weighted sum  sum_k (k+1) B_k  of a window, as a two-level segmented running sum:
+//   level 1 (k_reduce1): each thread owns L consecutive buckets (running sum, multiexp_jacobian.go:44-52 restricted to
+//   its segment), then the block combines its threads' (S_t, W_t) with a suffix scan in LDS;
+//   level 2 (k_reduce2): one block per window combines the level-1 block results the same way.
+// Identity used:  sum_{k in [base, base+T*L)} (k-base+1) B_k = sum_t W_t + L * sum_{t>=1} Suf_t,
+//   S_t = sum of segment t, W_t = sum_{k in seg t} (k-lo_t+1) B_k, Suf_t = sum_{t'>=t} S_t'.
+template <class F, int TPB>
+__device__ __forceinline__ void block_combine(XYZZ<F> S, XYZZ<F> W, uint32_t log2L, XYZZ<F> *lds, XYZZ<F> &S_out,
+                                              XYZZ<F> &W_out) {
+    const uint32_t t = threadIdx.x;
+    // inclusive suffix scan of S over threads (Hillis-Steele)
+    lds[t] = S;
+    __syncthreads();
+    XYZZ<F> suf = S;
+    for (uint32_t d = 1; d < TPB; d <<= 1) {
+        XYZZ<F> o = XYZZ<F>::infinity();
+        if (t + d < TPB) o = lds[t + d];
+        __syncthreads();
+        xyzz_add(suf, o);
+        lds[t] = suf;
+        __syncthreads();
+    }
+    S_out = lds[0];
+    __syncthreads();
+    // U = sum_{t>=1} Suf_t ; V = sum_t W_t   (tree reductions)
+    XYZZ<F> U = t >= 1 ? suf : XYZZ<F>::infinity();
+    lds[t] = U;
+    __syncthreads();
+    for (uint32_t d = TPB / 2; d >= 1; d >>= 1) {
+        if (t < d) {
+            XYZZ<F> o = lds[t + d];
+            xyzz_add(U, o);
+            lds[t] = U;
+        }
+        __syncthreads();
+    }
+    U = lds[0];
+    __syncthreads();
+    lds[t] = W;
+    __syncthreads();
+    for (uint32_t d = TPB / 2; d >= 1; d >>= 1) {
+        if (t < d) {
+            XYZZ<F> o = lds[t + d];
+            xyzz_add(W, o);
+            lds[t] = W;
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        for (uint32_t i = 0; i < log2L; ++i) U = xyzz_double(U);
+        xyzz_add(W, U);
+        W_out = W;
+    }
+}
+
+// grid = (nblocks1, nwin_local), block = TPB threads, each thread L = 2^log2L buckets.
+// out1[(k*nblocks1 + blk)*2 + {0,1}] = (S_blk, W_blk)
+template <class F, int TPB>
+__global__ void __launch_bounds__(TPB) k_reduce1(const void *__restrict__ buckets, uint32_t nbuckets, uint32_t log2L,
+                                                 void *__restrict__ out1) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    XYZZ<F> *lds = reinterpret_cast<XYZZ<F> *>(lds_raw);
+    const uint32_t k = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
+    const uint32_t L = 1u << log2L;
+    const uint32_t lo = (blk * TPB + t) * L;
+    XYZZ<F> run = XYZZ<F>::infinity(), tot = XYZZ<F>::infinity();
+    for (uint32_t j = L; j-- > 0;) {
+        const uint32_t b = lo + j;
+        if (b < nbuckets) {
+            XYZZ<F> B = load_struct<XYZZ<F>>(buckets, (size_t)k * nbuckets + b);
+            xyzz_add(run, B);
+        }
+        xyzz_add(tot, run);
+    }
+    XYZZ<F> S_out, W_out;
+    block_combine<F, TPB>(run, tot, log2L, lds, S_out, W_out);
+    if (t == 0) {
+        store_struct(out1, ((size_t)k * gridDim.x + blk) * 2 + 0, S_out);
+        store_struct(out1, ((size_t)k * gridDim.x + blk) * 2 + 1, W_out);
+    }
+}
+
+// grid = nwin_local, block = TPB >= nblocks1 threads. Thread j holds level-1 block j: (S_j, W_j) covering
+// TPB1*L buckets = 2^log2span. window_total[k] = sum_j W_j + span * sum_j j*S_j.
+template <class F, int TPB>
+__global__ void __launch_bounds__(TPB) k_reduce2(const void *__restrict__ in1, uint32_t nblocks1, uint32_t log2span,
+                                                 void *__restrict__ window_totals) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    XYZZ<F> *lds = reinterpret_cast<XYZZ<F> *>(lds_raw);
+    const uint32_t k = blockIdx.x, t = threadIdx.x;
+    XYZZ<F> S = XYZZ<F>::infinity(), W = XYZZ<F>::infinity();
+    if (t < nblocks1) {
+        S = load_struct<XYZZ<F>>(in1, ((size_t)k * nblocks1 + t) * 2 + 0);
+        W = load_struct<XYZZ<F>>(in1, ((size_t)k * nblocks1 + t) * 2 + 1);
+    }
+    XYZZ<F> S_out, W_out;
+    block_combine<F, TPB>(S, W, log2span, lds, S_out, W_out);
+    if (t == 0) store_struct(window_totals, k, W_out);
+}
+
+}  // namespace gmsm

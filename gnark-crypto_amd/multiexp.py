@@ -1,0 +1,151 @@
+"""Host-side mirror of gnark-crypto's MultiExp API on top of the C ABI (include/gmsm.h).
+
+The reference's host language is Go; no Go toolchain exists in this environment, so the mirror above the C ABI is
+Python (ctypes), keeping the reference's names, argument meaning and error behaviour
+(ecc/bn254/multiexp.go:20-71, ecc/ecc.go:107-110):
+
+    cfg = MultiExpConfig(NbTasks=0)
+    p, err = G1Affine("bn254").MultiExp(points, scalars, cfg)      # -> (affine limbs, None) or (None, error string)
+    j, err = G1Jac("bn254").MultiExp(points, scalars, cfg)         # -> Jacobian limbs
+
+`points` is a numpy uint64 array (n, 2*coord_limbs) in the memory layout of Go's []G1Affine / []G2Affine and
+`scalars` is (n, fr_limbs) in the layout of []fr.Element (both Montgomery form), i.e. exactly what a cgo caller passes
+with unsafe.Pointer(&points[0]).  The cgo stub a maintainer would add is in INTEGRATION.md.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from .curves import CURVES
+
+ERR_LEN = "len(points) != len(scalars)"                      # multiexp.go:63
+ERR_NBTASKS = "invalid config: config.NbTasks > 1024"        # multiexp.go:70
+
+
+@dataclass
+class MultiExpConfig:
+    """ecc.MultiExpConfig (ecc/ecc.go:107-110). NbTasks is validated like the reference and otherwise ignored: the
+    GPU grid replaces the goroutine pool."""
+    NbTasks: int = 0
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_lib.ctypes.c_void_p)
+
+
+class _Group:
+    group = None  # "g1" / "g2"
+
+    def __init__(self, curve="bn254"):
+        self.curve = CURVES[curve] if isinstance(curve, str) else curve
+        self.gid = _lib.GROUP_IDS[(self.curve.name, self.group)]
+        ext = 1 if self.group == "g1" else self.curve.g2_ext
+        self.coord_limbs = self.curve.fp_limbs * ext
+        self.fr_limbs = self.curve.fr_limbs
+        self.aff_limbs = 2 * self.coord_limbs
+        self.jac_limbs = 3 * self.coord_limbs
+        self.xyzz_limbs = 4 * self.coord_limbs
+
+    def _check(self, points, scalars):
+        points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, self.aff_limbs)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, self.fr_limbs)
+        return points, scalars
+
+    def _error(self, rc):
+        if rc == _lib.GMSM_ERR_LEN:
+            return ERR_LEN
+        if rc == _lib.GMSM_ERR_CONFIG:
+            return ERR_NBTASKS
+        return "gmsm: " + _lib.last_error()
+
+    def _multiexp_jac(self, points, scalars, config):
+        L = _lib.load()
+        points, scalars = self._check(points, scalars)
+        out = np.zeros(self.jac_limbs, dtype=np.uint64)
+        rc = L.gmsm_multiexp(self.gid, _ptr(points), points.shape[0], _ptr(scalars), scalars.shape[0],
+                             int(config.NbTasks), _ptr(out))
+        return (out, None) if rc == 0 else (None, self._error(rc))
+
+    def _multiexp_affine(self, points, scalars, config):
+        L = _lib.load()
+        points, scalars = self._check(points, scalars)
+        out = np.zeros(self.aff_limbs, dtype=np.uint64)
+        rc = L.gmsm_multiexp_affine(self.gid, _ptr(points), points.shape[0], _ptr(scalars), scalars.shape[0],
+                                    int(config.NbTasks), _ptr(out))
+        return (out, None) if rc == 0 else (None, self._error(rc))
+
+    # ---- device-resident path (pointers are raw device addresses, e.g. torch.Tensor.data_ptr())
+    def multiexp_device(self, d_points, d_scalars, n, stream=0):
+        L = _lib.load()
+        out = np.zeros(self.jac_limbs, dtype=np.uint64)
+        rc = L.gmsm_multiexp_device(self.gid, d_points, d_scalars, n, stream or None, _ptr(out))
+        if rc:
+            raise RuntimeError(self._error(rc))
+        return out
+
+    def default_window_bits(self, n):
+        return int(_lib.load().gmsm_default_window_bits(self.gid, n))
+
+    def num_windows(self, c):
+        return int(_lib.load().gmsm_num_windows(self.gid, c))
+
+    def window_sums_device(self, d_points, d_scalars, n, c, win_first=0, win_stride=1, stream=0):
+        """XYZZ totals of windows win_first, win_first+win_stride, ... (window sharding across GPUs)."""
+        L = _lib.load()
+        nwin = self.num_windows(c)
+        nloc = max(0, (nwin - win_first + win_stride - 1) // win_stride) if win_first < nwin else 0
+        out = np.zeros((nloc, self.xyzz_limbs), dtype=np.uint64)
+        rc = L.gmsm_window_sums_device(self.gid, d_points, d_scalars, n, c, win_first, win_stride, stream or None, _ptr(out))
+        if rc:
+            raise RuntimeError(self._error(rc))
+        return out
+
+    def fold_windows(self, xyzz_windows, c):
+        L = _lib.load()
+        xyzz_windows = np.ascontiguousarray(xyzz_windows, dtype=np.uint64)
+        assert xyzz_windows.size == self.num_windows(c) * self.xyzz_limbs
+        out = np.zeros(self.jac_limbs, dtype=np.uint64)
+        rc = L.gmsm_fold_windows(self.gid, c, _ptr(xyzz_windows), _ptr(out))
+        if rc:
+            raise RuntimeError(self._error(rc))
+        return out
+
+    def jac_to_affine(self, jac):
+        L = _lib.load()
+        jac = np.ascontiguousarray(jac, dtype=np.uint64)
+        out = np.zeros(self.aff_limbs, dtype=np.uint64)
+        rc = L.gmsm_jac_to_affine(self.gid, _ptr(jac), _ptr(out))
+        if rc:
+            raise RuntimeError(self._error(rc))
+        return out
+
+
+class G1Jac(_Group):
+    group = "g1"
+
+    def MultiExp(self, points, scalars, config=MultiExpConfig()):
+        """(*G1Jac).MultiExp (multiexp.go:32): returns (jacobian_limbs, None) or (None, error)."""
+        return self._multiexp_jac(points, scalars, config)
+
+
+class G1Affine(_Group):
+    group = "g1"
+
+    def MultiExp(self, points, scalars, config=MultiExpConfig()):
+        """(*G1Affine).MultiExp (multiexp.go:20): returns (affine_limbs, None) or (None, error)."""
+        return self._multiexp_affine(points, scalars, config)
+
+
+class G2Jac(_Group):
+    group = "g2"
+
+    def MultiExp(self, points, scalars, config=MultiExpConfig()):
+        return self._multiexp_jac(points, scalars, config)
+
+
+class G2Affine(_Group):
+    group = "g2"
+
+    def MultiExp(self, points, scalars, config=MultiExpConfig()):
+        return self._multiexp_affine(points, scalars, config)

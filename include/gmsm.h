@@ -1,0 +1,119 @@
+/* gmsm.h -- C ABI of the MI355X multi-scalar-multiplication engine (libgmsm.so).
+ *
+ * Drop-in boundary for gnark-crypto's  (*G1Jac).MultiExp / (*G2Jac).MultiExp
+ *   ecc/bn254/multiexp.go:32 (G1) and :357 (G2); ecc/bls12-381/multiexp.go:32,:355; ecc/bw6-761/multiexp.go:32,:306
+ * A build-tagged Go file per curve package replaces the body of those methods (after the two argument checks,
+ * multiexp.go:61-71) with one cgo call to the matching symbol below; (*G1Affine).MultiExp, Fold, kzg.Commit,
+ * pedersen etc. route through it unchanged.  INTEGRATION.md shows the cgo stub.
+ *
+ * Memory layout (identical to the Go slices, so `unsafe.Pointer(&points[0])` is passed without copying):
+ *   points   n x {X,Y}           each coordinate = fp.Element  = FP_LIMBS little-endian uint64, Montgomery form;
+ *                                G2 over Fp2: X.A0, X.A1, Y.A0, Y.A1.  The affine point (0,0) is infinity.
+ *   scalars  n x fr.Element      FR_LIMBS little-endian uint64, Montgomery form.
+ *   out_jac  {X,Y,Z}             Jacobian, Montgomery form; Z = 0 (X = Y = 1) for infinity.  Any representative of
+ *                                the group element (as in the reference, callers compare with Equal or FromJacobian).
+ *   curve      FP_LIMBS FR_LIMBS   G1Affine  G2Affine  (bytes)
+ *   bn254         4        4          64       128
+ *   bls12_381     6        4          96       192
+ *   bw6_761      12        6         192       192     (G2 is over Fp)
+ *
+ * Return codes:  GMSM_OK, GMSM_ERR_LEN  ("len(points) != len(scalars)", multiexp.go:63),
+ *                GMSM_ERR_CONFIG ("invalid config: config.NbTasks > 1024", multiexp.go:70),
+ *                >= GMSM_ERR_DEVICE: HIP/runtime failure -- gmsm_last_error() has the text.  There is NO CPU
+ *                fallback inside this library: without a usable gfx950 device every compute entry fails loudly.
+ *
+ * Threading: every entry point is re-entrant and may be called concurrently from any OS thread (goroutines
+ * migrate); calls on one device are serialised internally on that device's context.
+ * Ownership: the caller owns all buffers; host pointers are not retained after return.
+ */
+#ifndef GMSM_H
+#define GMSM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMSM_OK 0
+#define GMSM_ERR_LEN 1
+#define GMSM_ERR_CONFIG 2
+#define GMSM_ERR_DEVICE 3
+#define GMSM_ERR_ARG 4
+
+/* group ids for the generic entry points */
+enum gmsm_group {
+    GMSM_BN254_G1 = 0,
+    GMSM_BN254_G2 = 1,
+    GMSM_BLS12_381_G1 = 2,
+    GMSM_BLS12_381_G2 = 3,
+    GMSM_BW6_761_G1 = 4,
+    GMSM_BW6_761_G2 = 5,
+    GMSM_NUM_GROUPS = 6
+};
+
+/* ---- drop-in entries: host pointers in, Jacobian out (replaces (*GxJac).MultiExp after its argument checks;
+ *      the checks are repeated here so that the error behaviour is identical when called directly). ---- */
+int gmsm_bn254_g1_multiexp(const uint64_t *points, size_t n_points, const uint64_t *scalars, size_t n_scalars,
+                           int nb_tasks, uint64_t *out_jac); /* ecc/bn254/multiexp.go:32 */
+int gmsm_bn254_g2_multiexp(const uint64_t *points, size_t n_points, const uint64_t *scalars, size_t n_scalars,
+                           int nb_tasks, uint64_t *out_jac); /* ecc/bn254/multiexp.go:357 */
+int gmsm_bls12_381_g1_multiexp(const uint64_t *points, size_t n_points, const uint64_t *scalars, size_t n_scalars,
+                               int nb_tasks, uint64_t *out_jac); /* ecc/bls12-381/multiexp.go:32 */
+int gmsm_bls12_381_g2_multiexp(const uint64_t *points, size_t n_points, const uint64_t *scalars, size_t n_scalars,
+                               int nb_tasks, uint64_t *out_jac); /* ecc/bls12-381/multiexp.go:355 */
+int gmsm_bw6_761_g1_multiexp(const uint64_t *points, size_t n_points, const uint64_t *scalars, size_t n_scalars,
+                             int nb_tasks, uint64_t *out_jac); /* ecc/bw6-761/multiexp.go:32 */
+int gmsm_bw6_761_g2_multiexp(const uint64_t *points, size_t n_points, const uint64_t *scalars, size_t n_scalars,
+                             int nb_tasks, uint64_t *out_jac); /* ecc/bw6-761/multiexp.go:306 */
+
+/* Same, selected by id. */
+int gmsm_multiexp(int group, const uint64_t *points, size_t n_points, const uint64_t *scalars, size_t n_scalars,
+                  int nb_tasks, uint64_t *out_jac);
+
+/* (*GxAffine).MultiExp (multiexp.go:20-27): MultiExp followed by FromJacobian (g1.go:150-166); out_affine = {X,Y},
+ * (0,0) for infinity.  This is the canonical value parity is defined on. */
+int gmsm_multiexp_affine(int group, const uint64_t *points, size_t n_points, const uint64_t *scalars,
+                         size_t n_scalars, int nb_tasks, uint64_t *out_affine);
+
+/* ---- device-resident entries (bases/scalars already in HBM: the SRS-resident fast path).
+ *      d_points / d_scalars are device pointers with the layouts above; hip_stream is a hipStream_t (NULL = default
+ *      stream); the call returns after the result has been copied back to out_jac (host memory). ---- */
+int gmsm_multiexp_device(int group, const void *d_points, const void *d_scalars, size_t n, void *hip_stream,
+                         uint64_t *out_jac);
+
+/* ---- window-sharded pieces (multi-GPU: windows win_first, win_first+win_stride, ... of the c-bit decomposition are
+ *      handled by this device; the tiny per-window totals are exchanged by the caller, e.g. one RCCL all-gather).
+ *      out_xyzz (host) receives nwin_local x {X,Y,ZZ,ZZZ} extended-Jacobian window totals
+ *      (= what processChunkG1Jacobian sends on chRes, multiexp_jacobian.go:60). ---- */
+unsigned gmsm_default_window_bits(int group, size_t n);            /* the engine's choice of c for n points */
+unsigned gmsm_num_windows(int group, unsigned c);                  /* computeNbChunks, multiexp.go:681 */
+int gmsm_window_sums_device(int group, const void *d_points, const void *d_scalars, size_t n, unsigned c,
+                            unsigned win_first, unsigned win_stride, void *hip_stream, uint64_t *out_xyzz);
+/* Horner fold of all nwin = gmsm_num_windows(group,c) window totals (msmReduceChunk, multiexp.go:302-315) -> Jacobian */
+int gmsm_fold_windows(int group, unsigned c, const uint64_t *xyzz_windows, uint64_t *out_jac);
+/* FromJacobian (g1.go:150-166) */
+int gmsm_jac_to_affine(int group, const uint64_t *jac, uint64_t *out_affine);
+
+/* ---- introspection / test hooks (used by tests/ to check each stage against the oracle) ---- */
+size_t gmsm_affine_limbs(int group);   /* uint64 limbs of one affine point */
+size_t gmsm_scalar_limbs(int group);
+/* digits[nwin][n] (uint32 codes: 0 skip, d>0 -> 2d, d<0 -> 2(-d-1)+1) for host scalars; test hook for k_decompose */
+int gmsm_debug_decompose(int group, const uint64_t *scalars, size_t n, unsigned c, uint32_t *out_digits);
+/* element-wise field ops on device: op 0 mul, 1 add, 2 sub, 3 neg, 4 dbl, 5 sqr, 6 from_mont; field 0 = fp, 1 = fr,
+ * 2 = the group's coordinate field (Fp2 for G2 where applicable).  a,b,out: count x limbs host arrays. */
+int gmsm_debug_field_op(int group, int field, int op, const uint64_t *a, const uint64_t *b, size_t count, uint64_t *out);
+/* device group-law hook: out[i] = XYZZ accumulation of  acc[i] (+/-) pts[i]  (op 0 add_mixed, 1 sub_mixed),
+ * op 2: out[i] = acc[i] + acc2[i] (xyzz add), op 3: out[i] = 2*acc[i]. */
+int gmsm_debug_group_op(int group, int op, const uint64_t *acc, const uint64_t *pts_or_acc2, size_t count, uint64_t *out);
+
+int gmsm_device_count(void);
+int gmsm_set_device(int device);          /* device used by subsequent calls of this thread (default 0) */
+const char *gmsm_last_error(void);        /* thread-local text of the last failure */
+const char *gmsm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMSM_H */

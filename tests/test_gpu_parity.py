@@ -1,0 +1,236 @@
+"""GPU parity tests: every stage of the HIP pipeline, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Bit-exact: integer work, the bar is equality of limbs (affine X,Y Montgomery limbs for MSM results).
+Run with `pytest -m gpu` on an MI355X."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import ALL_GROUPS, int_to_limbs, random_field_limbs, random_scalars, rng_for, scalars_from_ints
+
+pytestmark = pytest.mark.gpu
+
+P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _group(gm, curve, which):
+    return (gm.G1Affine if which == "g1" else gm.G2Affine)(curve)
+
+
+def _edge_values(modulus, nlimbs, R):
+    vals = [0, 1, 2, modulus - 1, modulus - 2, R % modulus, R * R % modulus, (1 << 64) - 1, 1 << 64, (1 << (64 * (nlimbs - 1))) - 1,
+            modulus >> 1, (modulus >> 1) + 1]
+    return np.array([int_to_limbs(v % modulus, nlimbs) for v in vals], dtype=np.uint64)
+
+
+# ------------------------------------------------------------------ field kernels
+@pytest.mark.parametrize("curve,which", ALL_GROUPS)
+def test_field_ops_match_oracle(gm, oracle_mod, curve, which):
+    L = gm._lib.load()
+    g = _group(gm, curve, which)
+    c = g.curve
+    rng = rng_for(1, g.gid)
+    fields = [(0, f"{c.name}_fp", c.p, c.fp_limbs, c.fp_R), (1, f"{c.name}_fr", c.r, c.fr_limbs, c.fr_R)]
+    for fid, name, mod, nl, R in fields:
+        F = oracle_mod.Field(name, nl)
+        a = np.concatenate([_edge_values(mod, nl, R), random_field_limbs(rng, mod, nl, 500)])
+        b = np.concatenate([random_field_limbs(rng, mod, nl, 500), _edge_values(mod, nl, R)])
+        # all pairs of edge values too
+        e = _edge_values(mod, nl, R)
+        a = np.concatenate([a, np.repeat(e, len(e), axis=0)])
+        b = np.concatenate([b, np.tile(e, (len(e), 1))])
+        for op, fn in [(0, F.mul), (1, F.add), (2, F.sub)]:
+            out = np.zeros_like(a)
+            assert L.gmsm_debug_field_op(g.gid, fid, op, P(a), P(b), len(a), P(out)) == 0, gm._lib.last_error()
+            exp = np.array([fn(x, y) for x, y in zip(a, b)])
+            assert (out == exp).all(), (name, op)
+        for op, fn in [(3, F.neg), (4, F.dbl), (5, F.sqr), (6, F.from_mont)]:
+            out = np.zeros_like(a)
+            assert L.gmsm_debug_field_op(g.gid, fid, op, P(a), None, len(a), P(out)) == 0, gm._lib.last_error()
+            exp = np.array([fn(x) for x in a])
+            assert (out == exp).all(), (name, op)
+    if g.coord_limbs != c.fp_limbs:  # Fp2
+        F = oracle_mod.Field(f"{c.name}_e2", 2 * c.fp_limbs)
+        a = random_field_limbs(rng, c.p, c.fp_limbs, 600).reshape(300, -1)
+        b = random_field_limbs(rng, c.p, c.fp_limbs, 600).reshape(300, -1)
+        a[0] = 0
+        b[1] = 0
+        a[2, c.fp_limbs:] = 0
+        b[3, : c.fp_limbs] = 0
+        for op, fn in [(0, F.mul), (1, F.add), (2, F.sub)]:
+            out = np.zeros_like(a)
+            assert L.gmsm_debug_field_op(g.gid, 2, op, P(a), P(b), len(a), P(out)) == 0, gm._lib.last_error()
+            assert (out == np.array([fn(x, y) for x, y in zip(a, b)])).all(), ("e2", op)
+        for op, fn in [(3, F.neg), (4, F.dbl), (5, F.sqr)]:
+            out = np.zeros_like(a)
+            assert L.gmsm_debug_field_op(g.gid, 2, op, P(a), None, len(a), P(out)) == 0, gm._lib.last_error()
+            assert (out == np.array([fn(x) for x in a])).all(), ("e2", op)
+
+
+# ------------------------------------------------------------------ group law incl. every special case
+@pytest.mark.parametrize("curve,which", ALL_GROUPS)
+def test_group_ops_match_oracle(gm, oracle_mod, curve, which):
+    L = gm._lib.load()
+    g = _group(gm, curve, which)
+    o = oracle_mod.Oracle(curve, which)
+    n = 48
+    pts = o.gen_points(n, 7, 11)
+    other = o.gen_points(n, 1000, 13)
+    # accumulators: running sums in XYZZ (non-trivial ZZ/ZZZ)
+    accs = []
+    acc = o.xyzz_infinity()
+    for i in range(n):
+        acc = o.xyzz_add_mixed(acc, other[i])
+        accs.append(acc.copy())
+    accs = np.array(accs)
+    # special cases (g1.go:829-854): acc = infinity; point = infinity (0,0); acc == point (doubling); acc == -point
+    accs[0] = o.xyzz_infinity()
+    pts[1] = 0
+    accs[2] = o.xyzz_add_mixed(o.xyzz_infinity(), pts[2])                 # P + P
+    accs[3] = o.xyzz_add_mixed(o.xyzz_infinity(), pts[3], negate=True)    # -P + P = inf
+    accs[4] = o.xyzz_double(o.xyzz_add_mixed(o.xyzz_infinity(), pts[4]))  # 2P (ZZ != 1) + P
+    t = o.xyzz_add_mixed(o.xyzz_infinity(), pts[5]); t = o.xyzz_add_mixed(t, pts[6]); t = o.xyzz_add_mixed(t, pts[6], negate=True)
+    accs[5] = t                                                            # (P5 + P6 - P6) has ZZ != 1, equals P5 -> doubling branch
+    for op, neg in [(0, False), (1, True)]:
+        out = np.zeros_like(accs)
+        assert L.gmsm_debug_group_op(g.gid, op, P(accs), P(pts), n, P(out)) == 0, gm._lib.last_error()
+        exp = np.array([o.xyzz_add_mixed(a, p, negate=neg) for a, p in zip(accs, pts)])
+        assert (out == exp).all(), ("add_mixed", op, np.nonzero((out != exp).any(axis=1))[0])
+    accs2 = np.roll(accs, 7, axis=0).copy()
+    accs2[10] = accs[10]           # P + P via full add -> double
+    accs2[11] = o.xyzz_infinity()
+    out = np.zeros_like(accs)
+    assert L.gmsm_debug_group_op(g.gid, 2, P(accs), P(accs2), n, P(out)) == 0, gm._lib.last_error()
+    exp = np.array([o.xyzz_add(a, b) for a, b in zip(accs, accs2)])
+    assert (out == exp).all(), "xyzz_add"
+    out = np.zeros_like(accs)
+    assert L.gmsm_debug_group_op(g.gid, 3, P(accs), None, n, P(out)) == 0, gm._lib.last_error()
+    exp = np.array([o.xyzz_double(a) for a in accs])
+    assert (out == exp).all(), "xyzz_double"
+
+
+# ------------------------------------------------------------------ scalar decomposition == partitionScalars
+@pytest.mark.parametrize("curve,which", [("bn254", "g1"), ("bls12_381", "g1"), ("bw6_761", "g1")])
+def test_decompose_matches_partition_scalars(gm, oracle_mod, curve, which):
+    L = gm._lib.load()
+    g = _group(gm, curve, which)
+    o = oracle_mod.Oracle(curve, which)
+    c_ = g.curve
+    rng = rng_for(3, g.gid)
+    n = 1000
+    sc = random_scalars(rng, c_, n)
+    edge = scalars_from_ints(c_, [0, 1, 2, c_.r - 1, c_.r - 2, (1 << 16) - 1, 1 << 16, 1 << 15, (1 << 15) - 1, (1 << 64) - 1, 1 << 64,
+                                  (1 << 128) + 12345, c_.r >> 1])
+    sc[: len(edge)] = edge
+    for c in [2, 3, 4, 5, 8, 10, 11, 13, 15, 16]:
+        nwin = o.nb_chunks(c)
+        out = np.zeros((nwin, n), dtype=np.uint32)
+        assert L.gmsm_debug_decompose(g.gid, P(sc), n, c, P(out)) == 0, gm._lib.last_error()
+        exp = o.partition_scalars(sc, c).astype(np.uint32)
+        assert (out == exp).all(), (curve, c)
+
+
+# ------------------------------------------------------------------ MSM
+def _msm_gpu_affine(g, points, scalars):
+    aff, err = g.MultiExp(points, scalars)
+    assert err is None, err
+    return aff
+
+
+@pytest.mark.parametrize("curve,which", ALL_GROUPS)
+def test_msm_sum_of_squares_identity_all_c(gm, oracle_mod, pyref_mod, curve, which):
+    """multiexp_test.go:95-126: MSM({i*G},{i*mixer}) for every window size, plus the closed form
+    mixer*n(n+1)(2n+1)/6*G (multiexp_test.go:54-60) checked with the independent big-int model."""
+    import torch
+    g = _group(gm, curve, which)
+    o = oracle_mod.Oracle(curve, which)
+    grp = pyref_mod.Group(g.curve, which)
+    n = 73
+    pts = o.gen_points(n, 1, 1)
+    for idx in (5, 17, 40, 66):  # sprinkle infinities (multiexp_test.go:48-52)
+        pts[idx] = 0
+    mixer = 0x1F2E3D4C5B6A79880123456789ABCDEF0FEDCBA9876543211122334455667788 % g.curve.r
+    sc = scalars_from_ints(g.curve, [(i + 1) * mixer for i in range(n)])
+    total = sum((i + 1) ** 2 for i in range(n) if i not in (5, 17, 40, 66)) * mixer % g.curve.r
+    expected = grp.mul(total, grp.gen)
+    exp_limbs = np.array(grp.point_to_limbs(expected), dtype=np.uint64)
+    assert (o.msm_affine(pts, sc, c=7) == exp_limbs).all()
+    d_pts = torch.from_numpy(pts.view(np.int64)).cuda()
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    for c in range(2, 17):
+        w = g.window_sums_device(d_pts.data_ptr(), d_sc.data_ptr(), n, c)
+        aff = g.jac_to_affine(g.fold_windows(w, c))
+        assert (aff == exp_limbs).all(), (curve, which, c)
+    assert (_msm_gpu_affine(g, pts, sc) == exp_limbs).all()
+
+
+@pytest.mark.parametrize("curve,which", ALL_GROUPS)
+def test_msm_edge_cases(gm, oracle_mod, curve, which):
+    g = _group(gm, curve, which)
+    gj = (gm.G1Jac if which == "g1" else gm.G2Jac)(curve)
+    o = oracle_mod.Oracle(curve, which)
+    c_ = g.curve
+    rng = rng_for(5, g.gid)
+    # n = 0 -> infinity, no error (Z = 0)
+    jac, err = gj.MultiExp(np.zeros((0, g.aff_limbs), dtype=np.uint64), np.zeros((0, g.fr_limbs), dtype=np.uint64))
+    assert err is None and (jac[2 * g.coord_limbs:] == 0).all()
+    aff, err = g.MultiExp(np.zeros((0, g.aff_limbs), dtype=np.uint64), np.zeros((0, g.fr_limbs), dtype=np.uint64))
+    assert err is None and (aff == 0).all()
+    # error behaviour (multiexp.go:61-71)
+    _, err = g.MultiExp(np.zeros((3, g.aff_limbs), dtype=np.uint64), np.zeros((2, g.fr_limbs), dtype=np.uint64))
+    assert err == "len(points) != len(scalars)"
+    _, err = g.MultiExp(np.zeros((3, g.aff_limbs), dtype=np.uint64), np.zeros((3, g.fr_limbs), dtype=np.uint64), gm.MultiExpConfig(NbTasks=1025))
+    assert err == "invalid config: config.NbTasks > 1024"
+    for n in (1, 2, 3, 31, 257):
+        pts = o.gen_points(n, 3 + n, 5)
+        sc = random_scalars(rng, c_, n)
+        assert (_msm_gpu_affine(g, pts, sc) == o.msm_affine(pts, sc)).all(), n
+    n = 200
+    pts = o.gen_points(n, 99, 7)
+    # all-zero scalars -> infinity (multiexp_test.go:164-182)
+    assert (_msm_gpu_affine(g, pts, np.zeros((n, g.fr_limbs), dtype=np.uint64)) == 0).all()
+    # all-infinity points -> infinity (multiexp_test.go:128-162)
+    sc = random_scalars(rng, c_, n)
+    assert (_msm_gpu_affine(g, np.zeros_like(pts), sc) == 0).all()
+    # special scalars: 1, 2, r-1, powers of two on window boundaries, single-limb values, all equal
+    vals = [1, 2, c_.r - 1, 1 << 16, 1 << 32, (1 << 16) - 1, 1 << 15, 12345, (1 << 64) - 1] + [1 << (13 * j) for j in range(1, 12)]
+    sc2 = scalars_from_ints(c_, (vals * (n // len(vals) + 1))[:n])
+    assert (_msm_gpu_affine(g, pts, sc2) == o.msm_affine(pts, sc2)).all()
+    sc3 = np.tile(sc[:1], (n, 1))  # all scalars equal: every window has a single giant bucket
+    assert (_msm_gpu_affine(g, pts, sc3) == o.msm_affine(pts, sc3)).all()
+    # duplicated (point, scalar) pairs force the doubling branch (multiexp_test.go:241-245); P and -P pairs force P+(-P)
+    pts4, sc4 = pts.copy(), sc.copy()
+    pts4[100:190] = pts4[10:100]
+    sc4[100:190] = sc4[10:100]
+    assert (_msm_gpu_affine(g, pts4, sc4) == o.msm_affine(pts4, sc4)).all()
+    same = np.tile(pts[:1], (n, 1))  # one base repeated (cf. the 4-point quick SRS, kzg.go:91-115)
+    assert (_msm_gpu_affine(g, same, sc) == o.msm_affine(same, sc)).all()
+    assert (_msm_gpu_affine(g, same, sc3) == o.msm_affine(same, sc3)).all()
+
+
+@pytest.mark.parametrize("curve,which,logn", [("bn254", "g1", 14), ("bn254", "g1", 16), ("bn254", "g2", 13),
+                                              ("bls12_381", "g1", 13), ("bls12_381", "g2", 12), ("bw6_761", "g1", 12),
+                                              ("bw6_761", "g2", 11)])
+def test_msm_random_matches_oracle(gm, oracle_mod, curve, which, logn):
+    g = _group(gm, curve, which)
+    o = oracle_mod.Oracle(curve, which)
+    n = (1 << logn) + 1  # 2^k + 1: ragged chunking
+    rng = rng_for(6, g.gid, logn)
+    pts = o.gen_points(n, int(rng.integers(1, 2**62)), int(rng.integers(1, 2**62)), nthreads=8)
+    sc = random_scalars(rng, g.curve, n)
+    pts[[3, n // 3, n // 2, n - 2]] = 0  # 4 infinities (multiexp_test.go:48-52)
+    sc[::5, 1:] = 0                      # "smallvalues"-like: every 5th stored scalar is a single limb (multiexp_test.go:319)
+    assert (_msm_gpu_affine(g, pts, sc) == o.msm_affine(pts, sc, nthreads=8)).all()
+
+
+def test_msm_bn254_g1_2p20_config(gm, oracle_mod):
+    """BASELINE config C2: BN254 G1, n = 2^20, against the oracle on the same seeded input."""
+    g = gm.G1Affine("bn254")
+    o = oracle_mod.Oracle("bn254", "g1")
+    n = 1 << 20
+    rng = rng_for(2, 20)
+    pts = o.gen_points(n, int(rng.integers(1, 2**62)), int(rng.integers(1, 2**62)), nthreads=16)
+    sc = random_scalars(rng, g.curve, n)
+    got = _msm_gpu_affine(g, pts, sc)
+    exp = o.msm_affine(pts, sc, c=16, nthreads=16)
+    assert (got == exp).all()
