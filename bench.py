@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- G1 MSM/sec (BN254) on MI355X, the metric of BASELINE.json.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--logn 20]
+
+One "step" = one complete MultiExp (device-resident bases and scalars -> Jacobian result on the host) of
+n = 2^logn points.  N = 1: the whole MSM on one GPU (BASELINE config C2 at the default logn = 20).  N > 1 (launched by
+torch.distributed.run, one rank per GPU): the windows of the SAME MSM are sharded round-robin over the ranks, every
+rank holds all bases, the per-window totals are exchanged with one RCCL all-gather and folded (strong scaling of one
+MSM, as BASELINE.json's north_star describes).
+
+Rank 0 prints one JSON line.  Besides the contract fields it carries
+  roofline      dominant kernel (k_accumulate): algorithmic bytes per launch (96 B/point x n) / mean
+                launch duration from HIP events recorded on the launch stream inside libgmsm; peak = 8000 GB/s
+  int_roofline  the bound that actually binds: field multiplications per second against the v_mad_u64_u32 issue peak
+  cpu_baseline  the oracle (C restatement of gnark-crypto's algorithm, kind "port") timed on this box's host cores
+  bit_exact     GPU affine result == oracle affine result on the timed input
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+STAGES = ["decompose", "histogram", "scans", "scatter", "accumulate", "reduce"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--logn", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    gm = importlib.import_module("gnark-crypto_amd")
+    lib = gm._lib.load()
+    assert lib.gmsm_set_device(local_rank) == 0, gm._lib.last_error()
+    g = gm.G1Jac("bn254")
+    n = 1 << args.logn
+
+    # synthetic, deterministic, on-curve inputs: P_i = [k0 + i*k1] G; scalars uniform (stored limbs
+    # uniform in [0, r) by rejection)
+    rng = np.random.default_rng([0x6D736D, args.logn])
+    k0, k1 = int(rng.integers(1, 2**62)), int(rng.integers(1, 2**62))
+    pts = g.generate_points(n, k0, k1)
+    sc = np.zeros((n, 4), dtype=np.uint64)
+    todo = np.arange(n)
+    r_limbs = [(g.curve.r >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+    while todo.size:
+        cand = rng.integers(0, 2**64, size=(todo.size, 4), dtype=np.uint64)
+        cand[:, 3] &= np.uint64((1 << 62) - 1)
+        lt = np.zeros(todo.size, dtype=bool)
+        eq = np.ones(todo.size, dtype=bool)
+        for i in (3, 2, 1, 0):
+            lt |= eq & (cand[:, i] < np.uint64(r_limbs[i]))
+            eq &= cand[:, i] == np.uint64(r_limbs[i])
+        sc[todo[lt]] = cand[lt]
+        todo = todo[~lt]
+
+    d_pts = torch.from_numpy(pts.view(np.int64)).cuda()
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    c = g.default_window_bits(n)
+    nwin = g.num_windows(c)
+
+    def step():
+        if world == 1:
+            return g.multiexp_device(d_pts.data_ptr(), d_sc.data_ptr(), n, stream)
+        # window sharding: rank r owns windows r, r+world, ...; exchange = one all-gather of <= ceil(nwin/world) XYZZ
+        mine = g.window_sums_device(d_pts.data_ptr(), d_sc.data_ptr(), n, c, rank, world, stream)
+        per = (nwin + world - 1) // world
+        buf = np.zeros((per, g.xyzz_limbs), dtype=np.uint64)
+        buf[: mine.shape[0]] = mine
+        t_in = torch.from_numpy(buf.view(np.int64)).cuda()
+        t_out = torch.empty((world, per, g.xyzz_limbs), dtype=torch.int64, device="cuda")
+        dist.all_gather_into_tensor(t_out, t_in)
+        allw = t_out.cpu().numpy().view(np.uint64)
+        totals = np.zeros((nwin, g.xyzz_limbs), dtype=np.uint64)
+        for w in range(nwin):
+            totals[w] = allw[w % world, w // world]
+        return g.fold_windows(totals, c)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        jac = step()
+    lib.gmsm_set_profiling(1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        jac = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    stage_ms = (_ctypes_double * len(STAGES))()
+    calls = _ctypes_ulong(0)
+    lib.gmsm_get_stage_times(stage_ms, len(STAGES), _byref(calls))
+    lib.gmsm_set_profiling(0)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = args.steps / dt
+        ncalls = max(1, calls.value)
+        stages = {name: stage_ms[i] / ncalls for i, name in enumerate(STAGES)}
+        acc_ms = stages["accumulate"]
+        algorithmic_bytes = 96 * n * (len(range(rank, nwin, world)) / nwin)  # this rank's share of the windows
+        achieved = algorithmic_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
+        # integer roofline of the same kernel: 10 field mul per mixed add (8M+2S, g1.go:822), n*(windows of this rank)
+        # mixed adds, each mul = 2*8^2+8 = 136 v_mad_u64_u32-class ops at 4 cycles / wave64 / SIMD (measured,
+        # tools/ubench_valu.hip): peak = 1024 SIMD * 64 lanes / 4 cycles * 2.4 GHz = 39.3e12 mad/s
+        madds = n * len(range(rank, nwin, world))
+        mulmods_per_s = madds * 10 / (acc_ms * 1e-3) if acc_ms > 0 else 0.0
+        int_peak = 1024 * 64 / 4 * 2.4e9 / 136
+        out = {
+            "metric": "G1 MSM/sec (BN254)", "value": value, "unit": "MSM/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u32 limbs (256-bit Montgomery)", "data": "synthetic",
+            "config": {"workload": f"BN254 G1 MultiExp 2^{args.logn} points, bases+scalars resident in HBM",
+                       "points": n, "window_bits": c, "windows": nwin,
+                       "parallelism": "single GPU" if world == 1 else f"window-sharded x{world} + RCCL all-gather"},
+            "points_per_s": value * n,
+            "stage_ms": stages,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None, "kernel": "k_accumulate",
+                         "algorithmic_bytes_per_launch": algorithmic_bytes, "avg_launch_ms": acc_ms},
+            "int_roofline": {"achieved_mulmod_per_s": mulmods_per_s, "peak_mulmod_per_s": int_peak,
+                             "frac": mulmods_per_s / int_peak},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out.update(cpu_baseline(g, pts, sc, jac))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(g, pts, sc, gpu_jac):
+    """The oracle = C restatement of gnark-crypto's MultiExp (bestC, split recursion, one task per (leaf, window),
+    extended-Jacobian buckets; the batch-affine bucket variant is off), on all host cores.  Bounded: repeats whole
+    MSMs until ~10 s have elapsed (at least 1)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle  # test infrastructure, used here only as the reported baseline and the checker
+    o = oracle.Oracle("bn254", "g1")
+    cores = os.cpu_count() or 1
+    reps, t_total, jac = 0, 0.0, None
+    while reps < 1 or (t_total < 10.0 and reps < 50):
+        t0 = time.perf_counter()
+        err, jac = o.multiexp(pts, sc, nb_tasks=0, num_cpu=cores, nthreads=cores)
+        t_total += time.perf_counter() - t0
+        reps += 1
+        assert err == 0
+    exact = bool((o.jac_to_affine(jac) == g.jac_to_affine(gpu_jac)).all())
+    return {
+        "cpu_baseline": {"value": reps / t_total, "unit": "MSM/s", "cores": cores, "kind": "port",
+                         "sample": f"{reps} full MSM(s) of the same 2^{int(np.log2(len(pts)))} input, {t_total:.1f} s total; "
+                                   "C restatement of gnark-crypto's algorithm (ext-Jacobian buckets, batch-affine off)"},
+        "bit_exact": exact,
+    }
+
+
+import ctypes as _ct  # noqa: E402
+
+_ctypes_double = _ct.c_double
+_ctypes_ulong = _ct.c_ulong
+_byref = _ct.byref
+
+if __name__ == "__main__":
+    main()

@@ -25,7 +25,8 @@ ABI_SYMBOLS = [
     "gmsm_bw6_761_g1_multiexp", "gmsm_bw6_761_g2_multiexp", "gmsm_multiexp", "gmsm_multiexp_affine",
     "gmsm_multiexp_device", "gmsm_default_window_bits", "gmsm_num_windows", "gmsm_window_sums_device",
     "gmsm_fold_windows", "gmsm_jac_to_affine", "gmsm_affine_limbs", "gmsm_scalar_limbs", "gmsm_debug_decompose",
-    "gmsm_debug_field_op", "gmsm_debug_group_op", "gmsm_device_count", "gmsm_set_device", "gmsm_last_error",
+    "gmsm_debug_field_op", "gmsm_debug_group_op", "gmsm_generate_points", "gmsm_set_profiling", "gmsm_get_stage_times",
+    "gmsm_device_count", "gmsm_set_device", "gmsm_last_error",
     "gmsm_version",
 ]
 
@@ -86,6 +87,12 @@ def load():
     L.gmsm_debug_field_op.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, u64p, u64p, sz, u64p]
     L.gmsm_debug_group_op.restype = ctypes.c_int
     L.gmsm_debug_group_op.argtypes = [ctypes.c_int, ctypes.c_int, u64p, u64p, sz, u64p]
+    L.gmsm_generate_points.restype = ctypes.c_int
+    L.gmsm_generate_points.argtypes = [ctypes.c_int, u64p, u64p, u64p, ctypes.c_int, sz, ctypes.c_int, u64p]
+    L.gmsm_set_profiling.restype = None
+    L.gmsm_set_profiling.argtypes = [ctypes.c_int]
+    L.gmsm_get_stage_times.restype = ctypes.c_int
+    L.gmsm_get_stage_times.argtypes = [vp, ctypes.c_int, vp]
     L.gmsm_device_count.restype = ctypes.c_int
     L.gmsm_set_device.restype = ctypes.c_int
     L.gmsm_set_device.argtypes = [ctypes.c_int]

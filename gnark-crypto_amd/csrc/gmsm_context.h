@@ -44,6 +44,7 @@ struct Context {
     hipStream_t stream = nullptr;  // used when the caller passes no stream
     DeviceBuffer points, scalars;  // staging for the host-pointer entry
     DeviceBuffer digits, sorted, blockhist, counts, starts, buckets, partials, totals;
+    hipEvent_t events[8] = {nullptr};  // stage boundaries when profiling is on
     void *pinned = nullptr;  // pinned host buffer for the window totals
     size_t pinned_cap = 0;
     int init(int dev) {
@@ -59,6 +60,44 @@ struct Context {
         HIP_TRY(hipHostMalloc(&pinned, bytes, hipHostMallocDefault));
         pinned_cap = bytes;
         return GMSM_OK;
+    }
+};
+
+// Per-stage device timing (HIP events on the stream the kernels are launched on). Off by default; bench.py switches
+// it on to obtain the dominant kernel's duration for the roofline record.
+enum Stage {
+    STAGE_DECOMPOSE = 0,
+    STAGE_HIST,
+    STAGE_SCAN,
+    STAGE_SCATTER,
+    STAGE_ACCUMULATE,
+    STAGE_REDUCE,
+    STAGE_END,
+    STAGE_COUNT = STAGE_END
+};
+
+bool profiling_enabled();
+void record_stage_times(const float *ms);  // adds one call's stage durations to the thread-independent accumulators
+
+struct StageTimer {
+    Context &ctx;
+    hipStream_t stream;
+    bool on;
+    StageTimer(Context &c, hipStream_t s) : ctx(c), stream(s), on(profiling_enabled()) {
+        if (on && !ctx.events[0])
+            for (int i = 0; i <= STAGE_END; ++i) (void)hipEventCreate(&ctx.events[i]);
+    }
+    void mark(int stage) {
+        if (on) (void)hipEventRecord(ctx.events[stage], stream);
+    }
+    void collect() {  // call after the stream has been synchronised
+        if (!on) return;
+        float ms[STAGE_COUNT];
+        for (int i = 0; i < STAGE_COUNT; ++i) {
+            ms[i] = 0.f;
+            (void)hipEventElapsedTime(&ms[i], ctx.events[i], ctx.events[i + 1]);
+        }
+        record_stage_times(ms);
     }
 };
 
@@ -107,6 +146,8 @@ struct GroupVTable {
     int (*debug_decompose)(const uint64_t *scalars, size_t n, unsigned c, uint32_t *out_digits);
     int (*debug_field_op)(int field, int op, const uint64_t *a, const uint64_t *b, size_t count, uint64_t *out);
     int (*debug_group_op)(int op, const uint64_t *acc, const uint64_t *other, size_t count, uint64_t *out);
+    void (*generate_points)(const uint64_t *base, const uint64_t *k0, const uint64_t *k1, int klimbs, size_t n, int nthreads,
+                            uint64_t *out);
 };
 
 }  // namespace gmsm

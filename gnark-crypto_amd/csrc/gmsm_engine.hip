@@ -12,6 +12,18 @@ int fail(int code, const std::string &msg) {
     return code;
 }
 
+static std::mutex g_prof_mu;
+static bool g_profiling = false;
+static double g_stage_ms[STAGE_COUNT] = {0};
+static unsigned long g_stage_calls = 0;
+
+bool profiling_enabled() { return g_profiling; }
+void record_stage_times(const float *ms) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int i = 0; i < STAGE_COUNT; ++i) g_stage_ms[i] += ms[i];
+    ++g_stage_calls;
+}
+
 static std::mutex g_ctx_mu;
 static std::vector<Context *> g_ctx;
 
@@ -169,6 +181,29 @@ GMSM_EXPORT int gmsm_debug_group_op(int group, int op, const uint64_t *acc, cons
     VT_OR_FAIL(group);
     if (count == 0) return GMSM_OK;
     return vt->debug_group_op(op, acc, other, count, out);
+}
+
+GMSM_EXPORT int gmsm_generate_points(int group, const uint64_t *base_affine, const uint64_t *k0, const uint64_t *k1,
+                                     int klimbs, size_t n, int nthreads, uint64_t *out_points) {
+    VT_OR_FAIL(group);
+    if (klimbs < 1 || klimbs > 16) return fail(GMSM_ERR_ARG, "klimbs out of range");
+    if (n) vt->generate_points(base_affine, k0, k1, klimbs, n, nthreads, out_points);
+    return GMSM_OK;
+}
+
+GMSM_EXPORT void gmsm_set_profiling(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_profiling = on != 0;
+    for (int i = 0; i < STAGE_COUNT; ++i) g_stage_ms[i] = 0;
+    g_stage_calls = 0;
+}
+
+GMSM_EXPORT int gmsm_get_stage_times(double *out_ms, int max_stages, unsigned long *out_calls) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int n = max_stages < (int)STAGE_COUNT ? max_stages : (int)STAGE_COUNT;
+    for (int i = 0; i < n; ++i) out_ms[i] = g_stage_ms[i];
+    if (out_calls) *out_calls = g_stage_calls;
+    return n;
 }
 
 GMSM_EXPORT int gmsm_device_count(void) {

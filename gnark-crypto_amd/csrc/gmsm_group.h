@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 #include "gmsm_context.h"
 #include "gmsm_kernels.h"
@@ -74,7 +76,9 @@ struct Group {
         uint32_t *blockhist = (uint32_t *)ctx.blockhist.ptr, *counts = (uint32_t *)ctx.counts.ptr;
         uint32_t *starts = (uint32_t *)ctx.starts.ptr;
 
+        StageTimer timer(ctx, stream);
         // 1. signed-digit decomposition
+        timer.mark(STAGE_DECOMPOSE);
         hipLaunchKernelGGL((k_decompose<FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                            (const uint32_t *)d_scalars, n, plan, digits);
         // 2. group point references by bucket (counting sort per window)
@@ -86,12 +90,16 @@ struct Group {
             HIP_TRY(hipFuncSetAttribute((const void *)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_done = true;
         }
+        timer.mark(STAGE_HIST);
         hipLaunchKernelGGL(k_hist, dim3(nchunks, nw), dim3(1024), hist_lds, stream, digits, n, NB, chunk_len, blockhist);
+        timer.mark(STAGE_SCAN);
         hipLaunchKernelGGL(k_colscan, dim3((NB + 255) / 256, nw), dim3(256), 0, stream, blockhist, nchunks, NB, counts);
         hipLaunchKernelGGL(k_rowscan, dim3(nw), dim3(1024), 0, stream, counts, NB, starts);
+        timer.mark(STAGE_SCATTER);
         hipLaunchKernelGGL(k_scatter, dim3(nchunks, nw), dim3(1024), hist_lds, stream, digits, n, NB, chunk_len,
                            blockhist, starts, sorted);
         // 3. bucket accumulation
+        timer.mark(STAGE_ACCUMULATE);
         hipLaunchKernelGGL((k_accumulate<F>), dim3((NB + 255) / 256, nw), dim3(256), 0, stream, d_points, n, NB, starts,
                            sorted, ctx.buckets.ptr);
         // 4. bucket reduction -> window totals
@@ -103,13 +111,16 @@ struct Group {
                                         (int)(RED2_TPB * sizeof(Ext))));
             red_attr_done = true;
         }
+        timer.mark(STAGE_REDUCE);
         hipLaunchKernelGGL((k_reduce1<F, RED_TPB>), dim3(nblocks1, nw), dim3(RED_TPB), RED_TPB * sizeof(Ext), stream,
                            ctx.buckets.ptr, NB, log2L, ctx.partials.ptr);
         hipLaunchKernelGGL((k_reduce2<F, RED2_TPB>), dim3(nw), dim3(RED2_TPB), RED2_TPB * sizeof(Ext), stream,
                            ctx.partials.ptr, nblocks1, log2span, ctx.totals.ptr);
+        timer.mark(STAGE_END);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(ctx.pinned, ctx.totals.ptr, (size_t)nw * sizeof(Ext), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        timer.collect();
         memcpy(host_xyzz, ctx.pinned, (size_t)nw * sizeof(Ext));
         return GMSM_OK;
     }
@@ -123,6 +134,76 @@ struct Group {
             xyzz_add(acc, totals[j]);
         }
         return jac_from_xyzz(acc);
+    }
+
+    // out[i] = [k0 + i*k1] base for i < n (affine). Host-side, multi-threaded: start point by double-and-add, then
+    // repeated mixed addition of step = [k1]base with block-wise batch normalisation (one inversion per block).
+    // Utility for building SRS-like on-curve bases (cf. BatchScalarMultiplicationG1, ecc/bn254/g1.go:1039, and the
+    // i*G walk of multiexp_test.go:40-46); bench.py uses it for its synthetic inputs.
+    static Ext scalar_mul(const Aff &a, const uint64_t *k, int klimbs) {
+        Ext acc = Ext::infinity();
+        for (int i = klimbs * 64 - 1; i >= 0; --i) {
+            acc = xyzz_double(acc);
+            if ((k[i / 64] >> (i % 64)) & 1) xyzz_add_mixed(acc, a, false);
+        }
+        return acc;
+    }
+    static void batch_to_affine(Aff *out, const Ext *in, size_t count, F *scratch) {
+        F acc = F::one();
+        for (size_t i = 0; i < count; ++i) {
+            scratch[i] = acc;
+            if (!in[i].zzz.is_zero()) acc = fp_mul(acc, in[i].zzz);
+        }
+        F inv = fp_inv(acc);
+        for (size_t i = count; i-- > 0;) {
+            if (in[i].zzz.is_zero()) {
+                out[i] = Aff{F::zero(), F::zero()};
+                continue;
+            }
+            F zi = fp_mul(inv, scratch[i]);  // 1/zzz_i
+            inv = fp_mul(inv, in[i].zzz);
+            F izz = fp_mul(fp_mul(fp_sqr(zi), in[i].zz), in[i].zz);  // zz^2/zzz^2 = 1/zz
+            out[i].x = fp_mul(in[i].x, izz);
+            out[i].y = fp_mul(in[i].y, zi);
+        }
+    }
+    static void generate_points(const uint64_t *base_limbs, const uint64_t *k0, const uint64_t *k1, int klimbs, size_t n,
+                                int nthreads, uint64_t *out_limbs) {
+        Aff base;
+        memcpy(&base, base_limbs, sizeof base);
+        Aff *out = reinterpret_cast<Aff *>(out_limbs);
+        Aff step;
+        {
+            Ext s = scalar_mul(base, k1, klimbs);
+            F scratch;
+            batch_to_affine(&step, &s, 1, &scratch);
+        }
+        if (nthreads < 1) nthreads = 1;
+        const size_t per = (n + (size_t)nthreads - 1) / (size_t)nthreads;
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; ++t) {
+            const size_t s = (size_t)t * per, e = std::min(n, s + per);
+            if (s >= e) break;
+            th.emplace_back([=, &base, &step]() {
+                constexpr size_t BLK = 1024;
+                std::vector<Ext> blk(BLK);
+                std::vector<F> scr(BLK);
+                Ext cur = scalar_mul(base, k0, klimbs);
+                uint64_t s64 = (uint64_t)s;
+                Ext off = scalar_mul(step, &s64, 1);
+                xyzz_add(cur, off);
+                for (size_t i = s; i < e;) {
+                    const size_t cnt = std::min(BLK, e - i);
+                    for (size_t k = 0; k < cnt; ++k) {
+                        blk[k] = cur;
+                        xyzz_add_mixed(cur, step, false);
+                    }
+                    batch_to_affine(out + i, blk.data(), cnt, scr.data());
+                    i += cnt;
+                }
+            });
+        }
+        for (auto &t : th) t.join();
     }
 
     static int multiexp_device(Context &ctx, const void *d_points, const void *d_scalars, size_t n, hipStream_t stream,
@@ -332,11 +413,15 @@ struct VTableOf {
     static int debug_group_op(int op, const uint64_t *acc, const uint64_t *other, size_t count, uint64_t *out) {
         return debug_group<G>(op, acc, other, count, out);
     }
+    static void generate_points(const uint64_t *base, const uint64_t *k0, const uint64_t *k1, int klimbs, size_t n,
+                                int nthreads, uint64_t *out) {
+        G::generate_points(base, k0, k1, klimbs, n, nthreads, out);
+    }
     static const GroupVTable *get() {
         static const GroupVTable vt = {G::FR_BITS,      G::AFF_BYTES,   G::SCALAR_BYTES, sizeof(typename G::J),
                                        sizeof(typename G::Ext), &multiexp_host, &multiexp_device, &window_sums,
                                        &fold,           &jac_to_affine, &debug_decompose, &debug_field_op,
-                                       &debug_group_op};
+                                       &debug_group_op, &generate_points};
         return &vt;
     }
 };

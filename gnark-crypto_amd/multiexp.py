@@ -75,6 +75,35 @@ class _Group:
                                     int(config.NbTasks), _ptr(out))
         return (out, None) if rc == 0 else (None, self._error(rc))
 
+    # ---- utilities
+    @property
+    def generator(self):
+        """Affine generator of the group in Montgomery limbs (bn254.go:110-123 etc.)."""
+        c = self.curve
+        mont = lambda v: [(v * c.fp_R % c.p >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(c.fp_limbs)]
+        if self.group == "g1":
+            vals = mont(c.g1[0]) + mont(c.g1[1])
+        elif c.g2_ext == 1:
+            vals = mont(c.g2[0]) + mont(c.g2[1])
+        else:
+            (x0, x1), (y0, y1) = c.g2
+            vals = mont(x0) + mont(x1) + mont(y0) + mont(y1)
+        return np.array(vals, dtype=np.uint64)
+
+    def generate_points(self, n, k0, k1, nthreads=None, base=None):
+        """points[i] = [k0 + i*k1] * base (default: the generator): on-curve, distinct, r-torsion synthetic bases."""
+        import os
+        L = _lib.load()
+        base = self.generator if base is None else np.ascontiguousarray(base, dtype=np.uint64)
+        nl = self.fr_limbs
+        limbs = lambda v: np.array([(v % self.curve.r >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(nl)], dtype=np.uint64)
+        a0, a1 = limbs(k0), limbs(k1)
+        out = np.zeros((n, self.aff_limbs), dtype=np.uint64)
+        rc = L.gmsm_generate_points(self.gid, _ptr(base), _ptr(a0), _ptr(a1), nl, n, nthreads or os.cpu_count() or 1, _ptr(out))
+        if rc:
+            raise RuntimeError(self._error(rc))
+        return out
+
     # ---- device-resident path (pointers are raw device addresses, e.g. torch.Tensor.data_ptr())
     def multiexp_device(self, d_points, d_scalars, n, stream=0):
         L = _lib.load()

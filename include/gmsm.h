@@ -108,6 +108,19 @@ int gmsm_debug_field_op(int group, int field, int op, const uint64_t *a, const u
  * op 2: out[i] = acc[i] + acc2[i] (xyzz add), op 3: out[i] = 2*acc[i]. */
 int gmsm_debug_group_op(int group, int op, const uint64_t *acc, const uint64_t *pts_or_acc2, size_t count, uint64_t *out);
 
+/* ---- utilities ---- */
+/* out_points[i] = [k0 + i*k1] * base, i < n (affine, Go layout). k0,k1: plain (non-Montgomery) little-endian limbs.
+ * Host-side, nthreads worker threads. For building SRS-like synthetic bases (cf. BatchScalarMultiplicationG1,
+ * ecc/bn254/g1.go:1039). */
+int gmsm_generate_points(int group, const uint64_t *base_affine, const uint64_t *k0, const uint64_t *k1, int klimbs,
+                         size_t n, int nthreads, uint64_t *out_points);
+/* Per-stage device timing with HIP events on the launch stream. gmsm_set_profiling(1) resets and enables the
+ * accumulators; gmsm_get_stage_times copies the summed milliseconds of up to max_stages stages
+ * (0 decompose, 1 histogram, 2 scans, 3 scatter, 4 bucket accumulation, 5 bucket reduction) and the number of
+ * pipeline runs they cover; returns the number of stages written. */
+void gmsm_set_profiling(int on);
+int gmsm_get_stage_times(double *out_ms, int max_stages, unsigned long *out_calls);
+
 int gmsm_device_count(void);
 int gmsm_set_device(int device);          /* device used by subsequent calls of this thread (default 0) */
 const char *gmsm_last_error(void);        /* thread-local text of the last failure */

@@ -413,13 +413,26 @@ static long GF(cost_function)(long nb_tasks, long nb_cpus, long cost_per_task) {
 }
 
 /* (*G1Jac).MultiExp (multiexp.go:32-146). num_cpu stands in for runtime.NumCPU(); nthreads = worker threads
- * actually used.  Returns 0 ok, 1 length mismatch, 2 bad config -- the two reference errors (:61-71). */
-static int GF(multiexp)(JAC *out, const AFF *points, size_t n_points, const SFT *scalars, size_t n_scalars,
-                        int nb_tasks, int num_cpu, int nthreads) {
-    if (n_points != n_scalars) return 1;
-    if (nb_tasks <= 0) nb_tasks = num_cpu * 2;
-    else if (nb_tasks > 1024) return 2;
-    size_t n = n_points;
+ * actually used.  Returns 0 ok, 1 length mismatch, 2 bad config -- the two reference errors (:61-71).
+ *
+ * The reference recursion (split in halves while that lowers its cost model, each half in its own goroutine, every
+ * window of every leaf in its own goroutine) is restated as: plan the same leaves with the same cost model, run all
+ * (leaf, window) tasks of all leaves on one pool of nthreads workers, then combine exactly like the recursion does
+ * (p = MultiExp(upper half); p.AddAssign(MultiExp(lower half)), multiexp.go:128-139). */
+typedef struct {
+    size_t off, n;
+    unsigned c, c_alloc, nb;
+    uint16_t *digits;
+    XYZZ *totals;
+    JAC result;
+} GF(leaf_t);
+
+typedef struct {
+    GF(leaf_t) *leaves;
+    size_t nleaves, cap;
+} GF(plan_t);
+
+static void GF(plan_rec)(GF(plan_t) *plan, size_t off, size_t n, int nb_tasks) {
     unsigned C = GF(best_c)(n);
     long nbc = GF(nb_chunks)(C);
     long pre = GF(cost_function)(nbc, nb_tasks, (long)(n + ((size_t)1 << C)));
@@ -427,14 +440,141 @@ static int GF(multiexp)(JAC *out, const AFF *points, size_t n_points, const SFT 
     long post = GF(cost_function)(2 * (long)GF(nb_chunks)(c2), nb_tasks, (long)(n / 2 + ((size_t)1 << c2)));
     if (post < pre) {
         int half_tasks = (nb_tasks + 1) / 2; /* ceil(nbTasks/2) */
-        JAC lo;
-        int e1 = GF(multiexp)(&lo, points, n / 2, scalars, n / 2, half_tasks, num_cpu, nthreads);
-        int e2 = GF(multiexp)(out, points + n / 2, n - n / 2, scalars + n / 2, n - n / 2, half_tasks, num_cpu, nthreads);
-        if (e1 || e2) return e1 ? e1 : e2;
-        GF(jac_add_assign)(out, &lo);
-        return 0;
+        GF(plan_rec)(plan, off, n / 2, half_tasks);               /* _p: points[:n/2] */
+        GF(plan_rec)(plan, off + n / 2, n - n / 2, half_tasks);   /* p:  points[n/2:] */
+        return;
     }
-    GF(inner_msm)(out, C, points, scalars, n, nthreads);
+    if (plan->nleaves == plan->cap) {
+        plan->cap = plan->cap ? plan->cap * 2 : 16;
+        plan->leaves = (GF(leaf_t) *)realloc(plan->leaves, plan->cap * sizeof(GF(leaf_t)));
+    }
+    GF(leaf_t) *lf = &plan->leaves[plan->nleaves++];
+    lf->off = off; lf->n = n; lf->c = C; lf->nb = GF(nb_chunks)(C);
+    unsigned avail = lf->nb * C - SF_BITS, lastc = C + 1 - avail;
+    lf->c_alloc = lastc > C ? lastc : C;
+    lf->digits = NULL; lf->totals = NULL;
+}
+
+/* same recursion again, consuming leaf results in plan order */
+static void GF(combine_rec)(GF(plan_t) *plan, size_t *next, size_t n, int nb_tasks, JAC *out) {
+    unsigned C = GF(best_c)(n);
+    long nbc = GF(nb_chunks)(C);
+    long pre = GF(cost_function)(nbc, nb_tasks, (long)(n + ((size_t)1 << C)));
+    unsigned c2 = GF(best_c)(n / 2);
+    long post = GF(cost_function)(2 * (long)GF(nb_chunks)(c2), nb_tasks, (long)(n / 2 + ((size_t)1 << c2)));
+    if (post < pre) {
+        int half_tasks = (nb_tasks + 1) / 2;
+        JAC lo;
+        GF(combine_rec)(plan, next, n / 2, half_tasks, &lo);
+        GF(combine_rec)(plan, next, n - n / 2, half_tasks, out);
+        GF(jac_add_assign)(out, &lo);
+        return;
+    }
+    *out = plan->leaves[(*next)++].result;
+}
+
+typedef struct {
+    GF(plan_t) *plan;
+    const AFF *points;
+    const SFT *scalars;
+    size_t next_part;   /* partition phase: (leaf, block) cursor flattened over leaves */
+    size_t next_task;   /* chunk phase: flattened (leaf, window) cursor */
+    size_t ntasks;
+    unsigned max_c_alloc;
+    pthread_mutex_t mu;
+} GF(pool_t);
+
+static void *GF(pool_partition)(void *arg) {
+    GF(pool_t) *pool = (GF(pool_t) *)arg;
+    const size_t blk = 4096;
+    for (;;) {
+        pthread_mutex_lock(&pool->mu);
+        size_t cur = pool->next_part;
+        pool->next_part += blk;
+        pthread_mutex_unlock(&pool->mu);
+        /* cur indexes the concatenation of all leaves (they tile [0, n_total) in order) */
+        GF(plan_t) *plan = pool->plan;
+        GF(leaf_t) *last = &plan->leaves[plan->nleaves - 1];
+        if (cur >= last->off + last->n) break;
+        for (size_t l = 0; l < plan->nleaves; ++l) {
+            GF(leaf_t) *lf = &plan->leaves[l];
+            size_t s = cur > lf->off ? cur : lf->off;
+            size_t e = cur + blk < lf->off + lf->n ? cur + blk : lf->off + lf->n;
+            if (s < e) GF(partition_range)(pool->scalars + lf->off, lf->n, lf->c, lf->digits, s - lf->off, e - lf->off);
+        }
+    }
+    return NULL;
+}
+
+static void *GF(pool_chunks)(void *arg) {
+    GF(pool_t) *pool = (GF(pool_t) *)arg;
+    XYZZ *buckets = (XYZZ *)malloc(sizeof(XYZZ) << (pool->max_c_alloc - 1));
+    for (;;) {
+        pthread_mutex_lock(&pool->mu);
+        size_t t = pool->next_task++;
+        pthread_mutex_unlock(&pool->mu);
+        if (t >= pool->ntasks) break;
+        /* locate (leaf, window): windows handed out top first within each leaf */
+        GF(plan_t) *plan = pool->plan;
+        size_t l = 0;
+        while (t >= plan->leaves[l].nb) { t -= plan->leaves[l].nb; ++l; }
+        GF(leaf_t) *lf = &plan->leaves[l];
+        unsigned j = lf->nb - 1 - (unsigned)t;
+        GF(process_chunk)(lf->c_alloc, pool->points + lf->off, lf->digits + (size_t)j * lf->n, lf->n, buckets, &lf->totals[j]);
+    }
+    free(buckets);
+    return NULL;
+}
+
+static int GF(multiexp)(JAC *out, const AFF *points, size_t n_points, const SFT *scalars, size_t n_scalars,
+                        int nb_tasks, int num_cpu, int nthreads) {
+    if (n_points != n_scalars) return 1;
+    if (nb_tasks <= 0) nb_tasks = num_cpu * 2;
+    else if (nb_tasks > 1024) return 2;
+    if (nthreads < 1) nthreads = 1;
+    GF(plan_t) plan = {NULL, 0, 0};
+    GF(plan_rec)(&plan, 0, n_points, nb_tasks);
+    GF(pool_t) pool;
+    pool.plan = &plan; pool.points = points; pool.scalars = scalars;
+    pool.next_part = 0; pool.next_task = 0; pool.ntasks = 0; pool.max_c_alloc = 2;
+    pthread_mutex_init(&pool.mu, NULL);
+    for (size_t l = 0; l < plan.nleaves; ++l) {
+        GF(leaf_t) *lf = &plan.leaves[l];
+        lf->digits = (uint16_t *)calloc((size_t)lf->nb * (lf->n ? lf->n : 1), sizeof(uint16_t));
+        lf->totals = (XYZZ *)malloc(sizeof(XYZZ) * lf->nb);
+        pool.ntasks += lf->nb;
+        if (lf->c_alloc > pool.max_c_alloc) pool.max_c_alloc = lf->c_alloc;
+    }
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    if (n_points) {
+        if (nthreads == 1) GF(pool_partition)(&pool);
+        else {
+            for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, GF(pool_partition), &pool);
+            for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+        }
+    }
+    int nw = (size_t)nthreads < pool.ntasks ? nthreads : (int)pool.ntasks;
+    if (nw <= 1) GF(pool_chunks)(&pool);
+    else {
+        for (int t = 0; t < nw; ++t) pthread_create(&th[t], NULL, GF(pool_chunks), &pool);
+        for (int t = 0; t < nw; ++t) pthread_join(th[t], NULL);
+    }
+    free(th);
+    for (size_t l = 0; l < plan.nleaves; ++l) { /* msmReduceChunk per leaf */
+        GF(leaf_t) *lf = &plan.leaves[l];
+        XYZZ acc = lf->totals[lf->nb - 1];
+        for (int j = (int)lf->nb - 2; j >= 0; --j) {
+            for (unsigned k = 0; k < lf->c; ++k) GF(xyzz_double)(&acc, &acc);
+            GF(xyzz_add)(&acc, &lf->totals[j]);
+        }
+        GF(jac_from_xyzz)(&lf->result, &acc);
+        free(lf->digits);
+        free(lf->totals);
+    }
+    size_t next = 0;
+    GF(combine_rec)(&plan, &next, n_points, nb_tasks, out);
+    pthread_mutex_destroy(&pool.mu);
+    free(plan.leaves);
     return 0;
 }
 
