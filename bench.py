@@ -83,22 +83,16 @@ def main():
     c = g.default_window_bits(n)
     nwin = g.num_windows(c)
 
+    sharding = importlib.import_module("gnark-crypto_amd.sharding")
+    gather = sharding.torch_all_gather(dist, torch.device("cuda", local_rank)) if world > 1 else None
+
     def step():
         if world == 1:
             return g.multiexp_device(d_pts.data_ptr(), d_sc.data_ptr(), n, stream)
-        # window sharding: rank r owns windows r, r+world, ...; exchange = one all-gather of <= ceil(nwin/world) XYZZ
-        mine = g.window_sums_device(d_pts.data_ptr(), d_sc.data_ptr(), n, c, rank, world, stream)
-        per = (nwin + world - 1) // world
-        buf = np.zeros((per, g.xyzz_limbs), dtype=np.uint64)
-        buf[: mine.shape[0]] = mine
-        t_in = torch.from_numpy(buf.view(np.int64)).cuda()
-        t_out = torch.empty((world, per, g.xyzz_limbs), dtype=torch.int64, device="cuda")
-        dist.all_gather_into_tensor(t_out, t_in)
-        allw = t_out.cpu().numpy().view(np.uint64)
-        totals = np.zeros((nwin, g.xyzz_limbs), dtype=np.uint64)
-        for w in range(nwin):
-            totals[w] = allw[w % world, w // world]
-        return g.fold_windows(totals, c)
+        # window sharding: rank r owns windows r, r+world, ...; one RCCL all-gather of <= ceil(nwin/world) XYZZ totals
+        return sharding.sharded_multiexp(
+            g, lambda c_, first, stride: g.window_sums_device(d_pts.data_ptr(), d_sc.data_ptr(), n, c_, first, stride, stream),
+            c, rank, world, gather)
 
     def barrier():
         torch.cuda.synchronize()

@@ -1,0 +1,92 @@
+"""C-ABI checks that need no GPU: the library loads, exports every symbol include/gmsm.h declares, reproduces the
+reference's argument errors, fails loudly (no CPU fallback) when no device exists, and its host-side pieces (window
+fold, FromJacobian, base generator) agree with the oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ALL_GROUPS, random_scalars, rng_for
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+
+
+def test_library_exports_every_declared_symbol(gm):
+    hdr = open(os.path.join(ROOT, "include", "gmsm.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(gmsm_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = gm._lib.load()
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert declared == set(gm._lib.ABI_SYMBOLS)
+    assert lib.gmsm_version().startswith(b"gmsm")
+
+
+@pytest.mark.parametrize("curve,which", ALL_GROUPS)
+def test_layout_sizes(gm, curve, which):
+    lib = gm._lib.load()
+    g = (gm.G1Affine if which == "g1" else gm.G2Affine)(curve)
+    assert lib.gmsm_affine_limbs(g.gid) == g.aff_limbs
+    assert lib.gmsm_scalar_limbs(g.gid) == g.fr_limbs
+    sizes = {"bn254": (8, 16), "bls12_381": (12, 24), "bw6_761": (24, 24)}[curve]
+    assert g.aff_limbs == sizes[0 if which == "g1" else 1]
+    # computeNbChunks (multiexp.go:681)
+    for c in (2, 5, 11, 16):
+        assert lib.gmsm_num_windows(g.gid, c) == (g.curve.fr_bits + c - 1) // c
+
+
+def test_reference_argument_errors(gm):
+    g = gm.G1Jac("bn254")
+    pts = np.zeros((3, 8), dtype=np.uint64)
+    _, err = g.MultiExp(pts, np.zeros((2, 4), dtype=np.uint64))
+    assert err == "len(points) != len(scalars)"            # ecc/bn254/multiexp.go:63
+    _, err = g.MultiExp(pts, np.zeros((3, 4), dtype=np.uint64), gm.MultiExpConfig(NbTasks=1025))
+    assert err == "invalid config: config.NbTasks > 1024"  # multiexp.go:70
+    lib = gm._lib.load()
+    out = np.zeros(12, dtype=np.uint64)
+    assert lib.gmsm_multiexp(99, P(pts), 3, P(pts), 3, 0, P(out)) == gm._lib.GMSM_ERR_ARG
+
+
+def test_no_silent_cpu_fallback(gm):
+    """Without a device a compute call must fail with GMSM_ERR_DEVICE, not compute on the host."""
+    lib = gm._lib.load()
+    if lib.gmsm_device_count() > 0:
+        pytest.skip("a GPU is present")
+    g = gm.G1Affine("bn254")
+    pts = g.generate_points(4, 1, 1)
+    res, err = g.MultiExp(pts, np.ones((4, 4), dtype=np.uint64))
+    assert res is None and "no usable HIP device" in err and "no CPU fallback" in err
+
+
+@pytest.mark.parametrize("curve,which", ALL_GROUPS)
+def test_host_fold_and_to_affine_match_oracle(gm, oracle_mod, curve, which):
+    """gmsm_fold_windows (msmReduceChunk, multiexp.go:302-315) and gmsm_jac_to_affine (FromJacobian, g1.go:150-166) run
+    on the host: feed them the oracle's per-window totals and compare with the oracle's own fold."""
+    g = (gm.G1Affine if which == "g1" else gm.G2Affine)(curve)
+    o = oracle_mod.Oracle(curve, which)
+    rng = rng_for(21, g.gid)
+    n = 150
+    pts = o.gen_points(n, 17, 5)
+    sc = random_scalars(rng, g.curve, n)
+    for c in (4, 9, 16):
+        digits = o.partition_scalars(sc, c)
+        lastc = c + 1 - (o.nb_chunks(c) * c - g.curve.fr_bits)
+        totals = np.stack([o.process_chunk(max(c, lastc), pts, digits[j]) for j in range(o.nb_chunks(c))])
+        jac = g.fold_windows(totals, c)
+        assert (g.jac_to_affine(jac) == o.msm_affine(pts, sc, c=c)).all()
+    inf = np.stack([o.xyzz_infinity()] * g.num_windows(16))
+    assert (g.jac_to_affine(g.fold_windows(inf, 16)) == 0).all()
+
+
+@pytest.mark.parametrize("curve,which", ALL_GROUPS)
+def test_generate_points_matches_oracle(gm, oracle_mod, curve, which):
+    g = (gm.G1Affine if which == "g1" else gm.G2Affine)(curve)
+    o = oracle_mod.Oracle(curve, which)
+    assert (g.generator == o.generator).all()
+    a = g.generate_points(2500, 0xABCDEF, 0x1234567, nthreads=3)
+    b = o.gen_points(2500, 0xABCDEF, 0x1234567, nthreads=2)
+    assert (a == b).all()

@@ -1,0 +1,84 @@
+"""The N > 1 path (window sharding + all-gather + fold) with world_size 2 over gloo on CPU.  The per-window totals come
+from the oracle (stand-in for gmsm_window_sums_device, which needs a GPU); sharding, packing, the collective and the
+product's host-side fold are the code bench.py runs on N GPUs."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, curve, which, c, n, q):
+    try:
+        import importlib
+        for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        import torch.distributed as dist
+        import torch
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        gm = importlib.import_module("gnark-crypto_amd")
+        sharding = importlib.import_module("gnark-crypto_amd.sharding")
+        import oracle
+        from conftest import random_scalars, rng_for
+        g = (gm.G1Affine if which == "g1" else gm.G2Affine)(curve)
+        o = oracle.Oracle(curve, which)
+        pts = o.gen_points(n, 77, 3)
+        sc = random_scalars(rng_for(31, n), g.curve, n)
+        digits = o.partition_scalars(sc, c)
+        lastc = c + 1 - (o.nb_chunks(c) * c - g.curve.fr_bits)
+
+        def window_sums(c_, first, stride):
+            return np.stack([o.process_chunk(max(c_, lastc), pts, digits[w]) for w in range(first, o.nb_chunks(c_), stride)])
+
+        jac = sharding.sharded_multiexp(g, window_sums, c, rank, world, sharding.torch_all_gather(dist, torch.device("cpu")))
+        ok = bool((g.jac_to_affine(jac) == o.msm_affine(pts, sc, c=c)).all())
+        q.put((rank, ok, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        q.put((rank, False, repr(e)))
+
+
+@pytest.mark.parametrize("curve,which,c", [("bn254", "g1", 16), ("bn254", "g1", 11), ("bls12_381", "g2", 13)])
+def test_window_sharded_multiexp_gloo_world2(curve, which, c):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_worker, args=(r, world, port, curve, which, c, 300, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in results), results
+
+
+def test_sharding_layout():
+    import importlib
+    sharding = importlib.import_module("gnark-crypto_amd.sharding")
+    for nwin in (16, 17, 24, 29):
+        for world in (1, 2, 4, 8):
+            owned = [sharding.owned_windows(nwin, r, world) for r in range(world)]
+            assert sorted(w for o in owned for w in o) == list(range(nwin))
+            per = sharding.slots_per_rank(nwin, world)
+            g = np.zeros((world, per, 4), dtype=np.uint64)
+            for r in range(world):
+                loc = np.array([[w, w, w, w] for w in owned[r]], dtype=np.uint64).reshape(-1, 4)
+                g[r] = sharding.pack_local(loc, nwin, world, 4)
+            tot = sharding.unpack_gathered(g, nwin, world, 4)
+            assert (tot[:, 0] == np.arange(nwin)).all()
