@@ -1,0 +1,254 @@
+// Unsaturated ("lazy") prime-field arithmetic for the bucket-accumulation hot loop on gfx950.
+//
+// Why a second representation: measured on MI355X (tools/ubench_valu.hip, profiles/r01_valu_issue_rates.log)
+// v_mad_u64_u32 (32x32+64 -> 64) issues every 4 cycles per wave64, the same as v_add_co/v_addc_co, and it has a
+// 64-bit addend but no carry-in.  With saturated 32-bit limbs every product needs a second carry instruction and the
+// compiler adds ~2 register moves to build the 64-bit addend pair (r01a: 128 mads + 105 v_lshl_add_u64 + 320 v_mov per
+// field multiplication).  With UL limbs of UW < 32 bits, a whole column of the product (2*UL partial products) fits one
+// 64-bit accumulator, so the Montgomery product is product-scanning with exactly ONE v_mad_u64_u32 per partial
+// product, one 64-bit shift per column, and no carry chains:  (2*UL^2 + UL) multiplies vs 2*N^2 + N with ~3x the
+// instructions around them.
+//
+// Representation: value = sum l[i] * 2^(UW*i), i < UL; "nearly normalised" limbs l[i] <= 2^UW + 2^3 (top limb free);
+// values are NOT reduced modulo q after every step: each op documents the bound (in multiples of q) it needs and gives.
+// Montgomery radix 2^(UL*UW) (BN254: 9 x 29 = 261 bits, 7 spare bits over q), so products of operands up to ~13q
+// still come out below 2q..3q without any conditional subtraction.
+//
+// Bit-exactness: these are exact integer computations modulo q; fpu_to_sat() returns the canonical (fully reduced)
+// saturated Montgomery limbs the reference would hold, so results are compared limb-for-limb with the oracle.
+//
+// Replaces in the reference (same role, different shape): fp.Element Mul/Square/Add/Sub/Double/Neg,
+// ecc/bn254/fp/element.go:386-454 and element_purego.go:46-213 (asm: field/asm/element_4w_amd64.s:208-304).
+#pragma once
+#include "gmsm_field.h"
+
+namespace gmsm {
+
+template <class P>
+struct FpU {
+    static constexpr int L = P::UL;
+    static constexpr int W = P::UW;
+    static constexpr uint32_t MASK = (1u << P::UW) - 1u;
+    uint32_t l[L];
+};
+
+// One-level carry pass: limbs <= 2^32-1 in, limbs <= 2^W + 2^(32-W) out (top limb absorbs its carry). Value unchanged.
+template <class P>
+GMSM_HD void fpu_carry(FpU<P> &a) {
+    constexpr int L = P::UL, W = P::UW;
+    constexpr uint32_t MASK = FpU<P>::MASK;
+    uint32_t c[L];
+#pragma unroll
+    for (int i = 0; i < L - 1; ++i) c[i] = a.l[i] >> W;
+#pragma unroll
+    for (int i = L - 1; i >= 1; --i) a.l[i] = (i < L - 1 ? (a.l[i] & MASK) : a.l[i]) + c[i - 1];
+    a.l[0] &= MASK;
+}
+
+// a + b. Value bound: bound(a) + bound(b). Inputs nearly normalised.
+template <class P>
+GMSM_HD FpU<P> fpu_add(const FpU<P> &a, const FpU<P> &b) {
+    FpU<P> r;
+#pragma unroll
+    for (int i = 0; i < P::UL; ++i) r.l[i] = a.l[i] + b.l[i];
+    fpu_carry(r);
+    return r;
+}
+
+template <class P>
+GMSM_HD FpU<P> fpu_dbl(const FpU<P> &a) {
+    FpU<P> r;
+#pragma unroll
+    for (int i = 0; i < P::UL; ++i) r.l[i] = a.l[i] << 1;
+    fpu_carry(r);
+    return r;
+}
+
+// a - b + K*q with K = 4 or 16: requires b < K*q (strictly: top limb of b <= top limb of the redundant K*q) and b's
+// limbs < 2^(W+2). Value bound: bound(a) + K.
+template <class P, int K>
+GMSM_HD FpU<P> fpu_sub(const FpU<P> &a, const FpU<P> &b) {
+    FpU<P> r;
+#pragma unroll
+    for (int i = 0; i < P::UL; ++i) r.l[i] = a.l[i] + (K == 4 ? P::UK4[i] : P::UK16[i]) - b.l[i];
+    fpu_carry(r);
+    return r;
+}
+
+// K*q - b (the negation used for subMixed): requires b < 4q.
+template <class P>
+GMSM_HD FpU<P> fpu_neg4(const FpU<P> &b) {
+    FpU<P> r;
+#pragma unroll
+    for (int i = 0; i < P::UL; ++i) r.l[i] = P::UK4[i] - b.l[i];
+    fpu_carry(r);
+    return r;
+}
+
+// Montgomery product a*b*2^-(L*W) mod q, product scanning. Requires limbs of a, b <= 2^(W+1) and
+// bound(a)*bound(b) <= 2^(L*W)/q * (B-1) for the output bound B (BN254: 2^261/q = 169, so 13q x 13q -> < 2q).
+// Output limbs are normalised (< 2^W), top limb holds the rest.
+template <class P>
+GMSM_HD FpU<P> fpu_mul(const FpU<P> &a, const FpU<P> &b) {
+    constexpr int L = P::UL, W = P::UW;
+    constexpr uint32_t MASK = FpU<P>::MASK;
+    uint32_t m[L];
+    FpU<P> r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * P::UQ[k - i];
+        m[k] = ((uint32_t)acc * P::UQINV) & MASK;
+        acc += (uint64_t)m[k] * P::UQ[0];
+        acc >>= W;
+    }
+#pragma unroll
+    for (int k = L; k < 2 * L - 1; ++k) {
+#pragma unroll
+        for (int i = k - L + 1; i < L; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = k - L + 1; i < L; ++i) acc += (uint64_t)m[i] * P::UQ[k - i];
+        r.l[k - L] = (uint32_t)acc & MASK;
+        acc >>= W;
+    }
+    r.l[L - 1] = (uint32_t)acc;
+    return r;
+}
+
+// Montgomery square: cross products once with a doubled operand (L(L+1)/2 instead of L^2 products for a*a).
+template <class P>
+GMSM_HD FpU<P> fpu_sqr(const FpU<P> &a) {
+    constexpr int L = P::UL, W = P::UW;
+    constexpr uint32_t MASK = FpU<P>::MASK;
+    uint32_t m[L], d[L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) d[i] = a.l[i] << 1;
+    FpU<P> r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+#pragma unroll
+        for (int i = 0; 2 * i < k; ++i) acc += (uint64_t)d[i] * a.l[k - i];
+        if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * P::UQ[k - i];
+        m[k] = ((uint32_t)acc * P::UQINV) & MASK;
+        acc += (uint64_t)m[k] * P::UQ[0];
+        acc >>= W;
+    }
+#pragma unroll
+    for (int k = L; k < 2 * L - 1; ++k) {
+#pragma unroll
+        for (int i = k - L + 1; 2 * i < k; ++i) acc += (uint64_t)d[i] * a.l[k - i];
+        if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+        for (int i = k - L + 1; i < L; ++i) acc += (uint64_t)m[i] * P::UQ[k - i];
+        r.l[k - L] = (uint32_t)acc & MASK;
+        acc >>= W;
+    }
+    r.l[L - 1] = (uint32_t)acc;
+    return r;
+}
+
+// ------------------------------------------------------------------ conversions
+// Split the N saturated 32-bit words of a value < 2^(L*W) into L limbs of W bits (no arithmetic).
+template <class P>
+GMSM_HD FpU<P> fpu_unpack(const uint32_t *w) {
+    constexpr int L = P::UL, W = P::UW, N = P::N;
+    FpU<P> r;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const int bit = i * W, j = bit >> 5, s = bit & 31;
+        uint32_t v = j < N ? (w[j] >> s) : 0u;
+        if (s + W > 32 && j + 1 < N) v |= w[j + 1] << (32 - s);
+        r.l[i] = i < L - 1 ? (v & FpU<P>::MASK) : v;
+    }
+    return r;
+}
+
+// Pack fully normalised limbs (value < 2^(32N)) into N saturated words.
+template <class P>
+GMSM_HD void fpu_pack(const FpU<P> &a, uint32_t *w) {
+    constexpr int L = P::UL, W = P::UW, N = P::N;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        // word j covers bits [32j, 32j+32)
+        const int lo_limb = (32 * j) / W, s = 32 * j - lo_limb * W;
+        uint32_t v = a.l[lo_limb] >> s;
+        if (lo_limb + 1 < L) v |= a.l[lo_limb + 1] << (W - s);
+        if (2 * W - s < 32 && lo_limb + 2 < L) v |= a.l[lo_limb + 2] << (2 * W - s);
+        w[j] = v;
+    }
+}
+
+// Exact sequential normalisation (all limbs < 2^W, top limb carries the rest).
+template <class P>
+GMSM_HD void fpu_normalize(FpU<P> &a) {
+    constexpr int L = P::UL, W = P::UW;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < L - 1; ++i) {
+        uint32_t t = a.l[i] + c;
+        a.l[i] = t & FpU<P>::MASK;
+        c = t >> W;
+    }
+    a.l[L - 1] += c;
+}
+
+// value >= q ? value - q : value, for a fully normalised value < 2q; result canonical.
+template <class P>
+GMSM_HD void fpu_cond_sub_q(FpU<P> &a) {
+    constexpr int L = P::UL, W = P::UW;
+    uint32_t d[L];
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        uint32_t t = a.l[i] - P::UQ[i] - borrow;
+        borrow = (i < L - 1) ? (t >> 31) : (t >> 31);  // limbs < 2^31, so bit 31 set <=> negative
+        d[i] = (i < L - 1) ? (t & FpU<P>::MASK) : t;
+    }
+#pragma unroll
+    for (int i = 0; i < L; ++i) a.l[i] = borrow ? a.l[i] : d[i];
+    (void)W;
+}
+
+// Saturated Montgomery (x*2^(32N), canonical) -> unsaturated Montgomery (x*2^(L*W)), value < 2q.
+template <class P>
+GMSM_HD FpU<P> fpu_from_sat(const Fp<P> &x) {
+    FpU<P> u = fpu_unpack<P>(x.l);
+    FpU<P> c;
+#pragma unroll
+    for (int i = 0; i < P::UL; ++i) c.l[i] = P::UCIN[i];
+    return fpu_mul(u, c);
+}
+
+// Unsaturated Montgomery (any lazy value within the fpu_mul input bounds) -> canonical saturated Montgomery limbs.
+template <class P>
+GMSM_HD Fp<P> fpu_to_sat(const FpU<P> &a) {
+    FpU<P> c;
+#pragma unroll
+    for (int i = 0; i < P::UL; ++i) c.l[i] = P::UCOUT[i];
+    FpU<P> r = fpu_mul(a, c);  // < 2q, limbs normalised
+    fpu_cond_sub_q(r);
+    Fp<P> z;
+    fpu_pack(r, z.l);
+    return z;
+}
+
+// Exact test "value == 0 mod q" for a product-class value (normalised limbs, value < 3q): compares with 0, q, 2q.
+template <class P>
+GMSM_HD bool fpu_is_zero_lt3q(const FpU<P> &a) {
+    uint32_t z0 = 0, z1 = 0, z2 = 0;
+#pragma unroll
+    for (int i = 0; i < P::UL; ++i) {
+        z0 |= a.l[i];
+        z1 |= a.l[i] ^ P::UQ1[i];
+        z2 |= a.l[i] ^ P::UQ2[i];
+    }
+    return z0 == 0 || z1 == 0 || z2 == 0;
+}
+
+}  // namespace gmsm

@@ -14,6 +14,12 @@
 namespace gmsm {
 
 // ------------------------------------------------------------------ one (curve, group)
+template <class T> struct IsPrimeField { static constexpr bool value = false; };
+template <class P> struct IsPrimeField<Fp<P>> { static constexpr bool value = true; };
+#ifndef GMSM_FAST_PATH_MAX_LIMBS
+#define GMSM_FAST_PATH_MAX_LIMBS 12
+#endif
+
 template <class F_, class FrP_>
 struct Group {
     using F = F_;
@@ -24,6 +30,9 @@ struct Group {
     static constexpr unsigned FR_BITS = FrP::BITS;
     static constexpr size_t AFF_BYTES = sizeof(Aff);
     static constexpr size_t SCALAR_BYTES = sizeof(Fp<FrP>);
+    // unsaturated-limb accumulation (gmsm_fieldu.h) for groups whose coordinates live in Fp; Fp2 groups use the generic
+    // saturated kernel
+    static constexpr bool FAST_PATH = IsPrimeField<F>::value && F::N <= GMSM_FAST_PATH_MAX_LIMBS;
     static constexpr int RED_TPB = 256;
     static constexpr int RED2_TPB = 64;
 
@@ -77,10 +86,19 @@ struct Group {
         uint32_t *starts = (uint32_t *)ctx.starts.ptr;
 
         StageTimer timer(ctx, stream);
-        // 1. signed-digit decomposition
+        // 0. (fast path) rewrite the bases into the unsaturated Montgomery domain + infinity flags
         timer.mark(STAGE_DECOMPOSE);
+        const uint8_t *skip = nullptr;
+        if constexpr (FAST_PATH) {
+            if ((rc = ctx.upoints.ensure(n * AFF_BYTES))) return rc;
+            if ((rc = ctx.skip.ensure(n))) return rc;
+            hipLaunchKernelGGL((k_convert_points<typename F::Params>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                               stream, d_points, n, ctx.upoints.ptr, (uint8_t *)ctx.skip.ptr);
+            skip = (const uint8_t *)ctx.skip.ptr;
+        }
+        // 1. signed-digit decomposition
         hipLaunchKernelGGL((k_decompose<FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                           (const uint32_t *)d_scalars, n, plan, digits);
+                           (const uint32_t *)d_scalars, n, plan, digits, skip);
         // 2. group point references by bucket (counting sort per window)
         const size_t hist_lds = (size_t)NB * 4;
         if (hist_lds > 160 * 1024) return fail(GMSM_ERR_ARG, "window too wide for the LDS histogram (c <= 16)");
@@ -100,8 +118,13 @@ struct Group {
                            blockhist, starts, sorted);
         // 3. bucket accumulation
         timer.mark(STAGE_ACCUMULATE);
-        hipLaunchKernelGGL((k_accumulate<F>), dim3((NB + 255) / 256, nw), dim3(256), 0, stream, d_points, n, NB, starts,
-                           sorted, ctx.buckets.ptr);
+        if constexpr (FAST_PATH) {
+            hipLaunchKernelGGL((k_accumulate_u<typename F::Params>), dim3((NB + 255) / 256, nw), dim3(256), 0, stream,
+                               ctx.upoints.ptr, n, NB, starts, sorted, ctx.buckets.ptr);
+        } else {
+            hipLaunchKernelGGL((k_accumulate<F>), dim3((NB + 255) / 256, nw), dim3(256), 0, stream, d_points, n, NB, starts,
+                               sorted, ctx.buckets.ptr);
+        }
         // 4. bucket reduction -> window totals
         static bool red_attr_done = false;
         if (!red_attr_done) {
@@ -349,7 +372,7 @@ static int debug_decompose_impl(const uint64_t *scalars, size_t n, unsigned c, u
     if ((rc = ctx->digits.ensure((size_t)plan.nwin_total * n * 4))) return rc;
     HIP_TRY(hipMemcpy(ctx->scalars.ptr, scalars, n * G::SCALAR_BYTES, hipMemcpyHostToDevice));
     hipLaunchKernelGGL((k_decompose<typename G::FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const uint32_t *)ctx->scalars.ptr, n, plan, (uint32_t *)ctx->digits.ptr);
+                       (const uint32_t *)ctx->scalars.ptr, n, plan, (uint32_t *)ctx->digits.ptr, (const uint8_t *)nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpy(out_digits, ctx->digits.ptr, (size_t)plan.nwin_total * n * 4, hipMemcpyDeviceToHost));

@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gmsm_curve.h"
+#include "gmsm_fieldu.h"
 
 namespace gmsm {
 
@@ -54,7 +55,8 @@ __device__ __forceinline__ void store_struct(void *base, size_t index, const T &
 // One thread per scalar. digits is [nwin_local][n] (window-major, coalesced stores).
 template <class FrP>
 __global__ void __launch_bounds__(256) k_decompose(const uint32_t *__restrict__ scalars, size_t n, WindowPlan plan,
-                                                   uint32_t *__restrict__ digits) {
+                                                   uint32_t *__restrict__ digits,
+                                                   const uint8_t *__restrict__ skip /* may be null */) {
     constexpr int NR = FrP::N;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -65,13 +67,13 @@ __global__ void __launch_bounds__(256) k_decompose(const uint32_t *__restrict__ 
 #pragma unroll
         for (int k = 0; k < NR / 4; ++k) dst[k] = src[k];
     }
-    const bool zero = s.is_zero();  // multiexp.go:743
+    // zero scalars (multiexp.go:743) and points at infinity (g1.go:825) contribute nothing
+    const bool zero = s.is_zero() || (skip != nullptr && skip[i] != 0);
     s = fp_from_mont(s);
     const uint32_t c = plan.c;
     const uint32_t mask = (1u << c) - 1u;
     const int max = (1 << (c - 1)) - 1;
     int carry = 0;
-    uint32_t next_local = 0;  // next local window slot expected
     for (uint32_t w = 0; w < plan.nwin_total; ++w) {
         const uint32_t bit = w * c, idx = bit >> 5, sh = bit & 31;
         // up to 3 words can contribute when c > 32-sh ... c <= 24 is enforced on the host: 2 words suffice
@@ -94,7 +96,6 @@ __global__ void __launch_bounds__(256) k_decompose(const uint32_t *__restrict__ 
         if (w >= plan.win_first && (w - plan.win_first) % plan.win_stride == 0) {
             const uint32_t k = (w - plan.win_first) / plan.win_stride;
             if (k < plan.nwin_local) digits[(size_t)k * n + i] = zero ? 0u : code;
-            (void)next_local;
         }
     }
 }
@@ -206,6 +207,114 @@ __global__ void __launch_bounds__(256) k_accumulate(const void *__restrict__ poi
         xyzz_add_mixed(acc, p, (v & 1u) != 0);
     }
     store_struct(buckets, (size_t)k * nbuckets + b, acc);
+}
+
+// ------------------------------------------------------------------ bucket accumulation, unsaturated fast path
+// G1-type groups (coordinates in Fp). The bases are first rewritten once per call into the unsaturated Montgomery
+// domain (k_convert_points: 2 field multiplications per point, against 10 per mixed add per window), packed back into
+// the same 2N words per point so the gather in the hot loop still moves 64 B per BN254 point.
+template <class P>
+struct UAffine {
+    uint32_t x[P::N], y[P::N];  // packed limbs of x*2^(UL*UW) mod q and y*2^(UL*UW) mod q (values < 2q)
+};
+
+template <class P>
+__global__ void __launch_bounds__(256) k_convert_points(const void *__restrict__ points, size_t n, void *__restrict__ upoints,
+                                                        uint8_t *__restrict__ skip) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<Fp<P>> a = load_struct<Affine<Fp<P>>>(points, i);
+    skip[i] = a.is_infinity() ? 1 : 0;
+    FpU<P> ux = fpu_from_sat(a.x), uy = fpu_from_sat(a.y);
+    UAffine<P> u;
+    fpu_pack(ux, u.x);
+    fpu_pack(uy, u.y);
+    store_struct(upoints, i, u);
+}
+
+template <class P>
+struct XYZZU {
+    FpU<P> x, y, zz, zzz;
+};
+
+// Everything the fast path does not handle (P + P, P + (-P)): convert to the saturated representation, run the generic
+// group law with all of the reference's special cases (g1.go:846-854), convert back. Reached only when the
+// x-coordinates coincide, i.e. for duplicated bases / repeated scalars.
+template <class P>
+__device__ __noinline__ void madd_slow(XYZZU<P> &acc, bool &inf, const FpU<P> &px, const FpU<P> &py, bool negate) {
+    XYZZ<Fp<P>> s;
+    s.x = fpu_to_sat(acc.x);
+    s.y = fpu_to_sat(acc.y);
+    s.zz = fpu_to_sat(acc.zz);
+    s.zzz = fpu_to_sat(acc.zzz);
+    Affine<Fp<P>> a{fpu_to_sat(px), fpu_to_sat(py)};
+    xyzz_add_mixed(s, a, negate);
+    inf = s.zz.is_zero();
+    acc.x = fpu_from_sat(s.x);
+    acc.y = fpu_from_sat(s.y);
+    acc.zz = fpu_from_sat(s.zz);
+    acc.zzz = fpu_from_sat(s.zzz);
+}
+
+// acc += (+-)(px, py); madd-2008-s (g1.go:822-873) on lazy values. Bounds in multiples of q (BN254, 2^261/q = 169;
+// mul(a,b) < ab/169 + 1):  ZZ,ZZZ,PP.. < 3;  acc.x < 11, acc.y < 7;  Pv,Rv < 18.
+template <class P>
+__device__ __forceinline__ void madd_u(XYZZU<P> &acc, bool &inf, const FpU<P> &px, const FpU<P> &py_in, bool negate) {
+    if (inf) {
+        acc.x = px;
+        acc.y = negate ? fpu_neg4<P>(py_in) : py_in;
+#pragma unroll
+        for (int i = 0; i < P::UL; ++i) acc.zz.l[i] = acc.zzz.l[i] = P::UONE[i];
+        inf = false;
+        return;
+    }
+    const FpU<P> py = negate ? fpu_neg4<P>(py_in) : py_in;           // < 6
+    const FpU<P> Pv = fpu_sub<P, 16>(fpu_mul(px, acc.zz), acc.x);    // < 18
+    const FpU<P> Rv = fpu_sub<P, 16>(fpu_mul(py, acc.zzz), acc.y);   // < 18
+    const FpU<P> PP = fpu_sqr(Pv);                                   // < 3
+    // Pv == 0 mod q  <=>  PP == 0 mod q (q prime); PP is a normalised product < 3q: cheap pre-filter on its low limb
+    const uint32_t l0 = PP.l[0];
+    if (l0 == 0u || l0 == P::UQ1[0] || l0 == P::UQ2[0]) {
+        if (fpu_is_zero_lt3q(PP)) {
+            madd_slow<P>(acc, inf, px, py_in, negate);
+            return;
+        }
+    }
+    const FpU<P> PPP = fpu_mul(Pv, PP);                              // < 2
+    const FpU<P> Q = fpu_mul(acc.x, PP);                             // < 2
+    const FpU<P> RR = fpu_sqr(Rv);                                   // < 3
+    const FpU<P> X3 = fpu_sub<P, 4>(fpu_sub<P, 4>(RR, PPP), fpu_dbl(Q));      // < 3 + 4 + 4 = 11
+    const FpU<P> Y3 = fpu_sub<P, 4>(fpu_mul(fpu_sub<P, 16>(Q, X3), Rv), fpu_mul(acc.y, PPP));  // < 3 + 4 = 7
+    acc.x = X3;
+    acc.y = Y3;
+    acc.zz = fpu_mul(acc.zz, PP);
+    acc.zzz = fpu_mul(acc.zzz, PPP);
+}
+
+template <class P>
+__global__ void __launch_bounds__(256) k_accumulate_u(const void *__restrict__ upoints, size_t n, uint32_t nbuckets,
+                                                      const uint32_t *__restrict__ starts,
+                                                      const uint32_t *__restrict__ sorted, void *__restrict__ buckets) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (b >= nbuckets) return;
+    const uint32_t *st = starts + (size_t)k * (nbuckets + 1);
+    const uint32_t lo = st[b], hi = st[b + 1];
+    const uint32_t *ent = sorted + (size_t)k * n;
+    XYZZU<P> acc;
+    bool inf = true;
+    for (uint32_t e = lo; e < hi; ++e) {
+        const uint32_t v = ent[e];
+        const UAffine<P> p = load_struct<UAffine<P>>(upoints, v >> 1);
+        madd_u<P>(acc, inf, fpu_unpack<P>(p.x), fpu_unpack<P>(p.y), (v & 1u) != 0);
+    }
+    XYZZ<Fp<P>> out = XYZZ<Fp<P>>::infinity();
+    if (!inf) {
+        out.x = fpu_to_sat(acc.x);
+        out.y = fpu_to_sat(acc.y);
+        out.zz = fpu_to_sat(acc.zz);
+        out.zzz = fpu_to_sat(acc.zzz);
+    }
+    store_struct(buckets, (size_t)k * nbuckets + b, out);
 }
 
 // ------------------------------------------------------------------ bucket reduction

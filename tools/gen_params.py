@@ -76,7 +76,46 @@ def cxx_field(prefix, q, n64):
     out += f"    static constexpr uint32_t QINV = 0x{(-pow(q, -1, 1 << 32)) % (1 << 32):08x}u; /* -q^-1 mod 2^32 */\n"
     out += arr("ONE", R % q)
     out += arr("RSQ", R * R % q)
+    out += unsat_block(q, n64)
     out += "};\n"
+    return out
+
+
+# Unsaturated ("lazy") representation used by the bucket-accumulation hot loop: UL limbs of UW bits, Montgomery
+# radix 2^(UL*UW).  UW is chosen so that a column of 2*UL products of (UW+1)-bit limbs fits a 64-bit accumulator.
+UNSAT = {254: (9, 29), 381: (14, 28), 761: (28, 28), 255: (9, 29), 377: (14, 28)}
+
+
+def redundant_multiple(q, k, UL, UW, borrow_units=4):
+    """k*q written with limbs K_i = k_i + borrow_units*2^UW (i < UL-1), top limb reduced accordingly, so that
+    a_i + K_i - b_i never underflows for b_i < borrow_units*2^UW.  sum K_i 2^(UW i) == k*q exactly."""
+    v = k * q
+    limbs = [(v >> (UW * i)) & ((1 << UW) - 1) for i in range(UL - 1)] + [v >> (UW * (UL - 1))]
+    for i in range(UL - 1):
+        limbs[i] += borrow_units << UW
+        limbs[i + 1] -= borrow_units
+    assert limbs[-1] > 0 and sum(l << (UW * i) for i, l in enumerate(limbs)) == v
+    assert all(l < (1 << 32) for l in limbs)
+    return limbs
+
+
+def unsat_block(q, n64):
+    UL, UW = UNSAT[q.bit_length()]
+    T = UL * UW
+    S = 64 * n64
+    mask = (1 << UW) - 1
+    ulimbs = lambda v: [(v >> (UW * i)) & mask for i in range(UL - 1)] + [v >> (UW * (UL - 1))]
+    uarr = lambda name, vals: f"    static constexpr uint32_t {name}[{UL}] = {{" + ", ".join(f"0x{x:08x}u" for x in vals) + "};\n"
+    out = f"    /* unsaturated form: {UL} limbs x {UW} bits, Montgomery radix 2^{T} */\n"
+    out += f"    static constexpr int UL = {UL};\n    static constexpr int UW = {UW};\n"
+    out += uarr("UQ", ulimbs(q))
+    out += f"    static constexpr uint32_t UQINV = 0x{(-pow(q, -1, 1 << UW)) % (1 << UW):08x}u; /* -q^-1 mod 2^UW */\n"
+    out += uarr("UONE", ulimbs((1 << T) % q))                      # 1 in the 2^T Montgomery domain
+    out += uarr("UCIN", ulimbs(pow(2, 2 * T - S, q)))              # montmul'(x*2^S, UCIN) = x*2^T
+    out += uarr("UCOUT", ulimbs(pow(2, S, q)))                     # montmul'(x*2^T, UCOUT) = x*2^S
+    out += uarr("UK4", redundant_multiple(q, 4, UL, UW))
+    out += uarr("UK16", redundant_multiple(q, 16, UL, UW))
+    out += uarr("UQ1", ulimbs(q)) + uarr("UQ2", ulimbs(2 * q))     # candidates for the exact zero test of a value < 3q
     return out
 
 
