@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libgmsm.so")
+LIB_PATH = os.environ.get("GMSM_LIB") or os.path.join(CSRC, "libgmsm.so")  # GMSM_LIB: A/B builds
 
 GMSM_OK, GMSM_ERR_LEN, GMSM_ERR_CONFIG, GMSM_ERR_DEVICE, GMSM_ERR_ARG = 0, 1, 2, 3, 4
 

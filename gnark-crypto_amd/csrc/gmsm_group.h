@@ -118,9 +118,24 @@ struct Group {
                            blockhist, starts, sorted);
         // 3. bucket accumulation
         timer.mark(STAGE_ACCUMULATE);
+        const uint32_t *reduce_starts = nullptr;
         if constexpr (FAST_PATH) {
-            hipLaunchKernelGGL((k_accumulate_u<typename F::Params>), dim3((NB + 255) / 256, nw), dim3(256), 0, stream,
-                               ctx.upoints.ptr, n, NB, starts, sorted, ctx.buckets.ptr);
+            // entry-parallel segmented accumulation: seg entries per thread, >= ~4 waves per SIMD when n allows
+            uint32_t seg = env_uint("GMSM_SEG", 0);
+            if (seg == 0) {
+                seg = (uint32_t)std::min<size_t>(256, std::max<size_t>(16, ((size_t)nw * n) / (65536 * 6)));
+            }
+            const uint32_t tpw = (uint32_t)((n + seg - 1) / seg);  // threads per window (upper bound: <= n entries)
+            if ((rc = ctx.seg_partials.ensure((size_t)nw * tpw * 2 * sizeof(Ext)))) return rc;
+            if ((rc = ctx.seg_flags.ensure((size_t)nw * tpw * 4))) return rc;
+            if ((rc = ctx.seg_bucket.ensure((size_t)nw * tpw * 4))) return rc;
+            hipLaunchKernelGGL((k_accumulate_seg<typename F::Params>), dim3((tpw + 255) / 256, nw), dim3(256), 0, stream,
+                               ctx.upoints.ptr, n, NB, seg, starts, sorted, ctx.buckets.ptr, ctx.seg_partials.ptr,
+                               (uint32_t *)ctx.seg_flags.ptr, (uint32_t *)ctx.seg_bucket.ptr, tpw);
+            hipLaunchKernelGGL((k_fixup_seg<F>), dim3((tpw + 255) / 256, nw), dim3(256), 0, stream, NB,
+                               ctx.seg_partials.ptr, (const uint32_t *)ctx.seg_flags.ptr,
+                               (const uint32_t *)ctx.seg_bucket.ptr, tpw, ctx.buckets.ptr);
+            reduce_starts = starts;
         } else {
             hipLaunchKernelGGL((k_accumulate<F>), dim3((NB + 255) / 256, nw), dim3(256), 0, stream, d_points, n, NB, starts,
                                sorted, ctx.buckets.ptr);
@@ -136,7 +151,7 @@ struct Group {
         }
         timer.mark(STAGE_REDUCE);
         hipLaunchKernelGGL((k_reduce1<F, RED_TPB>), dim3(nblocks1, nw), dim3(RED_TPB), RED_TPB * sizeof(Ext), stream,
-                           ctx.buckets.ptr, NB, log2L, ctx.partials.ptr);
+                           ctx.buckets.ptr, NB, log2L, ctx.partials.ptr, reduce_starts);
         hipLaunchKernelGGL((k_reduce2<F, RED2_TPB>), dim3(nw), dim3(RED2_TPB), RED2_TPB * sizeof(Ext), stream,
                            ctx.partials.ptr, nblocks1, log2span, ctx.totals.ptr);
         timer.mark(STAGE_END);

@@ -237,23 +237,22 @@ struct XYZZU {
     FpU<P> x, y, zz, zzz;
 };
 
-// Everything the fast path does not handle (P + P, P + (-P)): convert to the saturated representation, run the generic
-// group law with all of the reference's special cases (g1.go:846-854), convert back. Reached only when the
-// x-coordinates coincide, i.e. for duplicated bases / repeated scalars.
+// acc = [2](px, py) for an affine (px, py): doubleMixed / doubleNegMixed (g1.go:933-985, dbl-2008-s-1 with ZZ = 1), on lazy
+// values; py is already negated by the caller for the subMixed case. Bounds (multiples of q): px < 2, py < 6.
 template <class P>
-__device__ __noinline__ void madd_slow(XYZZU<P> &acc, bool &inf, const FpU<P> &px, const FpU<P> &py, bool negate) {
-    XYZZ<Fp<P>> s;
-    s.x = fpu_to_sat(acc.x);
-    s.y = fpu_to_sat(acc.y);
-    s.zz = fpu_to_sat(acc.zz);
-    s.zzz = fpu_to_sat(acc.zzz);
-    Affine<Fp<P>> a{fpu_to_sat(px), fpu_to_sat(py)};
-    xyzz_add_mixed(s, a, negate);
-    inf = s.zz.is_zero();
-    acc.x = fpu_from_sat(s.x);
-    acc.y = fpu_from_sat(s.y);
-    acc.zz = fpu_from_sat(s.zz);
-    acc.zzz = fpu_from_sat(s.zzz);
+__device__ __forceinline__ void double_mixed_u(XYZZU<P> &acc, const FpU<P> &px, const FpU<P> &py) {
+    const FpU<P> U = fpu_dbl(py);                                       // < 12
+    const FpU<P> V = fpu_sqr(U);                                        // < 2
+    const FpU<P> W = fpu_mul(U, V);                                     // < 2
+    const FpU<P> S = fpu_mul(px, V);                                    // < 2
+    const FpU<P> XX = fpu_sqr(px);                                      // < 2
+    const FpU<P> M = fpu_add(fpu_add(XX, XX), XX);                      // < 6
+    const FpU<P> X3 = fpu_sub<P, 4>(fpu_sqr(M), fpu_dbl(S));            // < 2 + 4
+    const FpU<P> Y3 = fpu_sub<P, 4>(fpu_mul(fpu_sub<P, 16>(S, X3), M), fpu_mul(W, py));  // < 2 + 4
+    acc.x = X3;
+    acc.y = Y3;
+    acc.zz = V;
+    acc.zzz = W;
 }
 
 // acc += (+-)(px, py); madd-2008-s (g1.go:822-873) on lazy values. Bounds in multiples of q (BN254, 2^261/q = 169;
@@ -276,7 +275,9 @@ __device__ __forceinline__ void madd_u(XYZZU<P> &acc, bool &inf, const FpU<P> &p
     const uint32_t l0 = PP.l[0];
     if (l0 == 0u || l0 == P::UQ1[0] || l0 == P::UQ2[0]) {
         if (fpu_is_zero_lt3q(PP)) {
-            madd_slow<P>(acc, inf, px, py_in, negate);
+            // same x-coordinate (g1.go:846-854): acc == +-(px, py). Rv == 0 mod q <=> Rv^2 == 0 mod q.
+            if (fpu_is_zero_lt3q(fpu_sqr(Rv))) double_mixed_u<P>(acc, px, py);  // P + P
+            else inf = true;                                                    // P + (-P)
             return;
         }
     }
@@ -315,6 +316,131 @@ __global__ void __launch_bounds__(256) k_accumulate_u(const void *__restrict__ u
         out.zzz = fpu_to_sat(acc.zzz);
     }
     store_struct(buckets, (size_t)k * nbuckets + b, out);
+}
+
+// ------------------------------------------------------------------ entry-parallel segmented accumulation
+// Load-balanced form of the accumulation: every thread takes SEG consecutive entries of a window's bucket-sorted
+// reference list (not one bucket), so the work per lane is the same whatever the bucket-size distribution is
+// (uniform scalars, the reference's "smallvalues"/"redundancy" benchmark distributions, multiexp_test.go:319-334, or
+// all scalars equal).  A run of entries that lies completely inside the thread's range is a finished bucket and is
+// stored directly; a run that continues into a neighbouring thread is stored as a partial (slot 0: run open to the
+// left, slot 1: run open only to the right) and k_fixup_seg adds the chain of partials of each split bucket.
+// Buckets without entries are never written: k_reduce1 recognises them from `starts`.
+struct SegFlags {
+    static constexpr uint32_t HAS_P0 = 1u;         // first run continues from the previous thread
+    static constexpr uint32_t P0_OPEN_RIGHT = 2u;  // ... and also continues into the next thread
+    static constexpr uint32_t HAS_P1 = 4u;         // last run starts in this thread and continues into the next
+};
+
+template <class P>
+__device__ __forceinline__ XYZZ<Fp<P>> xyzzu_to_sat(const XYZZU<P> &acc, bool inf) {
+    XYZZ<Fp<P>> out = XYZZ<Fp<P>>::infinity();
+    if (!inf) {
+        out.x = fpu_to_sat(acc.x);
+        out.y = fpu_to_sat(acc.y);
+        out.zz = fpu_to_sat(acc.zz);
+        out.zzz = fpu_to_sat(acc.zzz);
+    }
+    return out;
+}
+
+// grid = (ceil(max_entries/(256*seg)), nwin_local)
+#ifndef GMSM_ACC_MINW
+#define GMSM_ACC_MINW 3
+#endif
+template <class P>
+__global__ void __launch_bounds__(256, GMSM_ACC_MINW) k_accumulate_seg(const void *__restrict__ upoints, size_t n, uint32_t nbuckets,
+                                                           uint32_t seg, const uint32_t *__restrict__ starts,
+                                                           const uint32_t *__restrict__ sorted, void *__restrict__ buckets,
+                                                           void *__restrict__ partials, uint32_t *__restrict__ pflags,
+                                                           uint32_t *__restrict__ pbucket, uint32_t threads_per_win) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    const uint32_t *st = starts + (size_t)k * (nbuckets + 1);
+    const uint32_t total = st[nbuckets];
+    const size_t tg = (size_t)k * threads_per_win + t;
+    const uint64_t e0_64 = (uint64_t)t * seg;
+    if (t >= threads_per_win) return;
+    if (e0_64 >= total) {
+        pflags[tg] = 0;
+        return;
+    }
+    const uint32_t e0 = (uint32_t)e0_64;
+    const uint32_t e1 = (total - e0 > seg) ? e0 + seg : total;
+    // bucket containing entry e0: largest b with st[b] <= e0 (then st[b+1] > e0 because empty buckets have equal starts)
+    uint32_t lo = 0, hi = nbuckets;  // invariant: st[lo] <= e0 < st[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (st[mid] <= e0) lo = mid; else hi = mid;
+    }
+    uint32_t b = lo;
+    uint32_t bend = st[b + 1];
+    bool open_left = st[b] < e0;
+    uint32_t flags = 0;
+    const uint32_t *ent = sorted + (size_t)k * n;
+    XYZZU<P> acc;
+    bool inf = true;
+    uint32_t v = ent[e0];
+    UAffine<P> p = load_struct<UAffine<P>>(upoints, v >> 1);
+    for (uint32_t e = e0; e < e1; ++e) {
+        if (e == bend) {  // the current run is complete on the right
+            XYZZ<Fp<P>> out = xyzzu_to_sat<P>(acc, inf);
+            if (open_left) {
+                store_struct(partials, tg * 2 + 0, out);
+                flags |= SegFlags::HAS_P0;
+                open_left = false;
+            } else {
+                store_struct(buckets, (size_t)k * nbuckets + b, out);
+            }
+            inf = true;
+            ++b;
+            while (st[b + 1] == e) ++b;  // skip empty buckets
+            bend = st[b + 1];
+        }
+        // prefetch the next entry's point while this one is being added
+        const uint32_t vc = v;
+        const UAffine<P> pc = p;
+        if (e + 1 < e1) {
+            v = ent[e + 1];
+            p = load_struct<UAffine<P>>(upoints, v >> 1);
+        }
+        madd_u<P>(acc, inf, fpu_unpack<P>(pc.x), fpu_unpack<P>(pc.y), (vc & 1u) != 0);
+    }
+    {
+        const bool open_right = bend > e1;
+        XYZZ<Fp<P>> out = xyzzu_to_sat<P>(acc, inf);
+        if (open_left) {
+            store_struct(partials, tg * 2 + 0, out);
+            flags |= SegFlags::HAS_P0 | (open_right ? SegFlags::P0_OPEN_RIGHT : 0u);
+        } else if (open_right) {
+            store_struct(partials, tg * 2 + 1, out);
+            flags |= SegFlags::HAS_P1;
+            pbucket[tg] = b;
+        } else {
+            store_struct(buckets, (size_t)k * nbuckets + b, out);
+        }
+    }
+    pflags[tg] = flags;
+}
+
+// One thread per accumulation thread: the thread whose last run opened a split bucket (HAS_P1) adds the chain of
+// partials that follow it and stores the bucket.
+template <class F>
+__global__ void __launch_bounds__(256) k_fixup_seg(uint32_t nbuckets, const void *__restrict__ partials,
+                                                   const uint32_t *__restrict__ pflags, const uint32_t *__restrict__ pbucket,
+                                                   uint32_t threads_per_win, void *__restrict__ buckets) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (t >= threads_per_win) return;
+    const size_t base = (size_t)k * threads_per_win;
+    if (!(pflags[base + t] & SegFlags::HAS_P1)) return;
+    XYZZ<F> acc = load_struct<XYZZ<F>>(partials, (base + t) * 2 + 1);
+    for (uint32_t u = t + 1; u < threads_per_win; ++u) {
+        const uint32_t f = pflags[base + u];
+        if (!(f & SegFlags::HAS_P0)) break;
+        XYZZ<F> q = load_struct<XYZZ<F>>(partials, (base + u) * 2 + 0);
+        xyzz_add(acc, q);
+        if (!(f & SegFlags::P0_OPEN_RIGHT)) break;
+    }
+    store_struct(buckets, (size_t)k * nbuckets + pbucket[base + t], acc);
 }
 
 // ------------------------------------------------------------------ bucket reduction
@@ -377,7 +503,8 @@ __device__ __forceinline__ void block_combine(XYZZ<F> S, XYZZ<F> W, uint32_t log
 // out1[(k*nblocks1 + blk)*2 + {0,1}] = (S_blk, W_blk)
 template <class F, int TPB>
 __global__ void __launch_bounds__(TPB) k_reduce1(const void *__restrict__ buckets, uint32_t nbuckets, uint32_t log2L,
-                                                 void *__restrict__ out1) {
+                                                 void *__restrict__ out1,
+                                                 const uint32_t *__restrict__ starts /* null: every bucket is stored */) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     XYZZ<F> *lds = reinterpret_cast<XYZZ<F> *>(lds_raw);
     const uint32_t k = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
@@ -386,7 +513,12 @@ __global__ void __launch_bounds__(TPB) k_reduce1(const void *__restrict__ bucket
     XYZZ<F> run = XYZZ<F>::infinity(), tot = XYZZ<F>::infinity();
     for (uint32_t j = L; j-- > 0;) {
         const uint32_t b = lo + j;
-        if (b < nbuckets) {
+        bool present = b < nbuckets;
+        if (present && starts != nullptr) {
+            const uint32_t *st = starts + (size_t)k * (nbuckets + 1);
+            present = st[b + 1] > st[b];
+        }
+        if (present) {
             XYZZ<F> B = load_struct<XYZZ<F>>(buckets, (size_t)k * nbuckets + b);
             xyzz_add(run, B);
         }
