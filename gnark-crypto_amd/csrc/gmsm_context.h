@@ -44,6 +44,7 @@ struct Context {
     hipStream_t stream = nullptr;  // used when the caller passes no stream
     DeviceBuffer points, scalars;  // staging for the host-pointer entry
     DeviceBuffer upoints, skip;    // bases rewritten for the unsaturated fast path + infinity flags
+    DeviceBuffer seg_lvl;  // hierarchical chain fixup: level partials, flags, long-chain flags
     DeviceBuffer seg_partials, seg_flags, seg_bucket;  // split-bucket partial sums of the segmented accumulation
     DeviceBuffer digits, sorted, blockhist, counts, starts, buckets, partials, totals;
     hipEvent_t events[8] = {nullptr};  // stage boundaries when profiling is on

@@ -33,7 +33,12 @@ struct Group {
     // unsaturated-limb accumulation (gmsm_fieldu.h) for groups whose coordinates live in Fp; Fp2 groups use the generic
     // saturated kernel
     static constexpr bool FAST_PATH = IsPrimeField<F>::value && F::N <= GMSM_FAST_PATH_MAX_LIMBS;
-    static constexpr int RED_TPB = 256;
+    template <bool Fast, class Dummy = void> struct OpsSel { using type = SatOps<F>; };
+    template <class Dummy> struct OpsSel<true, Dummy> { using type = UnsatOps<typename F::Params>; };
+    using Ops = typename OpsSel<FAST_PATH>::type;  // arithmetic of the fixup / reduction kernels
+    using OpsElem = typename Ops::Elem;
+    static_assert(2 * (sizeof(XYZZ<F>) > 256 ? 128 : 256) * sizeof(OpsElem) <= 160 * 1024, "reduction LDS budget");
+    static constexpr int RED_TPB = sizeof(XYZZ<F>) > 256 ? 128 : 256;  // 2*TPB*sizeof(Elem) of LDS must fit 160 KiB
     static constexpr int RED2_TPB = 64;
 
     static WindowPlan make_plan(unsigned c, unsigned win_first, unsigned win_stride) {
@@ -132,9 +137,30 @@ struct Group {
             hipLaunchKernelGGL((k_accumulate_seg<typename F::Params>), dim3((tpw + 255) / 256, nw), dim3(256), 0, stream,
                                ctx.upoints.ptr, n, NB, seg, starts, sorted, ctx.buckets.ptr, ctx.seg_partials.ptr,
                                (uint32_t *)ctx.seg_flags.ptr, (uint32_t *)ctx.seg_bucket.ptr, tpw);
-            hipLaunchKernelGGL((k_fixup_seg<F>), dim3((tpw + 255) / 256, nw), dim3(256), 0, stream, NB,
+            // chain fixup: short chains in place, long ones through two hierarchical levels (no-ops unless flagged)
+            const uint32_t span1 = 64;
+            const uint32_t t1 = (tpw + span1 - 1) / span1;  // level-1 outputs per window
+            const uint32_t span2 = t1;                      // level 2: one thread per window closes everything
+            const size_t lvl_parts = ((size_t)nw * t1 + nw) * 2 * sizeof(Ext);
+            if ((rc = ctx.seg_lvl.ensure(lvl_parts + ((size_t)nw * t1 * 2 + (size_t)nw * 3) * 4 + 256))) return rc;
+            char *lvl = (char *)ctx.seg_lvl.ptr;
+            void *parts1 = lvl;
+            void *parts2 = lvl + (size_t)nw * t1 * 2 * sizeof(Ext);  // nw * 2 records
+            uint32_t *flags1 = (uint32_t *)(lvl + lvl_parts);
+            uint32_t *pb1 = flags1 + (size_t)nw * t1;
+            uint32_t *flags2 = pb1 + (size_t)nw * t1;
+            uint32_t *pb2 = flags2 + nw;
+            uint32_t *long_flag = pb2 + nw;
+            HIP_TRY(hipMemsetAsync(long_flag, 0, (size_t)nw * 4, stream));
+            hipLaunchKernelGGL((k_fixup_seg<Ops>), dim3((tpw + 255) / 256, nw), dim3(256), 0, stream, NB,
                                ctx.seg_partials.ptr, (const uint32_t *)ctx.seg_flags.ptr,
-                               (const uint32_t *)ctx.seg_bucket.ptr, tpw, ctx.buckets.ptr);
+                               (const uint32_t *)ctx.seg_bucket.ptr, tpw, ctx.buckets.ptr, long_flag);
+            hipLaunchKernelGGL((k_fixup_level<Ops>), dim3((t1 + 255) / 256, nw), dim3(256), 0, stream, NB,
+                               ctx.seg_partials.ptr, (const uint32_t *)ctx.seg_flags.ptr,
+                               (const uint32_t *)ctx.seg_bucket.ptr, tpw, span1, parts1, flags1, pb1, t1, ctx.buckets.ptr,
+                               long_flag);
+            hipLaunchKernelGGL((k_fixup_level<Ops>), dim3(1, nw), dim3(256), 0, stream, NB, parts1, flags1, pb1, t1, span2,
+                               parts2, flags2, pb2, 1u, ctx.buckets.ptr, long_flag);
             reduce_starts = starts;
         } else {
             hipLaunchKernelGGL((k_accumulate<F>), dim3((NB + 255) / 256, nw), dim3(256), 0, stream, d_points, n, NB, starts,
@@ -143,16 +169,16 @@ struct Group {
         // 4. bucket reduction -> window totals
         static bool red_attr_done = false;
         if (!red_attr_done) {
-            HIP_TRY(hipFuncSetAttribute((const void *)k_reduce1<F, RED_TPB>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)(RED_TPB * sizeof(Ext))));
-            HIP_TRY(hipFuncSetAttribute((const void *)k_reduce2<F, RED2_TPB>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)(RED2_TPB * sizeof(Ext))));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_reduce1<Ops, RED_TPB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(2 * RED_TPB * sizeof(OpsElem))));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_reduce2<Ops, RED2_TPB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(2 * RED2_TPB * sizeof(OpsElem))));
             red_attr_done = true;
         }
         timer.mark(STAGE_REDUCE);
-        hipLaunchKernelGGL((k_reduce1<F, RED_TPB>), dim3(nblocks1, nw), dim3(RED_TPB), RED_TPB * sizeof(Ext), stream,
+        hipLaunchKernelGGL((k_reduce1<Ops, RED_TPB>), dim3(nblocks1, nw), dim3(RED_TPB), 2 * RED_TPB * sizeof(OpsElem), stream,
                            ctx.buckets.ptr, NB, log2L, ctx.partials.ptr, reduce_starts);
-        hipLaunchKernelGGL((k_reduce2<F, RED2_TPB>), dim3(nw), dim3(RED2_TPB), RED2_TPB * sizeof(Ext), stream,
+        hipLaunchKernelGGL((k_reduce2<Ops, RED2_TPB>), dim3(nw), dim3(RED2_TPB), 2 * RED2_TPB * sizeof(OpsElem), stream,
                            ctx.partials.ptr, nblocks1, log2span, ctx.totals.ptr);
         timer.mark(STAGE_END);
         HIP_TRY(hipGetLastError());

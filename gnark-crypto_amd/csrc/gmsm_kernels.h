@@ -15,8 +15,7 @@
 // Sorted entry: (point_index << 1) | negate.
 #pragma once
 #include <hip/hip_runtime.h>
-#include "gmsm_curve.h"
-#include "gmsm_fieldu.h"
+#include "gmsm_curveu.h"
 
 namespace gmsm {
 
@@ -233,66 +232,6 @@ __global__ void __launch_bounds__(256) k_convert_points(const void *__restrict__
 }
 
 template <class P>
-struct XYZZU {
-    FpU<P> x, y, zz, zzz;
-};
-
-// acc = [2](px, py) for an affine (px, py): doubleMixed / doubleNegMixed (g1.go:933-985, dbl-2008-s-1 with ZZ = 1), on lazy
-// values; py is already negated by the caller for the subMixed case. Bounds (multiples of q): px < 2, py < 6.
-template <class P>
-__device__ __forceinline__ void double_mixed_u(XYZZU<P> &acc, const FpU<P> &px, const FpU<P> &py) {
-    const FpU<P> U = fpu_dbl(py);                                       // < 12
-    const FpU<P> V = fpu_sqr(U);                                        // < 2
-    const FpU<P> W = fpu_mul(U, V);                                     // < 2
-    const FpU<P> S = fpu_mul(px, V);                                    // < 2
-    const FpU<P> XX = fpu_sqr(px);                                      // < 2
-    const FpU<P> M = fpu_add(fpu_add(XX, XX), XX);                      // < 6
-    const FpU<P> X3 = fpu_sub<P, 4>(fpu_sqr(M), fpu_dbl(S));            // < 2 + 4
-    const FpU<P> Y3 = fpu_sub<P, 4>(fpu_mul(fpu_sub<P, 16>(S, X3), M), fpu_mul(W, py));  // < 2 + 4
-    acc.x = X3;
-    acc.y = Y3;
-    acc.zz = V;
-    acc.zzz = W;
-}
-
-// acc += (+-)(px, py); madd-2008-s (g1.go:822-873) on lazy values. Bounds in multiples of q (BN254, 2^261/q = 169;
-// mul(a,b) < ab/169 + 1):  ZZ,ZZZ,PP.. < 3;  acc.x < 11, acc.y < 7;  Pv,Rv < 18.
-template <class P>
-__device__ __forceinline__ void madd_u(XYZZU<P> &acc, bool &inf, const FpU<P> &px, const FpU<P> &py_in, bool negate) {
-    if (inf) {
-        acc.x = px;
-        acc.y = negate ? fpu_neg4<P>(py_in) : py_in;
-#pragma unroll
-        for (int i = 0; i < P::UL; ++i) acc.zz.l[i] = acc.zzz.l[i] = P::UONE[i];
-        inf = false;
-        return;
-    }
-    const FpU<P> py = negate ? fpu_neg4<P>(py_in) : py_in;           // < 6
-    const FpU<P> Pv = fpu_sub<P, 16>(fpu_mul(px, acc.zz), acc.x);    // < 18
-    const FpU<P> Rv = fpu_sub<P, 16>(fpu_mul(py, acc.zzz), acc.y);   // < 18
-    const FpU<P> PP = fpu_sqr(Pv);                                   // < 3
-    // Pv == 0 mod q  <=>  PP == 0 mod q (q prime); PP is a normalised product < 3q: cheap pre-filter on its low limb
-    const uint32_t l0 = PP.l[0];
-    if (l0 == 0u || l0 == P::UQ1[0] || l0 == P::UQ2[0]) {
-        if (fpu_is_zero_lt3q(PP)) {
-            // same x-coordinate (g1.go:846-854): acc == +-(px, py). Rv == 0 mod q <=> Rv^2 == 0 mod q.
-            if (fpu_is_zero_lt3q(fpu_sqr(Rv))) double_mixed_u<P>(acc, px, py);  // P + P
-            else inf = true;                                                    // P + (-P)
-            return;
-        }
-    }
-    const FpU<P> PPP = fpu_mul(Pv, PP);                              // < 2
-    const FpU<P> Q = fpu_mul(acc.x, PP);                             // < 2
-    const FpU<P> RR = fpu_sqr(Rv);                                   // < 3
-    const FpU<P> X3 = fpu_sub<P, 4>(fpu_sub<P, 4>(RR, PPP), fpu_dbl(Q));      // < 3 + 4 + 4 = 11
-    const FpU<P> Y3 = fpu_sub<P, 4>(fpu_mul(fpu_sub<P, 16>(Q, X3), Rv), fpu_mul(acc.y, PPP));  // < 3 + 4 = 7
-    acc.x = X3;
-    acc.y = Y3;
-    acc.zz = fpu_mul(acc.zz, PP);
-    acc.zzz = fpu_mul(acc.zzz, PPP);
-}
-
-template <class P>
 __global__ void __launch_bounds__(256) k_accumulate_u(const void *__restrict__ upoints, size_t n, uint32_t nbuckets,
                                                       const uint32_t *__restrict__ starts,
                                                       const uint32_t *__restrict__ sorted, void *__restrict__ buckets) {
@@ -422,25 +361,94 @@ __global__ void __launch_bounds__(256, GMSM_ACC_MINW) k_accumulate_seg(const voi
     pflags[tg] = flags;
 }
 
-// One thread per accumulation thread: the thread whose last run opened a split bucket (HAS_P1) adds the chain of
-// partials that follow it and stores the bucket.
-template <class F>
+// Chain fixup. A split bucket is a chain  P1[t0], P0[t0+1], ..., P0[t1]  of partial sums of consecutive accumulation
+// threads.  k_fixup_seg: the thread that owns the chain head adds up to MAXWALK followers (random scalars: 1); a
+// longer chain (tiny top window, repeated scalars, every scalar equal) raises long_flag[window] and is left to
+// k_fixup_level, which re-reduces all chains of a flagged window hierarchically: each thread walks `span`
+// consecutive threads of the previous level, stores chains that close inside its span, and emits at most two open
+// partials in the same (flags, partials, pbucket) format for the next level.  The host launches two levels with
+// spans that cover any n < 2^31; a level is a no-op for windows whose flag is clear.
+template <class A>
 __global__ void __launch_bounds__(256) k_fixup_seg(uint32_t nbuckets, const void *__restrict__ partials,
                                                    const uint32_t *__restrict__ pflags, const uint32_t *__restrict__ pbucket,
-                                                   uint32_t threads_per_win, void *__restrict__ buckets) {
+                                                   uint32_t threads_per_win, void *__restrict__ buckets,
+                                                   uint32_t *__restrict__ long_flag) {
+    constexpr uint32_t MAXWALK = 3;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
     if (t >= threads_per_win) return;
     const size_t base = (size_t)k * threads_per_win;
     if (!(pflags[base + t] & SegFlags::HAS_P1)) return;
-    XYZZ<F> acc = load_struct<XYZZ<F>>(partials, (base + t) * 2 + 1);
-    for (uint32_t u = t + 1; u < threads_per_win; ++u) {
+    typename A::Elem acc = A::load(partials, (base + t) * 2 + 1);
+    bool closed = false;
+    for (uint32_t u = t + 1; u < threads_per_win && u <= t + MAXWALK; ++u) {
         const uint32_t f = pflags[base + u];
-        if (!(f & SegFlags::HAS_P0)) break;
-        XYZZ<F> q = load_struct<XYZZ<F>>(partials, (base + u) * 2 + 0);
-        xyzz_add(acc, q);
-        if (!(f & SegFlags::P0_OPEN_RIGHT)) break;
+        if (!(f & SegFlags::HAS_P0)) { closed = true; break; }
+        typename A::Elem q = A::load(partials, (base + u) * 2 + 0);
+        A::add(acc, q);
+        if (!(f & SegFlags::P0_OPEN_RIGHT)) { closed = true; break; }
     }
-    store_struct(buckets, (size_t)k * nbuckets + pbucket[base + t], acc);
+    if (closed) A::store(buckets, (size_t)k * nbuckets + pbucket[base + t], acc);
+    else long_flag[k] = 1u;  // benign race: every writer stores 1
+}
+
+// grid = (ceil(t_out/256), nwin). Level input: t_in threads per window; output: t_out = ceil(t_in/span).
+template <class A>
+__global__ void __launch_bounds__(256) k_fixup_level(uint32_t nbuckets, const void *__restrict__ parts_in,
+                                                     const uint32_t *__restrict__ flags_in,
+                                                     const uint32_t *__restrict__ pbucket_in, uint32_t t_in, uint32_t span,
+                                                     void *__restrict__ parts_out, uint32_t *__restrict__ flags_out,
+                                                     uint32_t *__restrict__ pbucket_out, uint32_t t_out,
+                                                     void *__restrict__ buckets, const uint32_t *__restrict__ long_flag) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (u >= t_out) return;
+    const size_t obase = (size_t)k * t_out;
+    if (!long_flag[k]) {
+        flags_out[obase + u] = 0;
+        return;
+    }
+    const size_t ibase = (size_t)k * t_in;
+    const uint32_t lo = u * span, hi = (t_in - lo > span) ? lo + span : t_in;
+    typename A::Elem acc = A::infinity();
+    bool valid = false, open_left = false;
+    uint32_t dest = 0, oflags = 0;
+    for (uint32_t t = lo; t < hi; ++t) {
+        const uint32_t f = flags_in[ibase + t];
+        if (f & SegFlags::HAS_P0) {
+            if (!valid) {  // the chain's head lies before this span
+                valid = true;
+                open_left = true;
+                acc = A::infinity();
+            }
+            typename A::Elem q = A::load(parts_in, (ibase + t) * 2 + 0);
+            A::add(acc, q);
+            if (!(f & SegFlags::P0_OPEN_RIGHT)) {  // chain closes here
+                if (open_left) {
+                    A::store(parts_out, (obase + u) * 2 + 0, acc);
+                    oflags |= SegFlags::HAS_P0;
+                } else {
+                    A::store(buckets, (size_t)k * nbuckets + dest, acc);
+                }
+                valid = false;
+            }
+        }
+        if (f & SegFlags::HAS_P1) {  // a new chain starts (any previous one closed at this thread's P0)
+            acc = A::load(parts_in, (ibase + t) * 2 + 1);
+            valid = true;
+            open_left = false;
+            dest = pbucket_in[ibase + t];
+        }
+    }
+    if (valid) {  // chain continues into the next span
+        if (open_left) {
+            A::store(parts_out, (obase + u) * 2 + 0, acc);
+            oflags |= SegFlags::HAS_P0 | SegFlags::P0_OPEN_RIGHT;
+        } else {
+            A::store(parts_out, (obase + u) * 2 + 1, acc);
+            oflags |= SegFlags::HAS_P1;
+            pbucket_out[obase + u] = dest;
+        }
+    }
+    flags_out[obase + u] = oflags;
 }
 
 // ------------------------------------------------------------------ bucket reduction
@@ -450,67 +458,62 @@ __global__ void __launch_bounds__(256) k_fixup_seg(uint32_t nbuckets, const void
 //   level 2 (k_reduce2): one block per window combines the level-1 block results the same way.
 // Identity used:  sum_{k in [base, base+T*L)} (k-base+1) B_k = sum_t W_t + L * sum_{t>=1} Suf_t,
 //   S_t = sum of segment t, W_t = sum_{k in seg t} (k-lo_t+1) B_k, Suf_t = sum_{t'>=t} S_t'.
-template <class F, int TPB>
-__device__ __forceinline__ void block_combine(XYZZ<F> S, XYZZ<F> W, uint32_t log2L, XYZZ<F> *lds, XYZZ<F> &S_out,
-                                              XYZZ<F> &W_out) {
+template <class A, int TPB>
+__device__ __forceinline__ void block_combine(typename A::Elem S, typename A::Elem W, uint32_t log2L, typename A::Elem *lds,
+                                              typename A::Elem &S_out, typename A::Elem &W_out) {
+    using E = typename A::Elem;
     const uint32_t t = threadIdx.x;
     // inclusive suffix scan of S over threads (Hillis-Steele)
     lds[t] = S;
     __syncthreads();
-    XYZZ<F> suf = S;
+    E suf = S;
     for (uint32_t d = 1; d < TPB; d <<= 1) {
-        XYZZ<F> o = XYZZ<F>::infinity();
+        E o = A::infinity();
         if (t + d < TPB) o = lds[t + d];
         __syncthreads();
-        xyzz_add(suf, o);
+        A::add(suf, o);
         lds[t] = suf;
         __syncthreads();
     }
     S_out = lds[0];
     __syncthreads();
-    // U = sum_{t>=1} Suf_t ; V = sum_t W_t   (tree reductions)
-    XYZZ<F> U = t >= 1 ? suf : XYZZ<F>::infinity();
+    // U = sum_{t>=1} Suf_t ; V = sum_t W_t   (one tree, two sums per level)
+    E U = t >= 1 ? suf : A::infinity();
+    E *ldsW = lds + TPB;
     lds[t] = U;
+    ldsW[t] = W;
     __syncthreads();
     for (uint32_t d = TPB / 2; d >= 1; d >>= 1) {
         if (t < d) {
-            XYZZ<F> o = lds[t + d];
-            xyzz_add(U, o);
+            E o = lds[t + d];
+            A::add(U, o);
             lds[t] = U;
-        }
-        __syncthreads();
-    }
-    U = lds[0];
-    __syncthreads();
-    lds[t] = W;
-    __syncthreads();
-    for (uint32_t d = TPB / 2; d >= 1; d >>= 1) {
-        if (t < d) {
-            XYZZ<F> o = lds[t + d];
-            xyzz_add(W, o);
-            lds[t] = W;
+            E o2 = ldsW[t + d];
+            A::add(W, o2);
+            ldsW[t] = W;
         }
         __syncthreads();
     }
     if (t == 0) {
-        for (uint32_t i = 0; i < log2L; ++i) U = xyzz_double(U);
-        xyzz_add(W, U);
+        for (uint32_t i = 0; i < log2L; ++i) A::dbl(U);
+        A::add(W, U);
         W_out = W;
     }
 }
 
 // grid = (nblocks1, nwin_local), block = TPB threads, each thread L = 2^log2L buckets.
 // out1[(k*nblocks1 + blk)*2 + {0,1}] = (S_blk, W_blk)
-template <class F, int TPB>
+template <class A, int TPB>
 __global__ void __launch_bounds__(TPB) k_reduce1(const void *__restrict__ buckets, uint32_t nbuckets, uint32_t log2L,
                                                  void *__restrict__ out1,
                                                  const uint32_t *__restrict__ starts /* null: every bucket is stored */) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    XYZZ<F> *lds = reinterpret_cast<XYZZ<F> *>(lds_raw);
+    using E = typename A::Elem;
+    E *lds = reinterpret_cast<E *>(lds_raw);
     const uint32_t k = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
     const uint32_t L = 1u << log2L;
     const uint32_t lo = (blk * TPB + t) * L;
-    XYZZ<F> run = XYZZ<F>::infinity(), tot = XYZZ<F>::infinity();
+    E run = A::infinity(), tot = A::infinity();
     for (uint32_t j = L; j-- > 0;) {
         const uint32_t b = lo + j;
         bool present = b < nbuckets;
@@ -519,35 +522,36 @@ __global__ void __launch_bounds__(TPB) k_reduce1(const void *__restrict__ bucket
             present = st[b + 1] > st[b];
         }
         if (present) {
-            XYZZ<F> B = load_struct<XYZZ<F>>(buckets, (size_t)k * nbuckets + b);
-            xyzz_add(run, B);
+            E B = A::load(buckets, (size_t)k * nbuckets + b);
+            A::add(run, B);
         }
-        xyzz_add(tot, run);
+        A::add(tot, run);
     }
-    XYZZ<F> S_out, W_out;
-    block_combine<F, TPB>(run, tot, log2L, lds, S_out, W_out);
+    E S_out, W_out;
+    block_combine<A, TPB>(run, tot, log2L, lds, S_out, W_out);
     if (t == 0) {
-        store_struct(out1, ((size_t)k * gridDim.x + blk) * 2 + 0, S_out);
-        store_struct(out1, ((size_t)k * gridDim.x + blk) * 2 + 1, W_out);
+        A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 0, S_out);
+        A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 1, W_out);
     }
 }
 
 // grid = nwin_local, block = TPB >= nblocks1 threads. Thread j holds level-1 block j: (S_j, W_j) covering
 // TPB1*L buckets = 2^log2span. window_total[k] = sum_j W_j + span * sum_j j*S_j.
-template <class F, int TPB>
+template <class A, int TPB>
 __global__ void __launch_bounds__(TPB) k_reduce2(const void *__restrict__ in1, uint32_t nblocks1, uint32_t log2span,
                                                  void *__restrict__ window_totals) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    XYZZ<F> *lds = reinterpret_cast<XYZZ<F> *>(lds_raw);
+    using E = typename A::Elem;
+    E *lds = reinterpret_cast<E *>(lds_raw);
     const uint32_t k = blockIdx.x, t = threadIdx.x;
-    XYZZ<F> S = XYZZ<F>::infinity(), W = XYZZ<F>::infinity();
+    E S = A::infinity(), W = A::infinity();
     if (t < nblocks1) {
-        S = load_struct<XYZZ<F>>(in1, ((size_t)k * nblocks1 + t) * 2 + 0);
-        W = load_struct<XYZZ<F>>(in1, ((size_t)k * nblocks1 + t) * 2 + 1);
+        S = A::load(in1, ((size_t)k * nblocks1 + t) * 2 + 0);
+        W = A::load(in1, ((size_t)k * nblocks1 + t) * 2 + 1);
     }
-    XYZZ<F> S_out, W_out;
-    block_combine<F, TPB>(S, W, log2span, lds, S_out, W_out);
-    if (t == 0) store_struct(window_totals, k, W_out);
+    E S_out, W_out;
+    block_combine<A, TPB>(S, W, log2span, lds, S_out, W_out);
+    if (t == 0) A::store(window_totals, k, W_out);
 }
 
 }  // namespace gmsm

@@ -234,3 +234,33 @@ def test_msm_bn254_g1_2p20_config(gm, oracle_mod):
     got = _msm_gpu_affine(g, pts, sc)
     exp = o.msm_affine(pts, sc, c=16, nthreads=16)
     assert (got == exp).all()
+
+
+@pytest.mark.parametrize("curve,which", [("bn254", "g1"), ("bls12_381", "g1"), ("bn254", "g2")])
+def test_msm_skewed_bucket_distributions(gm, oracle_mod, curve, which):
+    """Distributions that put very many points in one bucket (long partial-sum chains in the segmented accumulation):
+    all scalars equal, runs of 100 equal scalars ("redundancy", multiexp_test.go:327-334), every 5th scalar = raw limb 1
+    ("smallvalues", :319-325), a single repeated base, and window sizes whose top window has only a few bits."""
+    import torch
+    g = _group(gm, curve, which)
+    o = oracle_mod.Oracle(curve, which)
+    n = 20000 if which == "g1" else 6000
+    rng = rng_for(7, g.gid)
+    pts = o.gen_points(n, 12345, 999, nthreads=8)
+    sc = random_scalars(rng, g.curve, n)
+    equal = np.tile(sc[:1], (n, 1))
+    assert (_msm_gpu_affine(g, pts, equal) == o.msm_affine(pts, equal, nthreads=8)).all()
+    redundancy = np.repeat(sc[: (n + 99) // 100], 100, axis=0)[:n]
+    assert (_msm_gpu_affine(g, pts, redundancy) == o.msm_affine(pts, redundancy, nthreads=8)).all()
+    small = sc.copy()
+    small[::5] = 0
+    small[::5, 0] = 1
+    assert (_msm_gpu_affine(g, pts, small) == o.msm_affine(pts, small, nthreads=8)).all()
+    same_base = np.tile(pts[:1], (n, 1))
+    assert (_msm_gpu_affine(g, same_base, equal) == o.msm_affine(same_base, equal, nthreads=8)).all()
+    assert (_msm_gpu_affine(g, same_base, sc) == o.msm_affine(same_base, sc, nthreads=8)).all()
+    d_pts = torch.from_numpy(pts.view(np.int64)).cuda()
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    for c in (9, 12, 13, 14):
+        w = g.window_sums_device(d_pts.data_ptr(), d_sc.data_ptr(), n, c)
+        assert (g.jac_to_affine(g.fold_windows(w, c)) == o.msm_affine(pts, sc, c=c, nthreads=8)).all(), c
