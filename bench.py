@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--logn", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--curve", default="bn254", help="exploration only: bn254 | bls12_381 | bw6_761")
+    ap.add_argument("--group", default="g1", help="exploration only: g1 | g2")
     args = ap.parse_args()
 
     import torch
@@ -55,7 +57,7 @@ def main():
     gm = importlib.import_module("gnark-crypto_amd")
     lib = gm._lib.load()
     assert lib.gmsm_set_device(local_rank) == 0, gm._lib.last_error()
-    g = gm.G1Jac("bn254")
+    g = (gm.G1Jac if args.group == "g1" else gm.G2Jac)(args.curve)
     n = 1 << args.logn
 
     # synthetic, deterministic, on-curve inputs: P_i = [k0 + i*k1] G; scalars uniform (stored limbs
@@ -63,15 +65,17 @@ def main():
     rng = np.random.default_rng([0x6D736D, args.logn])
     k0, k1 = int(rng.integers(1, 2**62)), int(rng.integers(1, 2**62))
     pts = g.generate_points(n, k0, k1)
-    sc = np.zeros((n, 4), dtype=np.uint64)
+    nl = g.fr_limbs
+    sc = np.zeros((n, nl), dtype=np.uint64)
     todo = np.arange(n)
-    r_limbs = [(g.curve.r >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+    r_limbs = [(g.curve.r >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(nl)]
+    top_bits = g.curve.fr_bits - 64 * (nl - 1)
     while todo.size:
-        cand = rng.integers(0, 2**64, size=(todo.size, 4), dtype=np.uint64)
-        cand[:, 3] &= np.uint64((1 << 62) - 1)
+        cand = rng.integers(0, 2**64, size=(todo.size, nl), dtype=np.uint64)
+        cand[:, nl - 1] &= np.uint64((1 << top_bits) - 1)
         lt = np.zeros(todo.size, dtype=bool)
         eq = np.ones(todo.size, dtype=bool)
-        for i in (3, 2, 1, 0):
+        for i in range(nl - 1, -1, -1):
             lt |= eq & (cand[:, i] < np.uint64(r_limbs[i]))
             eq &= cand[:, i] == np.uint64(r_limbs[i])
         sc[todo[lt]] = cand[lt]
@@ -124,7 +128,8 @@ def main():
         ncalls = max(1, calls.value)
         stages = {name: stage_ms[i] / ncalls for i, name in enumerate(STAGES)}
         acc_ms = stages["accumulate"]
-        algorithmic_bytes = 96 * n * (len(range(rank, nwin, world)) / nwin)  # this rank's share of the windows
+        bytes_per_point = 8 * (g.aff_limbs + g.fr_limbs)  # affine point + scalar (BN254 G1: 96 B)
+        algorithmic_bytes = bytes_per_point * n * (len(range(rank, nwin, world)) / nwin)  # this rank's share of the windows
         achieved = algorithmic_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
         # integer roofline of the same kernel: 10 field mul per mixed add (8M+2S, g1.go:822), n*(windows of this rank)
         # mixed adds, each mul = 2*8^2+8 = 136 v_mad_u64_u32-class ops at 4 cycles / wave64 / SIMD (measured,
@@ -133,10 +138,10 @@ def main():
         mulmods_per_s = madds * 10 / (acc_ms * 1e-3) if acc_ms > 0 else 0.0
         int_peak = 1024 * 64 / 4 * 2.4e9 / 136
         out = {
-            "metric": "G1 MSM/sec (BN254)", "value": value, "unit": "MSM/s", "n_gpus": world, "steps": args.steps,
+            "metric": "G1 MSM/sec (BN254)" if (args.curve, args.group) == ("bn254", "g1") else f"{args.group.upper()} MSM/sec ({args.curve})", "value": value, "unit": "MSM/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u32 limbs (256-bit Montgomery)", "data": "synthetic",
-            "config": {"workload": f"BN254 G1 MultiExp 2^{args.logn} points, bases+scalars resident in HBM",
+            "config": {"workload": f"{args.curve.upper()} {args.group.upper()} MultiExp 2^{args.logn} points, bases+scalars resident in HBM",
                        "points": n, "window_bits": c, "windows": nwin,
                        "parallelism": "single GPU" if world == 1 else f"window-sharded x{world} + RCCL all-gather"},
             "points_per_s": value * n,
@@ -148,20 +153,20 @@ def main():
                              "frac": mulmods_per_s / int_peak},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out.update(cpu_baseline(g, pts, sc, jac))
+            out.update(cpu_baseline(g, pts, sc, jac, args.curve, args.group))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(g, pts, sc, gpu_jac):
+def cpu_baseline(g, pts, sc, gpu_jac, curve="bn254", group="g1"):
     """The oracle = C restatement of gnark-crypto's MultiExp (bestC, split recursion, one task per (leaf, window),
     extended-Jacobian buckets; the batch-affine bucket variant is off), on all host cores.  Bounded: repeats whole
     MSMs until ~10 s have elapsed (at least 1)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle  # test infrastructure, used here only as the reported baseline and the checker
-    o = oracle.Oracle("bn254", "g1")
+    o = oracle.Oracle(curve, group)
     cores = os.cpu_count() or 1
     reps, t_total, jac = 0, 0.0, None
     while reps < 1 or (t_total < 10.0 and reps < 50):

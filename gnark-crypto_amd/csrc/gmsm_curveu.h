@@ -37,16 +37,16 @@ GMSM_HD bool fpu_prod_is_zero(const FpU<P> &a) {
 }
 
 // acc = [2](px, py), affine input (doubleMixed / doubleNegMixed, g1.go:933-985); px < 2, py < 6.
-template <class P>
+template <class P, bool INL = true>
 GMSM_HD void double_mixed_u(XYZZU<P> &acc, const FpU<P> &px, const FpU<P> &py) {
     const FpU<P> U = fpu_dbl(py);                                       // < 12
-    const FpU<P> V = fpu_sqr(U);                                        // < 2
-    const FpU<P> W = fpu_mul(U, V);                                     // < 2
-    const FpU<P> S = fpu_mul(px, V);                                    // < 2
-    const FpU<P> XX = fpu_sqr(px);                                      // < 2
+    const FpU<P> V = fsqr<INL>(U);                                        // < 2
+    const FpU<P> W = fmul<INL>(U, V);                                     // < 2
+    const FpU<P> S = fmul<INL>(px, V);                                    // < 2
+    const FpU<P> XX = fsqr<INL>(px);                                      // < 2
     const FpU<P> M = fpu_add(fpu_add(XX, XX), XX);                      // < 6
-    const FpU<P> X3 = fpu_sub<P, 4>(fpu_sqr(M), fpu_dbl(S));            // < 6
-    const FpU<P> Y3 = fpu_sub<P, 4>(fpu_mul(fpu_sub<P, 16>(S, X3), M), fpu_mul(W, py));  // < 6
+    const FpU<P> X3 = fpu_sub<P, 4>(fsqr<INL>(M), fpu_dbl(S));            // < 6
+    const FpU<P> Y3 = fpu_sub<P, 4>(fmul<INL>(fpu_sub<P, 16>(S, X3), M), fmul<INL>(W, py));  // < 6
     acc.x = X3;
     acc.y = Y3;
     acc.zz = V;
@@ -54,7 +54,7 @@ GMSM_HD void double_mixed_u(XYZZU<P> &acc, const FpU<P> &px, const FpU<P> &py) {
 }
 
 // acc += (+-)(px, py): addMixed / subMixed (g1.go:822-930, madd-2008-s). px, py_in < 2.
-template <class P>
+template <class P, bool INL = true>
 GMSM_HD void madd_u(XYZZU<P> &acc, bool &inf, const FpU<P> &px, const FpU<P> &py_in, bool negate) {
     const FpU<P> py = negate ? fpu_neg4<P>(py_in) : py_in;           // < 6
     if (inf) {
@@ -65,44 +65,44 @@ GMSM_HD void madd_u(XYZZU<P> &acc, bool &inf, const FpU<P> &px, const FpU<P> &py
         inf = false;
         return;
     }
-    const FpU<P> Pv = fpu_sub<P, 16>(fpu_mul(px, acc.zz), acc.x);    // < 18
-    const FpU<P> Rv = fpu_sub<P, 16>(fpu_mul(py, acc.zzz), acc.y);   // < 18
-    const FpU<P> PP = fpu_sqr(Pv);                                   // < 3
+    const FpU<P> Pv = fpu_sub<P, 16>(fmul<INL>(px, acc.zz), acc.x);    // < 18
+    const FpU<P> Rv = fpu_sub<P, 16>(fmul<INL>(py, acc.zzz), acc.y);   // < 18
+    const FpU<P> PP = fsqr<INL>(Pv);                                   // < 3
     if (fpu_prod_is_zero(PP)) {                                      // same x (g1.go:846-854); Pv == 0 <=> Pv^2 == 0
-        if (fpu_prod_is_zero(fpu_sqr(Rv))) double_mixed_u<P>(acc, px, py);  // P + P
+        if (fpu_prod_is_zero(fsqr<INL>(Rv))) double_mixed_u<P, INL>(acc, px, py);  // P + P
         else inf = true;                                                    // P + (-P)
         return;
     }
-    const FpU<P> PPP = fpu_mul(Pv, PP);                              // < 2
-    const FpU<P> Q = fpu_mul(acc.x, PP);                             // < 2
-    const FpU<P> RR = fpu_sqr(Rv);                                   // < 3
+    const FpU<P> PPP = fmul<INL>(Pv, PP);                              // < 2
+    const FpU<P> Q = fmul<INL>(acc.x, PP);                             // < 2
+    const FpU<P> RR = fsqr<INL>(Rv);                                   // < 3
     const FpU<P> X3 = fpu_sub<P, 4>(fpu_sub<P, 4>(RR, PPP), fpu_dbl(Q));                       // < 11
-    const FpU<P> Y3 = fpu_sub<P, 4>(fpu_mul(fpu_sub<P, 16>(Q, X3), Rv), fpu_mul(acc.y, PPP));  // < 7
+    const FpU<P> Y3 = fpu_sub<P, 4>(fmul<INL>(fpu_sub<P, 16>(Q, X3), Rv), fmul<INL>(acc.y, PPP));  // < 7
     acc.x = X3;
     acc.y = Y3;
-    acc.zz = fpu_mul(acc.zz, PP);
-    acc.zzz = fpu_mul(acc.zzz, PPP);
+    acc.zz = fmul<INL>(acc.zz, PP);
+    acc.zzz = fmul<INL>(acc.zzz, PPP);
 }
 
 // r = [2]q (g1.go:795-817, dbl-2008-s-1, a = 0); q not infinity.
-template <class P>
+template <class P, bool INL = true>
 GMSM_HD XYZZU<P> double_u(const XYZZU<P> &q) {
     const FpU<P> U = fpu_dbl(q.y);                                      // < 14
-    const FpU<P> V = fpu_sqr(U);                                        // < 3
-    const FpU<P> W = fpu_mul(U, V);                                     // < 2
-    const FpU<P> S = fpu_mul(q.x, V);                                   // < 2
-    const FpU<P> XX = fpu_sqr(q.x);                                     // < 2
+    const FpU<P> V = fsqr<INL>(U);                                        // < 3
+    const FpU<P> W = fmul<INL>(U, V);                                     // < 2
+    const FpU<P> S = fmul<INL>(q.x, V);                                   // < 2
+    const FpU<P> XX = fsqr<INL>(q.x);                                     // < 2
     const FpU<P> M = fpu_add(fpu_add(XX, XX), XX);                      // < 6
     XYZZU<P> r;
-    r.x = fpu_sub<P, 4>(fpu_sqr(M), fpu_dbl(S));                        // < 6
-    r.y = fpu_sub<P, 4>(fpu_mul(fpu_sub<P, 16>(S, r.x), M), fpu_mul(W, q.y));  // < 6
-    r.zz = fpu_mul(V, q.zz);
-    r.zzz = fpu_mul(W, q.zzz);
+    r.x = fpu_sub<P, 4>(fsqr<INL>(M), fpu_dbl(S));                        // < 6
+    r.y = fpu_sub<P, 4>(fmul<INL>(fpu_sub<P, 16>(S, r.x), M), fmul<INL>(W, q.y));  // < 6
+    r.zz = fmul<INL>(V, q.zz);
+    r.zzz = fmul<INL>(W, q.zzz);
     return r;
 }
 
 // p += q (g1.go:736-788, add-2008-s), infinity carried as flags.
-template <class P>
+template <class P, bool INL = true>
 GMSM_HD void add_u(XYZZU<P> &p, bool &pinf, const XYZZU<P> &q, bool qinf) {
     if (qinf) return;
     if (pinf) {
@@ -110,26 +110,26 @@ GMSM_HD void add_u(XYZZU<P> &p, bool &pinf, const XYZZU<P> &q, bool qinf) {
         pinf = false;
         return;
     }
-    const FpU<P> U2 = fpu_mul(q.x, p.zz);                               // < 2
-    const FpU<P> U1 = fpu_mul(p.x, q.zz);                               // < 2
-    const FpU<P> S2 = fpu_mul(q.y, p.zzz);                              // < 2
-    const FpU<P> S1 = fpu_mul(p.y, q.zzz);                              // < 2
+    const FpU<P> U2 = fmul<INL>(q.x, p.zz);                               // < 2
+    const FpU<P> U1 = fmul<INL>(p.x, q.zz);                               // < 2
+    const FpU<P> S2 = fmul<INL>(q.y, p.zzz);                              // < 2
+    const FpU<P> S1 = fmul<INL>(p.y, q.zzz);                              // < 2
     const FpU<P> A = fpu_sub<P, 4>(U2, U1);                             // < 6
     const FpU<P> B = fpu_sub<P, 4>(S2, S1);                             // < 6
-    const FpU<P> PP = fpu_sqr(A);                                       // < 2
+    const FpU<P> PP = fsqr<INL>(A);                                       // < 2
     if (fpu_prod_is_zero(PP)) {
-        if (fpu_prod_is_zero(fpu_sqr(B))) p = double_u<P>(q);
+        if (fpu_prod_is_zero(fsqr<INL>(B))) p = double_u<P, INL>(q);
         else pinf = true;
         return;
     }
-    const FpU<P> PPP = fpu_mul(A, PP);                                  // < 2
-    const FpU<P> Q = fpu_mul(U1, PP);                                   // < 2
-    const FpU<P> V = fpu_mul(S1, PPP);                                  // < 2
-    const FpU<P> X3 = fpu_sub<P, 4>(fpu_sub<P, 4>(fpu_sqr(B), PPP), fpu_dbl(Q));  // < 2 + 4 + 4
-    p.y = fpu_sub<P, 4>(fpu_mul(fpu_sub<P, 16>(Q, X3), B), V);          // < 6
+    const FpU<P> PPP = fmul<INL>(A, PP);                                  // < 2
+    const FpU<P> Q = fmul<INL>(U1, PP);                                   // < 2
+    const FpU<P> V = fmul<INL>(S1, PPP);                                  // < 2
+    const FpU<P> X3 = fpu_sub<P, 4>(fpu_sub<P, 4>(fsqr<INL>(B), PPP), fpu_dbl(Q));  // < 2 + 4 + 4
+    p.y = fpu_sub<P, 4>(fmul<INL>(fpu_sub<P, 16>(Q, X3), B), V);          // < 6
     p.x = X3;
-    p.zz = fpu_mul(fpu_mul(p.zz, q.zz), PP);
-    p.zzz = fpu_mul(fpu_mul(p.zzz, q.zzz), PPP);
+    p.zz = fmul<INL>(fmul<INL>(p.zz, q.zz), PP);
+    p.zzz = fmul<INL>(fmul<INL>(p.zzz, q.zzz), PPP);
 }
 
 // ------------------------------------------------------------------ arithmetic policies
@@ -168,44 +168,74 @@ struct SatOps {
 };
 
 template <class P>
+struct UnsatElem {
+    XYZZU<P> v;
+    bool inf;
+};
+
+template <class P, bool INL>
+__device__ __forceinline__ UnsatElem<P> unsat_load(const void *base, size_t i) {
+    using Mem = XYZZ<Fp<P>>;
+    const Mem m = policy_load<Mem>(base, i);
+    UnsatElem<P> e;
+    e.inf = m.zz.is_zero();
+    e.v.x = fpu_from_sat<P, INL>(m.x);
+    e.v.y = fpu_from_sat<P, INL>(m.y);
+    e.v.zz = fpu_from_sat<P, INL>(m.zz);
+    e.v.zzz = fpu_from_sat<P, INL>(m.zzz);
+    return e;
+}
+
+template <class P, bool INL>
+__device__ __forceinline__ void unsat_store(void *base, size_t i, const UnsatElem<P> &e) {
+    using Mem = XYZZ<Fp<P>>;
+    Mem m = Mem::infinity();
+    if (!e.inf) {
+        m.x = fpu_to_sat<P, INL>(e.v.x);
+        m.y = fpu_to_sat<P, INL>(e.v.y);
+        m.zz = fpu_to_sat<P, INL>(e.v.zz);
+        m.zzz = fpu_to_sat<P, INL>(e.v.zzz);
+    }
+    policy_store<Mem>(base, i, m);
+}
+
+template <class P>
+__device__ __forceinline__ UnsatElem<P> unsat_infinity() {
+    UnsatElem<P> e;
+    e.inf = true;
+    e.v.x = e.v.y = fpu_one<P>();
+    e.v.zz = e.v.zzz = fpu_one<P>();
+    return e;
+}
+
+// Fully inlined policy: fastest when the kernel holds few call sites (k_fixup_seg, k_reduce1/2).
+template <class P>
 struct UnsatOps {
     using Field = Fp<P>;
     using Mem = XYZZ<Fp<P>>;
-    struct Elem {
-        XYZZU<P> v;
-        bool inf;
-    };
-    __device__ static __forceinline__ Elem infinity() {
-        Elem e;
-        e.inf = true;
-        e.v.x = e.v.y = fpu_one<P>();
-        e.v.zz = e.v.zzz = fpu_one<P>();
-        return e;
-    }
-    __device__ static __forceinline__ Elem load(const void *base, size_t i) {
-        const Mem m = policy_load<Mem>(base, i);
-        Elem e;
-        e.inf = m.zz.is_zero();
-        e.v.x = fpu_from_sat(m.x);
-        e.v.y = fpu_from_sat(m.y);
-        e.v.zz = fpu_from_sat(m.zz);
-        e.v.zzz = fpu_from_sat(m.zzz);
-        return e;
-    }
-    __device__ static __forceinline__ Mem to_mem(const Elem &e) {
-        Mem m = Mem::infinity();
-        if (!e.inf) {
-            m.x = fpu_to_sat(e.v.x);
-            m.y = fpu_to_sat(e.v.y);
-            m.zz = fpu_to_sat(e.v.zz);
-            m.zzz = fpu_to_sat(e.v.zzz);
-        }
-        return m;
-    }
-    __device__ static __forceinline__ void store(void *base, size_t i, const Elem &e) { policy_store<Mem>(base, i, to_mem(e)); }
-    __device__ static __forceinline__ void add(Elem &p, const Elem &q) { add_u<P>(p.v, p.inf, q.v, q.inf); }
+    using Elem = UnsatElem<P>;
+    __device__ static __forceinline__ Elem infinity() { return unsat_infinity<P>(); }
+    __device__ static __forceinline__ Elem load(const void *base, size_t i) { return unsat_load<P, true>(base, i); }
+    __device__ static __forceinline__ void store(void *base, size_t i, const Elem &e) { unsat_store<P, true>(base, i, e); }
+    __device__ static __forceinline__ void add(Elem &p, const Elem &q) { add_u<P, true>(p.v, p.inf, q.v, q.inf); }
     __device__ static __forceinline__ void dbl(Elem &p) {
-        if (!p.inf) p.v = double_u<P>(p.v);
+        if (!p.inf) p.v = double_u<P, true>(p.v);
+    }
+};
+
+// Out-of-line policy on the out-of-line multiplier: smallest code. k_fixup_level has five call sites of the group
+// operations inside one loop and ran 15x slower fully inlined (instruction-cache overflow).
+template <class P>
+struct UnsatOpsNI {
+    using Field = Fp<P>;
+    using Mem = XYZZ<Fp<P>>;
+    using Elem = UnsatElem<P>;
+    __device__ static __forceinline__ Elem infinity() { return unsat_infinity<P>(); }
+    __device__ static __noinline__ Elem load(const void *base, size_t i) { return unsat_load<P, false>(base, i); }
+    __device__ static __noinline__ void store(void *base, size_t i, const Elem &e) { unsat_store<P, false>(base, i, e); }
+    __device__ static __noinline__ void add(Elem &p, const Elem &q) { add_u<P, false>(p.v, p.inf, q.v, q.inf); }
+    __device__ static __noinline__ void dbl(Elem &p) {
+        if (!p.inf) p.v = double_u<P, false>(p.v);
     }
 };
 

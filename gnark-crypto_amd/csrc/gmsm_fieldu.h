@@ -153,6 +153,28 @@ GMSM_HD FpU<P> fpu_sqr(const FpU<P> &a) {
     return r;
 }
 
+// Out-of-line copies for the kernels whose instruction footprint matters more than a call (chain fixup, bucket
+// reduction: a fully inlined XYZZ addition is ~25 KB of code and those kernels would otherwise hold several copies,
+// overflowing the 64 KB instruction cache -- measured: 15x slower). The accumulation loop keeps the inlined forms.
+template <class P>
+__host__ __device__ __noinline__ FpU<P> fpu_mul_ni(FpU<P> a, FpU<P> b) {
+    return fpu_mul(a, b);
+}
+template <class P>
+__host__ __device__ __noinline__ FpU<P> fpu_sqr_ni(FpU<P> a) {
+    return fpu_sqr(a);
+}
+template <bool INL, class P>
+GMSM_HD FpU<P> fmul(const FpU<P> &a, const FpU<P> &b) {
+    if constexpr (INL) return fpu_mul(a, b);
+    else return fpu_mul_ni<P>(a, b);
+}
+template <bool INL, class P>
+GMSM_HD FpU<P> fsqr(const FpU<P> &a) {
+    if constexpr (INL) return fpu_sqr(a);
+    else return fpu_sqr_ni<P>(a);
+}
+
 // ------------------------------------------------------------------ conversions
 // Split the N saturated 32-bit words of a value < 2^(L*W) into L limbs of W bits (no arithmetic).
 template <class P>
@@ -216,22 +238,22 @@ GMSM_HD void fpu_cond_sub_q(FpU<P> &a) {
 }
 
 // Saturated Montgomery (x*2^(32N), canonical) -> unsaturated Montgomery (x*2^(L*W)), value < 2q.
-template <class P>
+template <class P, bool INL = true>
 GMSM_HD FpU<P> fpu_from_sat(const Fp<P> &x) {
     FpU<P> u = fpu_unpack<P>(x.l);
     FpU<P> c;
 #pragma unroll
     for (int i = 0; i < P::UL; ++i) c.l[i] = P::UCIN[i];
-    return fpu_mul(u, c);
+    return fmul<INL>(u, c);
 }
 
 // Unsaturated Montgomery (any lazy value within the fpu_mul input bounds) -> canonical saturated Montgomery limbs.
-template <class P>
+template <class P, bool INL = true>
 GMSM_HD Fp<P> fpu_to_sat(const FpU<P> &a) {
     FpU<P> c;
 #pragma unroll
     for (int i = 0; i < P::UL; ++i) c.l[i] = P::UCOUT[i];
-    FpU<P> r = fpu_mul(a, c);  // < 2q, limbs normalised
+    FpU<P> r = fmul<INL>(a, c);  // < 2q, limbs normalised
     fpu_cond_sub_q(r);
     Fp<P> z;
     fpu_pack(r, z.l);

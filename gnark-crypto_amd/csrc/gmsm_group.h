@@ -35,7 +35,10 @@ struct Group {
     static constexpr bool FAST_PATH = IsPrimeField<F>::value && F::N <= GMSM_FAST_PATH_MAX_LIMBS;
     template <bool Fast, class Dummy = void> struct OpsSel { using type = SatOps<F>; };
     template <class Dummy> struct OpsSel<true, Dummy> { using type = UnsatOps<typename F::Params>; };
-    using Ops = typename OpsSel<FAST_PATH>::type;  // arithmetic of the fixup / reduction kernels
+    template <bool Fast, class Dummy = void> struct OpsNISel { using type = SatOps<F>; };
+    template <class Dummy> struct OpsNISel<true, Dummy> { using type = UnsatOpsNI<typename F::Params>; };
+    using Ops = typename OpsSel<FAST_PATH>::type;      // arithmetic of k_fixup_seg and the reduction kernels
+    using OpsNI = typename OpsNISel<FAST_PATH>::type;  // small-code variant for k_fixup_level
     using OpsElem = typename Ops::Elem;
     static_assert(2 * (sizeof(XYZZ<F>) > 256 ? 128 : 256) * sizeof(OpsElem) <= 160 * 1024, "reduction LDS budget");
     static constexpr int RED_TPB = sizeof(XYZZ<F>) > 256 ? 128 : 256;  // 2*TPB*sizeof(Elem) of LDS must fit 160 KiB
@@ -65,7 +68,8 @@ struct Group {
         if (n >= ((size_t)1 << 31)) return fail(GMSM_ERR_ARG, "n must be < 2^31");
         const uint32_t NB = plan.nbuckets;
         // chunks: ~256 (window, chunk) blocks in flight, each at least 4096 digits
-        uint32_t nchunks = std::max<uint32_t>(1, 512 / nw);
+        uint32_t nchunks = env_uint("GMSM_NCHUNKS", 0);
+        if (nchunks == 0) nchunks = std::max<uint32_t>(1, 512 / nw);
         nchunks = (uint32_t)std::min<size_t>(nchunks, (n + 4095) / 4096);
         const size_t chunk_len = (n + nchunks - 1) / nchunks;
         // reduction geometry
@@ -128,7 +132,7 @@ struct Group {
             // entry-parallel segmented accumulation: seg entries per thread, >= ~4 waves per SIMD when n allows
             uint32_t seg = env_uint("GMSM_SEG", 0);
             if (seg == 0) {
-                seg = (uint32_t)std::min<size_t>(256, std::max<size_t>(16, ((size_t)nw * n) / (65536 * 6)));
+                seg = (uint32_t)std::min<size_t>(256, std::max<size_t>(32, ((size_t)nw * n) / (65536 * 4)));
             }
             const uint32_t tpw = (uint32_t)((n + seg - 1) / seg);  // threads per window (upper bound: <= n entries)
             if ((rc = ctx.seg_partials.ensure((size_t)nw * tpw * 2 * sizeof(Ext)))) return rc;
@@ -155,11 +159,11 @@ struct Group {
             hipLaunchKernelGGL((k_fixup_seg<Ops>), dim3((tpw + 255) / 256, nw), dim3(256), 0, stream, NB,
                                ctx.seg_partials.ptr, (const uint32_t *)ctx.seg_flags.ptr,
                                (const uint32_t *)ctx.seg_bucket.ptr, tpw, ctx.buckets.ptr, long_flag);
-            hipLaunchKernelGGL((k_fixup_level<Ops>), dim3((t1 + 255) / 256, nw), dim3(256), 0, stream, NB,
+            hipLaunchKernelGGL((k_fixup_level<OpsNI>), dim3((t1 + 255) / 256, nw), dim3(256), 0, stream, NB,
                                ctx.seg_partials.ptr, (const uint32_t *)ctx.seg_flags.ptr,
                                (const uint32_t *)ctx.seg_bucket.ptr, tpw, span1, parts1, flags1, pb1, t1, ctx.buckets.ptr,
                                long_flag);
-            hipLaunchKernelGGL((k_fixup_level<Ops>), dim3(1, nw), dim3(256), 0, stream, NB, parts1, flags1, pb1, t1, span2,
+            hipLaunchKernelGGL((k_fixup_level<OpsNI>), dim3(1, nw), dim3(256), 0, stream, NB, parts1, flags1, pb1, t1, span2,
                                parts2, flags2, pb2, 1u, ctx.buckets.ptr, long_flag);
             reduce_starts = starts;
         } else {

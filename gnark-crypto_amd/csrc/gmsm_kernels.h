@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(256, GMSM_ACC_MINW) k_accumulate_seg(const voi
 }
 
 // Chain fixup. A split bucket is a chain  P1[t0], P0[t0+1], ..., P0[t1]  of partial sums of consecutive accumulation
-// threads.  k_fixup_seg: the thread that owns the chain head adds up to MAXWALK followers (random scalars: 1); a
+// threads.  k_fixup_seg: the thread that owns the chain head adds up to MAXWALK followers (random scalars: 1-3); a
 // longer chain (tiny top window, repeated scalars, every scalar equal) raises long_flag[window] and is left to
 // k_fixup_level, which re-reduces all chains of a flagged window hierarchically: each thread walks `span`
 // consecutive threads of the previous level, stores chains that close inside its span, and emits at most two open
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(256) k_fixup_seg(uint32_t nbuckets, const void
                                                    const uint32_t *__restrict__ pflags, const uint32_t *__restrict__ pbucket,
                                                    uint32_t threads_per_win, void *__restrict__ buckets,
                                                    uint32_t *__restrict__ long_flag) {
-    constexpr uint32_t MAXWALK = 3;
+    constexpr uint32_t MAXWALK = 48;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
     if (t >= threads_per_win) return;
     const size_t base = (size_t)k * threads_per_win;
