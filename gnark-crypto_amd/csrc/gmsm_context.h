@@ -50,9 +50,13 @@ struct Context {
     hipEvent_t events[8] = {nullptr};  // stage boundaries when profiling is on
     void *pinned = nullptr;  // pinned host buffer for the window totals
     size_t pinned_cap = 0;
+    int num_cus = 256;
     int init(int dev) {
         device = dev;
         HIP_TRY(hipSetDevice(dev));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        num_cus = prop.multiProcessorCount;
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         return GMSM_OK;
     }
@@ -121,18 +125,23 @@ static inline unsigned env_uint(const char *name, unsigned dflt) {
 }
 
 // Window width. The affine result does not depend on it (the reference asserts exactly that for c in 2..16,
-// multiexp_test.go:95-126), so it is purely a cost choice: n*nwin mixed adds in k_accumulate against
-// 2*nbuckets*nwin full adds (with a serial depth) in k_reduce.  GMSM_C overrides for experiments.
+// multiexp_test.go:95-126), so it is purely a cost choice. Measured on MI355X (BN254 G1): below ~2^17 points the
+// pipeline is latency-bound (~0.8-1.1 ms whatever c), from 2^18 on c = 16 (the largest window whose 2^15-entry
+// histogram fits the 160 KiB LDS) minimises the n*nwin mixed additions. A candidate is skipped when its top window
+// holds so few bits that the buckets of that window would be split over very long chains of accumulation threads.
+// GMSM_C overrides for experiments.
 static inline unsigned choose_c(unsigned fr_bits, size_t n) {
     unsigned forced = env_uint("GMSM_C", 0);
-    if (forced >= 2 && forced <= 24) return forced;
-    (void)fr_bits;
-    unsigned lg = 0;
-    while (((size_t)1 << (lg + 1)) <= n) ++lg;
-    int c = (int)lg - 4;
-    if (c < 4) c = 4;
-    if (c > 16) c = 16;
-    return (unsigned)c;
+    if (forced >= 2 && forced <= 16) return forced;
+    const unsigned cmax = n < ((size_t)1 << 13) ? 8u : n < ((size_t)1 << 15) ? 13u : n < ((size_t)1 << 17) ? 15u : 16u;
+    for (unsigned c = cmax; c + 4 >= cmax && c >= 4; --c) {
+        const unsigned nwin = num_windows(fr_bits, c);
+        const unsigned top_bits = fr_bits - (nwin - 1) * c;
+        size_t seg = (size_t)nwin * n / 196608;
+        seg = seg < 32 ? 32 : seg > 256 ? 256 : seg;
+        if ((n >> top_bits) <= 40 * seg) return c;
+    }
+    return cmax;
 }
 
 struct GroupVTable {

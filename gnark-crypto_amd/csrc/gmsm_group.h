@@ -132,7 +132,18 @@ struct Group {
             // entry-parallel segmented accumulation: seg entries per thread, >= ~4 waves per SIMD when n allows
             uint32_t seg = env_uint("GMSM_SEG", 0);
             if (seg == 0) {
-                seg = (uint32_t)std::min<size_t>(256, std::max<size_t>(32, ((size_t)nw * n) / (65536 * 4)));
+                // every thread does the same work, so the launch should be a whole number of resident "rounds":
+                // capacity = CUs x 3 workgroups (160 VGPRs -> 3 waves/SIMD) x 256 threads
+                const size_t capacity = (size_t)ctx.num_cus * 3 * 256;
+                for (size_t r = 1;; ++r) {
+                    size_t s = ((size_t)nw * n + r * capacity - 1) / (r * capacity);
+                    if (s <= 256) {
+                        // nw*ceil(n/s) threads must not exceed r*capacity: round s up until it holds
+                        while (s < 256 && (size_t)nw * ((n + s - 1) / s) > r * capacity) ++s;
+                        seg = (uint32_t)std::max<size_t>(s, 32);
+                        break;
+                    }
+                }
             }
             const uint32_t tpw = (uint32_t)((n + seg - 1) / seg);  // threads per window (upper bound: <= n entries)
             if ((rc = ctx.seg_partials.ensure((size_t)nw * tpw * 2 * sizeof(Ext)))) return rc;
