@@ -34,7 +34,11 @@ struct Group {
     // saturated kernel
     static constexpr bool FAST_PATH = IsPrimeField<F>::value && F::N <= GMSM_FAST_PATH_MAX_LIMBS;
     template <bool Fast, class Dummy = void> struct OpsSel { using type = SatOps<F>; };
+#ifdef GMSM_REDUCE_SMALL
+    template <class Dummy> struct OpsSel<true, Dummy> { using type = UnsatOpsSmall<typename F::Params>; };
+#else
     template <class Dummy> struct OpsSel<true, Dummy> { using type = UnsatOps<typename F::Params>; };
+#endif
     template <bool Fast, class Dummy = void> struct OpsNISel { using type = SatOps<F>; };
     template <class Dummy> struct OpsNISel<true, Dummy> { using type = UnsatOpsNI<typename F::Params>; };
     using Ops = typename OpsSel<FAST_PATH>::type;      // arithmetic of k_fixup_seg and the reduction kernels
@@ -73,7 +77,7 @@ struct Group {
         nchunks = (uint32_t)std::min<size_t>(nchunks, (n + 4095) / 4096);
         const size_t chunk_len = (n + nchunks - 1) / nchunks;
         // reduction geometry
-        uint32_t log2L = 3;
+        uint32_t log2L = env_uint("GMSM_LOG2L", 3);
         while ((((size_t)NB + ((size_t)RED_TPB << log2L) - 1) / ((size_t)RED_TPB << log2L)) > (size_t)RED2_TPB) ++log2L;
         const uint32_t nblocks1 = (uint32_t)(((size_t)NB + ((size_t)RED_TPB << log2L) - 1) / ((size_t)RED_TPB << log2L));
         uint32_t log2span = log2L;

@@ -477,23 +477,37 @@ __device__ __forceinline__ void block_combine(typename A::Elem S, typename A::El
     }
     S_out = lds[0];
     __syncthreads();
-    // U = sum_{t>=1} Suf_t ; V = sum_t W_t   (one tree, two sums per level)
+    // U = sum_{t>=1} Suf_t and V = sum_t W_t as two trees run side by side: the lower half of the threads reduces U, the
+    // upper half reduces W (one addition per level instead of two on the critical path)
     E U = t >= 1 ? suf : A::infinity();
     E *ldsW = lds + TPB;
     lds[t] = U;
     ldsW[t] = W;
     __syncthreads();
-    for (uint32_t d = TPB / 2; d >= 1; d >>= 1) {
-        if (t < d) {
-            E o = lds[t + d];
-            A::add(U, o);
-            lds[t] = U;
-            E o2 = ldsW[t + d];
-            A::add(W, o2);
-            ldsW[t] = W;
+    constexpr uint32_t H = TPB / 2;
+    const bool upper = t >= H;
+    const uint32_t tt = upper ? t - H : t;
+    E *arr = upper ? ldsW : lds;
+    // first level folds TPB -> H elements in both arrays: thread tt of each half adds element tt + H
+    E mine = arr[tt];
+    {
+        E o = arr[tt + H];
+        A::add(mine, o);
+    }
+    __syncthreads();
+    arr[tt] = mine;
+    __syncthreads();
+    for (uint32_t d = H / 2; d >= 1; d >>= 1) {
+        if (tt < d) {
+            E o = arr[tt + d];
+            A::add(mine, o);
         }
         __syncthreads();
+        if (tt < d) arr[tt] = mine;
+        __syncthreads();
     }
+    U = lds[0];
+    W = ldsW[0];
     if (t == 0) {
         for (uint32_t i = 0; i < log2L; ++i) A::dbl(U);
         A::add(W, U);
