@@ -160,6 +160,19 @@ def main():
         dist.destroy_process_group()
 
 
+def effective_cpus():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box exposes
+    256 hardware threads but limits the container to a 16-CPU quota)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(g, pts, sc, gpu_jac, curve="bn254", group="g1"):
     """The oracle = C restatement of gnark-crypto's MultiExp (bestC, split recursion, one task per (leaf, window),
     extended-Jacobian buckets; the batch-affine bucket variant is off), on all host cores.  Bounded: repeats whole
@@ -167,17 +180,19 @@ def cpu_baseline(g, pts, sc, gpu_jac, curve="bn254", group="g1"):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle  # test infrastructure, used here only as the reported baseline and the checker
     o = oracle.Oracle(curve, group)
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()
+    threads = min(2 * cores, len(os.sched_getaffinity(0)))  # 2 software threads per allowed core measured best
     reps, t_total, jac = 0, 0.0, None
     while reps < 1 or (t_total < 10.0 and reps < 50):
         t0 = time.perf_counter()
-        err, jac = o.multiexp(pts, sc, nb_tasks=0, num_cpu=cores, nthreads=cores)
+        err, jac = o.multiexp(pts, sc, nb_tasks=0, num_cpu=cores, nthreads=threads)
         t_total += time.perf_counter() - t0
         reps += 1
         assert err == 0
     exact = bool((o.jac_to_affine(jac) == g.jac_to_affine(gpu_jac)).all())
     return {
         "cpu_baseline": {"value": reps / t_total, "unit": "MSM/s", "cores": cores, "kind": "port",
+                         "threads": threads,
                          "sample": f"{reps} full MSM(s) of the same 2^{int(np.log2(len(pts)))} input, {t_total:.1f} s total; "
                                    "C restatement of gnark-crypto's algorithm (ext-Jacobian buckets, batch-affine off)"},
         "bit_exact": exact,

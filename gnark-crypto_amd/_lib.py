@@ -102,5 +102,17 @@ def load():
     return L
 
 
+def effective_cpus():
+    """Cores this process may use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def last_error():
     return load().gmsm_last_error().decode()

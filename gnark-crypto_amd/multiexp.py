@@ -99,7 +99,7 @@ class _Group:
         limbs = lambda v: np.array([(v % self.curve.r >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(nl)], dtype=np.uint64)
         a0, a1 = limbs(k0), limbs(k1)
         out = np.zeros((n, self.aff_limbs), dtype=np.uint64)
-        rc = L.gmsm_generate_points(self.gid, _ptr(base), _ptr(a0), _ptr(a1), nl, n, nthreads or os.cpu_count() or 1, _ptr(out))
+        rc = L.gmsm_generate_points(self.gid, _ptr(base), _ptr(a0), _ptr(a1), nl, n, nthreads or 2 * _lib.effective_cpus(), _ptr(out))
         if rc:
             raise RuntimeError(self._error(rc))
         return out
