@@ -223,22 +223,6 @@ struct UnsatOps {
     }
 };
 
-// Inlined group operations on the out-of-line multiplier (operands travel in VGPRs, no scratch): ~3 KB per addition
-// instead of ~25 KB, so a kernel with many call sites stays inside the 64 KB instruction cache.
-template <class P>
-struct UnsatOpsSmall {
-    using Field = Fp<P>;
-    using Mem = XYZZ<Fp<P>>;
-    using Elem = UnsatElem<P>;
-    __device__ static __forceinline__ Elem infinity() { return unsat_infinity<P>(); }
-    __device__ static __forceinline__ Elem load(const void *base, size_t i) { return unsat_load<P, false>(base, i); }
-    __device__ static __forceinline__ void store(void *base, size_t i, const Elem &e) { unsat_store<P, false>(base, i, e); }
-    __device__ static __forceinline__ void add(Elem &p, const Elem &q) { add_u<P, false>(p.v, p.inf, q.v, q.inf); }
-    __device__ static __forceinline__ void dbl(Elem &p) {
-        if (!p.inf) p.v = double_u<P, false>(p.v);
-    }
-};
-
 // Out-of-line policy on the out-of-line multiplier: smallest code. k_fixup_level has five call sites of the group
 // operations inside one loop and ran 15x slower fully inlined (instruction-cache overflow).
 template <class P>

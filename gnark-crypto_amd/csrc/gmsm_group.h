@@ -34,11 +34,7 @@ struct Group {
     // saturated kernel
     static constexpr bool FAST_PATH = IsPrimeField<F>::value && F::N <= GMSM_FAST_PATH_MAX_LIMBS;
     template <bool Fast, class Dummy = void> struct OpsSel { using type = SatOps<F>; };
-#ifdef GMSM_REDUCE_SMALL
-    template <class Dummy> struct OpsSel<true, Dummy> { using type = UnsatOpsSmall<typename F::Params>; };
-#else
     template <class Dummy> struct OpsSel<true, Dummy> { using type = UnsatOps<typename F::Params>; };
-#endif
     template <bool Fast, class Dummy = void> struct OpsNISel { using type = SatOps<F>; };
     template <class Dummy> struct OpsNISel<true, Dummy> { using type = UnsatOpsNI<typename F::Params>; };
     using Ops = typename OpsSel<FAST_PATH>::type;      // arithmetic of k_fixup_seg and the reduction kernels

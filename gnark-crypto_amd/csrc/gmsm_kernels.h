@@ -231,32 +231,6 @@ __global__ void __launch_bounds__(256) k_convert_points(const void *__restrict__
     store_struct(upoints, i, u);
 }
 
-template <class P>
-__global__ void __launch_bounds__(256) k_accumulate_u(const void *__restrict__ upoints, size_t n, uint32_t nbuckets,
-                                                      const uint32_t *__restrict__ starts,
-                                                      const uint32_t *__restrict__ sorted, void *__restrict__ buckets) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
-    if (b >= nbuckets) return;
-    const uint32_t *st = starts + (size_t)k * (nbuckets + 1);
-    const uint32_t lo = st[b], hi = st[b + 1];
-    const uint32_t *ent = sorted + (size_t)k * n;
-    XYZZU<P> acc;
-    bool inf = true;
-    for (uint32_t e = lo; e < hi; ++e) {
-        const uint32_t v = ent[e];
-        const UAffine<P> p = load_struct<UAffine<P>>(upoints, v >> 1);
-        madd_u<P>(acc, inf, fpu_unpack<P>(p.x), fpu_unpack<P>(p.y), (v & 1u) != 0);
-    }
-    XYZZ<Fp<P>> out = XYZZ<Fp<P>>::infinity();
-    if (!inf) {
-        out.x = fpu_to_sat(acc.x);
-        out.y = fpu_to_sat(acc.y);
-        out.zz = fpu_to_sat(acc.zz);
-        out.zzz = fpu_to_sat(acc.zzz);
-    }
-    store_struct(buckets, (size_t)k * nbuckets + b, out);
-}
-
 // ------------------------------------------------------------------ entry-parallel segmented accumulation
 // Load-balanced form of the accumulation: every thread takes SEG consecutive entries of a window's bucket-sorted
 // reference list (not one bucket), so the work per lane is the same whatever the bucket-size distribution is
