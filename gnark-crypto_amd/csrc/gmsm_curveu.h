@@ -11,14 +11,16 @@
 //   stored coordinates: x < 11, y < 7, zz, zzz < 3;   mul(a,b) < a*b/169 + 1.
 #pragma once
 #include "gmsm_curve.h"
-#include "gmsm_fieldu.h"
+#include "gmsm_field2u.h"
 
 namespace gmsm {
 
-template <class P>
-struct XYZZU {
-    FpU<P> x, y, zz, zzz;
+template <class U>
+struct XYZZL {  // extended-Jacobian point over a lazy element type (FpU<P> or Fp2U<P>)
+    U x, y, zz, zzz;
 };
+template <class P>
+using XYZZU = XYZZL<FpU<P>>;
 
 template <class P>
 GMSM_HD FpU<P> fpu_one() {
@@ -132,6 +134,118 @@ GMSM_HD void add_u(XYZZU<P> &p, bool &pinf, const XYZZU<P> &q, bool qinf) {
     p.zzz = fmul<INL>(fmul<INL>(p.zzz, q.zzz), PPP);
 }
 
+// ------------------------------------------------------------------ generic group law on the reduced class
+// Same formulas on the lz_ interface (gmsm_field2u.h): every stored value is in R = [0,4q) with normalised limbs, so
+// the zero tests are exact without bound tracking. Used for the Fp2 groups (G2 of BN254 and BLS12-381).
+template <class U, bool INL>
+GMSM_HD void double_mixed_g(XYZZL<U> &acc, const U &px, const U &py) {
+    const U Uu = lz_dbl(py);
+    const U V = lz_sqr<INL>(Uu);
+    const U W = lz_mul<INL>(Uu, V);
+    const U S = lz_mul<INL>(px, V);
+    const U XX = lz_sqr<INL>(px);
+    const U M = lz_add(lz_dbl(XX), XX);
+    const U X3 = lz_sub(lz_sqr<INL>(M), lz_dbl(S));
+    const U Y3 = lz_sub(lz_mul<INL>(lz_sub(S, X3), M), lz_mul<INL>(W, py));
+    acc.x = X3;
+    acc.y = Y3;
+    acc.zz = V;
+    acc.zzz = W;
+}
+
+template <class U, bool INL>
+GMSM_HD void madd_g(XYZZL<U> &acc, bool &inf, const U &px, const U &py_in, bool negate) {
+    const U py = negate ? lz_sub(lz_zero((const U *)nullptr), py_in) : py_in;
+    if (inf) {
+        acc.x = px;
+        acc.y = py;
+        acc.zz = lz_one((const U *)nullptr);
+        acc.zzz = lz_one((const U *)nullptr);
+        inf = false;
+        return;
+    }
+    const U Pv = lz_sub(lz_mul<INL>(px, acc.zz), acc.x);
+    const U Rv = lz_sub(lz_mul<INL>(py, acc.zzz), acc.y);
+    if (lz_is_zero(Pv)) {  // g2.go: same special cases as g1.go:846-854
+        if (lz_is_zero(Rv)) double_mixed_g<U, INL>(acc, px, py);
+        else inf = true;
+        return;
+    }
+    const U PP = lz_sqr<INL>(Pv);
+    const U PPP = lz_mul<INL>(Pv, PP);
+    const U Q = lz_mul<INL>(acc.x, PP);
+    const U X3 = lz_sub(lz_sub(lz_sqr<INL>(Rv), PPP), lz_dbl(Q));
+    const U Y3 = lz_sub(lz_mul<INL>(lz_sub(Q, X3), Rv), lz_mul<INL>(acc.y, PPP));
+    acc.x = X3;
+    acc.y = Y3;
+    acc.zz = lz_mul<INL>(acc.zz, PP);
+    acc.zzz = lz_mul<INL>(acc.zzz, PPP);
+}
+
+template <class U, bool INL>
+GMSM_HD XYZZL<U> double_g(const XYZZL<U> &q) {
+    const U Uu = lz_dbl(q.y);
+    const U V = lz_sqr<INL>(Uu);
+    const U W = lz_mul<INL>(Uu, V);
+    const U S = lz_mul<INL>(q.x, V);
+    const U XX = lz_sqr<INL>(q.x);
+    const U M = lz_add(lz_dbl(XX), XX);
+    XYZZL<U> r;
+    r.x = lz_sub(lz_sqr<INL>(M), lz_dbl(S));
+    r.y = lz_sub(lz_mul<INL>(lz_sub(S, r.x), M), lz_mul<INL>(W, q.y));
+    r.zz = lz_mul<INL>(V, q.zz);
+    r.zzz = lz_mul<INL>(W, q.zzz);
+    return r;
+}
+
+template <class U, bool INL>
+GMSM_HD void add_g(XYZZL<U> &p, bool &pinf, const XYZZL<U> &q, bool qinf) {
+    if (qinf) return;
+    if (pinf) {
+        p = q;
+        pinf = false;
+        return;
+    }
+    const U U2 = lz_mul<INL>(q.x, p.zz);
+    const U U1 = lz_mul<INL>(p.x, q.zz);
+    const U S2 = lz_mul<INL>(q.y, p.zzz);
+    const U S1 = lz_mul<INL>(p.y, q.zzz);
+    const U A = lz_sub(U2, U1);
+    const U B = lz_sub(S2, S1);
+    if (lz_is_zero(A)) {
+        if (lz_is_zero(B)) p = double_g<U, INL>(q);
+        else pinf = true;
+        return;
+    }
+    const U PP = lz_sqr<INL>(A);
+    const U PPP = lz_mul<INL>(A, PP);
+    const U Q = lz_mul<INL>(U1, PP);
+    const U V = lz_mul<INL>(S1, PPP);
+    const U X3 = lz_sub(lz_sub(lz_sqr<INL>(B), PPP), lz_dbl(Q));
+    p.y = lz_sub(lz_mul<INL>(lz_sub(Q, X3), B), V);
+    p.x = X3;
+    p.zz = lz_mul<INL>(lz_mul<INL>(p.zz, q.zz), PP);
+    p.zzz = lz_mul<INL>(lz_mul<INL>(p.zzz, q.zzz), PPP);
+}
+
+// ---- dispatch: prime-field elements use the bound-tracked forms above, Fp2 elements the reduced-class forms ----
+template <bool INL, class P>
+GMSM_HD void lz_madd(XYZZL<FpU<P>> &acc, bool &inf, const FpU<P> &px, const FpU<P> &py, bool negate) {
+    madd_u<P, INL>(acc, inf, px, py, negate);
+}
+template <bool INL, class P>
+GMSM_HD void lz_madd(XYZZL<Fp2U<P>> &acc, bool &inf, const Fp2U<P> &px, const Fp2U<P> &py, bool negate) {
+    madd_g<Fp2U<P>, INL>(acc, inf, px, py, negate);
+}
+template <bool INL, class P>
+GMSM_HD void lz_padd(XYZZL<FpU<P>> &p, bool &pinf, const XYZZL<FpU<P>> &q, bool qinf) { add_u<P, INL>(p, pinf, q, qinf); }
+template <bool INL, class P>
+GMSM_HD void lz_padd(XYZZL<Fp2U<P>> &p, bool &pinf, const XYZZL<Fp2U<P>> &q, bool qinf) { add_g<Fp2U<P>, INL>(p, pinf, q, qinf); }
+template <bool INL, class P>
+GMSM_HD XYZZL<FpU<P>> lz_pdbl(const XYZZL<FpU<P>> &q) { return double_u<P, INL>(q); }
+template <bool INL, class P>
+GMSM_HD XYZZL<Fp2U<P>> lz_pdbl(const XYZZL<Fp2U<P>> &q) { return double_g<Fp2U<P>, INL>(q); }
+
 // ------------------------------------------------------------------ arithmetic policies
 template <class T>
 __device__ __forceinline__ T policy_load(const void *base, size_t index) {
@@ -167,75 +281,75 @@ struct SatOps {
     __device__ static __forceinline__ void dbl(Elem &p) { p.v = xyzz_double(p.v); }
 };
 
-template <class P>
+template <class U>
 struct UnsatElem {
-    XYZZU<P> v;
+    XYZZL<U> v;
     bool inf;
 };
 
-template <class P, bool INL>
-__device__ __forceinline__ UnsatElem<P> unsat_load(const void *base, size_t i) {
-    using Mem = XYZZ<Fp<P>>;
+template <class U, bool INL>
+__device__ __forceinline__ UnsatElem<U> unsat_load(const void *base, size_t i) {
+    using T = LzTraits<U>;
+    using Mem = XYZZ<typename T::Sat>;
     const Mem m = policy_load<Mem>(base, i);
-    UnsatElem<P> e;
+    UnsatElem<U> e;
     e.inf = m.zz.is_zero();
-    e.v.x = fpu_from_sat<P, INL>(m.x);
-    e.v.y = fpu_from_sat<P, INL>(m.y);
-    e.v.zz = fpu_from_sat<P, INL>(m.zz);
-    e.v.zzz = fpu_from_sat<P, INL>(m.zzz);
+    e.v.x = T::template from_sat<INL>(m.x);
+    e.v.y = T::template from_sat<INL>(m.y);
+    e.v.zz = T::template from_sat<INL>(m.zz);
+    e.v.zzz = T::template from_sat<INL>(m.zzz);
     return e;
 }
 
-template <class P, bool INL>
-__device__ __forceinline__ void unsat_store(void *base, size_t i, const UnsatElem<P> &e) {
-    using Mem = XYZZ<Fp<P>>;
+template <class U, bool INL>
+__device__ __forceinline__ void unsat_store(void *base, size_t i, const UnsatElem<U> &e) {
+    using T = LzTraits<U>;
+    using Mem = XYZZ<typename T::Sat>;
     Mem m = Mem::infinity();
     if (!e.inf) {
-        m.x = fpu_to_sat<P, INL>(e.v.x);
-        m.y = fpu_to_sat<P, INL>(e.v.y);
-        m.zz = fpu_to_sat<P, INL>(e.v.zz);
-        m.zzz = fpu_to_sat<P, INL>(e.v.zzz);
+        m.x = T::template to_sat<INL>(e.v.x);
+        m.y = T::template to_sat<INL>(e.v.y);
+        m.zz = T::template to_sat<INL>(e.v.zz);
+        m.zzz = T::template to_sat<INL>(e.v.zzz);
     }
     policy_store<Mem>(base, i, m);
 }
 
-template <class P>
-__device__ __forceinline__ UnsatElem<P> unsat_infinity() {
-    UnsatElem<P> e;
+template <class U>
+__device__ __forceinline__ UnsatElem<U> unsat_infinity() {
+    UnsatElem<U> e;
     e.inf = true;
-    e.v.x = e.v.y = fpu_one<P>();
-    e.v.zz = e.v.zzz = fpu_one<P>();
+    e.v.x = e.v.y = lz_one((const U *)nullptr);
+    e.v.zz = e.v.zzz = lz_one((const U *)nullptr);
     return e;
 }
 
 // Fully inlined policy: fastest when the kernel holds few call sites (k_fixup_seg, k_reduce1/2).
-template <class P>
+template <class U>
 struct UnsatOps {
-    using Field = Fp<P>;
-    using Mem = XYZZ<Fp<P>>;
-    using Elem = UnsatElem<P>;
-    __device__ static __forceinline__ Elem infinity() { return unsat_infinity<P>(); }
-    __device__ static __forceinline__ Elem load(const void *base, size_t i) { return unsat_load<P, true>(base, i); }
-    __device__ static __forceinline__ void store(void *base, size_t i, const Elem &e) { unsat_store<P, true>(base, i, e); }
-    __device__ static __forceinline__ void add(Elem &p, const Elem &q) { add_u<P, true>(p.v, p.inf, q.v, q.inf); }
+    using Mem = XYZZ<typename LzTraits<U>::Sat>;
+    using Elem = UnsatElem<U>;
+    __device__ static __forceinline__ Elem infinity() { return unsat_infinity<U>(); }
+    __device__ static __forceinline__ Elem load(const void *base, size_t i) { return unsat_load<U, true>(base, i); }
+    __device__ static __forceinline__ void store(void *base, size_t i, const Elem &e) { unsat_store<U, true>(base, i, e); }
+    __device__ static __forceinline__ void add(Elem &p, const Elem &q) { lz_padd<true>(p.v, p.inf, q.v, q.inf); }
     __device__ static __forceinline__ void dbl(Elem &p) {
-        if (!p.inf) p.v = double_u<P, true>(p.v);
+        if (!p.inf) p.v = lz_pdbl<true>(p.v);
     }
 };
 
 // Out-of-line policy on the out-of-line multiplier: smallest code. k_fixup_level has five call sites of the group
-// operations inside one loop and ran 15x slower fully inlined (instruction-cache overflow).
-template <class P>
+// operations inside one loop.
+template <class U>
 struct UnsatOpsNI {
-    using Field = Fp<P>;
-    using Mem = XYZZ<Fp<P>>;
-    using Elem = UnsatElem<P>;
-    __device__ static __forceinline__ Elem infinity() { return unsat_infinity<P>(); }
-    __device__ static __noinline__ Elem load(const void *base, size_t i) { return unsat_load<P, false>(base, i); }
-    __device__ static __noinline__ void store(void *base, size_t i, const Elem &e) { unsat_store<P, false>(base, i, e); }
-    __device__ static __noinline__ void add(Elem &p, const Elem &q) { add_u<P, false>(p.v, p.inf, q.v, q.inf); }
+    using Mem = XYZZ<typename LzTraits<U>::Sat>;
+    using Elem = UnsatElem<U>;
+    __device__ static __forceinline__ Elem infinity() { return unsat_infinity<U>(); }
+    __device__ static __noinline__ Elem load(const void *base, size_t i) { return unsat_load<U, false>(base, i); }
+    __device__ static __noinline__ void store(void *base, size_t i, const Elem &e) { unsat_store<U, false>(base, i, e); }
+    __device__ static __noinline__ void add(Elem &p, const Elem &q) { lz_padd<false>(p.v, p.inf, q.v, q.inf); }
     __device__ static __noinline__ void dbl(Elem &p) {
-        if (!p.inf) p.v = double_u<P, false>(p.v);
+        if (!p.inf) p.v = lz_pdbl<false>(p.v);
     }
 };
 

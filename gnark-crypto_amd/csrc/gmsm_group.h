@@ -14,11 +14,9 @@
 namespace gmsm {
 
 // ------------------------------------------------------------------ one (curve, group)
-template <class T> struct IsPrimeField { static constexpr bool value = false; };
-template <class P> struct IsPrimeField<Fp<P>> { static constexpr bool value = true; };
-#ifndef GMSM_FAST_PATH_MAX_LIMBS
-#define GMSM_FAST_PATH_MAX_LIMBS 12
-#endif
+template <class T> struct LazyOf;
+template <class P> struct LazyOf<Fp<P>> { using type = FpU<P>; };
+template <class P> struct LazyOf<Fp2<P>> { using type = Fp2U<P>; };
 
 template <class F_, class FrP_>
 struct Group {
@@ -32,12 +30,17 @@ struct Group {
     static constexpr size_t SCALAR_BYTES = sizeof(Fp<FrP>);
     // unsaturated-limb accumulation (gmsm_fieldu.h) for groups whose coordinates live in Fp; Fp2 groups use the generic
     // saturated kernel
-    static constexpr bool FAST_PATH = IsPrimeField<F>::value && F::N <= GMSM_FAST_PATH_MAX_LIMBS;
-    template <bool Fast, class Dummy = void> struct OpsSel { using type = SatOps<F>; };
-    template <class Dummy> struct OpsSel<true, Dummy> { using type = UnsatOps<typename F::Params>; };
+    static constexpr bool FAST_PATH = true;  // every group in scope runs on the lazy-limb representation
+    using U = typename LazyOf<F>::type;      // FpU<P> for Fp coordinates, Fp2U<P> for Fp2 coordinates
+    // fully inlined group operations in k_fixup_seg / k_reduce* only where one XYZZ addition is small enough (9- and
+    // 14-limb prime fields); Fp2 and the 28-limb field use the out-of-line forms (a single inlined Fp2 or BW6-761
+    // addition is 60-350 KB of code: instruction-cache misses and minutes of compile time)
+    static constexpr bool INLINE_OPS = sizeof(U) <= 14 * 4;
+    template <bool Fast, class Dummy = void> struct OpsSel { using type = UnsatOpsNI<U>; };
+    template <class Dummy> struct OpsSel<true, Dummy> { using type = UnsatOps<U>; };
     template <bool Fast, class Dummy = void> struct OpsNISel { using type = SatOps<F>; };
-    template <class Dummy> struct OpsNISel<true, Dummy> { using type = UnsatOpsNI<typename F::Params>; };
-    using Ops = typename OpsSel<FAST_PATH>::type;      // arithmetic of k_fixup_seg and the reduction kernels
+    template <class Dummy> struct OpsNISel<true, Dummy> { using type = UnsatOpsNI<U>; };
+    using Ops = typename OpsSel<INLINE_OPS>::type;     // arithmetic of k_fixup_seg and the reduction kernels
     using OpsNI = typename OpsNISel<FAST_PATH>::type;  // small-code variant for k_fixup_level
     using OpsElem = typename Ops::Elem;
     static_assert(2 * (sizeof(XYZZ<F>) > 256 ? 128 : 256) * sizeof(OpsElem) <= 160 * 1024, "reduction LDS budget");
@@ -101,7 +104,7 @@ struct Group {
         if constexpr (FAST_PATH) {
             if ((rc = ctx.upoints.ensure(n * AFF_BYTES))) return rc;
             if ((rc = ctx.skip.ensure(n))) return rc;
-            hipLaunchKernelGGL((k_convert_points<typename F::Params>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+            hipLaunchKernelGGL((k_convert_points<U>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                                stream, d_points, n, ctx.upoints.ptr, (uint8_t *)ctx.skip.ptr);
             skip = (const uint8_t *)ctx.skip.ptr;
         }
@@ -134,7 +137,7 @@ struct Group {
             if (seg == 0) {
                 // every thread does the same work, so the launch should be a whole number of resident "rounds":
                 // capacity = CUs x 3 workgroups (160 VGPRs -> 3 waves/SIMD) x 256 threads
-                const size_t capacity = (size_t)ctx.num_cus * 3 * 256;
+                const size_t capacity = (size_t)ctx.num_cus * AccWaves<U>::value * 256;
                 for (size_t r = 1;; ++r) {
                     size_t s = ((size_t)nw * n + r * capacity - 1) / (r * capacity);
                     if (s <= 256) {
@@ -149,7 +152,7 @@ struct Group {
             if ((rc = ctx.seg_partials.ensure((size_t)nw * tpw * 2 * sizeof(Ext)))) return rc;
             if ((rc = ctx.seg_flags.ensure((size_t)nw * tpw * 4))) return rc;
             if ((rc = ctx.seg_bucket.ensure((size_t)nw * tpw * 4))) return rc;
-            hipLaunchKernelGGL((k_accumulate_seg<typename F::Params>), dim3((tpw + 255) / 256, nw), dim3(256), 0, stream,
+            hipLaunchKernelGGL((k_accumulate_seg<U>), dim3((tpw + 255) / 256, nw), dim3(256), 0, stream,
                                ctx.upoints.ptr, n, NB, seg, starts, sorted, ctx.buckets.ptr, ctx.seg_partials.ptr,
                                (uint32_t *)ctx.seg_flags.ptr, (uint32_t *)ctx.seg_bucket.ptr, tpw);
             // chain fixup: short chains in place, long ones through two hierarchical levels (no-ops unless flagged)

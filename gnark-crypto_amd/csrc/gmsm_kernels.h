@@ -212,22 +212,23 @@ __global__ void __launch_bounds__(256) k_accumulate(const void *__restrict__ poi
 // G1-type groups (coordinates in Fp). The bases are first rewritten once per call into the unsaturated Montgomery
 // domain (k_convert_points: 2 field multiplications per point, against 10 per mixed add per window), packed back into
 // the same 2N words per point so the gather in the hot loop still moves 64 B per BN254 point.
-template <class P>
-struct UAffine {
-    uint32_t x[P::N], y[P::N];  // packed limbs of x*2^(UL*UW) mod q and y*2^(UL*UW) mod q (values < 2q)
+template <class U>
+struct UAffine {  // packed lazy-domain coordinates (values < 2q): same size as the Go affine point
+    uint32_t x[LzTraits<U>::PACKED_WORDS], y[LzTraits<U>::PACKED_WORDS];
 };
 
-template <class P>
+template <class U>
 __global__ void __launch_bounds__(256) k_convert_points(const void *__restrict__ points, size_t n, void *__restrict__ upoints,
                                                         uint8_t *__restrict__ skip) {
+    using T = LzTraits<U>;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Affine<Fp<P>> a = load_struct<Affine<Fp<P>>>(points, i);
+    Affine<typename T::Sat> a = load_struct<Affine<typename T::Sat>>(points, i);
     skip[i] = a.is_infinity() ? 1 : 0;
-    FpU<P> ux = fpu_from_sat(a.x), uy = fpu_from_sat(a.y);
-    UAffine<P> u;
-    fpu_pack(ux, u.x);
-    fpu_pack(uy, u.y);
+    const U ux = T::template from_sat<true>(a.x), uy = T::template from_sat<true>(a.y);
+    UAffine<U> u;
+    T::pack(ux, u.x);
+    T::pack(uy, u.y);
     store_struct(upoints, i, u);
 }
 
@@ -245,24 +246,28 @@ struct SegFlags {
     static constexpr uint32_t HAS_P1 = 4u;         // last run starts in this thread and continues into the next
 };
 
-template <class P>
-__device__ __forceinline__ XYZZ<Fp<P>> xyzzu_to_sat(const XYZZU<P> &acc, bool inf) {
-    XYZZ<Fp<P>> out = XYZZ<Fp<P>>::infinity();
+template <class U>
+__device__ __forceinline__ XYZZ<typename LzTraits<U>::Sat> xyzzu_to_sat(const XYZZL<U> &acc, bool inf) {
+    using T = LzTraits<U>;
+    XYZZ<typename T::Sat> out = XYZZ<typename T::Sat>::infinity();
     if (!inf) {
-        out.x = fpu_to_sat(acc.x);
-        out.y = fpu_to_sat(acc.y);
-        out.zz = fpu_to_sat(acc.zz);
-        out.zzz = fpu_to_sat(acc.zzz);
+        out.x = T::template to_sat<true>(acc.x);
+        out.y = T::template to_sat<true>(acc.y);
+        out.zz = T::template to_sat<true>(acc.zz);
+        out.zzz = T::template to_sat<true>(acc.zzz);
     }
     return out;
 }
 
 // grid = (ceil(max_entries/(256*seg)), nwin_local)
-#ifndef GMSM_ACC_MINW
-#define GMSM_ACC_MINW 3
-#endif
-template <class P>
-__global__ void __launch_bounds__(256, GMSM_ACC_MINW) k_accumulate_seg(const void *__restrict__ upoints, size_t n, uint32_t nbuckets,
+// waves per SIMD the accumulation kernel is compiled for: 3 for 9-limb coordinates (160 VGPRs, no spills), 2 for 14-limb
+// ones and Fp2 over 9 limbs, 1 (all 512 registers) beyond
+template <class U> struct AccWaves { static constexpr int value = 1; };
+template <class P> struct AccWaves<FpU<P>> { static constexpr int value = P::UL <= 9 ? 3 : (P::UL <= 14 ? 2 : 1); };
+template <class P> struct AccWaves<Fp2U<P>> { static constexpr int value = P::UL <= 9 ? 2 : 1; };
+
+template <class U>
+__global__ void __launch_bounds__(256, AccWaves<U>::value) k_accumulate_seg(const void *__restrict__ upoints, size_t n, uint32_t nbuckets,
                                                            uint32_t seg, const uint32_t *__restrict__ starts,
                                                            const uint32_t *__restrict__ sorted, void *__restrict__ buckets,
                                                            void *__restrict__ partials, uint32_t *__restrict__ pflags,
@@ -290,13 +295,14 @@ __global__ void __launch_bounds__(256, GMSM_ACC_MINW) k_accumulate_seg(const voi
     bool open_left = st[b] < e0;
     uint32_t flags = 0;
     const uint32_t *ent = sorted + (size_t)k * n;
-    XYZZU<P> acc;
+    using T = LzTraits<U>;
+    XYZZL<U> acc;
     bool inf = true;
     uint32_t v = ent[e0];
-    UAffine<P> p = load_struct<UAffine<P>>(upoints, v >> 1);
+    UAffine<U> p = load_struct<UAffine<U>>(upoints, v >> 1);
     for (uint32_t e = e0; e < e1; ++e) {
         if (e == bend) {  // the current run is complete on the right
-            XYZZ<Fp<P>> out = xyzzu_to_sat<P>(acc, inf);
+            XYZZ<typename T::Sat> out = xyzzu_to_sat<U>(acc, inf);
             if (open_left) {
                 store_struct(partials, tg * 2 + 0, out);
                 flags |= SegFlags::HAS_P0;
@@ -311,16 +317,16 @@ __global__ void __launch_bounds__(256, GMSM_ACC_MINW) k_accumulate_seg(const voi
         }
         // prefetch the next entry's point while this one is being added
         const uint32_t vc = v;
-        const UAffine<P> pc = p;
+        const UAffine<U> pc = p;
         if (e + 1 < e1) {
             v = ent[e + 1];
-            p = load_struct<UAffine<P>>(upoints, v >> 1);
+            p = load_struct<UAffine<U>>(upoints, v >> 1);
         }
-        madd_u<P>(acc, inf, fpu_unpack<P>(pc.x), fpu_unpack<P>(pc.y), (vc & 1u) != 0);
+        lz_madd<true>(acc, inf, T::unpack(pc.x), T::unpack(pc.y), (vc & 1u) != 0);
     }
     {
         const bool open_right = bend > e1;
-        XYZZ<Fp<P>> out = xyzzu_to_sat<P>(acc, inf);
+        XYZZ<typename T::Sat> out = xyzzu_to_sat<U>(acc, inf);
         if (open_left) {
             store_struct(partials, tg * 2 + 0, out);
             flags |= SegFlags::HAS_P0 | (open_right ? SegFlags::P0_OPEN_RIGHT : 0u);

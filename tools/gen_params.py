@@ -116,6 +116,7 @@ def unsat_block(q, n64):
     out += uarr("UK4", redundant_multiple(q, 4, UL, UW))
     out += uarr("UK16", redundant_multiple(q, 16, UL, UW))
     out += uarr("UQ1", ulimbs(q)) + uarr("UQ2", ulimbs(2 * q))     # candidates for the exact zero test of a value < 3q
+    out += uarr("UQ3", ulimbs(3 * q)) + uarr("UQ4", ulimbs(4 * q))  # reduced-class ([0,4q)) arithmetic of the Fp2 path
     return out
 
 
