@@ -271,9 +271,11 @@ template <class F>
 struct SatOps {
     using Field = F;
     using Mem = XYZZ<F>;  // record in HBM: canonical saturated Montgomery, infinity <=> zz == 0
+    using Final = XYZZ<F>;
     struct Elem {
         XYZZ<F> v;
     };
+    __device__ static __forceinline__ void store_final(void *base, size_t i, const Elem &e) { policy_store<Mem>(base, i, e.v); }
     __device__ static __forceinline__ Elem infinity() { return Elem{XYZZ<F>::infinity()}; }
     __device__ static __forceinline__ Elem load(const void *base, size_t i) { return Elem{policy_load<Mem>(base, i)}; }
     __device__ static __forceinline__ void store(void *base, size_t i, const Elem &e) { policy_store<Mem>(base, i, e.v); }
@@ -287,22 +289,40 @@ struct UnsatElem {
     bool inf;
 };
 
-template <class U, bool INL>
+// Bucket / partial-sum records of the lazy path live in HBM in the lazy representation itself (4 x element limbs, no
+// conversion on either side): infinity <=> every limb of zz is zero (a finite point has zz != 0 mod q, so its limbs
+// cannot all vanish). Only the per-window totals leave the device and are converted to canonical saturated limbs.
+template <class U>
+GMSM_HD bool lz_limbs_all_zero(const U &a) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(&a);
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(U) / 4); ++i) acc |= w[i];
+    return acc == 0;
+}
+
+template <class U>
 __device__ __forceinline__ UnsatElem<U> unsat_load(const void *base, size_t i) {
-    using T = LzTraits<U>;
-    using Mem = XYZZ<typename T::Sat>;
-    const Mem m = policy_load<Mem>(base, i);
     UnsatElem<U> e;
-    e.inf = m.zz.is_zero();
-    e.v.x = T::template from_sat<INL>(m.x);
-    e.v.y = T::template from_sat<INL>(m.y);
-    e.v.zz = T::template from_sat<INL>(m.zz);
-    e.v.zzz = T::template from_sat<INL>(m.zzz);
+    e.v = policy_load<XYZZL<U>>(base, i);
+    e.inf = lz_limbs_all_zero(e.v.zz);
     return e;
 }
 
+template <class U>
+__device__ __forceinline__ void lazy_store(void *base, size_t i, const XYZZL<U> &v, bool inf) {
+    XYZZL<U> m = v;
+    if (inf) {
+        uint32_t *w = reinterpret_cast<uint32_t *>(&m.zz);
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(U) / 4); ++k) w[k] = 0;
+    }
+    policy_store<XYZZL<U>>(base, i, m);
+}
+
+// canonical saturated XYZZ for the host (window totals)
 template <class U, bool INL>
-__device__ __forceinline__ void unsat_store(void *base, size_t i, const UnsatElem<U> &e) {
+__device__ __forceinline__ void unsat_store_final(void *base, size_t i, const UnsatElem<U> &e) {
     using T = LzTraits<U>;
     using Mem = XYZZ<typename T::Sat>;
     Mem m = Mem::infinity();
@@ -327,11 +347,13 @@ __device__ __forceinline__ UnsatElem<U> unsat_infinity() {
 // Fully inlined policy: fastest when the kernel holds few call sites (k_fixup_seg, k_reduce1/2).
 template <class U>
 struct UnsatOps {
-    using Mem = XYZZ<typename LzTraits<U>::Sat>;
+    using Mem = XYZZL<U>;                              // bucket / partial record in HBM
+    using Final = XYZZ<typename LzTraits<U>::Sat>;     // window total handed to the host
     using Elem = UnsatElem<U>;
     __device__ static __forceinline__ Elem infinity() { return unsat_infinity<U>(); }
-    __device__ static __forceinline__ Elem load(const void *base, size_t i) { return unsat_load<U, true>(base, i); }
-    __device__ static __forceinline__ void store(void *base, size_t i, const Elem &e) { unsat_store<U, true>(base, i, e); }
+    __device__ static __forceinline__ Elem load(const void *base, size_t i) { return unsat_load<U>(base, i); }
+    __device__ static __forceinline__ void store(void *base, size_t i, const Elem &e) { lazy_store<U>(base, i, e.v, e.inf); }
+    __device__ static __forceinline__ void store_final(void *base, size_t i, const Elem &e) { unsat_store_final<U, true>(base, i, e); }
     __device__ static __forceinline__ void add(Elem &p, const Elem &q) { lz_padd<true>(p.v, p.inf, q.v, q.inf); }
     __device__ static __forceinline__ void dbl(Elem &p) {
         if (!p.inf) p.v = lz_pdbl<true>(p.v);
@@ -342,11 +364,13 @@ struct UnsatOps {
 // operations inside one loop.
 template <class U>
 struct UnsatOpsNI {
-    using Mem = XYZZ<typename LzTraits<U>::Sat>;
+    using Mem = XYZZL<U>;
+    using Final = XYZZ<typename LzTraits<U>::Sat>;
     using Elem = UnsatElem<U>;
     __device__ static __forceinline__ Elem infinity() { return unsat_infinity<U>(); }
-    __device__ static __noinline__ Elem load(const void *base, size_t i) { return unsat_load<U, false>(base, i); }
-    __device__ static __noinline__ void store(void *base, size_t i, const Elem &e) { unsat_store<U, false>(base, i, e); }
+    __device__ static __forceinline__ Elem load(const void *base, size_t i) { return unsat_load<U>(base, i); }
+    __device__ static __forceinline__ void store(void *base, size_t i, const Elem &e) { lazy_store<U>(base, i, e.v, e.inf); }
+    __device__ static __noinline__ void store_final(void *base, size_t i, const Elem &e) { unsat_store_final<U, false>(base, i, e); }
     __device__ static __noinline__ void add(Elem &p, const Elem &q) { lz_padd<false>(p.v, p.inf, q.v, q.inf); }
     __device__ static __noinline__ void dbl(Elem &p) {
         if (!p.inf) p.v = lz_pdbl<false>(p.v);

@@ -88,8 +88,10 @@ struct Group {
         if ((rc = ctx.blockhist.ensure((size_t)nw * nchunks * NB * 4))) return rc;
         if ((rc = ctx.counts.ensure((size_t)nw * NB * 4))) return rc;
         if ((rc = ctx.starts.ensure((size_t)nw * (NB + 1) * 4))) return rc;
-        if ((rc = ctx.buckets.ensure((size_t)nw * NB * sizeof(Ext)))) return rc;
-        if ((rc = ctx.partials.ensure((size_t)nw * nblocks1 * 2 * sizeof(Ext)))) return rc;
+        constexpr size_t REC = sizeof(typename Ops::Mem);  // bucket / partial record (lazy representation on the fast path)
+        static_assert(sizeof(typename Ops::Mem) == sizeof(typename OpsNI::Mem), "one record format per group");
+        if ((rc = ctx.buckets.ensure((size_t)nw * NB * REC))) return rc;
+        if ((rc = ctx.partials.ensure((size_t)nw * nblocks1 * 2 * REC))) return rc;
         if ((rc = ctx.totals.ensure((size_t)nw * sizeof(Ext)))) return rc;
         if ((rc = ctx.ensure_pinned((size_t)nw * sizeof(Ext)))) return rc;
 
@@ -149,7 +151,7 @@ struct Group {
                 }
             }
             const uint32_t tpw = (uint32_t)((n + seg - 1) / seg);  // threads per window (upper bound: <= n entries)
-            if ((rc = ctx.seg_partials.ensure((size_t)nw * tpw * 2 * sizeof(Ext)))) return rc;
+            if ((rc = ctx.seg_partials.ensure((size_t)nw * tpw * 2 * REC))) return rc;
             if ((rc = ctx.seg_flags.ensure((size_t)nw * tpw * 4))) return rc;
             if ((rc = ctx.seg_bucket.ensure((size_t)nw * tpw * 4))) return rc;
             hipLaunchKernelGGL((k_accumulate_seg<U>), dim3((tpw + 255) / 256, nw), dim3(256), 0, stream,
@@ -159,11 +161,11 @@ struct Group {
             const uint32_t span1 = 64;
             const uint32_t t1 = (tpw + span1 - 1) / span1;  // level-1 outputs per window
             const uint32_t span2 = t1;                      // level 2: one thread per window closes everything
-            const size_t lvl_parts = ((size_t)nw * t1 + nw) * 2 * sizeof(Ext);
+            const size_t lvl_parts = ((size_t)nw * t1 + nw) * 2 * REC;
             if ((rc = ctx.seg_lvl.ensure(lvl_parts + ((size_t)nw * t1 * 2 + (size_t)nw * 3) * 4 + 256))) return rc;
             char *lvl = (char *)ctx.seg_lvl.ptr;
             void *parts1 = lvl;
-            void *parts2 = lvl + (size_t)nw * t1 * 2 * sizeof(Ext);  // nw * 2 records
+            void *parts2 = lvl + (size_t)nw * t1 * 2 * REC;  // nw * 2 records
             uint32_t *flags1 = (uint32_t *)(lvl + lvl_parts);
             uint32_t *pb1 = flags1 + (size_t)nw * t1;
             uint32_t *flags2 = pb1 + (size_t)nw * t1;

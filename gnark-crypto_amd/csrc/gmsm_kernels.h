@@ -246,20 +246,6 @@ struct SegFlags {
     static constexpr uint32_t HAS_P1 = 4u;         // last run starts in this thread and continues into the next
 };
 
-template <class U>
-__device__ __forceinline__ XYZZ<typename LzTraits<U>::Sat> xyzzu_to_sat(const XYZZL<U> &acc, bool inf) {
-    using T = LzTraits<U>;
-    XYZZ<typename T::Sat> out = XYZZ<typename T::Sat>::infinity();
-    if (!inf) {
-        out.x = T::template to_sat<true>(acc.x);
-        out.y = T::template to_sat<true>(acc.y);
-        out.zz = T::template to_sat<true>(acc.zz);
-        out.zzz = T::template to_sat<true>(acc.zzz);
-    }
-    return out;
-}
-
-// grid = (ceil(max_entries/(256*seg)), nwin_local)
 // waves per SIMD the accumulation kernel is compiled for: 3 for 9-limb coordinates (160 VGPRs, no spills), 2 for 14-limb
 // ones and Fp2 over 9 limbs, 1 (all 512 registers) beyond
 template <class U> struct AccWaves { static constexpr int value = 1; };
@@ -302,13 +288,12 @@ __global__ void __launch_bounds__(256, AccWaves<U>::value) k_accumulate_seg(cons
     UAffine<U> p = load_struct<UAffine<U>>(upoints, v >> 1);
     for (uint32_t e = e0; e < e1; ++e) {
         if (e == bend) {  // the current run is complete on the right
-            XYZZ<typename T::Sat> out = xyzzu_to_sat<U>(acc, inf);
             if (open_left) {
-                store_struct(partials, tg * 2 + 0, out);
+                lazy_store<U>(partials, tg * 2 + 0, acc, inf);
                 flags |= SegFlags::HAS_P0;
                 open_left = false;
             } else {
-                store_struct(buckets, (size_t)k * nbuckets + b, out);
+                lazy_store<U>(buckets, (size_t)k * nbuckets + b, acc, inf);
             }
             inf = true;
             ++b;
@@ -326,16 +311,15 @@ __global__ void __launch_bounds__(256, AccWaves<U>::value) k_accumulate_seg(cons
     }
     {
         const bool open_right = bend > e1;
-        XYZZ<typename T::Sat> out = xyzzu_to_sat<U>(acc, inf);
         if (open_left) {
-            store_struct(partials, tg * 2 + 0, out);
+            lazy_store<U>(partials, tg * 2 + 0, acc, inf);
             flags |= SegFlags::HAS_P0 | (open_right ? SegFlags::P0_OPEN_RIGHT : 0u);
         } else if (open_right) {
-            store_struct(partials, tg * 2 + 1, out);
+            lazy_store<U>(partials, tg * 2 + 1, acc, inf);
             flags |= SegFlags::HAS_P1;
             pbucket[tg] = b;
         } else {
-            store_struct(buckets, (size_t)k * nbuckets + b, out);
+            lazy_store<U>(buckets, (size_t)k * nbuckets + b, acc, inf);
         }
     }
     pflags[tg] = flags;
@@ -545,7 +529,7 @@ __global__ void __launch_bounds__(TPB) k_reduce2(const void *__restrict__ in1, u
     }
     E S_out, W_out;
     block_combine<A, TPB>(S, W, log2span, lds, S_out, W_out);
-    if (t == 0) A::store(window_totals, k, W_out);
+    if (t == 0) A::store_final(window_totals, k, W_out);
 }
 
 }  // namespace gmsm

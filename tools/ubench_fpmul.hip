@@ -46,6 +46,43 @@ __device__ __forceinline__ FpU<PP> fpu_mul2(const FpU<PP> &a, const FpU<PP> &b) 
     return r;
 }
 
+// variant: single accumulator chain forced with inline asm (no v_lshl_add_u64 merges)
+__device__ __forceinline__ void mad_vv(uint64_t &acc, uint32_t a, uint32_t b) {
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+}
+__device__ __forceinline__ void mad_vs(uint64_t &acc, uint32_t a, uint32_t b) {
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(b) : "vcc");
+}
+template <class PP>
+__device__ __forceinline__ FpU<PP> fpu_mul_asm(const FpU<PP> &a, const FpU<PP> &b) {
+    constexpr int L = PP::UL, W = PP::UW;
+    constexpr uint32_t MASK = FpU<PP>::MASK;
+    uint32_t m[L];
+    FpU<PP> r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) mad_vv(acc, a.l[i], b.l[k - i]);
+#pragma unroll
+        for (int i = 0; i < k; ++i) mad_vs(acc, m[i], PP::UQ[k - i]);
+        m[k] = ((uint32_t)acc * PP::UQINV) & MASK;
+        mad_vs(acc, m[k], PP::UQ[0]);
+        acc >>= W;
+    }
+#pragma unroll
+    for (int k = L; k < 2 * L - 1; ++k) {
+#pragma unroll
+        for (int i = k - L + 1; i < L; ++i) mad_vv(acc, a.l[i], b.l[k - i]);
+#pragma unroll
+        for (int i = k - L + 1; i < L; ++i) mad_vs(acc, m[i], PP::UQ[k - i]);
+        r.l[k - L] = (uint32_t)acc & MASK;
+        acc >>= W;
+    }
+    r.l[L - 1] = (uint32_t)acc;
+    return r;
+}
+
 template <int MODE, int MINW>
 __global__ void __launch_bounds__(256, MINW) k_mul(uint32_t *out, uint32_t seed) {
     uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -64,6 +101,7 @@ __global__ void __launch_bounds__(256, MINW) k_mul(uint32_t *out, uint32_t seed)
             if constexpr (MODE == 1) { x = fpu_mul(x, y); y = fpu_mul(y, x); }
             if constexpr (MODE == 2) { x = fpu_sqr(x); y = fpu_sqr(y); }
             if constexpr (MODE == 3) { x = fpu_mul2(x, y); y = fpu_mul2(y, x); }
+            if constexpr (MODE == 5) { x = fpu_mul_asm(x, y); y = fpu_mul_asm(y, x); }
             if constexpr (MODE == 4) { FpU<P> t = fpu_mul(x, y); FpU<P> u = fpu_mul(y, y); x = t; y = u; }  // 2 independent muls
         }
         uint32_t s = 0; for (int i = 0; i < 9; ++i) s ^= x.l[i] ^ y.l[i];
@@ -96,6 +134,7 @@ int main() {
         run<2, 1>("unsat 9x29 sqr", d, bpc);
         run<3, 1>("unsat 9x29 mul, split acc", d, bpc);
         run<4, 1>("unsat 9x29 2 indep muls", d, bpc);
+        run<5, 1>("unsat 9x29 mul, asm single chain", d, bpc);
     }
     return 0;
 }
