@@ -422,18 +422,20 @@ __global__ void __launch_bounds__(256) k_fixup_level(uint32_t nbuckets, const vo
 //   level 2 (k_reduce2): one block per window combines the level-1 block results the same way.
 // Identity used:  sum_{k in [base, base+T*L)} (k-base+1) B_k = sum_t W_t + L * sum_{t>=1} Suf_t,
 //   S_t = sum of segment t, W_t = sum_{k in seg t} (k-lo_t+1) B_k, Suf_t = sum_{t'>=t} S_t'.
+// `active` (power of two, <= TPB): threads t >= active hold infinity and take no part, so the scan and the trees need only
+// log2(active) levels.
 template <class A, int TPB>
 __device__ __forceinline__ void block_combine(typename A::Elem S, typename A::Elem W, uint32_t log2L, typename A::Elem *lds,
-                                              typename A::Elem &S_out, typename A::Elem &W_out) {
+                                              typename A::Elem &S_out, typename A::Elem &W_out, uint32_t active = TPB) {
     using E = typename A::Elem;
     const uint32_t t = threadIdx.x;
     // inclusive suffix scan of S over threads (Hillis-Steele)
     lds[t] = S;
     __syncthreads();
     E suf = S;
-    for (uint32_t d = 1; d < TPB; d <<= 1) {
+    for (uint32_t d = 1; d < active; d <<= 1) {
         E o = A::infinity();
-        if (t + d < TPB) o = lds[t + d];
+        if (t + d < active) o = lds[t + d];
         __syncthreads();
         A::add(suf, o);
         lds[t] = suf;
@@ -448,18 +450,18 @@ __device__ __forceinline__ void block_combine(typename A::Elem S, typename A::El
     lds[t] = U;
     ldsW[t] = W;
     __syncthreads();
-    constexpr uint32_t H = TPB / 2;
-    const bool upper = t >= H;
-    const uint32_t tt = upper ? t - H : t;
+    const uint32_t H = active / 2;  // active >= 2
+    const bool upper = t >= TPB / 2;
+    const uint32_t tt = upper ? t - TPB / 2 : t;
     E *arr = upper ? ldsW : lds;
-    // first level folds TPB -> H elements in both arrays: thread tt of each half adds element tt + H
-    E mine = arr[tt];
-    {
+    // first level folds active -> H elements in both arrays: thread tt (< H) of each half adds element tt + H
+    E mine = arr[tt < active ? tt : 0];
+    if (tt < H) {
         E o = arr[tt + H];
         A::add(mine, o);
     }
     __syncthreads();
-    arr[tt] = mine;
+    if (tt < H) arr[tt] = mine;
     __syncthreads();
     for (uint32_t d = H / 2; d >= 1; d >>= 1) {
         if (tt < d) {
@@ -528,7 +530,9 @@ __global__ void __launch_bounds__(TPB) k_reduce2(const void *__restrict__ in1, u
         W = A::load(in1, ((size_t)k * nblocks1 + t) * 2 + 1);
     }
     E S_out, W_out;
-    block_combine<A, TPB>(S, W, log2span, lds, S_out, W_out);
+    uint32_t active = 2;
+    while (active < nblocks1) active <<= 1;
+    block_combine<A, TPB>(S, W, log2span, lds, S_out, W_out, active);
     if (t == 0) A::store_final(window_totals, k, W_out);
 }
 
