@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--logn", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--resident", action="store_true",
+                    help="register the bases once (gmsm_bases_register) and time MultiExp over the resident form")
     ap.add_argument("--curve", default="bn254", help="exploration only: bn254 | bls12_381 | bw6_761")
     ap.add_argument("--group", default="g1", help="exploration only: g1 | g2")
     args = ap.parse_args()
@@ -90,7 +92,11 @@ def main():
     sharding = importlib.import_module("gnark-crypto_amd.sharding")
     gather = sharding.torch_all_gather(dist, torch.device("cuda", local_rank)) if world > 1 else None
 
+    resident = g.register_bases(d_points=d_pts.data_ptr(), n=n) if (args.resident and world == 1) else None
+
     def step():
+        if resident is not None:
+            return resident.multiexp_device(d_sc.data_ptr(), n, stream)
         if world == 1:
             return g.multiexp_device(d_pts.data_ptr(), d_sc.data_ptr(), n, stream)
         # window sharding: rank r owns windows r, r+world, ...; one RCCL all-gather of <= ceil(nwin/world) XYZZ totals
@@ -142,7 +148,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u32 limbs (256-bit Montgomery)", "data": "synthetic",
             "config": {"workload": f"{args.curve.upper()} {args.group.upper()} MultiExp 2^{args.logn} points, bases+scalars resident in HBM",
-                       "points": n, "window_bits": c, "windows": nwin,
+                       "points": n, "window_bits": c, "windows": nwin, "resident_bases": resident is not None,
                        "parallelism": "single GPU" if world == 1 else f"window-sharded x{world} + RCCL all-gather"},
             "points_per_s": value * n,
             "stage_ms": stages,

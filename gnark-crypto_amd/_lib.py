@@ -23,7 +23,8 @@ GROUP_IDS = {
 ABI_SYMBOLS = [
     "gmsm_bn254_g1_multiexp", "gmsm_bn254_g2_multiexp", "gmsm_bls12_381_g1_multiexp", "gmsm_bls12_381_g2_multiexp",
     "gmsm_bw6_761_g1_multiexp", "gmsm_bw6_761_g2_multiexp", "gmsm_multiexp", "gmsm_multiexp_affine",
-    "gmsm_multiexp_device", "gmsm_default_window_bits", "gmsm_num_windows", "gmsm_window_sums_device",
+    "gmsm_multiexp_device", "gmsm_bases_register", "gmsm_bases_release", "gmsm_multiexp_bases",
+    "gmsm_multiexp_bases_device", "gmsm_default_window_bits", "gmsm_num_windows", "gmsm_window_sums_device",
     "gmsm_fold_windows", "gmsm_jac_to_affine", "gmsm_affine_limbs", "gmsm_scalar_limbs", "gmsm_debug_decompose",
     "gmsm_debug_field_op", "gmsm_debug_group_op", "gmsm_generate_points", "gmsm_set_profiling", "gmsm_get_stage_times",
     "gmsm_device_count", "gmsm_set_device", "gmsm_last_error",
@@ -67,6 +68,14 @@ def load():
     L.gmsm_multiexp_affine.argtypes = [ctypes.c_int, u64p, sz, u64p, sz, ctypes.c_int, u64p]
     L.gmsm_multiexp_device.restype = ctypes.c_int
     L.gmsm_multiexp_device.argtypes = [ctypes.c_int, vp, vp, sz, vp, u64p]
+    L.gmsm_bases_register.restype = ctypes.c_int
+    L.gmsm_bases_register.argtypes = [ctypes.c_int, u64p, vp, sz, vp]
+    L.gmsm_bases_release.restype = ctypes.c_int
+    L.gmsm_bases_release.argtypes = [ctypes.c_uint64]
+    L.gmsm_multiexp_bases.restype = ctypes.c_int
+    L.gmsm_multiexp_bases.argtypes = [ctypes.c_uint64, u64p, sz, ctypes.c_int, u64p]
+    L.gmsm_multiexp_bases_device.restype = ctypes.c_int
+    L.gmsm_multiexp_bases_device.argtypes = [ctypes.c_uint64, vp, sz, vp, u64p]
     L.gmsm_default_window_bits.restype = ctypes.c_uint
     L.gmsm_default_window_bits.argtypes = [ctypes.c_int, sz]
     L.gmsm_num_windows.restype = ctypes.c_uint

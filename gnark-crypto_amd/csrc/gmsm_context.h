@@ -38,6 +38,14 @@ struct DeviceBuffer {
     }
 };
 
+// Bases rewritten once into the lazy Montgomery domain and kept in HBM (gmsm_bases_register): the resident-SRS path.
+struct ResidentBases {
+    int group = -1;
+    int device = -1;
+    size_t n = 0;
+    DeviceBuffer upoints, skip;
+};
+
 struct Context {
     std::mutex mu;
     int device = -1;
@@ -150,9 +158,9 @@ struct GroupVTable {
     int (*multiexp_host)(const uint64_t *points, size_t n_points, const uint64_t *scalars, size_t n_scalars, int nb_tasks,
                          uint64_t *out_jac);
     int (*multiexp_device)(Context &ctx, const void *d_points, const void *d_scalars, size_t n, hipStream_t stream,
-                           uint64_t *out_jac);
+                           uint64_t *out_jac, const ResidentBases *resident);
     int (*window_sums)(Context &ctx, const void *d_points, const void *d_scalars, size_t n, unsigned c, unsigned win_first,
-                       unsigned win_stride, hipStream_t stream, uint64_t *out_xyzz);
+                       unsigned win_stride, hipStream_t stream, uint64_t *out_xyzz, const ResidentBases *resident);
     void (*fold)(const uint64_t *xyzz_windows, unsigned c, uint64_t *out_jac);
     void (*jac_to_affine)(const uint64_t *jac, uint64_t *out_affine);
     int (*debug_decompose)(const uint64_t *scalars, size_t n, unsigned c, uint32_t *out_digits);
@@ -160,6 +168,7 @@ struct GroupVTable {
     int (*debug_group_op)(int op, const uint64_t *acc, const uint64_t *other, size_t count, uint64_t *out);
     void (*generate_points)(const uint64_t *base, const uint64_t *k0, const uint64_t *k1, int klimbs, size_t n, int nthreads,
                             uint64_t *out);
+    int (*register_bases)(Context &ctx, const void *d_points, size_t n, hipStream_t stream, ResidentBases *out);
 };
 
 }  // namespace gmsm

@@ -115,7 +115,93 @@ GMSM_EXPORT int gmsm_multiexp_device(int group, const void *d_points, const void
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
-    return vt->multiexp_device(*ctx, d_points, d_scalars, n, hip_stream ? (hipStream_t)hip_stream : ctx->stream, out_jac);
+    return vt->multiexp_device(*ctx, d_points, d_scalars, n, hip_stream ? (hipStream_t)hip_stream : ctx->stream, out_jac,
+                               nullptr);
+}
+
+// ------------------------------------------------------------------ resident bases
+static std::mutex g_bases_mu;
+static std::vector<ResidentBases *> g_bases;  // handle = index + 1
+
+static ResidentBases *lookup_bases(uint64_t handle) {
+    std::lock_guard<std::mutex> lk(g_bases_mu);
+    if (handle == 0 || handle > g_bases.size()) return nullptr;
+    return g_bases[handle - 1];
+}
+
+GMSM_EXPORT int gmsm_bases_register(int group, const uint64_t *points, const void *d_points, size_t n,
+                                    uint64_t *out_handle) {
+    VT_OR_FAIL(group);
+    if ((points == nullptr) == (d_points == nullptr) && n)
+        return fail(GMSM_ERR_ARG, "gmsm_bases_register: give exactly one of points (host) / d_points (device)");
+    Context *ctx;
+    int rc = get_context(&ctx);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const void *src = d_points;
+    if (points && n) {
+        if ((rc = ctx->points.ensure(n * vt->aff_bytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->points.ptr, points, n * vt->aff_bytes, hipMemcpyHostToDevice, ctx->stream));
+        src = ctx->points.ptr;
+    }
+    ResidentBases *rb = new ResidentBases();
+    rb->group = group;
+    rb->device = ctx->device;
+    rc = vt->register_bases(*ctx, src, n, ctx->stream, rb);
+    if (rc) {
+        delete rb;
+        return rc;
+    }
+    std::lock_guard<std::mutex> lk2(g_bases_mu);
+    g_bases.push_back(rb);
+    *out_handle = g_bases.size();
+    return GMSM_OK;
+}
+
+GMSM_EXPORT int gmsm_bases_release(uint64_t handle) {
+    std::lock_guard<std::mutex> lk(g_bases_mu);
+    if (handle == 0 || handle > g_bases.size() || !g_bases[handle - 1]) return fail(GMSM_ERR_ARG, "unknown bases handle");
+    ResidentBases *rb = g_bases[handle - 1];
+    g_bases[handle - 1] = nullptr;
+    (void)hipSetDevice(rb->device);
+    if (rb->upoints.ptr) (void)hipFree(rb->upoints.ptr);
+    if (rb->skip.ptr) (void)hipFree(rb->skip.ptr);
+    delete rb;
+    return GMSM_OK;
+}
+
+static int multiexp_bases_impl(uint64_t handle, const uint64_t *scalars, const void *d_scalars, size_t n, int nb_tasks,
+                               void *hip_stream, uint64_t *out_jac) {
+    ResidentBases *rb = lookup_bases(handle);
+    if (!rb) return fail(GMSM_ERR_ARG, "unknown bases handle");
+    const GroupVTable *vt = vtable(rb->group);
+    if (n > rb->n) return fail(GMSM_ERR_LEN, "len(points) != len(scalars)");  // more scalars than registered bases
+    if (nb_tasks > 1024) return fail(GMSM_ERR_CONFIG, "invalid config: config.NbTasks > 1024");
+    Context *ctx;
+    int rc = get_context(&ctx);
+    if (rc) return rc;
+    if (ctx->device != rb->device) return fail(GMSM_ERR_ARG, "bases were registered on another device");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    const void *dsc = d_scalars;
+    if (scalars && n) {
+        if ((rc = ctx->scalars.ensure(n * vt->scalar_bytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->scalars.ptr, scalars, n * vt->scalar_bytes, hipMemcpyHostToDevice, stream));
+        dsc = ctx->scalars.ptr;
+    }
+    return vt->multiexp_device(*ctx, nullptr, dsc, n, stream, out_jac, rb);
+}
+
+GMSM_EXPORT int gmsm_multiexp_bases(uint64_t handle, const uint64_t *scalars, size_t n_scalars, int nb_tasks,
+                                    uint64_t *out_jac) {
+    return multiexp_bases_impl(handle, scalars, nullptr, n_scalars, nb_tasks, nullptr, out_jac);
+}
+
+GMSM_EXPORT int gmsm_multiexp_bases_device(uint64_t handle, const void *d_scalars, size_t n_scalars, void *hip_stream,
+                                           uint64_t *out_jac) {
+    return multiexp_bases_impl(handle, nullptr, d_scalars, n_scalars, 0, hip_stream, out_jac);
 }
 
 GMSM_EXPORT unsigned gmsm_default_window_bits(int group, size_t n) {
@@ -138,7 +224,7 @@ GMSM_EXPORT int gmsm_window_sums_device(int group, const void *d_points, const v
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     return vt->window_sums(*ctx, d_points, d_scalars, n, c, win_first, win_stride,
-                           hip_stream ? (hipStream_t)hip_stream : ctx->stream, out_xyzz);
+                           hip_stream ? (hipStream_t)hip_stream : ctx->stream, out_xyzz, nullptr);
 }
 
 GMSM_EXPORT int gmsm_fold_windows(int group, unsigned c, const uint64_t *xyzz_windows, uint64_t *out_jac) {

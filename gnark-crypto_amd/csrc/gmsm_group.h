@@ -60,8 +60,10 @@ struct Group {
     }
 
     // Runs the device pipeline for the windows of `plan`; host_xyzz receives plan.nwin_local window totals.
+    // d_points: Go-layout affine bases on the device, or nullptr when `resident` (bases already rewritten into the lazy
+    // domain by register_bases) is given.
     static int window_sums(Context &ctx, const void *d_points, const void *d_scalars, size_t n, const WindowPlan &plan,
-                           hipStream_t stream, Ext *host_xyzz) {
+                           hipStream_t stream, Ext *host_xyzz, const ResidentBases *resident = nullptr) {
         const uint32_t nw = plan.nwin_local;
         if (nw == 0) return GMSM_OK;
         if (n == 0) {
@@ -103,11 +105,16 @@ struct Group {
         // 0. (fast path) rewrite the bases into the unsaturated Montgomery domain + infinity flags
         timer.mark(STAGE_DECOMPOSE);
         const uint8_t *skip = nullptr;
-        if constexpr (FAST_PATH) {
+        const void *upoints = nullptr;
+        if (resident) {
+            upoints = resident->upoints.ptr;
+            skip = (const uint8_t *)resident->skip.ptr;
+        } else {
             if ((rc = ctx.upoints.ensure(n * AFF_BYTES))) return rc;
             if ((rc = ctx.skip.ensure(n))) return rc;
             hipLaunchKernelGGL((k_convert_points<U>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                                stream, d_points, n, ctx.upoints.ptr, (uint8_t *)ctx.skip.ptr);
+            upoints = ctx.upoints.ptr;
             skip = (const uint8_t *)ctx.skip.ptr;
         }
         // 1. signed-digit decomposition
@@ -155,7 +162,7 @@ struct Group {
             if ((rc = ctx.seg_flags.ensure((size_t)nw * tpw * 4))) return rc;
             if ((rc = ctx.seg_bucket.ensure((size_t)nw * tpw * 4))) return rc;
             hipLaunchKernelGGL((k_accumulate_seg<U>), dim3((tpw + 255) / 256, nw), dim3(256), 0, stream,
-                               ctx.upoints.ptr, n, NB, seg, starts, sorted, ctx.buckets.ptr, ctx.seg_partials.ptr,
+                               upoints, n, NB, seg, starts, sorted, ctx.buckets.ptr, ctx.seg_partials.ptr,
                                (uint32_t *)ctx.seg_flags.ptr, (uint32_t *)ctx.seg_bucket.ptr, tpw);
             // chain fixup: short chains in place, long ones through two hierarchical levels (no-ops unless flagged)
             const uint32_t span1 = 64;
@@ -290,12 +297,29 @@ struct Group {
         for (auto &t : th) t.join();
     }
 
+    // Rewrites n Go-layout bases (device memory) into the lazy domain once; the result serves any number of MultiExp
+    // calls over a prefix of the bases (kzg.Commit over pk.G1[:len(p)], ecc/bn254/kzg/kzg.go:159-176).
+    static int register_bases(Context &ctx, const void *d_points, size_t n, hipStream_t stream, ResidentBases *out) {
+        int rc;
+        if ((rc = out->upoints.ensure(n * AFF_BYTES))) return rc;
+        if ((rc = out->skip.ensure(n))) return rc;
+        if (n) {
+            hipLaunchKernelGGL((k_convert_points<U>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_points, n,
+                               out->upoints.ptr, (uint8_t *)out->skip.ptr);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
+        out->n = n;
+        (void)ctx;
+        return GMSM_OK;
+    }
+
     static int multiexp_device(Context &ctx, const void *d_points, const void *d_scalars, size_t n, hipStream_t stream,
-                               J *out) {
+                               J *out, const ResidentBases *resident = nullptr) {
         const unsigned c = choose_c(FR_BITS, n);
         WindowPlan plan = make_plan(c, 0, 1);
         std::vector<Ext> totals(plan.nwin_total);
-        int rc = window_sums(ctx, d_points, d_scalars, n, plan, stream, totals.data());
+        int rc = window_sums(ctx, d_points, d_scalars, n, plan, stream, totals.data(), resident);
         if (rc) return rc;
         *out = fold(totals.data(), c);
         return GMSM_OK;
@@ -454,20 +478,25 @@ struct VTableOf {
         return GMSM_OK;
     }
     static int multiexp_device(Context &ctx, const void *d_points, const void *d_scalars, size_t n, hipStream_t stream,
-                               uint64_t *out_jac) {
+                               uint64_t *out_jac, const ResidentBases *resident) {
         typename G::J j;
         if (n == 0) j = typename G::J{G::F::one(), G::F::one(), G::F::zero()};
         else {
-            int rc = G::multiexp_device(ctx, d_points, d_scalars, n, stream, &j);
+            int rc = G::multiexp_device(ctx, d_points, d_scalars, n, stream, &j, resident);
             if (rc) return rc;
         }
         memcpy(out_jac, &j, sizeof j);
         return GMSM_OK;
     }
     static int window_sums(Context &ctx, const void *d_points, const void *d_scalars, size_t n, unsigned c,
-                           unsigned win_first, unsigned win_stride, hipStream_t stream, uint64_t *out_xyzz) {
+                           unsigned win_first, unsigned win_stride, hipStream_t stream, uint64_t *out_xyzz,
+                           const ResidentBases *resident) {
         WindowPlan plan = G::make_plan(c, win_first, win_stride);
-        return G::window_sums(ctx, d_points, d_scalars, n, plan, stream, reinterpret_cast<typename G::Ext *>(out_xyzz));
+        return G::window_sums(ctx, d_points, d_scalars, n, plan, stream, reinterpret_cast<typename G::Ext *>(out_xyzz),
+                              resident);
+    }
+    static int register_bases(Context &ctx, const void *d_points, size_t n, hipStream_t stream, ResidentBases *out) {
+        return G::register_bases(ctx, d_points, n, stream, out);
     }
     static void fold(const uint64_t *xyzz_windows, unsigned c, uint64_t *out_jac) {
         typename G::J j = G::fold(reinterpret_cast<const typename G::Ext *>(xyzz_windows), c);
@@ -505,7 +534,7 @@ struct VTableOf {
         static const GroupVTable vt = {G::FR_BITS,      G::AFF_BYTES,   G::SCALAR_BYTES, sizeof(typename G::J),
                                        sizeof(typename G::Ext), &multiexp_host, &multiexp_device, &window_sums,
                                        &fold,           &jac_to_affine, &debug_decompose, &debug_field_op,
-                                       &debug_group_op, &generate_points};
+                                       &debug_group_op, &generate_points, &register_bases};
         return &vt;
     }
 };

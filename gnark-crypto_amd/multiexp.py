@@ -113,6 +113,21 @@ class _Group:
             raise RuntimeError(self._error(rc))
         return out
 
+    # ---- resident bases (device-resident SRS): register once, then MultiExp over any prefix with scalars only
+    def register_bases(self, points=None, d_points=None, n=None):
+        """Upload (host `points`) or adopt (`d_points` device pointer, n points) the bases; returns a ResidentBases."""
+        L = _lib.load()
+        handle = _lib.ctypes.c_uint64(0)
+        if points is not None:
+            points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, self.aff_limbs)
+            rc = L.gmsm_bases_register(self.gid, _ptr(points), None, points.shape[0], _lib.ctypes.byref(handle))
+            n = points.shape[0]
+        else:
+            rc = L.gmsm_bases_register(self.gid, None, d_points, n, _lib.ctypes.byref(handle))
+        if rc:
+            raise RuntimeError(self._error(rc))
+        return ResidentBases(self, handle.value, n)
+
     def default_window_bits(self, n):
         return int(_lib.load().gmsm_default_window_bits(self.gid, n))
 
@@ -148,6 +163,35 @@ class _Group:
         if rc:
             raise RuntimeError(self._error(rc))
         return out
+
+
+class ResidentBases:
+    """Bases kept on the device in the engine's internal form (gmsm_bases_register)."""
+
+    def __init__(self, group, handle, n):
+        self.group, self.handle, self.n = group, handle, n
+
+    def MultiExp(self, scalars, config=MultiExpConfig()):
+        """MultiExp(bases[:len(scalars)], scalars): returns (jacobian_limbs, None) or (None, error)."""
+        L = _lib.load()
+        g = self.group
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, g.fr_limbs)
+        out = np.zeros(g.jac_limbs, dtype=np.uint64)
+        rc = L.gmsm_multiexp_bases(self.handle, _ptr(scalars), scalars.shape[0], int(config.NbTasks), _ptr(out))
+        return (out, None) if rc == 0 else (None, g._error(rc))
+
+    def multiexp_device(self, d_scalars, n, stream=0):
+        L = _lib.load()
+        out = np.zeros(self.group.jac_limbs, dtype=np.uint64)
+        rc = L.gmsm_multiexp_bases_device(self.handle, d_scalars, n, stream or None, _ptr(out))
+        if rc:
+            raise RuntimeError(self.group._error(rc))
+        return out
+
+    def release(self):
+        if self.handle:
+            _lib.load().gmsm_bases_release(self.handle)
+            self.handle = 0
 
 
 class G1Jac(_Group):

@@ -83,6 +83,18 @@ int gmsm_multiexp_affine(int group, const uint64_t *points, size_t n_points, con
 int gmsm_multiexp_device(int group, const void *d_points, const void *d_scalars, size_t n, void *hip_stream,
                          uint64_t *out_jac);
 
+/* ---- resident bases (device-resident SRS): the bases of e.g. a KZG proving key
+ *      (ecc/bn254/kzg/kzg.go:35-37) are uploaded and rewritten into the engine's internal form once;
+ *      every later MultiExp over a prefix of them (kzg.Commit: pk.G1[:len(p)], kzg.go:159-176) sends only scalars.
+ *      Give exactly one of `points` (host, Go layout) / `d_points` (device, Go layout). ---- */
+int gmsm_bases_register(int group, const uint64_t *points, const void *d_points, size_t n, uint64_t *out_handle);
+int gmsm_bases_release(uint64_t handle);
+/* scalars on the host (n_scalars <= registered n) */
+int gmsm_multiexp_bases(uint64_t handle, const uint64_t *scalars, size_t n_scalars, int nb_tasks, uint64_t *out_jac);
+/* scalars already on the device */
+int gmsm_multiexp_bases_device(uint64_t handle, const void *d_scalars, size_t n_scalars, void *hip_stream,
+                               uint64_t *out_jac);
+
 /* ---- window-sharded pieces (multi-GPU: windows win_first, win_first+win_stride, ... of the c-bit decomposition are
  *      handled by this device; the tiny per-window totals are exchanged by the caller, e.g. one RCCL all-gather).
  *      out_xyzz (host) receives nwin_local x {X,Y,ZZ,ZZZ} extended-Jacobian window totals

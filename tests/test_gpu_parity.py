@@ -313,3 +313,28 @@ def test_baseline_config_full_size(gm, oracle_mod, curve, which, logn):
     mt, mu = gpu(t), gpu(u)
     lhs = o.jac_to_affine(o.xyzz_to_jac(o.xyzz_add_mixed(o.xyzz_add_mixed(o.xyzz_infinity(), ms), mt)))
     assert (lhs == mu).all()
+
+
+@pytest.mark.parametrize("curve,which", [("bn254", "g1"), ("bls12_381", "g2")])
+def test_resident_bases_prefix_multiexp(gm, oracle_mod, curve, which):
+    """Device-resident SRS (gmsm_bases_register): MultiExp over prefixes of the registered bases, as kzg.Commit does with
+    pk.G1[:len(p)] (ecc/bn254/kzg/kzg.go:159-176), equals the oracle; more scalars than bases is the length error."""
+    g = _group(gm, curve, which)
+    o = oracle_mod.Oracle(curve, which)
+    n = 3000
+    rng = rng_for(9, g.gid)
+    pts = o.gen_points(n, 4242, 77, nthreads=4)
+    pts[11] = 0
+    sc = random_scalars(rng, g.curve, n)
+    rb = g.register_bases(points=pts)
+    try:
+        for m in (n, 1777, 1, 0):
+            jac, err = rb.MultiExp(sc[:m])
+            assert err is None
+            assert (g.jac_to_affine(jac) == o.msm_affine(pts[:m], sc[:m])).all(), m
+        _, err = rb.MultiExp(np.zeros((n + 1, g.fr_limbs), dtype=np.uint64))
+        assert err == "len(points) != len(scalars)"
+        _, err = rb.MultiExp(sc, gm.MultiExpConfig(NbTasks=2000))
+        assert err == "invalid config: config.NbTasks > 1024"
+    finally:
+        rb.release()
