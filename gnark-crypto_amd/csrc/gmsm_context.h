@@ -54,6 +54,7 @@ struct Context {
     DeviceBuffer upoints, skip;    // bases rewritten for the unsaturated fast path + infinity flags
     DeviceBuffer seg_lvl;  // hierarchical chain fixup: level partials, flags, long-chain flags
     DeviceBuffer seg_partials, seg_flags, seg_bucket;  // split-bucket partial sums of the segmented accumulation
+    DeviceBuffer parted;  // coarse-partitioned references (two-level grouping)
     DeviceBuffer digits, sorted, blockhist, counts, starts, buckets, partials, totals;
     hipEvent_t events[8] = {nullptr};  // stage boundaries when profiling is on
     void *pinned = nullptr;  // pinned host buffer for the window totals

@@ -120,23 +120,67 @@ struct Group {
         // 1. signed-digit decomposition
         hipLaunchKernelGGL((k_decompose<FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                            (const uint32_t *)d_scalars, n, plan, digits, skip);
-        // 2. group point references by bucket (counting sort per window)
-        const size_t hist_lds = (size_t)NB * 4;
-        if (hist_lds > 160 * 1024) return fail(GMSM_ERR_ARG, "window too wide for the LDS histogram (c <= 16)");
-        static bool attr_done = false;
-        if (!attr_done) {
-            HIP_TRY(hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            HIP_TRY(hipFuncSetAttribute((const void *)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_done = true;
+        // 2. group point references by bucket
+        const bool two_level = env_uint("GMSM_SORT2", 1) != 0;
+        if (two_level) {
+            // fine buckets per partition: ~16 K references per partition for uniform scalars
+            uint32_t log2NB = 0;
+            while ((1u << log2NB) < NB) ++log2NB;
+            uint32_t log2n = 0;
+            while (((size_t)1 << log2n) < n) ++log2n;
+            const uint32_t lidx = log2n + 1;  // bits of (index << 1 | negate)
+            int fb = 14 + (int)log2NB - (int)log2n;
+            if (fb > (int)log2NB) fb = (int)log2NB;
+            if (fb < 0) fb = 0;
+            if (fb + lidx > 32) fb = 32 - lidx;
+            const uint32_t fbits = (uint32_t)fb;
+            const uint32_t nparts = NB >> fbits;
+            const uint32_t pchunks = (uint32_t)((n + PART_CHUNK - 1) / PART_CHUNK);  // chunk = one LDS staging buffer
+            const size_t pchunk_len = PART_CHUNK;
+            if ((rc = ctx.blockhist.ensure((size_t)nw * pchunks * nparts * 4))) return rc;
+            if ((rc = ctx.counts.ensure((size_t)nw * (2 * nparts + 1) * 4))) return rc;
+            if ((rc = ctx.parted.ensure((size_t)nw * n * 4))) return rc;
+            uint32_t *bh = (uint32_t *)ctx.blockhist.ptr, *part_base = (uint32_t *)ctx.counts.ptr;
+            uint32_t *part_pop = part_base + (size_t)nw * (nparts + 1);
+            uint32_t *parted = (uint32_t *)ctx.parted.ptr;
+            static bool attr2_done = false;
+            if (!attr2_done) {
+                HIP_TRY(hipFuncSetAttribute((const void *)k_part_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                HIP_TRY(hipFuncSetAttribute((const void *)k_part_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+                HIP_TRY(hipFuncSetAttribute((const void *)k_fine_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+                attr2_done = true;
+            }
+            timer.mark(STAGE_HIST);
+            hipLaunchKernelGGL(k_part_hist, dim3(pchunks, nw), dim3(1024), (size_t)nparts * 4, stream, digits, n, nparts, fbits,
+                               pchunk_len, bh);
+            timer.mark(STAGE_SCAN);
+            hipLaunchKernelGGL(k_part_colscan, dim3((nparts + 255) / 256, nw), dim3(256), 0, stream, bh, pchunks, nparts,
+                               part_pop);
+            hipLaunchKernelGGL(k_part_rowscan, dim3(nw), dim3(1024), 0, stream, part_pop, nparts, part_base);
+            timer.mark(STAGE_SCATTER);
+            hipLaunchKernelGGL(k_part_scatter, dim3(pchunks, nw), dim3(1024),
+                               (size_t)nparts * 8 + (size_t)PART_CHUNK * 6, stream, digits, n, nparts, fbits, lidx, pchunk_len,
+                               bh, part_base, parted);
+            hipLaunchKernelGGL(k_fine_sort, dim3(nparts, nw), dim3(1024), ((size_t)4 << fbits), stream, parted, n, NB, fbits,
+                               lidx, part_base, sorted, starts);
+        } else {
+            const size_t hist_lds = (size_t)NB * 4;
+            if (hist_lds > 160 * 1024) return fail(GMSM_ERR_ARG, "window too wide for the LDS histogram (c <= 16)");
+            static bool attr_done = false;
+            if (!attr_done) {
+                HIP_TRY(hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                HIP_TRY(hipFuncSetAttribute((const void *)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_done = true;
+            }
+            timer.mark(STAGE_HIST);
+            hipLaunchKernelGGL(k_hist, dim3(nchunks, nw), dim3(1024), hist_lds, stream, digits, n, NB, chunk_len, blockhist);
+            timer.mark(STAGE_SCAN);
+            hipLaunchKernelGGL(k_colscan, dim3((NB + 255) / 256, nw), dim3(256), 0, stream, blockhist, nchunks, NB, counts);
+            hipLaunchKernelGGL(k_rowscan, dim3(nw), dim3(1024), 0, stream, counts, NB, starts);
+            timer.mark(STAGE_SCATTER);
+            hipLaunchKernelGGL(k_scatter, dim3(nchunks, nw), dim3(1024), hist_lds, stream, digits, n, NB, chunk_len,
+                               blockhist, starts, sorted);
         }
-        timer.mark(STAGE_HIST);
-        hipLaunchKernelGGL(k_hist, dim3(nchunks, nw), dim3(1024), hist_lds, stream, digits, n, NB, chunk_len, blockhist);
-        timer.mark(STAGE_SCAN);
-        hipLaunchKernelGGL(k_colscan, dim3((NB + 255) / 256, nw), dim3(256), 0, stream, blockhist, nchunks, NB, counts);
-        hipLaunchKernelGGL(k_rowscan, dim3(nw), dim3(1024), 0, stream, counts, NB, starts);
-        timer.mark(STAGE_SCATTER);
-        hipLaunchKernelGGL(k_scatter, dim3(nchunks, nw), dim3(1024), hist_lds, stream, digits, n, NB, chunk_len,
-                           blockhist, starts, sorted);
         // 3. bucket accumulation
         timer.mark(STAGE_ACCUMULATE);
         const uint32_t *reduce_starts = nullptr;

@@ -187,6 +187,228 @@ static __global__ void __launch_bounds__(1024) k_scatter(const uint32_t *__restr
     }
 }
 
+// ------------------------------------------------------------------ two-level grouping (coarse partition, fine sort)
+// The single-pass scatter above writes every 4-byte reference to an effectively random address of the window's
+// sorted array: rocprofv3 shows 32 B of HBM write per 4-byte store (r01f: 8.5 GB for 268 M references at 2^24).
+// Two-level form: (A) references are first distributed into P coarse partitions (bucket >> fbits) -- a workgroup
+// writes one contiguous run per partition; (B) one workgroup per (window, partition) counting-sorts its run by the low
+// bucket bits with the cursors in LDS; its scattered writes stay inside a region of a few tens of KB, i.e. they
+// coalesce in L2 before reaching HBM. Partition populations are ~16 K references for uniform scalars; any population
+// is handled (the fine pass streams its run twice), skewed inputs just lose the locality benefit.
+// Entry format between the passes: (fine_bucket << lidx) | (point_index << 1 | negate).
+
+// grid = (nchunks, nwin). LDS: P counters. blockhist[k][chunk][p]
+static __global__ void __launch_bounds__(1024) k_part_hist(const uint32_t *__restrict__ digits, size_t n, uint32_t nparts,
+                                                           uint32_t fbits, size_t chunk_len,
+                                                           uint32_t *__restrict__ blockhist) {
+    extern __shared__ uint32_t lds_cnt[];
+    const uint32_t chunk = blockIdx.x, k = blockIdx.y, nchunks = gridDim.x;
+    for (uint32_t p = threadIdx.x; p < nparts; p += blockDim.x) lds_cnt[p] = 0;
+    __syncthreads();
+    const size_t lo = (size_t)chunk * chunk_len;
+    const size_t hi = lo + chunk_len < n ? lo + chunk_len : n;
+    const uint32_t *d = digits + (size_t)k * n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t code = d[i];
+        if (code) atomicAdd(&lds_cnt[code_bucket(code) >> fbits], 1u);
+    }
+    __syncthreads();
+    uint32_t *out = blockhist + ((size_t)k * nchunks + chunk) * nparts;
+    for (uint32_t p = threadIdx.x; p < nparts; p += blockDim.x) out[p] = lds_cnt[p];
+}
+
+// grid = (ceil(nparts/256), nwin): one thread per (window, partition) turns the per-chunk counts into exclusive prefixes
+// over the chunks (in place) and emits the partition population.
+static __global__ void __launch_bounds__(256) k_part_colscan(uint32_t *__restrict__ blockhist, uint32_t nchunks, uint32_t nparts,
+                                                             uint32_t *__restrict__ part_pop) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (p >= nparts) return;
+    uint32_t *bh = blockhist + (size_t)k * nchunks * nparts + p;
+    uint32_t run = 0;
+    for (uint32_t ch = 0; ch < nchunks; ++ch) {
+        const uint32_t v = bh[(size_t)ch * nparts];
+        bh[(size_t)ch * nparts] = run;
+        run += v;
+    }
+    part_pop[(size_t)k * nparts + p] = run;
+}
+
+// grid = nwin, block = 1024: exclusive scan of the partition populations -> part_base[k][0..nparts]
+static __global__ void __launch_bounds__(1024) k_part_rowscan(const uint32_t *__restrict__ part_pop, uint32_t nparts,
+                                                              uint32_t *__restrict__ part_base) {
+    __shared__ uint32_t sums[1024];
+    const uint32_t k = blockIdx.x, t = threadIdx.x, T = blockDim.x;
+    const uint32_t *pp = part_pop + (size_t)k * nparts;
+    uint32_t *pb = part_base + (size_t)k * (nparts + 1);
+    const uint32_t per = (nparts + T - 1) / T;
+    const uint32_t plo = t * per, phi = plo + per < nparts ? plo + per : nparts;
+    uint32_t mine = 0;
+    for (uint32_t p = plo; p < phi; ++p) mine += pp[p];
+    sums[t] = mine;
+    __syncthreads();
+    for (uint32_t d = 1; d < T; d <<= 1) {
+        const uint32_t v = t >= d ? sums[t - d] : 0u;
+        __syncthreads();
+        sums[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = sums[t] - mine;
+    for (uint32_t p = plo; p < phi; ++p) {
+        pb[p] = run;
+        run += pp[p];
+    }
+    if (t == T - 1) pb[nparts] = sums[T - 1];
+}
+
+// grid = (nchunks, nwin), block = 1024, chunk_len <= PART_CHUNK. The chunk is first sorted by partition inside LDS
+// (staging buffer + partition id per slot), then written out slot by slot: consecutive slots of one partition go to
+// consecutive addresses, so every (chunk, partition) run leaves the CU as one burst instead of trickling out 4 bytes at
+// a time over the lifetime of the workgroup (which left L2 writing back partially filled lines: 4.4 ms at 2^24).
+constexpr uint32_t PART_CHUNK = 16384;
+static __global__ void __launch_bounds__(1024) k_part_scatter(const uint32_t *__restrict__ digits, size_t n, uint32_t nparts,
+                                                              uint32_t fbits, uint32_t lidx, size_t chunk_len,
+                                                              const uint32_t *__restrict__ blockhist,
+                                                              const uint32_t *__restrict__ part_base,
+                                                              uint32_t *__restrict__ parted) {
+    extern __shared__ uint32_t lds_ps[];
+    uint32_t *cnt = lds_ps;                 // [nparts] -> local cursor
+    uint32_t *lbase = lds_ps + nparts;      // [nparts] first staging slot of the partition
+    uint32_t *stage = lds_ps + 2 * nparts;  // [PART_CHUNK] entries sorted by partition
+    uint16_t *spid = reinterpret_cast<uint16_t *>(stage + PART_CHUNK);  // [PART_CHUNK] partition of each slot
+    __shared__ uint32_t scan_tmp[1024];
+    const uint32_t chunk = blockIdx.x, k = blockIdx.y, nchunks = gridDim.x, t = threadIdx.x, T = blockDim.x;
+    const uint32_t *goff = blockhist + ((size_t)k * nchunks + chunk) * nparts;  // prefix of (chunk, p) inside partition p
+    const uint32_t *pbase = part_base + (size_t)k * (nparts + 1);
+    for (uint32_t p = t; p < nparts; p += T) cnt[p] = 0;
+    __syncthreads();
+    const size_t lo = (size_t)chunk * chunk_len;
+    const size_t hi = lo + chunk_len < n ? lo + chunk_len : n;
+    const uint32_t *d = digits + (size_t)k * n;
+    const uint32_t fmask = (1u << fbits) - 1u;
+    constexpr int PER = PART_CHUNK / 1024;  // entries per thread, kept in registers between the two passes
+    uint32_t ent[PER];
+    uint32_t pid[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const size_t i = lo + (size_t)j * T + t;
+        uint32_t code = i < hi ? d[i] : 0u;
+        pid[j] = 0xFFFFFFFFu;
+        if (code) {
+            const uint32_t b = code_bucket(code);
+            pid[j] = b >> fbits;
+            ent[j] = ((b & fmask) << lidx) | ((uint32_t)i << 1) | (code & 1u);
+            atomicAdd(&cnt[pid[j]], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of cnt[] -> lbase[] (thread-serial chunks + block scan), cnt[] becomes the local cursor
+    const uint32_t per = (nparts + T - 1) / T;
+    const uint32_t plo = t * per, phi = plo + per < nparts ? plo + per : nparts;
+    uint32_t s = 0;
+    for (uint32_t p = plo; p < phi; ++p) s += cnt[p];
+    scan_tmp[t] = s;
+    __syncthreads();
+    for (uint32_t dd = 1; dd < T; dd <<= 1) {
+        const uint32_t v = t >= dd ? scan_tmp[t - dd] : 0u;
+        __syncthreads();
+        scan_tmp[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = scan_tmp[t] - s;
+    for (uint32_t p = plo; p < phi; ++p) {
+        const uint32_t c = cnt[p];
+        lbase[p] = run;
+        cnt[p] = run;
+        run += c;
+    }
+    const uint32_t total = scan_tmp[T - 1];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        if (pid[j] != 0xFFFFFFFFu) {
+            const uint32_t slot = atomicAdd(&cnt[pid[j]], 1u);
+            stage[slot] = ent[j];
+            spid[slot] = (uint16_t)pid[j];
+        }
+    }
+    __syncthreads();
+    uint32_t *out = parted + (size_t)k * n;
+    for (uint32_t slot = t; slot < total; slot += T) {
+        const uint32_t p = spid[slot];
+        out[pbase[p] + goff[p] + (slot - lbase[p])] = stage[slot];
+    }
+}
+
+// grid = (nparts, nwin), block = 1024. Counting sort of one partition by fine bucket; also emits starts[] of its buckets.
+static __global__ void __launch_bounds__(1024) k_fine_sort(const uint32_t *__restrict__ parted, size_t n, uint32_t nbuckets,
+                                                          uint32_t fbits, uint32_t lidx,
+                                                          const uint32_t *__restrict__ part_base,
+                                                          uint32_t *__restrict__ sorted, uint32_t *__restrict__ starts) {
+    extern __shared__ uint32_t lds_f[];  // 2^fbits counters
+    const uint32_t p = blockIdx.x, k = blockIdx.y, nparts = gridDim.x, t = threadIdx.x, T = blockDim.x;
+    const uint32_t nf = 1u << fbits;
+    const uint32_t *pb = part_base + (size_t)k * (nparts + 1);
+    const uint32_t lo = pb[p], hi = pb[p + 1];
+    const uint32_t *in = parted + (size_t)k * n;
+    uint32_t *out = sorted + (size_t)k * n;
+    uint32_t *st = starts + (size_t)k * (nbuckets + 1);
+    for (uint32_t f = t; f < nf; f += T) lds_f[f] = 0;
+    __syncthreads();
+    {   // 4 loads in flight per thread
+        uint32_t e = lo + t;
+        for (; e + 3 * T < hi; e += 4 * T) {
+            const uint32_t v0 = in[e], v1 = in[e + T], v2 = in[e + 2 * T], v3 = in[e + 3 * T];
+            atomicAdd(&lds_f[v0 >> lidx], 1u);
+            atomicAdd(&lds_f[v1 >> lidx], 1u);
+            atomicAdd(&lds_f[v2 >> lidx], 1u);
+            atomicAdd(&lds_f[v3 >> lidx], 1u);
+        }
+        for (; e < hi; e += T) atomicAdd(&lds_f[in[e] >> lidx], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the nf counters (nf <= 32768): thread-serial chunks + block scan
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (nf + T - 1) / T;
+    const uint32_t flo = t * per, fhi = flo + per < nf ? flo + per : nf;
+    uint32_t s = 0;
+    for (uint32_t f = flo; f < fhi; ++f) s += lds_f[f];
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < T; d <<= 1) {
+        const uint32_t v = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = lo + part[t] - s;
+    for (uint32_t f = flo; f < fhi; ++f) {
+        const uint32_t c = lds_f[f];
+        lds_f[f] = run;  // becomes the write cursor
+        st[(size_t)p * nf + f] = run;
+        run += c;
+    }
+    if (p == nparts - 1 && t == T - 1) st[nbuckets] = hi;
+    __syncthreads();
+    const uint32_t pmask = (1u << lidx) - 1u;
+    uint32_t e = lo + t;
+    for (; e + 3 * T < hi; e += 4 * T) {
+        const uint32_t v0 = in[e], v1 = in[e + T], v2 = in[e + 2 * T], v3 = in[e + 3 * T];
+        const uint32_t p0 = atomicAdd(&lds_f[v0 >> lidx], 1u);
+        const uint32_t p1 = atomicAdd(&lds_f[v1 >> lidx], 1u);
+        const uint32_t p2 = atomicAdd(&lds_f[v2 >> lidx], 1u);
+        const uint32_t p3 = atomicAdd(&lds_f[v3 >> lidx], 1u);
+        out[p0] = v0 & pmask;
+        out[p1] = v1 & pmask;
+        out[p2] = v2 & pmask;
+        out[p3] = v3 & pmask;
+    }
+    for (; e < hi; e += T) {
+        const uint32_t v = in[e];
+        const uint32_t pos = atomicAdd(&lds_f[v >> lidx], 1u);
+        out[pos] = v & pmask;
+    }
+}
+
 // ------------------------------------------------------------------ bucket accumulation (the hot loop)
 // One thread per (window, bucket): walks its sorted run, gathers the affine points, mixed-adds them into an XYZZ
 // accumulator held in VGPRs, stores the bucket.
