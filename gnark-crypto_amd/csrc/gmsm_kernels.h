@@ -197,6 +197,36 @@ static __global__ void __launch_bounds__(1024) k_scatter(const uint32_t *__restr
 // is handled (the fine pass streams its run twice), skewed inputs just lose the locality benefit.
 // Entry format between the passes: (fine_bucket << lidx) | (point_index << 1 | negate).
 
+// Exclusive scan of cnt[0..n) in LDS by the first wavefront of the workgroup (lane-serial chunks + a 6-step shuffle scan;
+// no workgroup barriers inside). Writes the exclusive prefix (plus `base`) to out[] and returns the total in every lane
+// of wave 0. Call from all threads; followed by a __syncthreads() by the caller.
+__device__ __forceinline__ uint32_t wave0_exclusive_scan(const uint32_t *cnt, uint32_t n, uint32_t base, uint32_t *out,
+                                                         uint32_t *out2 = nullptr) {
+    uint32_t total = 0;
+    if (threadIdx.x < 64) {
+        const uint32_t lane = threadIdx.x;
+        const uint32_t per = (n + 63) / 64;
+        const uint32_t lo = lane * per, hi = lo + per < n ? lo + per : n;
+        uint32_t s = 0;
+        for (uint32_t i = lo; i < hi; ++i) s += cnt[i];
+        uint32_t incl = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = __shfl_up(incl, d, 64);
+            if ((int)lane >= d) incl += v;
+        }
+        total = __shfl(incl, 63, 64);
+        uint32_t run = base + incl - s;
+        for (uint32_t i = lo; i < hi; ++i) {
+            const uint32_t c = cnt[i];
+            out[i] = run;
+            if (out2) out2[i] = run;
+            run += c;
+        }
+    }
+    return total;
+}
+
 // grid = (nchunks, nwin). LDS: P counters. blockhist[k][chunk][p]
 static __global__ void __launch_bounds__(1024) k_part_hist(const uint32_t *__restrict__ digits, size_t n, uint32_t nparts,
                                                            uint32_t fbits, size_t chunk_len,
@@ -275,7 +305,7 @@ static __global__ void __launch_bounds__(1024) k_part_scatter(const uint32_t *__
     uint32_t *lbase = lds_ps + nparts;      // [nparts] first staging slot of the partition
     uint32_t *stage = lds_ps + 2 * nparts;  // [PART_CHUNK] entries sorted by partition
     uint16_t *spid = reinterpret_cast<uint16_t *>(stage + PART_CHUNK);  // [PART_CHUNK] partition of each slot
-    __shared__ uint32_t scan_tmp[1024];
+    __shared__ uint32_t scan_tmp[1];
     const uint32_t chunk = blockIdx.x, k = blockIdx.y, nchunks = gridDim.x, t = threadIdx.x, T = blockDim.x;
     const uint32_t *goff = blockhist + ((size_t)k * nchunks + chunk) * nparts;  // prefix of (chunk, p) inside partition p
     const uint32_t *pbase = part_base + (size_t)k * (nparts + 1);
@@ -301,28 +331,13 @@ static __global__ void __launch_bounds__(1024) k_part_scatter(const uint32_t *__
         }
     }
     __syncthreads();
-    // exclusive scan of cnt[] -> lbase[] (thread-serial chunks + block scan), cnt[] becomes the local cursor
-    const uint32_t per = (nparts + T - 1) / T;
-    const uint32_t plo = t * per, phi = plo + per < nparts ? plo + per : nparts;
-    uint32_t s = 0;
-    for (uint32_t p = plo; p < phi; ++p) s += cnt[p];
-    scan_tmp[t] = s;
-    __syncthreads();
-    for (uint32_t dd = 1; dd < T; dd <<= 1) {
-        const uint32_t v = t >= dd ? scan_tmp[t - dd] : 0u;
-        __syncthreads();
-        scan_tmp[t] += v;
-        __syncthreads();
+    // exclusive scan of cnt[] -> lbase[]; cnt[] becomes the local cursor
+    {
+        const uint32_t tot = wave0_exclusive_scan(cnt, nparts, 0u, lbase, cnt);
+        if (t == 0) scan_tmp[0] = tot;
     }
-    uint32_t run = scan_tmp[t] - s;
-    for (uint32_t p = plo; p < phi; ++p) {
-        const uint32_t c = cnt[p];
-        lbase[p] = run;
-        cnt[p] = run;
-        run += c;
-    }
-    const uint32_t total = scan_tmp[T - 1];
     __syncthreads();
+    const uint32_t total = scan_tmp[0];
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         if (pid[j] != 0xFFFFFFFFu) {
@@ -366,28 +381,9 @@ static __global__ void __launch_bounds__(1024) k_fine_sort(const uint32_t *__res
         for (; e < hi; e += T) atomicAdd(&lds_f[in[e] >> lidx], 1u);
     }
     __syncthreads();
-    // exclusive scan of the nf counters (nf <= 32768): thread-serial chunks + block scan
-    __shared__ uint32_t part[1024];
-    const uint32_t per = (nf + T - 1) / T;
-    const uint32_t flo = t * per, fhi = flo + per < nf ? flo + per : nf;
-    uint32_t s = 0;
-    for (uint32_t f = flo; f < fhi; ++f) s += lds_f[f];
-    part[t] = s;
-    __syncthreads();
-    for (uint32_t d = 1; d < T; d <<= 1) {
-        const uint32_t v = t >= d ? part[t - d] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    uint32_t run = lo + part[t] - s;
-    for (uint32_t f = flo; f < fhi; ++f) {
-        const uint32_t c = lds_f[f];
-        lds_f[f] = run;  // becomes the write cursor
-        st[(size_t)p * nf + f] = run;
-        run += c;
-    }
-    if (p == nparts - 1 && t == T - 1) st[nbuckets] = hi;
+    // exclusive scan of the nf counters -> write cursors (in place) and starts[]
+    wave0_exclusive_scan(lds_f, nf, lo, lds_f, st + (size_t)p * nf);
+    if (p == nparts - 1 && t == 0) st[nbuckets] = hi;
     __syncthreads();
     const uint32_t pmask = (1u << lidx) - 1u;
     uint32_t e = lo + t;
