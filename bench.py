@@ -28,7 +28,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-STAGES = ["decompose", "histogram", "scans", "scatter", "accumulate", "reduce"]
+STAGES = ["decompose", "histogram", "scans", "scatter", "accumulate", "fixup", "reduce"]
 
 
 def main():
@@ -137,12 +137,13 @@ def main():
         bytes_per_point = 8 * (g.aff_limbs + g.fr_limbs)  # affine point + scalar (BN254 G1: 96 B)
         algorithmic_bytes = bytes_per_point * n * (len(range(rank, nwin, world)) / nwin)  # this rank's share of the windows
         achieved = algorithmic_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
-        # integer roofline of the same kernel: 10 field mul per mixed add (8M+2S, g1.go:822), n*(windows of this rank)
-        # mixed adds, each mul = 2*8^2+8 = 136 v_mad_u64_u32-class ops at 4 cycles / wave64 / SIMD (measured,
-        # tools/ubench_valu.hip): peak = 1024 SIMD * 64 lanes / 4 cycles * 2.4 GHz = 39.3e12 mad/s
+        # integer roofline of the same kernel: 10 field products per mixed add (8M+2S, g1.go:822), n*(windows of this
+        # rank) mixed adds; one lazy 9x29-bit Montgomery product = 171 v_mad_u64_u32/v_mul_lo_u32 + 18 v_lshrrev_b64, all
+        # 4 cycles / wave64 / SIMD (tools/ubench_valu.hip): issue peak = 1024 SIMD * 64 lanes * 2.4 GHz / (189 * 4)
+        # = 208e9 products/s at the nominal clock; tools/ubench_fpmul.hip measures 174-177e9 on the chip.
         madds = n * len(range(rank, nwin, world))
         mulmods_per_s = madds * 10 / (acc_ms * 1e-3) if acc_ms > 0 else 0.0
-        int_peak = 1024 * 64 / 4 * 2.4e9 / 136
+        int_peak = 1024 * 64 * 2.4e9 / (189 * 4)
         out = {
             "metric": "G1 MSM/sec (BN254)" if (args.curve, args.group) == ("bn254", "g1") else f"{args.group.upper()} MSM/sec ({args.curve})", "value": value, "unit": "MSM/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -153,10 +154,10 @@ def main():
             "points_per_s": value * n,
             "stage_ms": stages,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None, "kernel": "k_accumulate",
+                         "frac": achieved / 8000.0, "traffic": measured_traffic(args, world), "kernel": "k_accumulate_seg",
                          "algorithmic_bytes_per_launch": algorithmic_bytes, "avg_launch_ms": acc_ms},
             "int_roofline": {"achieved_mulmod_per_s": mulmods_per_s, "peak_mulmod_per_s": int_peak,
-                             "frac": mulmods_per_s / int_peak},
+                             "measured_peak_mulmod_per_s": 174e9, "frac": mulmods_per_s / int_peak},
         }
         if world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline(g, pts, sc, jac, args.curve, args.group))
@@ -164,6 +165,19 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(args, world):
+    """HBM/fabric bytes per k_accumulate_seg launch from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
+    profiles/traffic_r01.json); counters cannot be read from inside the timed run, so this is the profiled value for
+    the same workload, or None when the workload was not profiled."""
+    if world != 1 or (args.curve, args.group) != ("bn254", "g1"):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_r01.json")) as f:
+            return json.load(f)["k_accumulate_seg"].get(str(args.logn))
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def effective_cpus():

@@ -56,7 +56,7 @@ struct Context {
     DeviceBuffer seg_partials, seg_flags, seg_bucket;  // split-bucket partial sums of the segmented accumulation
     DeviceBuffer parted;  // coarse-partitioned references (two-level grouping)
     DeviceBuffer digits, sorted, blockhist, counts, starts, buckets, partials, totals;
-    hipEvent_t events[8] = {nullptr};  // stage boundaries when profiling is on
+    hipEvent_t events[10] = {nullptr};  // stage boundaries when profiling is on
     void *pinned = nullptr;  // pinned host buffer for the window totals
     size_t pinned_cap = 0;
     int num_cus = 256;
@@ -86,7 +86,8 @@ enum Stage {
     STAGE_HIST,
     STAGE_SCAN,
     STAGE_SCATTER,
-    STAGE_ACCUMULATE,
+    STAGE_ACCUMULATE,  // k_accumulate_seg alone: the dominant kernel of the roofline record
+    STAGE_FIXUP,
     STAGE_REDUCE,
     STAGE_END,
     STAGE_COUNT = STAGE_END

@@ -208,6 +208,7 @@ struct Group {
             hipLaunchKernelGGL((k_accumulate_seg<U>), dim3((tpw + 255) / 256, nw), dim3(256), 0, stream,
                                upoints, n, NB, seg, starts, sorted, ctx.buckets.ptr, ctx.seg_partials.ptr,
                                (uint32_t *)ctx.seg_flags.ptr, (uint32_t *)ctx.seg_bucket.ptr, tpw);
+            timer.mark(STAGE_FIXUP);
             // chain fixup: short chains in place, long ones through two hierarchical levels (no-ops unless flagged)
             const uint32_t span1 = 64;
             const uint32_t t1 = (tpw + span1 - 1) / span1;  // level-1 outputs per window

@@ -128,7 +128,8 @@ int gmsm_generate_points(int group, const uint64_t *base_affine, const uint64_t 
                          size_t n, int nthreads, uint64_t *out_points);
 /* Per-stage device timing with HIP events on the launch stream. gmsm_set_profiling(1) resets and enables the
  * accumulators; gmsm_get_stage_times copies the summed milliseconds of up to max_stages stages
- * (0 decompose, 1 histogram, 2 scans, 3 scatter, 4 bucket accumulation, 5 bucket reduction) and the number of
+ * (0 decompose, 1 histogram, 2 scans, 3 scatter, 4 bucket accumulation kernel, 5 split-bucket fixup, 6 bucket
+ * reduction) and the number of
  * pipeline runs they cover; returns the number of stages written. */
 void gmsm_set_profiling(int on);
 int gmsm_get_stage_times(double *out_ms, int max_stages, unsigned long *out_calls);
