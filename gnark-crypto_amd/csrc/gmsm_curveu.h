@@ -1,9 +1,9 @@
 // Extended-Jacobian group law on the unsaturated ("lazy") field representation of gmsm_fieldu.h, plus the two
 // arithmetic policies the bucket kernels are written against:
-//   SatOps<F>    -- generic saturated arithmetic (gmsm_curve.h), any coordinate field (Fp or Fp2)
-//   UnsatOps<P>  -- unsaturated arithmetic for groups with coordinates in Fp (all G1, BW6-761 G2)
-// Both present the same interface (Elem, load/store of the canonical saturated XYZZ record in memory, add, dbl), so the
-// fixup and reduction kernels are written once.
+//   UnsatOps<U>    -- group operations inlined into the kernel (9- and 14-limb prime fields)
+//   UnsatOpsNI<U>  -- out-of-line group operations on the out-of-line multiplier (Fp2, 28-limb field, k_fixup_level)
+// Both present the same interface (Elem, load/store of the lazy XYZZ record in memory, store_final, add, dbl), so the
+// fixup and reduction kernels are written once for every element type U (FpU<P> or Fp2U<P>).
 //
 // Same group semantics as the reference's g1JacExtended (ecc/bn254/g1.go:682-985): every special case is kept
 // (inf + P, P + inf, P + P -> doubling, P + (-P) -> infinity). Value bounds are stated in multiples of q and hold for
@@ -266,22 +266,6 @@ __device__ __forceinline__ void policy_store(void *base, size_t index, const T &
 #pragma unroll
     for (int i = 0; i < (int)(sizeof(T) / 16); ++i) dst[i] = src[i];
 }
-
-template <class F>
-struct SatOps {
-    using Field = F;
-    using Mem = XYZZ<F>;  // record in HBM: canonical saturated Montgomery, infinity <=> zz == 0
-    using Final = XYZZ<F>;
-    struct Elem {
-        XYZZ<F> v;
-    };
-    __device__ static __forceinline__ void store_final(void *base, size_t i, const Elem &e) { policy_store<Mem>(base, i, e.v); }
-    __device__ static __forceinline__ Elem infinity() { return Elem{XYZZ<F>::infinity()}; }
-    __device__ static __forceinline__ Elem load(const void *base, size_t i) { return Elem{policy_load<Mem>(base, i)}; }
-    __device__ static __forceinline__ void store(void *base, size_t i, const Elem &e) { policy_store<Mem>(base, i, e.v); }
-    __device__ static __forceinline__ void add(Elem &p, const Elem &q) { xyzz_add(p.v, q.v); }
-    __device__ static __forceinline__ void dbl(Elem &p) { p.v = xyzz_double(p.v); }
-};
 
 template <class U>
 struct UnsatElem {

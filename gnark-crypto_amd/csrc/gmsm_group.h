@@ -30,18 +30,15 @@ struct Group {
     static constexpr size_t SCALAR_BYTES = sizeof(Fp<FrP>);
     // unsaturated-limb accumulation (gmsm_fieldu.h) for groups whose coordinates live in Fp; Fp2 groups use the generic
     // saturated kernel
-    static constexpr bool FAST_PATH = true;  // every group in scope runs on the lazy-limb representation
-    using U = typename LazyOf<F>::type;      // FpU<P> for Fp coordinates, Fp2U<P> for Fp2 coordinates
+    using U = typename LazyOf<F>::type;  // lazy element type: FpU<P> for Fp coordinates, Fp2U<P> for Fp2 coordinates
     // fully inlined group operations in k_fixup_seg / k_reduce* only where one XYZZ addition is small enough (9- and
     // 14-limb prime fields); Fp2 and the 28-limb field use the out-of-line forms (a single inlined Fp2 or BW6-761
     // addition is 60-350 KB of code: instruction-cache misses and minutes of compile time)
     static constexpr bool INLINE_OPS = sizeof(U) <= 14 * 4;
     template <bool Fast, class Dummy = void> struct OpsSel { using type = UnsatOpsNI<U>; };
     template <class Dummy> struct OpsSel<true, Dummy> { using type = UnsatOps<U>; };
-    template <bool Fast, class Dummy = void> struct OpsNISel { using type = SatOps<F>; };
-    template <class Dummy> struct OpsNISel<true, Dummy> { using type = UnsatOpsNI<U>; };
     using Ops = typename OpsSel<INLINE_OPS>::type;     // arithmetic of k_fixup_seg and the reduction kernels
-    using OpsNI = typename OpsNISel<FAST_PATH>::type;  // small-code variant for k_fixup_level
+    using OpsNI = UnsatOpsNI<U>;                       // small-code variant for k_fixup_level
     using OpsElem = typename Ops::Elem;
     static_assert(2 * (sizeof(XYZZ<F>) > 256 ? 128 : 256) * sizeof(OpsElem) <= 160 * 1024, "reduction LDS budget");
     static constexpr int RED_TPB = sizeof(XYZZ<F>) > 256 ? 128 : 256;  // 2*TPB*sizeof(Elem) of LDS must fit 160 KiB
@@ -72,11 +69,6 @@ struct Group {
         }
         if (n >= ((size_t)1 << 31)) return fail(GMSM_ERR_ARG, "n must be < 2^31");
         const uint32_t NB = plan.nbuckets;
-        // chunks: ~256 (window, chunk) blocks in flight, each at least 4096 digits
-        uint32_t nchunks = env_uint("GMSM_NCHUNKS", 0);
-        if (nchunks == 0) nchunks = std::max<uint32_t>(1, 512 / nw);
-        nchunks = (uint32_t)std::min<size_t>(nchunks, (n + 4095) / 4096);
-        const size_t chunk_len = (n + nchunks - 1) / nchunks;
         // reduction geometry
         uint32_t log2L = env_uint("GMSM_LOG2L", 3);
         while ((((size_t)NB + ((size_t)RED_TPB << log2L) - 1) / ((size_t)RED_TPB << log2L)) > (size_t)RED2_TPB) ++log2L;
@@ -87,8 +79,6 @@ struct Group {
         int rc;
         if ((rc = ctx.digits.ensure((size_t)nw * n * 4))) return rc;
         if ((rc = ctx.sorted.ensure((size_t)nw * n * 4))) return rc;
-        if ((rc = ctx.blockhist.ensure((size_t)nw * nchunks * NB * 4))) return rc;
-        if ((rc = ctx.counts.ensure((size_t)nw * NB * 4))) return rc;
         if ((rc = ctx.starts.ensure((size_t)nw * (NB + 1) * 4))) return rc;
         constexpr size_t REC = sizeof(typename Ops::Mem);  // bucket / partial record (lazy representation on the fast path)
         static_assert(sizeof(typename Ops::Mem) == sizeof(typename OpsNI::Mem), "one record format per group");
@@ -98,11 +88,10 @@ struct Group {
         if ((rc = ctx.ensure_pinned((size_t)nw * sizeof(Ext)))) return rc;
 
         uint32_t *digits = (uint32_t *)ctx.digits.ptr, *sorted = (uint32_t *)ctx.sorted.ptr;
-        uint32_t *blockhist = (uint32_t *)ctx.blockhist.ptr, *counts = (uint32_t *)ctx.counts.ptr;
         uint32_t *starts = (uint32_t *)ctx.starts.ptr;
 
         StageTimer timer(ctx, stream);
-        // 0. (fast path) rewrite the bases into the unsaturated Montgomery domain + infinity flags
+        // 0. rewrite the bases into the lazy Montgomery domain + infinity flags (unless registered earlier)
         timer.mark(STAGE_DECOMPOSE);
         const uint8_t *skip = nullptr;
         const void *upoints = nullptr;
@@ -121,8 +110,7 @@ struct Group {
         hipLaunchKernelGGL((k_decompose<FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                            (const uint32_t *)d_scalars, n, plan, digits, skip);
         // 2. group point references by bucket
-        const bool two_level = env_uint("GMSM_SORT2", 1) != 0;
-        if (two_level) {
+        {
             // fine buckets per partition: ~16 K references per partition for uniform scalars
             uint32_t log2NB = 0;
             while ((1u << log2NB) < NB) ++log2NB;
@@ -163,28 +151,11 @@ struct Group {
                                bh, part_base, parted);
             hipLaunchKernelGGL(k_fine_sort, dim3(nparts, nw), dim3(1024), ((size_t)4 << fbits), stream, parted, n, NB, fbits,
                                lidx, part_base, sorted, starts);
-        } else {
-            const size_t hist_lds = (size_t)NB * 4;
-            if (hist_lds > 160 * 1024) return fail(GMSM_ERR_ARG, "window too wide for the LDS histogram (c <= 16)");
-            static bool attr_done = false;
-            if (!attr_done) {
-                HIP_TRY(hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                HIP_TRY(hipFuncSetAttribute((const void *)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_done = true;
-            }
-            timer.mark(STAGE_HIST);
-            hipLaunchKernelGGL(k_hist, dim3(nchunks, nw), dim3(1024), hist_lds, stream, digits, n, NB, chunk_len, blockhist);
-            timer.mark(STAGE_SCAN);
-            hipLaunchKernelGGL(k_colscan, dim3((NB + 255) / 256, nw), dim3(256), 0, stream, blockhist, nchunks, NB, counts);
-            hipLaunchKernelGGL(k_rowscan, dim3(nw), dim3(1024), 0, stream, counts, NB, starts);
-            timer.mark(STAGE_SCATTER);
-            hipLaunchKernelGGL(k_scatter, dim3(nchunks, nw), dim3(1024), hist_lds, stream, digits, n, NB, chunk_len,
-                               blockhist, starts, sorted);
         }
         // 3. bucket accumulation
         timer.mark(STAGE_ACCUMULATE);
-        const uint32_t *reduce_starts = nullptr;
-        if constexpr (FAST_PATH) {
+        const uint32_t *reduce_starts = starts;  // empty buckets are never written: the reduction consults starts[]
+        {
             // entry-parallel segmented accumulation: seg entries per thread, >= ~4 waves per SIMD when n allows
             uint32_t seg = env_uint("GMSM_SEG", 0);
             if (seg == 0) {
@@ -233,10 +204,6 @@ struct Group {
                                long_flag);
             hipLaunchKernelGGL((k_fixup_level<OpsNI>), dim3(1, nw), dim3(256), 0, stream, NB, parts1, flags1, pb1, t1, span2,
                                parts2, flags2, pb2, 1u, ctx.buckets.ptr, long_flag);
-            reduce_starts = starts;
-        } else {
-            hipLaunchKernelGGL((k_accumulate<F>), dim3((NB + 255) / 256, nw), dim3(256), 0, stream, d_points, n, NB, starts,
-                               sorted, ctx.buckets.ptr);
         }
         // 4. bucket reduction -> window totals
         static bool red_attr_done = false;

@@ -1,13 +1,15 @@
 // HIP kernels of the Pippenger pipeline (gfx950). One template per stage, instantiated per (curve, group) in
-// gmsm_engine.hip. Stage -> reference function it replaces:
+// gmsm_group_inst.hip. Stage -> reference function it replaces:
 //
 //   k_decompose        partitionScalars                    ecc/bn254/multiexp.go:709-803 (+ fr.Bits/fromMont, fr/element.go:855)
-//   k_hist/k_colscan/k_rowscan/k_scatter
+//   k_part_hist/k_part_colscan/k_part_rowscan/k_part_scatter/k_fine_sort
 //                      (no reference twin) group each window's point references by bucket, so that
-//                      every bucket is owned by exactly one accumulation thread -- replaces the reference's
+//                      every bucket is owned by one accumulation thread at a time -- replaces the reference's
 //                      "one goroutine walks all n digits of a window" (multiexp_jacobian.go:26-39)
-//   k_accumulate       bucket accumulation loop             multiexp_jacobian.go:26-39 (addMixed / subMixed)
-//   k_reduce           running-sum bucket reduction         multiexp_jacobian.go:44-52
+//   k_convert_points   rewrite the bases into the lazy Montgomery domain (once per call or per registered SRS)
+//   k_accumulate_seg   bucket accumulation loop             multiexp_jacobian.go:26-39 (addMixed / subMixed)
+//   k_fixup_seg/level  close buckets that were split over several accumulation threads
+//   k_reduce1/2        running-sum bucket reduction         multiexp_jacobian.go:44-52
 //   (host) fold        msmReduceChunkG1Affine               multiexp.go:302-315
 //
 // Digit code (same as the reference's uint16 digits, widened to 32 bit so c may exceed 16):
@@ -101,95 +103,9 @@ __global__ void __launch_bounds__(256) k_decompose(const uint32_t *__restrict__ 
 
 __device__ __forceinline__ uint32_t code_bucket(uint32_t code) { return (code >> 1) - ((code & 1u) ^ 1u); }
 
-// ------------------------------------------------------------------ counting sort by bucket
-// grid = (nchunks, nwin_local). LDS histogram of one (window, chunk); dynamic LDS = nbuckets * 4 B.
-static __global__ void __launch_bounds__(1024) k_hist(const uint32_t *__restrict__ digits, size_t n, uint32_t nbuckets,
-                                               size_t chunk_len, uint32_t *__restrict__ blockhist) {
-    extern __shared__ uint32_t lds_hist[];
-    const uint32_t chunk = blockIdx.x, k = blockIdx.y, nchunks = gridDim.x;
-    for (uint32_t b = threadIdx.x; b < nbuckets; b += blockDim.x) lds_hist[b] = 0;
-    __syncthreads();
-    const size_t lo = (size_t)chunk * chunk_len;
-    const size_t hi = lo + chunk_len < n ? lo + chunk_len : n;
-    const uint32_t *d = digits + (size_t)k * n;
-    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const uint32_t code = d[i];
-        if (code) atomicAdd(&lds_hist[code_bucket(code)], 1u);
-    }
-    __syncthreads();
-    uint32_t *out = blockhist + ((size_t)k * nchunks + chunk) * nbuckets;
-    for (uint32_t b = threadIdx.x; b < nbuckets; b += blockDim.x) out[b] = lds_hist[b];
-}
-
-// One thread per (window, bucket): turn the per-chunk counts into exclusive prefixes over chunks and emit the
-// bucket total.
-static __global__ void __launch_bounds__(256) k_colscan(uint32_t *__restrict__ blockhist, uint32_t nchunks, uint32_t nbuckets,
-                                                 uint32_t *__restrict__ counts) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
-    if (b >= nbuckets) return;
-    uint32_t run = 0;
-    for (uint32_t ch = 0; ch < nchunks; ++ch) {
-        uint32_t *p = blockhist + ((size_t)k * nchunks + ch) * nbuckets + b;
-        const uint32_t v = *p;
-        *p = run;
-        run += v;
-    }
-    counts[(size_t)k * nbuckets + b] = run;
-}
-
-// One block per window: exclusive scan of counts over buckets -> starts[k][0..nbuckets] (last = window total).
-static __global__ void __launch_bounds__(1024) k_rowscan(const uint32_t *__restrict__ counts, uint32_t nbuckets,
-                                                  uint32_t *__restrict__ starts) {
-    __shared__ uint32_t part[1024];
-    const uint32_t k = blockIdx.x, t = threadIdx.x, T = blockDim.x;
-    const uint32_t per = (nbuckets + T - 1) / T;
-    const uint32_t lo = t * per, hi = lo + per < nbuckets ? lo + per : nbuckets;
-    const uint32_t *c = counts + (size_t)k * nbuckets;
-    uint32_t s = 0;
-    for (uint32_t b = lo; b < hi; ++b) s += c[b];
-    part[t] = s;
-    __syncthreads();
-    for (uint32_t d = 1; d < T; d <<= 1) {  // Hillis-Steele inclusive scan
-        uint32_t v = t >= d ? part[t - d] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    uint32_t run = part[t] - s;  // exclusive
-    uint32_t *o = starts + (size_t)k * (nbuckets + 1);
-    for (uint32_t b = lo; b < hi; ++b) {
-        o[b] = run;
-        run += c[b];
-    }
-    if (t == T - 1) o[nbuckets] = part[T - 1];
-}
-
-// grid = (nchunks, nwin_local). LDS cursors = starts + chunk prefix; each digit takes the next slot of its bucket.
-static __global__ void __launch_bounds__(1024) k_scatter(const uint32_t *__restrict__ digits, size_t n, uint32_t nbuckets,
-                                                  size_t chunk_len, const uint32_t *__restrict__ blockhist,
-                                                  const uint32_t *__restrict__ starts, uint32_t *__restrict__ sorted) {
-    extern __shared__ uint32_t lds_cur[];
-    const uint32_t chunk = blockIdx.x, k = blockIdx.y, nchunks = gridDim.x;
-    const uint32_t *pre = blockhist + ((size_t)k * nchunks + chunk) * nbuckets;
-    const uint32_t *st = starts + (size_t)k * (nbuckets + 1);
-    for (uint32_t b = threadIdx.x; b < nbuckets; b += blockDim.x) lds_cur[b] = st[b] + pre[b];
-    __syncthreads();
-    const size_t lo = (size_t)chunk * chunk_len;
-    const size_t hi = lo + chunk_len < n ? lo + chunk_len : n;
-    const uint32_t *d = digits + (size_t)k * n;
-    uint32_t *out = sorted + (size_t)k * n;
-    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const uint32_t code = d[i];
-        if (code) {
-            const uint32_t pos = atomicAdd(&lds_cur[code_bucket(code)], 1u);
-            out[pos] = ((uint32_t)i << 1) | (code & 1u);
-        }
-    }
-}
-
 // ------------------------------------------------------------------ two-level grouping (coarse partition, fine sort)
-// The single-pass scatter above writes every 4-byte reference to an effectively random address of the window's
-// sorted array: rocprofv3 shows 32 B of HBM write per 4-byte store (r01f: 8.5 GB for 268 M references at 2^24).
+// A single-pass counting sort would write every 4-byte reference to an effectively random address of the window's
+// sorted array: rocprofv3 showed 32 B of HBM write per 4-byte store (r01f: 8.5 GB for 268 M references at 2^24).
 // Two-level form: (A) references are first distributed into P coarse partitions (bucket >> fbits) -- a workgroup
 // writes one contiguous run per partition; (B) one workgroup per (window, partition) counting-sorts its run by the low
 // bucket bits with the cursors in LDS; its scattered writes stay inside a region of a few tens of KB, i.e. they
@@ -406,28 +322,7 @@ static __global__ void __launch_bounds__(1024) k_fine_sort(const uint32_t *__res
 }
 
 // ------------------------------------------------------------------ bucket accumulation (the hot loop)
-// One thread per (window, bucket): walks its sorted run, gathers the affine points, mixed-adds them into an XYZZ
-// accumulator held in VGPRs, stores the bucket.
-template <class F>
-__global__ void __launch_bounds__(256) k_accumulate(const void *__restrict__ points, size_t n, uint32_t nbuckets,
-                                                    const uint32_t *__restrict__ starts,
-                                                    const uint32_t *__restrict__ sorted, void *__restrict__ buckets) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
-    if (b >= nbuckets) return;
-    const uint32_t *st = starts + (size_t)k * (nbuckets + 1);
-    const uint32_t lo = st[b], hi = st[b + 1];
-    const uint32_t *ent = sorted + (size_t)k * n;
-    XYZZ<F> acc = XYZZ<F>::infinity();
-    for (uint32_t e = lo; e < hi; ++e) {
-        const uint32_t v = ent[e];
-        Affine<F> p = load_struct<Affine<F>>(points, v >> 1);
-        xyzz_add_mixed(acc, p, (v & 1u) != 0);
-    }
-    store_struct(buckets, (size_t)k * nbuckets + b, acc);
-}
-
-// ------------------------------------------------------------------ bucket accumulation, unsaturated fast path
-// G1-type groups (coordinates in Fp). The bases are first rewritten once per call into the unsaturated Montgomery
+// The bases are first rewritten once per call (or once per registered SRS) into the lazy Montgomery
 // domain (k_convert_points: 2 field multiplications per point, against 10 per mixed add per window), packed back into
 // the same 2N words per point so the gather in the hot loop still moves 64 B per BN254 point.
 template <class U>
