@@ -535,63 +535,106 @@ __global__ void __launch_bounds__(256) k_fixup_level(uint32_t nbuckets, const vo
 //   level 2 (k_reduce2): one block per window combines the level-1 block results the same way.
 // Identity used:  sum_{k in [base, base+T*L)} (k-base+1) B_k = sum_t W_t + L * sum_{t>=1} Suf_t,
 //   S_t = sum of segment t, W_t = sum_{k in seg t} (k-lo_t+1) B_k, Suf_t = sum_{t'>=t} S_t'.
-// `active` (power of two, <= TPB): threads t >= active hold infinity and take no part, so the scan and the trees need only
-// log2(active) levels.
-template <class A, int TPB>
-__device__ __forceinline__ void block_combine(typename A::Elem S, typename A::Elem W, uint32_t log2L, typename A::Elem *lds,
-                                              typename A::Elem &S_out, typename A::Elem &W_out, uint32_t active = TPB) {
+// The whole reduction of a workgroup is ONE loop with ONE call site of the XYZZ addition (and one of the doubling): an
+// inlined addition is ~25 KB of straight-line code, and every additional call site that runs only a few times pays a
+// cold instruction fetch of that size (k_reduce2 spent half of its 225 us that way). Each step selects its operands
+// (X += Y) from the thread's registers or from LDS:
+//   serial  (2L steps)      even: run += B_j      odd: tot += run           (multiexp_jacobian.go:44-52 on L buckets)
+//   scan    (log2 active)   suf += suf[t + d]                               (inclusive suffix sums of S_t = run)
+//   trees   (log2 active)   lower half of the threads: U-tree over Suf_t (t >= 1); upper half: W-tree over tot
+//   finish  (log2L + 1)     thread 0: U = 2^log2L * U, then W += U
+// Identity:  sum_{k in [base, base+T*L)} (k-base+1) B_k = sum_t W_t + L * sum_{t>=1} Suf_t.
+// `active` (power of two, 2 <= active <= TPB): threads t >= active hold infinity.
+template <class A, int TPB, class LoadFn>
+__device__ __forceinline__ void reduce_program(LoadFn load_bucket, uint32_t L, typename A::Elem run, typename A::Elem tot,
+                                               uint32_t log2L, uint32_t active, typename A::Elem *lds,
+                                               typename A::Elem &S_out, typename A::Elem &W_out) {
     using E = typename A::Elem;
     const uint32_t t = threadIdx.x;
-    // inclusive suffix scan of S over threads (Hillis-Steele)
-    lds[t] = S;
-    __syncthreads();
-    E suf = S;
-    for (uint32_t d = 1; d < active; d <<= 1) {
-        E o = A::infinity();
-        if (t + d < active) o = lds[t + d];
-        __syncthreads();
-        A::add(suf, o);
-        lds[t] = suf;
-        __syncthreads();
-    }
-    S_out = lds[0];
-    __syncthreads();
-    // U = sum_{t>=1} Suf_t and V = sum_t W_t as two trees run side by side: the lower half of the threads reduces U, the
-    // upper half reduces W (one addition per level instead of two on the critical path)
-    E U = t >= 1 ? suf : A::infinity();
-    E *ldsW = lds + TPB;
-    lds[t] = U;
-    ldsW[t] = W;
-    __syncthreads();
-    const uint32_t H = active / 2;  // active >= 2
+    E *ldsA = lds, *ldsB = lds + TPB;
+    uint32_t lg = 0;
+    while ((1u << lg) < active) ++lg;
+    const uint32_t n_serial = 2 * L, n_scan = lg, n_tree = lg, n_fin = log2L + 1;
+    const uint32_t total = n_serial + n_scan + n_tree + n_fin;
     const bool upper = t >= TPB / 2;
     const uint32_t tt = upper ? t - TPB / 2 : t;
-    E *arr = upper ? ldsW : lds;
-    // first level folds active -> H elements in both arrays: thread tt (< H) of each half adds element tt + H
-    E mine = arr[tt < active ? tt : 0];
-    if (tt < H) {
-        E o = arr[tt + H];
-        A::add(mine, o);
-    }
-    __syncthreads();
-    if (tt < H) arr[tt] = mine;
-    __syncthreads();
-    for (uint32_t d = H / 2; d >= 1; d >>= 1) {
-        if (tt < d) {
-            E o = arr[tt + d];
-            A::add(mine, o);
+    E suf = A::infinity(), mine = A::infinity();
+#pragma nounroll
+    for (uint32_t s = 0; s < total; ++s) {
+        E X = A::infinity(), Y = A::infinity();
+        int dest = -1;  // 0 run, 1 tot, 2 suf, 3 mine
+        bool do_dbl = false;
+        if (s < n_serial) {
+            if ((s & 1u) == 0) {
+                X = run;
+                Y = load_bucket(L - 1 - (s >> 1));
+                dest = 0;
+            } else {
+                X = tot;
+                Y = run;
+                dest = 1;
+            }
+        } else if (s < n_serial + n_scan) {
+            const uint32_t step = s - n_serial, d = 1u << step;
+            if (step == 0) {
+                suf = run;
+                ldsA[t] = run;
+                __syncthreads();
+            }
+            X = suf;
+            if (t + d < active) Y = ldsA[t + d];
+            dest = 2;
+        } else if (s < n_serial + n_scan + n_tree) {
+            const uint32_t step = s - n_serial - n_scan;
+            if (step == 0) {  // tree inputs: U_t = Suf_t for t >= 1, W_t = tot
+                if (t == 0) S_out = suf;
+                __syncthreads();
+                ldsA[t] = t >= 1 ? suf : A::infinity();
+                ldsB[t] = tot;
+                __syncthreads();
+                E *arr0 = upper ? ldsB : ldsA;
+                mine = tt < active ? arr0[tt] : A::infinity();
+            }
+            const uint32_t d = active >> (step + 1);
+            E *arr = upper ? ldsB : ldsA;
+            X = mine;
+            if (tt < d) Y = arr[tt + d];
+            dest = 3;
+        } else {
+            const uint32_t step = s - n_serial - n_scan - n_tree;
+            if (step == 0) {  // hand the W total (upper half, tt == 0) to thread 0
+                __syncthreads();
+                if (upper && tt == 0) ldsB[0] = mine;
+                __syncthreads();
+                if (t == 0) {
+                    suf = mine;      // U total, reuse the register
+                    tot = ldsB[0];   // W total
+                }
+            }
+            if (step < log2L) {
+                do_dbl = (t == 0);
+            } else if (t == 0) {
+                X = tot;
+                Y = suf;
+                dest = 1;
+            }
+        }
+        __syncthreads();  // all LDS reads of this step are done
+        if (do_dbl) A::dbl(suf);
+        else if (dest >= 0) A::add(X, Y);
+        if (dest == 0) run = X;
+        else if (dest == 1) tot = X;
+        else if (dest == 2) {
+            suf = X;
+            ldsA[t] = suf;
+        } else if (dest == 3) {
+            mine = X;
+            E *arr = upper ? ldsB : ldsA;
+            if (tt < (active >> 1)) arr[tt] = mine;
         }
         __syncthreads();
-        if (tt < d) arr[tt] = mine;
-        __syncthreads();
     }
-    U = lds[0];
-    W = ldsW[0];
-    if (t == 0) {
-        for (uint32_t i = 0; i < log2L; ++i) A::dbl(U);
-        A::add(W, U);
-        W_out = W;
-    }
+    W_out = tot;  // meaningful in thread 0
 }
 
 // grid = (nblocks1, nwin_local), block = TPB threads, each thread L = 2^log2L buckets.
@@ -606,22 +649,15 @@ __global__ void __launch_bounds__(TPB) k_reduce1(const void *__restrict__ bucket
     const uint32_t k = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
     const uint32_t L = 1u << log2L;
     const uint32_t lo = (blk * TPB + t) * L;
-    E run = A::infinity(), tot = A::infinity();
-    for (uint32_t j = L; j-- > 0;) {
+    const uint32_t *st = starts ? starts + (size_t)k * (nbuckets + 1) : nullptr;
+    auto load_bucket = [&](uint32_t j) -> E {
         const uint32_t b = lo + j;
         bool present = b < nbuckets;
-        if (present && starts != nullptr) {
-            const uint32_t *st = starts + (size_t)k * (nbuckets + 1);
-            present = st[b + 1] > st[b];
-        }
-        if (present) {
-            E B = A::load(buckets, (size_t)k * nbuckets + b);
-            A::add(run, B);
-        }
-        A::add(tot, run);
-    }
-    E S_out, W_out;
-    block_combine<A, TPB>(run, tot, log2L, lds, S_out, W_out);
+        if (present && st != nullptr) present = st[b + 1] > st[b];
+        return present ? A::load(buckets, (size_t)k * nbuckets + b) : A::infinity();
+    };
+    E S_out = A::infinity(), W_out = A::infinity();
+    reduce_program<A, TPB>(load_bucket, L, A::infinity(), A::infinity(), log2L, (uint32_t)TPB, lds, S_out, W_out);
     if (t == 0) {
         A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 0, S_out);
         A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 1, W_out);
@@ -642,10 +678,11 @@ __global__ void __launch_bounds__(TPB) k_reduce2(const void *__restrict__ in1, u
         S = A::load(in1, ((size_t)k * nblocks1 + t) * 2 + 0);
         W = A::load(in1, ((size_t)k * nblocks1 + t) * 2 + 1);
     }
-    E S_out, W_out;
+    E S_out = A::infinity(), W_out = A::infinity();
     uint32_t active = 2;
     while (active < nblocks1) active <<= 1;
-    block_combine<A, TPB>(S, W, log2span, lds, S_out, W_out, active);
+    auto no_buckets = [&](uint32_t) -> E { return A::infinity(); };
+    reduce_program<A, TPB>(no_buckets, 0u, S, W, log2span, active, lds, S_out, W_out);
     if (t == 0) A::store_final(window_totals, k, W_out);
 }
 
