@@ -128,6 +128,51 @@ GMSM_HD Fp<P> fp_neg(const Fp<P> &x) {
 template <class P>
 GMSM_MUL_HD Fp<P> fp_mul(const Fp<P> x, const Fp<P> y) {
     constexpr int N = P::N;
+#if !defined(__HIP_DEVICE_COMPILE__)
+    // host (window fold, FromJacobian, base generator): the same CIOS on 64-bit limbs with a 128-bit accumulator
+    {
+        constexpr int M = N / 2;
+        uint64_t a[M], b[M], q[M], t64[M + 1];
+        for (int i = 0; i < M; ++i) {
+            a[i] = (uint64_t)x.l[2 * i] | ((uint64_t)x.l[2 * i + 1] << 32);
+            b[i] = (uint64_t)y.l[2 * i] | ((uint64_t)y.l[2 * i + 1] << 32);
+            q[i] = (uint64_t)P::Q[2 * i] | ((uint64_t)P::Q[2 * i + 1] << 32);
+        }
+        // -q^-1 mod 2^64 from the 32-bit constant by one Newton step
+        uint64_t qinv = P::QINV;                     // correct mod 2^32
+        qinv = qinv * (2 + q[0] * qinv);             // -q^-1 mod 2^64:  x' = x(2 + q x) for x = -q^-1
+        for (int i = 0; i <= M; ++i) t64[i] = 0;
+        for (int i = 0; i < M; ++i) {
+            unsigned __int128 c = 0;
+            for (int j = 0; j < M; ++j) {
+                c += (unsigned __int128)a[j] * b[i] + t64[j];
+                t64[j] = (uint64_t)c;
+                c >>= 64;
+            }
+            c += t64[M];
+            t64[M] = (uint64_t)c;
+            const uint64_t top = (uint64_t)(c >> 64);
+            const uint64_t m = t64[0] * qinv;
+            c = (unsigned __int128)m * q[0] + t64[0];
+            c >>= 64;
+            for (int j = 1; j < M; ++j) {
+                c += (unsigned __int128)m * q[j] + t64[j];
+                t64[j - 1] = (uint64_t)c;
+                c >>= 64;
+            }
+            c += t64[M];
+            t64[M - 1] = (uint64_t)c;
+            t64[M] = top + (uint64_t)(c >> 64);
+        }
+        Fp<P> z;
+        for (int i = 0; i < M; ++i) {
+            z.l[2 * i] = (uint32_t)t64[i];
+            z.l[2 * i + 1] = (uint32_t)(t64[i] >> 32);
+        }
+        fp_reduce_once(z);  // t64[M] == 0 for the moduli in scope (spare top bit): value < 2q
+        return z;
+    }
+#endif
     uint32_t t[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) t[i] = 0;

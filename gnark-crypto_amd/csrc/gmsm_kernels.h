@@ -361,8 +361,11 @@ struct SegFlags {
 
 // waves per SIMD the accumulation kernel is compiled for: 3 for 9-limb coordinates (160 VGPRs, no spills), 2 for 14-limb
 // ones and Fp2 over 9 limbs, 1 (all 512 registers) beyond
+#ifndef GMSM_W9
+#define GMSM_W9 3
+#endif
 template <class U> struct AccWaves { static constexpr int value = 1; };
-template <class P> struct AccWaves<FpU<P>> { static constexpr int value = P::UL <= 9 ? 3 : (P::UL <= 14 ? 2 : 1); };
+template <class P> struct AccWaves<FpU<P>> { static constexpr int value = P::UL <= 9 ? GMSM_W9 : (P::UL <= 14 ? 2 : 1); };
 template <class P> struct AccWaves<Fp2U<P>> { static constexpr int value = P::UL <= 9 ? 2 : 1; };
 
 template <class U>
