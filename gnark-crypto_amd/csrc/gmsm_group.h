@@ -135,7 +135,7 @@ struct Group {
             if (!attr2_done) {
                 HIP_TRY(hipFuncSetAttribute((const void *)k_part_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 HIP_TRY(hipFuncSetAttribute((const void *)k_part_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-                HIP_TRY(hipFuncSetAttribute((const void *)k_fine_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+                HIP_TRY(hipFuncSetAttribute((const void *)k_fine_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 attr2_done = true;
             }
             timer.mark(STAGE_HIST);
@@ -149,8 +149,12 @@ struct Group {
             hipLaunchKernelGGL(k_part_scatter, dim3(pchunks, nw), dim3(1024),
                                (size_t)nparts * 8 + (size_t)PART_CHUNK * 6, stream, digits, n, nparts, fbits, lidx, pchunk_len,
                                bh, part_base, parted);
-            hipLaunchKernelGGL(k_fine_sort, dim3(nparts, nw), dim3(1024), ((size_t)4 << fbits), stream, parted, n, NB, fbits,
-                               lidx, part_base, sorted, starts);
+            // staging slots of the fine pass: up to 96 KiB next to the 2^fbits counters; larger partitions go direct
+            const size_t fine_cnt_bytes = (size_t)4 << fbits;
+            const uint32_t stage_cap = fine_cnt_bytes >= 156 * 1024 ? 0u
+                                       : (uint32_t)std::min<size_t>(24576, (156 * 1024 - fine_cnt_bytes) / 4);
+            hipLaunchKernelGGL(k_fine_sort, dim3(nparts, nw), dim3(1024), ((size_t)4 << fbits) + (size_t)stage_cap * 4, stream,
+                               parted, n, NB, fbits, lidx, part_base, sorted, starts, stage_cap);
         }
         // 3. bucket accumulation
         timer.mark(STAGE_ACCUMULATE);

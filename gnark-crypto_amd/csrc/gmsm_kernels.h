@@ -274,8 +274,9 @@ static __global__ void __launch_bounds__(1024) k_part_scatter(const uint32_t *__
 static __global__ void __launch_bounds__(1024) k_fine_sort(const uint32_t *__restrict__ parted, size_t n, uint32_t nbuckets,
                                                           uint32_t fbits, uint32_t lidx,
                                                           const uint32_t *__restrict__ part_base,
-                                                          uint32_t *__restrict__ sorted, uint32_t *__restrict__ starts) {
-    extern __shared__ uint32_t lds_f[];  // 2^fbits counters
+                                                          uint32_t *__restrict__ sorted, uint32_t *__restrict__ starts,
+                                                          uint32_t stage_cap) {
+    extern __shared__ uint32_t lds_f[];  // 2^fbits counters, then stage_cap staging slots
     const uint32_t p = blockIdx.x, k = blockIdx.y, nparts = gridDim.x, t = threadIdx.x, T = blockDim.x;
     const uint32_t nf = 1u << fbits;
     const uint32_t *pb = part_base + (size_t)k * (nparts + 1);
@@ -302,6 +303,33 @@ static __global__ void __launch_bounds__(1024) k_fine_sort(const uint32_t *__res
     if (p == nparts - 1 && t == 0) st[nbuckets] = hi;
     __syncthreads();
     const uint32_t pmask = (1u << lidx) - 1u;
+    const uint32_t pop = hi - lo;
+    if (pop <= stage_cap) {
+        // the usual case: place the references inside LDS and write the sorted run out contiguously (scattered 4-byte
+        // global stores are limited to well under one lane per cycle per CU; this path has none)
+        uint32_t *stage = lds_f + nf;
+        uint32_t e = lo + t;
+        for (; e + 3 * T < hi; e += 4 * T) {
+            const uint32_t v0 = in[e], v1 = in[e + T], v2 = in[e + 2 * T], v3 = in[e + 3 * T];
+            const uint32_t p0 = atomicAdd(&lds_f[v0 >> lidx], 1u);
+            const uint32_t p1 = atomicAdd(&lds_f[v1 >> lidx], 1u);
+            const uint32_t p2 = atomicAdd(&lds_f[v2 >> lidx], 1u);
+            const uint32_t p3 = atomicAdd(&lds_f[v3 >> lidx], 1u);
+            stage[p0 - lo] = v0 & pmask;
+            stage[p1 - lo] = v1 & pmask;
+            stage[p2 - lo] = v2 & pmask;
+            stage[p3 - lo] = v3 & pmask;
+        }
+        for (; e < hi; e += T) {
+            const uint32_t v = in[e];
+            const uint32_t pos = atomicAdd(&lds_f[v >> lidx], 1u);
+            stage[pos - lo] = v & pmask;
+        }
+        __syncthreads();
+        for (uint32_t i = t; i < pop; i += T) out[lo + i] = stage[i];
+        return;
+    }
+    // oversized partition (skewed scalars): direct placement
     uint32_t e = lo + t;
     for (; e + 3 * T < hi; e += 4 * T) {
         const uint32_t v0 = in[e], v1 = in[e + T], v2 = in[e + 2 * T], v3 = in[e + 3 * T];
