@@ -338,3 +338,58 @@ def test_resident_bases_prefix_multiexp(gm, oracle_mod, curve, which):
         assert err == "invalid config: config.NbTasks > 1024"
     finally:
         rb.release()
+
+
+@pytest.mark.parametrize("curve,which,c", [("bn254", "g1", 16), ("bn254", "g1", 13), ("bls12_381", "g2", 16)])
+def test_window_sharded_pieces_on_one_gpu(gm, oracle_mod, curve, which, c):
+    """The multi-GPU decomposition executed rank by rank on one GPU: every "rank" computes the totals of its own windows
+    (gmsm_window_sums_device with win_first = rank, win_stride = world), the pieces are merged like the RCCL all-gather
+    does (gnark-crypto_amd/sharding.py) and folded; world sizes 2, 3, 8 (uneven ownership) must all equal the oracle."""
+    import importlib
+    import torch
+    sharding = importlib.import_module("gnark-crypto_amd.sharding")
+    g = _group(gm, curve, which)
+    o = oracle_mod.Oracle(curve, which)
+    n = 5000
+    rng = rng_for(10, g.gid, c)
+    pts = o.gen_points(n, 31337, 101, nthreads=4)
+    sc = random_scalars(rng, g.curve, n)
+    expected = o.msm_affine(pts, sc, c=c, nthreads=4)
+    d_pts = torch.from_numpy(pts.view(np.int64)).cuda()
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    nwin = g.num_windows(c)
+    for world in (2, 3, 8):
+        gathered = np.stack([
+            sharding.pack_local(g.window_sums_device(d_pts.data_ptr(), d_sc.data_ptr(), n, c, rank, world), nwin, world, g.xyzz_limbs)
+            for rank in range(world)])
+        totals = sharding.unpack_gathered(gathered, nwin, world, g.xyzz_limbs)
+        assert (g.jac_to_affine(g.fold_windows(totals, c)) == expected).all(), world
+
+
+def test_concurrent_multiexp_calls(gm, oracle_mod):
+    """The C ABI is re-entrant: three MultiExp calls in flight from different OS threads (BenchmarkManyMultiExpG1Reference,
+    multiexp_test.go:385-415) each return their own correct result."""
+    import threading
+    g = gm.G1Affine("bn254")
+    o = oracle_mod.Oracle("bn254", "g1")
+    n = 20000
+    jobs = []
+    for j in range(3):
+        rng = rng_for(11, j)
+        pts = o.gen_points(n, 1000 + j, 17 + j, nthreads=4)
+        sc = random_scalars(rng, g.curve, n)
+        jobs.append((pts, sc, o.msm_affine(pts, sc, nthreads=4)))
+    results = [None] * 3
+
+    def run(j):
+        for _ in range(5):
+            results[j] = g.MultiExp(jobs[j][0], jobs[j][1])
+
+    threads = [threading.Thread(target=run, args=(j,)) for j in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for j in range(3):
+        aff, err = results[j]
+        assert err is None and (aff == jobs[j][2]).all(), j
