@@ -78,7 +78,7 @@ GMSM_HD void madd_u(XYZZU<P> &acc, bool &inf, const FpU<P> &px, const FpU<P> &py
     const FpU<P> PPP = fmul<INL>(Pv, PP);                              // < 2
     const FpU<P> Q = fmul<INL>(acc.x, PP);                             // < 2
     const FpU<P> RR = fsqr<INL>(Rv);                                   // < 3
-    const FpU<P> X3 = fpu_sub<P, 4>(fpu_sub<P, 4>(RR, PPP), fpu_dbl(Q));                       // < 11
+    const FpU<P> X3 = fpu_sub_sub2<P>(RR, PPP, Q);                                              // < 3 + 8 = 11
     const FpU<P> Y3 = fpu_sub<P, 4>(fmul<INL>(fpu_sub<P, 16>(Q, X3), Rv), fmul<INL>(acc.y, PPP));  // < 7
     acc.x = X3;
     acc.y = Y3;

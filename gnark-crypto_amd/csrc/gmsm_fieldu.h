@@ -75,12 +75,23 @@ GMSM_HD FpU<P> fpu_sub(const FpU<P> &a, const FpU<P> &b) {
     return r;
 }
 
-// K*q - b (the negation used for subMixed): requires b < 4q.
+// 4q - b for a normalised b < 2q (the negation used for subMixed). UK4N borrows one unit per limb, so every result limb
+// is in (0, 2^(W+1)) and can feed the multiplier directly: no carry pass.
 template <class P>
 GMSM_HD FpU<P> fpu_neg4(const FpU<P> &b) {
     FpU<P> r;
 #pragma unroll
-    for (int i = 0; i < P::UL; ++i) r.l[i] = P::UK4[i] - b.l[i];
+    for (int i = 0; i < P::UL; ++i) r.l[i] = P::UK4N[i] - b.l[i];
+    return r;
+}
+
+// a - b - 2c + 8q in one pass (X3 = R^2 - PPP - 2Q): requires b + 2c < 8q limb-wise (b, c nearly normalised).
+// Value bound: bound(a) + 8.
+template <class P>
+GMSM_HD FpU<P> fpu_sub_sub2(const FpU<P> &a, const FpU<P> &b, const FpU<P> &c) {
+    FpU<P> r;
+#pragma unroll
+    for (int i = 0; i < P::UL; ++i) r.l[i] = a.l[i] + P::UK8[i] - b.l[i] - (c.l[i] << 1);
     fpu_carry(r);
     return r;
 }
