@@ -166,11 +166,12 @@ struct Group {
                 // every thread does the same work, so the launch should be a whole number of resident "rounds":
                 // capacity = CUs x 3 workgroups (160 VGPRs -> 3 waves/SIMD) x 256 threads
                 const size_t capacity = (size_t)ctx.num_cus * AccWaves<U>::value * 256;
+                const size_t SEG_MAX = env_uint("GMSM_SEGMAX", 512);  // measured: 512 best at 2^24, 256 at 2^22
                 for (size_t r = 1;; ++r) {
                     size_t s = ((size_t)nw * n + r * capacity - 1) / (r * capacity);
-                    if (s <= 256) {
+                    if (s <= SEG_MAX) {
                         // nw*ceil(n/s) threads must not exceed r*capacity: round s up until it holds
-                        while (s < 256 && (size_t)nw * ((n + s - 1) / s) > r * capacity) ++s;
+                        while (s < SEG_MAX && (size_t)nw * ((n + s - 1) / s) > r * capacity) ++s;
                         seg = (uint32_t)std::max<size_t>(s, 32);
                         break;
                     }
