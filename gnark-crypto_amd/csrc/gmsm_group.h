@@ -405,6 +405,69 @@ __global__ void k_group_op(int op, const XYZZ<F> *acc, const void *other, size_t
     out[i] = p;
 }
 
+// ---- the same hooks through the lazy-limb code paths (gmsm_fieldu.h / gmsm_field2u.h / gmsm_curveu.h): operands are
+// converted from canonical saturated limbs, the lazy operation runs, the result is converted back. This exercises
+// pack/unpack, the carry passes, the redundant-constant subtractions, the conditional reductions and the flag-based
+// infinity handling on edge values, independently of the MSM pipeline.
+template <class P> __device__ __forceinline__ FpU<P> dbg_add(const FpU<P> &a, const FpU<P> &b) { return fpu_add(a, b); }
+template <class P> __device__ __forceinline__ FpU<P> dbg_sub(const FpU<P> &a, const FpU<P> &b) { return fpu_sub<P, 4>(a, b); }
+template <class P> __device__ __forceinline__ FpU<P> dbg_neg(const FpU<P> &a) { return fpu_neg4<P>(a); }
+template <class P> __device__ __forceinline__ FpU<P> dbg_dbl(const FpU<P> &a) { return fpu_dbl(a); }
+template <class P> __device__ __forceinline__ Fp2U<P> dbg_add(const Fp2U<P> &a, const Fp2U<P> &b) { return lz_add(a, b); }
+template <class P> __device__ __forceinline__ Fp2U<P> dbg_sub(const Fp2U<P> &a, const Fp2U<P> &b) { return lz_sub(a, b); }
+template <class P> __device__ __forceinline__ Fp2U<P> dbg_neg(const Fp2U<P> &a) { return lz_sub(lz_zero((const Fp2U<P> *)nullptr), a); }
+template <class P> __device__ __forceinline__ Fp2U<P> dbg_dbl(const Fp2U<P> &a) { return lz_dbl(a); }
+
+template <class U>
+__global__ void k_lazy_field_op(int op, const typename LzTraits<U>::Sat *a, const typename LzTraits<U>::Sat *b, size_t count,
+                                typename LzTraits<U>::Sat *out) {
+    using T = LzTraits<U>;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const U x = T::template from_sat<true>(a[i]);
+    const U y = T::template from_sat<true>(b ? b[i] : a[i]);
+    U z;
+    switch (op) {
+        case 0: z = lz_mul<true>(x, y); break;
+        case 1: z = dbg_add(x, y); break;
+        case 2: z = dbg_sub(x, y); break;
+        case 3: z = dbg_neg(x); break;
+        case 4: z = dbg_dbl(x); break;
+        default: z = lz_sqr<true>(x); break;
+    }
+    out[i] = T::template to_sat<true>(z);
+}
+
+template <class U>
+__global__ void k_lazy_group_op(int op, const XYZZ<typename LzTraits<U>::Sat> *acc, const void *other, size_t count,
+                                XYZZ<typename LzTraits<U>::Sat> *out) {
+    using T = LzTraits<U>;
+    using S = typename T::Sat;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    auto to_lazy = [](const XYZZ<S> &m) {
+        UnsatElem<U> e;
+        e.inf = m.zz.is_zero();
+        e.v.x = T::template from_sat<true>(m.x);
+        e.v.y = T::template from_sat<true>(m.y);
+        e.v.zz = T::template from_sat<true>(m.zz);
+        e.v.zzz = T::template from_sat<true>(m.zzz);
+        return e;
+    };
+    UnsatElem<U> p = to_lazy(acc[i]);
+    if (op == 0 || op == 1) {
+        const Affine<S> a = reinterpret_cast<const Affine<S> *>(other)[i];
+        if (!a.is_infinity())  // the pipeline drops points at infinity before the accumulation (k_decompose skip flags)
+            lz_madd<true>(p.v, p.inf, T::template from_sat<true>(a.x), T::template from_sat<true>(a.y), op == 1);
+    } else if (op == 2) {
+        const UnsatElem<U> q = to_lazy(reinterpret_cast<const XYZZ<S> *>(other)[i]);
+        lz_padd<true>(p.v, p.inf, q.v, q.inf);
+    } else if (!p.inf) {
+        p.v = lz_pdbl<true>(p.v);
+    }
+    unsat_store_final<U, true>(out, i, p);
+}
+
 template <class FT, class Launch>
 static int run_elementwise(size_t in_bytes_a, const void *a, size_t in_bytes_b, const void *b, size_t out_bytes, void *out,
                            Launch launch) {
@@ -538,9 +601,30 @@ struct VTableOf {
             return debug_field<Fp<typename G::FrP>>(op, a, b, count, out);
         }
         if (op == 6) return fail(GMSM_ERR_ARG, "from_mont is defined on prime fields only");
+        if (field == 3) {  // coordinate field through the lazy-limb code
+            using U = typename G::U;
+            using S = typename LzTraits<U>::Sat;
+            return run_elementwise<S>(count * sizeof(S), a, b ? count * sizeof(S) : 0, b, count * sizeof(S), out,
+                                      [&](void *da, void *db, void *dout, hipStream_t s) {
+                                          hipLaunchKernelGGL((k_lazy_field_op<U>), dim3((unsigned)((count + 63) / 64)), dim3(64),
+                                                             0, s, op, (const S *)da, (const S *)db, count, (S *)dout);
+                                      });
+        }
         return debug_field<typename G::F>(op, a, b, count, out);
     }
     static int debug_group_op(int op, const uint64_t *acc, const uint64_t *other, size_t count, uint64_t *out) {
+        if (op >= 4) {  // 4..7 = ops 0..3 through the lazy-limb group law
+            using U = typename G::U;
+            using F = typename G::F;
+            const int lop = op - 4;
+            const size_t ob = (lop == 0 || lop == 1) ? sizeof(Affine<F>) : sizeof(XYZZ<F>);
+            return run_elementwise<F>(count * sizeof(XYZZ<F>), acc, other ? count * ob : 0, other, count * sizeof(XYZZ<F>), out,
+                                      [&](void *da, void *db, void *dout, hipStream_t s) {
+                                          hipLaunchKernelGGL((k_lazy_group_op<U>), dim3((unsigned)((count + 63) / 64)), dim3(64),
+                                                             0, s, lop, (const XYZZ<F> *)da, (const void *)db, count,
+                                                             (XYZZ<F> *)dout);
+                                      });
+        }
         return debug_group<G>(op, acc, other, count, out);
     }
     static void generate_points(const uint64_t *base, const uint64_t *k0, const uint64_t *k1, int klimbs, size_t n,

@@ -114,10 +114,12 @@ size_t gmsm_scalar_limbs(int group);
 /* digits[nwin][n] (uint32 codes: 0 skip, d>0 -> 2d, d<0 -> 2(-d-1)+1) for host scalars; test hook for k_decompose */
 int gmsm_debug_decompose(int group, const uint64_t *scalars, size_t n, unsigned c, uint32_t *out_digits);
 /* element-wise field ops on device: op 0 mul, 1 add, 2 sub, 3 neg, 4 dbl, 5 sqr, 6 from_mont; field 0 = fp, 1 = fr,
- * 2 = the group's coordinate field (Fp2 for G2 where applicable).  a,b,out: count x limbs host arrays. */
+ * 2 = the group's coordinate field (Fp2 for G2 where applicable), 3 = the same coordinate field computed by the lazy-limb
+ * code the pipeline uses (convert in, operate, convert out).  a,b,out: count x limbs host arrays. */
 int gmsm_debug_field_op(int group, int field, int op, const uint64_t *a, const uint64_t *b, size_t count, uint64_t *out);
 /* device group-law hook: out[i] = XYZZ accumulation of  acc[i] (+/-) pts[i]  (op 0 add_mixed, 1 sub_mixed),
- * op 2: out[i] = acc[i] + acc2[i] (xyzz add), op 3: out[i] = 2*acc[i]. */
+ * op 2: out[i] = acc[i] + acc2[i] (xyzz add), op 3: out[i] = 2*acc[i]; ops 4..7: the same four through the lazy-limb
+ * group law of the pipeline. */
 int gmsm_debug_group_op(int group, int op, const uint64_t *acc, const uint64_t *pts_or_acc2, size_t count, uint64_t *out);
 
 /* ---- utilities ---- */

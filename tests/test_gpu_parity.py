@@ -49,6 +49,26 @@ def test_field_ops_match_oracle(gm, oracle_mod, curve, which):
             assert L.gmsm_debug_field_op(g.gid, fid, op, P(a), None, len(a), P(out)) == 0, gm._lib.last_error()
             exp = np.array([fn(x) for x in a])
             assert (out == exp).all(), (name, op)
+    # the coordinate field through the lazy-limb code of the pipeline (field id 3)
+    if g.coord_limbs == c.fp_limbs:
+        F = oracle_mod.Field(f"{c.name}_fp", c.fp_limbs)
+        e = _edge_values(c.p, c.fp_limbs, c.fp_R)
+        a = np.concatenate([np.repeat(e, len(e), axis=0), random_field_limbs(rng, c.p, c.fp_limbs, 400)])
+        b = np.concatenate([np.tile(e, (len(e), 1)), random_field_limbs(rng, c.p, c.fp_limbs, 400)])
+    else:
+        F = oracle_mod.Field(f"{c.name}_e2", 2 * c.fp_limbs)
+        e1 = _edge_values(c.p, c.fp_limbs, c.fp_R)
+        e = np.concatenate([np.concatenate([x, y]) [None, :] for x in e1[:6] for y in e1[:6]])
+        a = np.concatenate([np.repeat(e, 6, axis=0)[: 200], random_field_limbs(rng, c.p, c.fp_limbs, 400).reshape(200, -1)])
+        b = np.concatenate([np.tile(e, (6, 1))[: 200], random_field_limbs(rng, c.p, c.fp_limbs, 400).reshape(200, -1)])
+    for op, fn in [(0, F.mul), (1, F.add), (2, F.sub)]:
+        out = np.zeros_like(a)
+        assert L.gmsm_debug_field_op(g.gid, 3, op, P(a), P(b), len(a), P(out)) == 0, gm._lib.last_error()
+        assert (out == np.array([fn(x, y) for x, y in zip(a, b)])).all(), ("lazy", op)
+    for op, fn in [(3, F.neg), (4, F.dbl), (5, F.sqr)]:
+        out = np.zeros_like(a)
+        assert L.gmsm_debug_field_op(g.gid, 3, op, P(a), None, len(a), P(out)) == 0, gm._lib.last_error()
+        assert (out == np.array([fn(x) for x in a])).all(), ("lazy", op)
     if g.coord_limbs != c.fp_limbs:  # Fp2
         F = oracle_mod.Field(f"{c.name}_e2", 2 * c.fp_limbs)
         a = random_field_limbs(rng, c.p, c.fp_limbs, 600).reshape(300, -1)
@@ -91,11 +111,19 @@ def test_group_ops_match_oracle(gm, oracle_mod, curve, which):
     accs[4] = o.xyzz_double(o.xyzz_add_mixed(o.xyzz_infinity(), pts[4]))  # 2P (ZZ != 1) + P
     t = o.xyzz_add_mixed(o.xyzz_infinity(), pts[5]); t = o.xyzz_add_mixed(t, pts[6]); t = o.xyzz_add_mixed(t, pts[6], negate=True)
     accs[5] = t                                                            # (P5 + P6 - P6) has ZZ != 1, equals P5 -> doubling branch
+    aff = lambda x: o.jac_to_affine(o.xyzz_to_jac(x))
     for op, neg in [(0, False), (1, True)]:
         out = np.zeros_like(accs)
         assert L.gmsm_debug_group_op(g.gid, op, P(accs), P(pts), n, P(out)) == 0, gm._lib.last_error()
         exp = np.array([o.xyzz_add_mixed(a, p, negate=neg) for a, p in zip(accs, pts)])
         assert (out == exp).all(), ("add_mixed", op, np.nonzero((out != exp).any(axis=1))[0])
+        # the lazy-limb group law of the pipeline (ops 4, 5): same formulas, same XYZZ representative
+        out2 = np.zeros_like(accs)
+        assert L.gmsm_debug_group_op(g.gid, op + 4, P(accs), P(pts), n, P(out2)) == 0, gm._lib.last_error()
+        assert all((aff(x) == aff(y)).all() for x, y in zip(out2, exp)), ("lazy add_mixed", op)
+        finite = exp[:, 2 * g.coord_limbs: 3 * g.coord_limbs].any(axis=1)  # zz != 0 (infinity may carry any X, Y)
+        assert (out2[finite] == exp[finite]).all(), ("lazy add_mixed representative", op)
+        assert (out2[~finite][:, 2 * g.coord_limbs:] == 0).all()
     accs2 = np.roll(accs, 7, axis=0).copy()
     accs2[10] = accs[10]           # P + P via full add -> double
     accs2[11] = o.xyzz_infinity()
@@ -103,10 +131,16 @@ def test_group_ops_match_oracle(gm, oracle_mod, curve, which):
     assert L.gmsm_debug_group_op(g.gid, 2, P(accs), P(accs2), n, P(out)) == 0, gm._lib.last_error()
     exp = np.array([o.xyzz_add(a, b) for a, b in zip(accs, accs2)])
     assert (out == exp).all(), "xyzz_add"
+    out2 = np.zeros_like(accs)
+    assert L.gmsm_debug_group_op(g.gid, 6, P(accs), P(accs2), n, P(out2)) == 0, gm._lib.last_error()
+    assert all((aff(x) == aff(y)).all() for x, y in zip(out2, exp)), "lazy xyzz_add"
     out = np.zeros_like(accs)
     assert L.gmsm_debug_group_op(g.gid, 3, P(accs), None, n, P(out)) == 0, gm._lib.last_error()
     exp = np.array([o.xyzz_double(a) for a in accs])
     assert (out == exp).all(), "xyzz_double"
+    out2 = np.zeros_like(accs)
+    assert L.gmsm_debug_group_op(g.gid, 7, P(accs), None, n, P(out2)) == 0, gm._lib.last_error()
+    assert all((aff(x) == aff(y)).all() for x, y in zip(out2, exp)), "lazy xyzz_double"
 
 
 # ------------------------------------------------------------------ scalar decomposition == partitionScalars
