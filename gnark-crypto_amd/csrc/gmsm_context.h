@@ -46,19 +46,46 @@ struct ResidentBases {
     DeviceBuffer upoints, skip;
 };
 
+
+// Everything one in-flight MultiExp needs on the device: scratch buffers, a pinned host buffer for the window totals, a
+// stream of its own (used when the caller gives none) and the stage events. A context owns two of them so that the
+// asynchronous entry points (gmsm_multiexp_bases_submit / _collect) can keep two MultiExp calls in flight: the sort and
+// accumulation of call i+1 overlap the latency-bound reduction, the copy-back and the host fold of call i.
+struct Workspace {
+    hipStream_t stream = nullptr;
+    DeviceBuffer upoints, skip;  // bases rewritten into the lazy domain + infinity flags (non-resident calls)
+    DeviceBuffer seg_lvl;        // hierarchical chain fixup: level partials, flags, long-chain flags
+    DeviceBuffer seg_partials, seg_flags, seg_bucket;  // split-bucket partial sums of the segmented accumulation
+    DeviceBuffer parted;         // coarse-partitioned references (two-level grouping)
+    DeviceBuffer digits, sorted, blockhist, counts, starts, buckets, partials, totals;
+    hipEvent_t events[10] = {nullptr};  // stage boundaries when profiling is on
+    void *pinned = nullptr;             // pinned host buffer for the window totals
+    size_t pinned_cap = 0;
+    // state of a submitted, not yet collected call
+    bool pending = false;
+    int pending_group = -1;
+    unsigned pending_c = 0;
+    uint32_t pending_nw = 0;
+    uint32_t pending_gen = 0;   // ticket generation: a stale or repeated ticket is refused
+    hipEvent_t dep = nullptr;   // orders the workspace stream after the caller's stream (scalars produced there)
+    bool pending_timed = false;
+    int ensure_pinned(size_t bytes) {
+        if (bytes <= pinned_cap) return GMSM_OK;
+        if (pinned) HIP_TRY(hipHostFree(pinned));
+        pinned = nullptr;
+        HIP_TRY(hipHostMalloc(&pinned, bytes, hipHostMallocDefault));
+        pinned_cap = bytes;
+        return GMSM_OK;
+    }
+};
+
 struct Context {
     std::mutex mu;
     int device = -1;
-    hipStream_t stream = nullptr;  // used when the caller passes no stream
-    DeviceBuffer points, scalars;  // staging for the host-pointer entry
-    DeviceBuffer upoints, skip;    // bases rewritten for the unsaturated fast path + infinity flags
-    DeviceBuffer seg_lvl;  // hierarchical chain fixup: level partials, flags, long-chain flags
-    DeviceBuffer seg_partials, seg_flags, seg_bucket;  // split-bucket partial sums of the segmented accumulation
-    DeviceBuffer parted;  // coarse-partitioned references (two-level grouping)
-    DeviceBuffer digits, sorted, blockhist, counts, starts, buckets, partials, totals;
-    hipEvent_t events[10] = {nullptr};  // stage boundaries when profiling is on
-    void *pinned = nullptr;  // pinned host buffer for the window totals
-    size_t pinned_cap = 0;
+    hipStream_t stream = nullptr;  // = ws[0].stream: used when the caller passes no stream
+    DeviceBuffer points, scalars;  // staging for the host-pointer entries
+    Workspace ws[2];
+    Workspace *free_workspace() { return !ws[0].pending ? &ws[0] : !ws[1].pending ? &ws[1] : nullptr; }
     int num_cus = 256;
     int init(int dev) {
         device = dev;
@@ -66,15 +93,8 @@ struct Context {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
         num_cus = prop.multiProcessorCount;
-        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        return GMSM_OK;
-    }
-    int ensure_pinned(size_t bytes) {
-        if (bytes <= pinned_cap) return GMSM_OK;
-        if (pinned) HIP_TRY(hipHostFree(pinned));
-        pinned = nullptr;
-        HIP_TRY(hipHostMalloc(&pinned, bytes, hipHostMallocDefault));
-        pinned_cap = bytes;
+        for (auto &w : ws) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+        stream = ws[0].stream;
         return GMSM_OK;
     }
 };
@@ -97,22 +117,21 @@ bool profiling_enabled();
 void record_stage_times(const float *ms);  // adds one call's stage durations to the thread-independent accumulators
 
 struct StageTimer {
-    Context &ctx;
+    Workspace &ws;
     hipStream_t stream;
     bool on;
-    StageTimer(Context &c, hipStream_t s) : ctx(c), stream(s), on(profiling_enabled()) {
-        if (on && !ctx.events[0])
-            for (int i = 0; i <= STAGE_END; ++i) (void)hipEventCreate(&ctx.events[i]);
+    StageTimer(Workspace &w, hipStream_t s) : ws(w), stream(s), on(profiling_enabled()) {
+        if (on && !ws.events[0])
+            for (int i = 0; i <= STAGE_END; ++i) (void)hipEventCreate(&ws.events[i]);
     }
     void mark(int stage) {
-        if (on) (void)hipEventRecord(ctx.events[stage], stream);
+        if (on) (void)hipEventRecord(ws.events[stage], stream);
     }
-    void collect() {  // call after the stream has been synchronised
-        if (!on) return;
+    static void collect(Workspace &ws) {  // call after the stream has been synchronised
         float ms[STAGE_COUNT];
         for (int i = 0; i < STAGE_COUNT; ++i) {
             ms[i] = 0.f;
-            (void)hipEventElapsedTime(&ms[i], ctx.events[i], ctx.events[i + 1]);
+            (void)hipEventElapsedTime(&ms[i], ws.events[i], ws.events[i + 1]);
         }
         record_stage_times(ms);
     }
@@ -171,6 +190,8 @@ struct GroupVTable {
     void (*generate_points)(const uint64_t *base, const uint64_t *k0, const uint64_t *k1, int klimbs, size_t n, int nthreads,
                             uint64_t *out);
     int (*register_bases)(Context &ctx, const void *d_points, size_t n, hipStream_t stream, ResidentBases *out);
+    int (*submit)(Context &ctx, Workspace &ws, const void *d_scalars, size_t n, const ResidentBases *resident);
+    int (*collect)(Workspace &ws, uint64_t *out_jac);
 };
 
 }  // namespace gmsm

@@ -204,6 +204,61 @@ GMSM_EXPORT int gmsm_multiexp_bases_device(uint64_t handle, const void *d_scalar
     return multiexp_bases_impl(handle, nullptr, d_scalars, n_scalars, 0, hip_stream, out_jac);
 }
 
+// ------------------------------------------------------------------ two MultiExp calls in flight
+// ticket = device << 40 | generation << 8 | (slot + 1)
+GMSM_EXPORT int gmsm_multiexp_bases_submit(uint64_t handle, const void *d_scalars, size_t n_scalars, void *hip_stream,
+                                           uint64_t *out_ticket) {
+    ResidentBases *rb = lookup_bases(handle);
+    if (!rb) return fail(GMSM_ERR_ARG, "unknown bases handle");
+    if (!out_ticket) return fail(GMSM_ERR_ARG, "out_ticket is null");
+    const GroupVTable *vt = vtable(rb->group);
+    if (n_scalars > rb->n) return fail(GMSM_ERR_LEN, "len(points) != len(scalars)");
+    Context *ctx;
+    int rc = get_context(&ctx);
+    if (rc) return rc;
+    if (ctx->device != rb->device) return fail(GMSM_ERR_ARG, "bases were registered on another device");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    Workspace *ws = ctx->free_workspace();
+    if (!ws) return fail(GMSM_ERR_ARG, "two MultiExp calls are already in flight: collect one first");
+    if (hip_stream) {  // the scalars are produced on the caller's stream: order our stream behind it
+        if (!ws->dep) HIP_TRY(hipEventCreateWithFlags(&ws->dep, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ws->dep, (hipStream_t)hip_stream));
+        HIP_TRY(hipStreamWaitEvent(ws->stream, ws->dep, 0));
+    }
+    if ((rc = vt->submit(*ctx, *ws, d_scalars, n_scalars, rb))) return rc;
+    ws->pending = true;
+    ws->pending_group = rb->group;
+    ++ws->pending_gen;
+    *out_ticket = ((uint64_t)ctx->device << 40) | ((uint64_t)(ws->pending_gen & 0xffffffffu) << 8) | (uint64_t)(ws - ctx->ws + 1);
+    return GMSM_OK;
+}
+
+GMSM_EXPORT int gmsm_multiexp_collect(uint64_t ticket, uint64_t *out_jac) {
+    const unsigned slot = (unsigned)(ticket & 0xff), dev = (unsigned)(ticket >> 40);
+    const uint32_t gen = (uint32_t)(ticket >> 8);
+    Context *ctx = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        if (dev < g_ctx.size()) ctx = g_ctx[dev];
+    }
+    if (!ctx || slot < 1 || slot > 2) return fail(GMSM_ERR_ARG, "unknown MultiExp ticket");
+    Workspace &ws = ctx->ws[slot - 1];
+    const GroupVTable *vt;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if (!ws.pending || ws.pending_gen != gen) return fail(GMSM_ERR_ARG, "unknown MultiExp ticket (already collected?)");
+        vt = vtable(ws.pending_group);
+    }
+    // The slot stays `pending` while we wait and fold, so nobody else touches it; the context lock is not held and the
+    // other slot can be submitted to meanwhile.
+    (void)hipSetDevice(ctx->device);
+    int rc = vt->collect(ws, out_jac);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ws.pending = false;
+    return rc;
+}
+
 GMSM_EXPORT unsigned gmsm_default_window_bits(int group, size_t n) {
     const GroupVTable *vt = vtable(group);
     return vt ? choose_c(vt->fr_bits, n) : 0;

@@ -61,10 +61,35 @@ struct Group {
     // domain by register_bases) is given.
     static int window_sums(Context &ctx, const void *d_points, const void *d_scalars, size_t n, const WindowPlan &plan,
                            hipStream_t stream, Ext *host_xyzz, const ResidentBases *resident = nullptr) {
+        Workspace *free_ws = ctx.free_workspace();
+        if (!free_ws) return fail(GMSM_ERR_ARG, "two submitted MultiExp calls are waiting for gmsm_multiexp_collect");
+        Workspace &ws = *free_ws;
+        int rc = enqueue_window_sums(ctx, ws, d_points, d_scalars, n, plan, stream, resident);
+        if (rc) return rc;
+        return collect_window_sums(ws, stream, plan.nwin_local, host_xyzz);
+    }
+
+    // Waits for the pipeline enqueued on `stream` and hands out the window totals (pinned buffer -> host_xyzz).
+    static int collect_window_sums(Workspace &ws, hipStream_t stream, uint32_t nw, Ext *host_xyzz) {
+        if (nw == 0) return GMSM_OK;
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (ws.pending_timed) StageTimer::collect(ws);
+        ws.pending_timed = false;
+        memcpy(host_xyzz, ws.pinned, (size_t)nw * sizeof(Ext));
+        return GMSM_OK;
+    }
+
+    // Launches every kernel of one MultiExp on `stream` and queues the copy of the window totals into ws.pinned; does
+    // not wait. All scratch comes from `ws`, so two workspaces can be in flight on two streams.
+    static int enqueue_window_sums(Context &ctx, Workspace &ws, const void *d_points, const void *d_scalars, size_t n,
+                                   const WindowPlan &plan, hipStream_t stream, const ResidentBases *resident) {
         const uint32_t nw = plan.nwin_local;
+        ws.pending_timed = false;
         if (nw == 0) return GMSM_OK;
         if (n == 0) {
-            for (uint32_t k = 0; k < nw; ++k) host_xyzz[k] = Ext::infinity();
+            int rc0 = ws.ensure_pinned((size_t)nw * sizeof(Ext));
+            if (rc0) return rc0;
+            for (uint32_t k = 0; k < nw; ++k) ((Ext *)ws.pinned)[k] = Ext::infinity();
             return GMSM_OK;
         }
         if (n >= ((size_t)1 << 31)) return fail(GMSM_ERR_ARG, "n must be < 2^31");
@@ -77,20 +102,20 @@ struct Group {
         for (int t = RED_TPB; t > 1; t >>= 1) ++log2span;
 
         int rc;
-        if ((rc = ctx.digits.ensure((size_t)nw * n * 4))) return rc;
-        if ((rc = ctx.sorted.ensure((size_t)nw * n * 4))) return rc;
-        if ((rc = ctx.starts.ensure((size_t)nw * (NB + 1) * 4))) return rc;
+        if ((rc = ws.digits.ensure((size_t)nw * n * 4))) return rc;
+        if ((rc = ws.sorted.ensure((size_t)nw * n * 4))) return rc;
+        if ((rc = ws.starts.ensure((size_t)nw * (NB + 1) * 4))) return rc;
         constexpr size_t REC = sizeof(typename Ops::Mem);  // bucket / partial record (lazy representation on the fast path)
         static_assert(sizeof(typename Ops::Mem) == sizeof(typename OpsNI::Mem), "one record format per group");
-        if ((rc = ctx.buckets.ensure((size_t)nw * NB * REC))) return rc;
-        if ((rc = ctx.partials.ensure((size_t)nw * nblocks1 * 2 * REC))) return rc;
-        if ((rc = ctx.totals.ensure((size_t)nw * sizeof(Ext)))) return rc;
-        if ((rc = ctx.ensure_pinned((size_t)nw * sizeof(Ext)))) return rc;
+        if ((rc = ws.buckets.ensure((size_t)nw * NB * REC))) return rc;
+        if ((rc = ws.partials.ensure((size_t)nw * nblocks1 * 2 * REC))) return rc;
+        if ((rc = ws.totals.ensure((size_t)nw * sizeof(Ext)))) return rc;
+        if ((rc = ws.ensure_pinned((size_t)nw * sizeof(Ext)))) return rc;
 
-        uint32_t *digits = (uint32_t *)ctx.digits.ptr, *sorted = (uint32_t *)ctx.sorted.ptr;
-        uint32_t *starts = (uint32_t *)ctx.starts.ptr;
+        uint32_t *digits = (uint32_t *)ws.digits.ptr, *sorted = (uint32_t *)ws.sorted.ptr;
+        uint32_t *starts = (uint32_t *)ws.starts.ptr;
 
-        StageTimer timer(ctx, stream);
+        StageTimer timer(ws, stream);
         // 0. rewrite the bases into the lazy Montgomery domain + infinity flags (unless registered earlier)
         timer.mark(STAGE_DECOMPOSE);
         const uint8_t *skip = nullptr;
@@ -99,12 +124,12 @@ struct Group {
             upoints = resident->upoints.ptr;
             skip = (const uint8_t *)resident->skip.ptr;
         } else {
-            if ((rc = ctx.upoints.ensure(n * AFF_BYTES))) return rc;
-            if ((rc = ctx.skip.ensure(n))) return rc;
+            if ((rc = ws.upoints.ensure(n * AFF_BYTES))) return rc;
+            if ((rc = ws.skip.ensure(n))) return rc;
             hipLaunchKernelGGL((k_convert_points<U>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                               stream, d_points, n, ctx.upoints.ptr, (uint8_t *)ctx.skip.ptr);
-            upoints = ctx.upoints.ptr;
-            skip = (const uint8_t *)ctx.skip.ptr;
+                               stream, d_points, n, ws.upoints.ptr, (uint8_t *)ws.skip.ptr);
+            upoints = ws.upoints.ptr;
+            skip = (const uint8_t *)ws.skip.ptr;
         }
         // 1. signed-digit decomposition
         hipLaunchKernelGGL((k_decompose<FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
@@ -125,12 +150,12 @@ struct Group {
             const uint32_t nparts = NB >> fbits;
             const uint32_t pchunks = (uint32_t)((n + PART_CHUNK - 1) / PART_CHUNK);  // chunk = one LDS staging buffer
             const size_t pchunk_len = PART_CHUNK;
-            if ((rc = ctx.blockhist.ensure((size_t)nw * pchunks * nparts * 4))) return rc;
-            if ((rc = ctx.counts.ensure((size_t)nw * (2 * nparts + 1) * 4))) return rc;
-            if ((rc = ctx.parted.ensure((size_t)nw * n * 4))) return rc;
-            uint32_t *bh = (uint32_t *)ctx.blockhist.ptr, *part_base = (uint32_t *)ctx.counts.ptr;
+            if ((rc = ws.blockhist.ensure((size_t)nw * pchunks * nparts * 4))) return rc;
+            if ((rc = ws.counts.ensure((size_t)nw * (2 * nparts + 1) * 4))) return rc;
+            if ((rc = ws.parted.ensure((size_t)nw * n * 4))) return rc;
+            uint32_t *bh = (uint32_t *)ws.blockhist.ptr, *part_base = (uint32_t *)ws.counts.ptr;
             uint32_t *part_pop = part_base + (size_t)nw * (nparts + 1);
-            uint32_t *parted = (uint32_t *)ctx.parted.ptr;
+            uint32_t *parted = (uint32_t *)ws.parted.ptr;
             static bool attr2_done = false;
             if (!attr2_done) {
                 HIP_TRY(hipFuncSetAttribute((const void *)k_part_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -178,20 +203,20 @@ struct Group {
                 }
             }
             const uint32_t tpw = (uint32_t)((n + seg - 1) / seg);  // threads per window (upper bound: <= n entries)
-            if ((rc = ctx.seg_partials.ensure((size_t)nw * tpw * 2 * REC))) return rc;
-            if ((rc = ctx.seg_flags.ensure((size_t)nw * tpw * 4))) return rc;
-            if ((rc = ctx.seg_bucket.ensure((size_t)nw * tpw * 4))) return rc;
+            if ((rc = ws.seg_partials.ensure((size_t)nw * tpw * 2 * REC))) return rc;
+            if ((rc = ws.seg_flags.ensure((size_t)nw * tpw * 4))) return rc;
+            if ((rc = ws.seg_bucket.ensure((size_t)nw * tpw * 4))) return rc;
             hipLaunchKernelGGL((k_accumulate_seg<U>), dim3((tpw + 255) / 256, nw), dim3(256), 0, stream,
-                               upoints, n, NB, seg, starts, sorted, ctx.buckets.ptr, ctx.seg_partials.ptr,
-                               (uint32_t *)ctx.seg_flags.ptr, (uint32_t *)ctx.seg_bucket.ptr, tpw);
+                               upoints, n, NB, seg, starts, sorted, ws.buckets.ptr, ws.seg_partials.ptr,
+                               (uint32_t *)ws.seg_flags.ptr, (uint32_t *)ws.seg_bucket.ptr, tpw);
             timer.mark(STAGE_FIXUP);
             // chain fixup: short chains in place, long ones through two hierarchical levels (no-ops unless flagged)
             const uint32_t span1 = 64;
             const uint32_t t1 = (tpw + span1 - 1) / span1;  // level-1 outputs per window
             const uint32_t span2 = t1;                      // level 2: one thread per window closes everything
             const size_t lvl_parts = ((size_t)nw * t1 + nw) * 2 * REC;
-            if ((rc = ctx.seg_lvl.ensure(lvl_parts + ((size_t)nw * t1 * 2 + (size_t)nw * 3) * 4 + 256))) return rc;
-            char *lvl = (char *)ctx.seg_lvl.ptr;
+            if ((rc = ws.seg_lvl.ensure(lvl_parts + ((size_t)nw * t1 * 2 + (size_t)nw * 3) * 4 + 256))) return rc;
+            char *lvl = (char *)ws.seg_lvl.ptr;
             void *parts1 = lvl;
             void *parts2 = lvl + (size_t)nw * t1 * 2 * REC;  // nw * 2 records
             uint32_t *flags1 = (uint32_t *)(lvl + lvl_parts);
@@ -201,14 +226,14 @@ struct Group {
             uint32_t *long_flag = pb2 + nw;
             HIP_TRY(hipMemsetAsync(long_flag, 0, (size_t)nw * 4, stream));
             hipLaunchKernelGGL((k_fixup_seg<Ops>), dim3((tpw + 255) / 256, nw), dim3(256), 0, stream, NB,
-                               ctx.seg_partials.ptr, (const uint32_t *)ctx.seg_flags.ptr,
-                               (const uint32_t *)ctx.seg_bucket.ptr, tpw, ctx.buckets.ptr, long_flag);
+                               ws.seg_partials.ptr, (const uint32_t *)ws.seg_flags.ptr,
+                               (const uint32_t *)ws.seg_bucket.ptr, tpw, ws.buckets.ptr, long_flag);
             hipLaunchKernelGGL((k_fixup_level<OpsNI>), dim3((t1 + 255) / 256, nw), dim3(256), 0, stream, NB,
-                               ctx.seg_partials.ptr, (const uint32_t *)ctx.seg_flags.ptr,
-                               (const uint32_t *)ctx.seg_bucket.ptr, tpw, span1, parts1, flags1, pb1, t1, ctx.buckets.ptr,
+                               ws.seg_partials.ptr, (const uint32_t *)ws.seg_flags.ptr,
+                               (const uint32_t *)ws.seg_bucket.ptr, tpw, span1, parts1, flags1, pb1, t1, ws.buckets.ptr,
                                long_flag);
             hipLaunchKernelGGL((k_fixup_level<OpsNI>), dim3(1, nw), dim3(256), 0, stream, NB, parts1, flags1, pb1, t1, span2,
-                               parts2, flags2, pb2, 1u, ctx.buckets.ptr, long_flag);
+                               parts2, flags2, pb2, 1u, ws.buckets.ptr, long_flag);
         }
         // 4. bucket reduction -> window totals
         static bool red_attr_done = false;
@@ -221,15 +246,13 @@ struct Group {
         }
         timer.mark(STAGE_REDUCE);
         hipLaunchKernelGGL((k_reduce1<Ops, RED_TPB>), dim3(nblocks1, nw), dim3(RED_TPB), 2 * RED_TPB * sizeof(OpsElem), stream,
-                           ctx.buckets.ptr, NB, log2L, ctx.partials.ptr, reduce_starts);
+                           ws.buckets.ptr, NB, log2L, ws.partials.ptr, reduce_starts);
         hipLaunchKernelGGL((k_reduce2<Ops, RED2_TPB>), dim3(nw), dim3(RED2_TPB), 2 * RED2_TPB * sizeof(OpsElem), stream,
-                           ctx.partials.ptr, nblocks1, log2span, ctx.totals.ptr);
+                           ws.partials.ptr, nblocks1, log2span, ws.totals.ptr);
         timer.mark(STAGE_END);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(ctx.pinned, ctx.totals.ptr, (size_t)nw * sizeof(Ext), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        timer.collect();
-        memcpy(host_xyzz, ctx.pinned, (size_t)nw * sizeof(Ext));
+        HIP_TRY(hipMemcpyAsync(ws.pinned, ws.totals.ptr, (size_t)nw * sizeof(Ext), hipMemcpyDeviceToHost, stream));
+        ws.pending_timed = timer.on;
         return GMSM_OK;
     }
 
@@ -339,6 +362,25 @@ struct Group {
         int rc = window_sums(ctx, d_points, d_scalars, n, plan, stream, totals.data(), resident);
         if (rc) return rc;
         *out = fold(totals.data(), c);
+        return GMSM_OK;
+    }
+
+    // Asynchronous pair (gmsm_multiexp_bases_submit / gmsm_multiexp_collect): submit launches the whole device pipeline
+    // on the workspace's own stream and returns; collect waits for it, then folds the windows on the host.
+    static int multiexp_submit(Context &ctx, Workspace &ws, const void *d_scalars, size_t n, const ResidentBases *resident) {
+        const unsigned c = choose_c(FR_BITS, n);
+        WindowPlan plan = make_plan(c, 0, 1);
+        int rc = enqueue_window_sums(ctx, ws, nullptr, d_scalars, n, plan, ws.stream, resident);
+        if (rc) return rc;
+        ws.pending_c = c;
+        ws.pending_nw = plan.nwin_total;
+        return GMSM_OK;
+    }
+    static int multiexp_collect(Workspace &ws, J *out) {
+        std::vector<Ext> totals(ws.pending_nw);
+        int rc = collect_window_sums(ws, ws.stream, ws.pending_nw, totals.data());
+        if (rc) return rc;
+        *out = fold(totals.data(), ws.pending_c);
         return GMSM_OK;
     }
 
@@ -534,13 +576,13 @@ static int debug_decompose_impl(const uint64_t *scalars, size_t n, unsigned c, u
     WindowPlan plan = G::make_plan(c, 0, 1);
     if (n == 0) return GMSM_OK;
     if ((rc = ctx->scalars.ensure(n * G::SCALAR_BYTES))) return rc;
-    if ((rc = ctx->digits.ensure((size_t)plan.nwin_total * n * 4))) return rc;
+    if ((rc = ctx->ws[0].digits.ensure((size_t)plan.nwin_total * n * 4))) return rc;
     HIP_TRY(hipMemcpy(ctx->scalars.ptr, scalars, n * G::SCALAR_BYTES, hipMemcpyHostToDevice));
     hipLaunchKernelGGL((k_decompose<typename G::FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const uint32_t *)ctx->scalars.ptr, n, plan, (uint32_t *)ctx->digits.ptr, (const uint8_t *)nullptr);
+                       (const uint32_t *)ctx->scalars.ptr, n, plan, (uint32_t *)ctx->ws[0].digits.ptr, (const uint8_t *)nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipMemcpy(out_digits, ctx->digits.ptr, (size_t)plan.nwin_total * n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_digits, ctx->ws[0].digits.ptr, (size_t)plan.nwin_total * n * 4, hipMemcpyDeviceToHost));
     return GMSM_OK;
 }
 
@@ -577,6 +619,16 @@ struct VTableOf {
     }
     static int register_bases(Context &ctx, const void *d_points, size_t n, hipStream_t stream, ResidentBases *out) {
         return G::register_bases(ctx, d_points, n, stream, out);
+    }
+    static int submit(Context &ctx, Workspace &ws, const void *d_scalars, size_t n, const ResidentBases *resident) {
+        return G::multiexp_submit(ctx, ws, d_scalars, n, resident);
+    }
+    static int collect(Workspace &ws, uint64_t *out_jac) {
+        typename G::J j;
+        int rc = G::multiexp_collect(ws, &j);
+        if (rc) return rc;
+        memcpy(out_jac, &j, sizeof j);
+        return GMSM_OK;
     }
     static void fold(const uint64_t *xyzz_windows, unsigned c, uint64_t *out_jac) {
         typename G::J j = G::fold(reinterpret_cast<const typename G::Ext *>(xyzz_windows), c);
@@ -635,7 +687,7 @@ struct VTableOf {
         static const GroupVTable vt = {G::FR_BITS,      G::AFF_BYTES,   G::SCALAR_BYTES, sizeof(typename G::J),
                                        sizeof(typename G::Ext), &multiexp_host, &multiexp_device, &window_sums,
                                        &fold,           &jac_to_affine, &debug_decompose, &debug_field_op,
-                                       &debug_group_op, &generate_points, &register_bases};
+                                       &debug_group_op, &generate_points, &register_bases, &submit, &collect};
         return &vt;
     }
 };

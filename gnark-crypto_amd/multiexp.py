@@ -188,6 +188,25 @@ class ResidentBases:
             raise RuntimeError(self.group._error(rc))
         return out
 
+    def submit(self, d_scalars, n, stream=0):
+        """gmsm_multiexp_bases_submit: launch MultiExp(bases[:n], d_scalars) without waiting; returns a ticket."""
+        import ctypes
+        L = _lib.load()
+        ticket = ctypes.c_uint64(0)
+        rc = L.gmsm_multiexp_bases_submit(self.handle, d_scalars, n, stream or None, ctypes.byref(ticket))
+        if rc:
+            raise RuntimeError(self.group._error(rc))
+        return ticket.value
+
+    def collect(self, ticket):
+        """gmsm_multiexp_collect: wait for a submitted MultiExp and return its Jacobian limbs."""
+        L = _lib.load()
+        out = np.zeros(self.group.jac_limbs, dtype=np.uint64)
+        rc = L.gmsm_multiexp_collect(ticket, _ptr(out))
+        if rc:
+            raise RuntimeError(self.group._error(rc))
+        return out
+
     def release(self):
         if self.handle:
             _lib.load().gmsm_bases_release(self.handle)

@@ -95,6 +95,18 @@ int gmsm_multiexp_bases(uint64_t handle, const uint64_t *scalars, size_t n_scala
 int gmsm_multiexp_bases_device(uint64_t handle, const void *d_scalars, size_t n_scalars, void *hip_stream,
                                uint64_t *out_jac);
 
+/* ---- two MultiExp calls in flight (the reference's equivalent is several goroutines calling
+ *      MultiExp at once, BenchmarkManyMultiExpG1Reference, ecc/bn254/multiexp_test.go:385-415).
+ *      submit launches the whole device pipeline for device-resident scalars over registered bases and returns without
+ *      waiting; collect waits, folds the windows and writes the Jacobian result. At most two tickets may be outstanding
+ *      per device (a third submit returns GMSM_ERR_ARG); d_scalars must stay valid until its ticket is collected.
+ *      hip_stream: the stream the scalars were produced on (the pipeline is ordered after it), or NULL if they are
+ *      already complete. The sort/accumulate of one call overlaps the latency-bound bucket reduction, copy-back and
+ *      host fold of the other. ---- */
+int gmsm_multiexp_bases_submit(uint64_t handle, const void *d_scalars, size_t n_scalars, void *hip_stream,
+                               uint64_t *out_ticket);
+int gmsm_multiexp_collect(uint64_t ticket, uint64_t *out_jac);
+
 /* ---- window-sharded pieces (multi-GPU: windows win_first, win_first+win_stride, ... of the c-bit decomposition are
  *      handled by this device; the tiny per-window totals are exchanged by the caller, e.g. one RCCL all-gather).
  *      out_xyzz (host) receives nwin_local x {X,Y,ZZ,ZZZ} extended-Jacobian window totals

@@ -374,6 +374,57 @@ def test_resident_bases_prefix_multiexp(gm, oracle_mod, curve, which):
         rb.release()
 
 
+@pytest.mark.parametrize("curve,which", [("bn254", "g1"), ("bls12_381", "g2")])
+def test_two_multiexp_in_flight(gm, oracle_mod, curve, which):
+    """gmsm_multiexp_bases_submit / gmsm_multiexp_collect: two MultiExp calls over the same resident bases in flight on
+    two workspaces (the GPU-side counterpart of BenchmarkManyMultiExpG1Reference, ecc/bn254/multiexp_test.go:385-415).
+    Every result equals the oracle whatever the collection order; a third submit, a repeated ticket and a synchronous
+    call with both slots taken are refused; a synchronous call with one slot taken uses the other one."""
+    import torch
+    g = _group(gm, curve, which)
+    o = oracle_mod.Oracle(curve, which)
+    n = 6000
+    rng = rng_for(21, g.gid)
+    pts = o.gen_points(n, 555, 99, nthreads=4)
+    sets = [(random_scalars(rng, g.curve, m), m) for m in (n, 4321, n, 17, 0, n)]
+    expect = [o.msm_affine(pts[:m], sc) for sc, m in sets]
+    d_sc = [torch.from_numpy(sc.view(np.int64).copy()).cuda() if m else torch.zeros(4, dtype=torch.int64).cuda() for sc, m in sets]
+    torch.cuda.synchronize()
+    rb = g.register_bases(points=pts)
+    try:
+        # rolling pipeline, depth 2, in-order collection
+        prev = None
+        got = []
+        for i, (_, m) in enumerate(sets):
+            t = rb.submit(d_sc[i].data_ptr(), m)
+            if prev is not None:
+                got.append(rb.collect(prev))
+            prev = t
+        got.append(rb.collect(prev))
+        for i, jac in enumerate(got):
+            assert (g.jac_to_affine(jac) == expect[i]).all(), i
+        # out-of-order collection + refusals
+        t0 = rb.submit(d_sc[0].data_ptr(), sets[0][1])
+        jac_sync = rb.multiexp_device(d_sc[1].data_ptr(), sets[1][1])  # one slot busy: the other one serves
+        assert (g.jac_to_affine(jac_sync) == expect[1]).all()
+        t1 = rb.submit(d_sc[1].data_ptr(), sets[1][1], stream=torch.cuda.current_stream().cuda_stream)
+        with pytest.raises(RuntimeError, match="already in flight"):
+            rb.submit(d_sc[2].data_ptr(), sets[2][1])
+        with pytest.raises(RuntimeError, match="waiting for gmsm_multiexp_collect"):
+            rb.multiexp_device(d_sc[2].data_ptr(), sets[2][1])
+        assert (g.jac_to_affine(rb.collect(t1)) == expect[1]).all()
+        with pytest.raises(RuntimeError, match="ticket"):
+            rb.collect(t1)
+        assert (g.jac_to_affine(rb.collect(t0)) == expect[0]).all()
+        with pytest.raises(RuntimeError, match="ticket"):
+            rb.collect(12345)
+        # everything is free again
+        jac, err = rb.MultiExp(sets[3][0])
+        assert err is None and (g.jac_to_affine(jac) == expect[3]).all()
+    finally:
+        rb.release()
+
+
 @pytest.mark.parametrize("curve,which,c", [("bn254", "g1", 16), ("bn254", "g1", 13), ("bls12_381", "g2", 16)])
 def test_window_sharded_pieces_on_one_gpu(gm, oracle_mod, curve, which, c):
     """The multi-GPU decomposition executed rank by rank on one GPU: every "rank" computes the totals of its own windows
