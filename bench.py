@@ -39,6 +39,10 @@ def main():
     ap.add_argument("--logn", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the two-in-flight (submit/collect) measurement")
+    ap.add_argument("--shard", default="auto", choices=["auto", "windows", "points"],
+                    help="N>1: decomposition of the one MultiExp over the ranks (gnark-crypto_amd/sharding.py)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N>1 code path (RCCL process group, device-side all-gather) even with one rank")
     ap.add_argument("--resident", action="store_true",
                     help="register the bases once (gmsm_bases_register) and time MultiExp over the resident form")
     ap.add_argument("--curve", default="bn254", help="exploration only: bn254 | bls12_381 | bw6_761")
@@ -54,8 +58,10 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if world > 1 or args.force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     gm = importlib.import_module("gnark-crypto_amd")
     lib = gm._lib.load()
@@ -91,19 +97,31 @@ def main():
     nwin = g.num_windows(c)
 
     sharding = importlib.import_module("gnark-crypto_amd.sharding")
-    gather = sharding.torch_all_gather(dist, torch.device("cuda", local_rank)) if world > 1 else None
+    sharded = world > 1 or args.force_dist
+    plan = exchange = None
+    if sharded:
+        # One MultiExp over all ranks (strong scaling): point or window decomposition (sharding.py), the totals stay on
+        # the device until ONE RCCL all-gather; every rank folds.
+        plan = sharding.shard_plan(g, n, rank, world, args.shard)
+        c, nwin = plan["c"], plan["nwin"]
+        exchange = sharding.Exchange(dist, torch.device("cuda", local_rank), plan["rows"], g.xyzz_limbs)
+        d_pts_loc, d_sc_loc, n_loc = d_pts[plan["lo"]:plan["hi"]], d_sc[plan["lo"]:plan["hi"]], plan["hi"] - plan["lo"]
 
-    resident = g.register_bases(d_points=d_pts.data_ptr(), n=n) if (args.resident and world == 1) else None
+    resident = None
+    if args.resident:
+        resident = (g.register_bases(d_points=d_pts_loc.data_ptr(), n=n_loc) if sharded
+                    else g.register_bases(d_points=d_pts.data_ptr(), n=n))
+
+    def enqueue(plan_, local):
+        g.window_sums_enqueue(d_pts_loc.data_ptr(), d_sc_loc.data_ptr(), n_loc, plan_["c"], plan_["win_first"],
+                              plan_["win_stride"], stream, local.data_ptr(), bases=resident)
 
     def step():
+        if sharded:
+            return sharding.sharded_multiexp_exchange(g, plan, enqueue, exchange)
         if resident is not None:
             return resident.multiexp_device(d_sc.data_ptr(), n, stream)
-        if world == 1:
-            return g.multiexp_device(d_pts.data_ptr(), d_sc.data_ptr(), n, stream)
-        # window sharding: rank r owns windows r, r+world, ...; one RCCL all-gather of <= ceil(nwin/world) XYZZ totals
-        return sharding.sharded_multiexp(
-            g, lambda c_, first, stride: g.window_sums_device(d_pts.data_ptr(), d_sc.data_ptr(), n, c_, first, stride, stream),
-            c, rank, world, gather)
+        return g.multiexp_device(d_pts.data_ptr(), d_sc.data_ptr(), n, stream)
 
     def barrier():
         torch.cuda.synchronize()
@@ -132,7 +150,7 @@ def main():
     # Two MultiExp calls in flight over resident bases (gmsm_multiexp_bases_submit/_collect): reported beside the
     # headline number, never instead of it. Every one of the K calls is submitted and collected inside the timed region.
     pipelined = None
-    if world == 1 and not args.no_pipeline:
+    if not sharded and not args.no_pipeline:
         rb2 = resident or g.register_bases(d_points=d_pts.data_ptr(), n=n)
 
         def run_pipelined(k):
@@ -164,13 +182,15 @@ def main():
         stages = {name: stage_ms[i] / ncalls for i, name in enumerate(STAGES)}
         acc_ms = stages["accumulate"]
         bytes_per_point = 8 * (g.aff_limbs + g.fr_limbs)  # affine point + scalar (BN254 G1: 96 B)
-        algorithmic_bytes = bytes_per_point * n * (len(range(rank, nwin, world)) / nwin)  # this rank's share of the windows
+        # this rank's share of the (point, window) pairs: all windows of its slice, or its windows of all points
+        my_pairs = (plan["hi"] - plan["lo"]) * len(range(plan["win_first"], nwin, plan["win_stride"])) if sharded else n * nwin
+        algorithmic_bytes = bytes_per_point * n * my_pairs / (n * nwin)
         achieved = algorithmic_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
         # integer roofline of the same kernel: 10 field products per mixed add (8M+2S, g1.go:822), n*(windows of this
         # rank) mixed adds; one lazy 9x29-bit Montgomery product = 171 v_mad_u64_u32/v_mul_lo_u32 + 18 v_lshrrev_b64, all
         # 4 cycles / wave64 / SIMD (tools/ubench_valu.hip): issue peak = 1024 SIMD * 64 lanes * 2.4 GHz / (189 * 4)
         # = 208e9 products/s at the nominal clock; tools/ubench_fpmul.hip measures 174-177e9 on the chip.
-        madds = n * len(range(rank, nwin, world))
+        madds = my_pairs
         mulmods_per_s = madds * 10 / (acc_ms * 1e-3) if acc_ms > 0 else 0.0
         int_peak = 1024 * 64 * 2.4e9 / (189 * 4)
         out = {
@@ -179,7 +199,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "u32 limbs (256-bit Montgomery)", "data": "synthetic",
             "config": {"workload": f"{args.curve.upper()} {args.group.upper()} MultiExp 2^{args.logn} points, bases+scalars resident in HBM",
                        "points": n, "window_bits": c, "windows": nwin, "resident_bases": resident is not None,
-                       "parallelism": "single GPU" if world == 1 else f"window-sharded x{world} + RCCL all-gather"},
+                       "parallelism": "single GPU" if not sharded else f"{plan['mode']}-sharded x{world} + one RCCL all-gather"},
             "points_per_s": value * n,
             "stage_ms": stages,
             "pipelined": pipelined,

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "gmsm_bw6_761_g1_multiexp", "gmsm_bw6_761_g2_multiexp", "gmsm_multiexp", "gmsm_multiexp_affine",
     "gmsm_multiexp_device", "gmsm_bases_register", "gmsm_bases_release", "gmsm_multiexp_bases",
     "gmsm_multiexp_bases_device", "gmsm_multiexp_bases_submit", "gmsm_multiexp_collect", "gmsm_default_window_bits", "gmsm_num_windows", "gmsm_window_sums_device",
-    "gmsm_fold_windows", "gmsm_jac_to_affine", "gmsm_affine_limbs", "gmsm_scalar_limbs", "gmsm_debug_decompose",
+    "gmsm_window_sums_enqueue", "gmsm_fold_window_sets", "gmsm_fold_windows", "gmsm_jac_to_affine", "gmsm_affine_limbs", "gmsm_scalar_limbs", "gmsm_debug_decompose",
     "gmsm_debug_field_op", "gmsm_debug_group_op", "gmsm_generate_points", "gmsm_set_profiling", "gmsm_get_stage_times",
     "gmsm_device_count", "gmsm_set_device", "gmsm_last_error",
     "gmsm_version",
@@ -86,6 +86,11 @@ def load():
     L.gmsm_num_windows.argtypes = [ctypes.c_int, ctypes.c_uint]
     L.gmsm_window_sums_device.restype = ctypes.c_int
     L.gmsm_window_sums_device.argtypes = [ctypes.c_int, vp, vp, sz, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, vp, u64p]
+    L.gmsm_window_sums_enqueue.restype = ctypes.c_int
+    L.gmsm_window_sums_enqueue.argtypes = [ctypes.c_int, vp, ctypes.c_uint64, vp, sz, ctypes.c_uint, ctypes.c_uint,
+                                           ctypes.c_uint, vp, vp]
+    L.gmsm_fold_window_sets.restype = ctypes.c_int
+    L.gmsm_fold_window_sets.argtypes = [ctypes.c_int, ctypes.c_uint, u64p, ctypes.c_uint, u64p]
     L.gmsm_fold_windows.restype = ctypes.c_int
     L.gmsm_fold_windows.argtypes = [ctypes.c_int, ctypes.c_uint, u64p, u64p]
     L.gmsm_jac_to_affine.restype = ctypes.c_int

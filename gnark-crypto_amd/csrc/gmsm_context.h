@@ -68,6 +68,9 @@ struct Workspace {
     uint32_t pending_nw = 0;
     uint32_t pending_gen = 0;   // ticket generation: a stale or repeated ticket is refused
     hipEvent_t dep = nullptr;   // orders the workspace stream after the caller's stream (scalars produced there)
+    bool uncollected = false;          // stage events of an enqueue-only call not yet added to the profile
+    hipEvent_t last_use = nullptr;     // recorded after the last call enqueued on this workspace ...
+    hipStream_t last_stream = nullptr; // ... on this stream: a call on another stream waits for it first
     bool pending_timed = false;
     int ensure_pinned(size_t bytes) {
         if (bytes <= pinned_cap) return GMSM_OK;
@@ -192,6 +195,10 @@ struct GroupVTable {
     int (*register_bases)(Context &ctx, const void *d_points, size_t n, hipStream_t stream, ResidentBases *out);
     int (*submit)(Context &ctx, Workspace &ws, const void *d_scalars, size_t n, const ResidentBases *resident);
     int (*collect)(Workspace &ws, uint64_t *out_jac);
+    int (*window_sums_enqueue)(Context &ctx, const void *d_points, const void *d_scalars, size_t n, unsigned c,
+                               unsigned win_first, unsigned win_stride, hipStream_t stream, void *d_out_xyzz,
+                               const ResidentBases *resident);
+    void (*fold_sets)(const uint64_t *xyzz_sets, unsigned nsets, unsigned c, uint64_t *out_jac);
 };
 
 }  // namespace gmsm

@@ -282,6 +282,36 @@ GMSM_EXPORT int gmsm_window_sums_device(int group, const void *d_points, const v
                            hip_stream ? (hipStream_t)hip_stream : ctx->stream, out_xyzz, nullptr);
 }
 
+GMSM_EXPORT int gmsm_window_sums_enqueue(int group, const void *d_points, uint64_t bases_handle, const void *d_scalars,
+                                         size_t n, unsigned c, unsigned win_first, unsigned win_stride, void *hip_stream,
+                                         void *d_out_xyzz) {
+    VT_OR_FAIL(group);
+    if (c < 2 || c > 16) return fail(GMSM_ERR_ARG, "c out of range (2..16)");
+    if (!d_out_xyzz) return fail(GMSM_ERR_ARG, "d_out_xyzz is null");
+    ResidentBases *rb = nullptr;
+    if (bases_handle) {
+        rb = lookup_bases(bases_handle);
+        if (!rb || rb->group != group) return fail(GMSM_ERR_ARG, "unknown bases handle");
+        if (n > rb->n) return fail(GMSM_ERR_LEN, "len(points) != len(scalars)");
+    }
+    Context *ctx;
+    int rc = get_context(&ctx);
+    if (rc) return rc;
+    if (rb && ctx->device != rb->device) return fail(GMSM_ERR_ARG, "bases were registered on another device");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return vt->window_sums_enqueue(*ctx, d_points, d_scalars, n, c, win_first, win_stride,
+                                   hip_stream ? (hipStream_t)hip_stream : ctx->stream, d_out_xyzz, rb);
+}
+
+GMSM_EXPORT int gmsm_fold_window_sets(int group, unsigned c, const uint64_t *xyzz_sets, unsigned nsets, uint64_t *out_jac) {
+    VT_OR_FAIL(group);
+    if (c < 2 || c > 24) return fail(GMSM_ERR_ARG, "c out of range");
+    if (nsets == 0) return fail(GMSM_ERR_ARG, "nsets must be >= 1");
+    vt->fold_sets(xyzz_sets, nsets, c, out_jac);
+    return GMSM_OK;
+}
+
 GMSM_EXPORT int gmsm_fold_windows(int group, unsigned c, const uint64_t *xyzz_windows, uint64_t *out_jac) {
     VT_OR_FAIL(group);
     if (c < 2 || c > 24) return fail(GMSM_ERR_ARG, "c out of range");

@@ -81,15 +81,28 @@ struct Group {
 
     // Launches every kernel of one MultiExp on `stream` and queues the copy of the window totals into ws.pinned; does
     // not wait. All scratch comes from `ws`, so two workspaces can be in flight on two streams.
+    // d_out != nullptr: the totals stay on the device (copied to d_out in stream order) instead of going to ws.pinned.
     static int enqueue_window_sums(Context &ctx, Workspace &ws, const void *d_points, const void *d_scalars, size_t n,
-                                   const WindowPlan &plan, hipStream_t stream, const ResidentBases *resident) {
+                                   const WindowPlan &plan, hipStream_t stream, const ResidentBases *resident,
+                                   void *d_out = nullptr) {
         const uint32_t nw = plan.nwin_local;
         ws.pending_timed = false;
         if (nw == 0) return GMSM_OK;
+        if (ws.uncollected) {  // stage events of an enqueue-only call (nobody waited for it): pick them up now
+            if (hipEventQuery(ws.events[STAGE_END]) == hipSuccess) StageTimer::collect(ws);
+            ws.uncollected = false;
+        }
+        // The workspace may still be in use by work enqueued earlier on another stream: order behind it.
+        if (ws.last_use && ws.last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, ws.last_use, 0));
         if (n == 0) {
             int rc0 = ws.ensure_pinned((size_t)nw * sizeof(Ext));
             if (rc0) return rc0;
+            if (d_out) HIP_TRY(hipStreamSynchronize(stream));  // an earlier copy out of ws.pinned may be in flight
             for (uint32_t k = 0; k < nw; ++k) ((Ext *)ws.pinned)[k] = Ext::infinity();
+            if (d_out) {
+                HIP_TRY(hipMemcpyAsync(d_out, ws.pinned, (size_t)nw * sizeof(Ext), hipMemcpyHostToDevice, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+            }
             return GMSM_OK;
         }
         if (n >= ((size_t)1 << 31)) return fail(GMSM_ERR_ARG, "n must be < 2^31");
@@ -251,9 +264,25 @@ struct Group {
                            ws.partials.ptr, nblocks1, log2span, ws.totals.ptr);
         timer.mark(STAGE_END);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(ws.pinned, ws.totals.ptr, (size_t)nw * sizeof(Ext), hipMemcpyDeviceToHost, stream));
+        if (d_out)
+            HIP_TRY(hipMemcpyAsync(d_out, ws.totals.ptr, (size_t)nw * sizeof(Ext), hipMemcpyDeviceToDevice, stream));
+        else
+            HIP_TRY(hipMemcpyAsync(ws.pinned, ws.totals.ptr, (size_t)nw * sizeof(Ext), hipMemcpyDeviceToHost, stream));
+        if (!ws.last_use) HIP_TRY(hipEventCreateWithFlags(&ws.last_use, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ws.last_use, stream));
+        ws.last_stream = stream;
         ws.pending_timed = timer.on;
         return GMSM_OK;
+    }
+
+    // Point-sharded MultiExp: `nsets` ranks each hold the nwin window totals of their own slice of the points; window w
+    // of the whole MultiExp is the sum over the ranks (g1JacExtended.add, g1.go:736), then the usual fold.
+    static J fold_sets(const Ext *sets, unsigned nsets, unsigned c) {
+        const unsigned nwin = num_windows(FR_BITS, c);
+        std::vector<Ext> totals(sets, sets + nwin);
+        for (unsigned s = 1; s < nsets; ++s)
+            for (unsigned w = 0; w < nwin; ++w) xyzz_add(totals[w], sets[(size_t)s * nwin + w]);
+        return fold(totals.data(), c);
     }
 
     // msmReduceChunk (multiexp.go:302-315): Horner from the top window down, then XYZZ -> Jacobian.
@@ -530,9 +559,9 @@ static int run_elementwise(size_t in_bytes_a, const void *a, size_t in_bytes_b, 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpy(out, dout, out_bytes, hipMemcpyDeviceToHost));
-    hipFree(da);
-    if (db) hipFree(db);
-    hipFree(dout);
+    (void)hipFree(da);
+    if (db) (void)hipFree(db);
+    (void)hipFree(dout);
     return GMSM_OK;
 }
 
@@ -620,6 +649,21 @@ struct VTableOf {
     static int register_bases(Context &ctx, const void *d_points, size_t n, hipStream_t stream, ResidentBases *out) {
         return G::register_bases(ctx, d_points, n, stream, out);
     }
+    static int window_sums_enqueue(Context &ctx, const void *d_points, const void *d_scalars, size_t n, unsigned c,
+                                   unsigned win_first, unsigned win_stride, hipStream_t stream, void *d_out_xyzz,
+                                   const ResidentBases *resident) {
+        WindowPlan plan = G::make_plan(c, win_first, win_stride);
+        Workspace *ws = ctx.free_workspace();
+        if (!ws) return fail(GMSM_ERR_ARG, "two submitted MultiExp calls are waiting for gmsm_multiexp_collect");
+        int rc = G::enqueue_window_sums(ctx, *ws, d_points, d_scalars, n, plan, stream, resident, d_out_xyzz);
+        ws->uncollected = ws->pending_timed;  // nobody waits for this call: its stage events are read by the next one
+        ws->pending_timed = false;
+        return rc;
+    }
+    static void fold_sets(const uint64_t *xyzz_sets, unsigned nsets, unsigned c, uint64_t *out_jac) {
+        typename G::J j = G::fold_sets(reinterpret_cast<const typename G::Ext *>(xyzz_sets), nsets, c);
+        memcpy(out_jac, &j, sizeof j);
+    }
     static int submit(Context &ctx, Workspace &ws, const void *d_scalars, size_t n, const ResidentBases *resident) {
         return G::multiexp_submit(ctx, ws, d_scalars, n, resident);
     }
@@ -687,7 +731,7 @@ struct VTableOf {
         static const GroupVTable vt = {G::FR_BITS,      G::AFF_BYTES,   G::SCALAR_BYTES, sizeof(typename G::J),
                                        sizeof(typename G::Ext), &multiexp_host, &multiexp_device, &window_sums,
                                        &fold,           &jac_to_affine, &debug_decompose, &debug_field_op,
-                                       &debug_group_op, &generate_points, &register_bases, &submit, &collect};
+                                       &debug_group_op, &generate_points, &register_bases, &submit, &collect, &window_sums_enqueue, &fold_sets};
         return &vt;
     }
 };

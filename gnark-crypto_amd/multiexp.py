@@ -145,6 +145,27 @@ class _Group:
             raise RuntimeError(self._error(rc))
         return out
 
+    def window_sums_enqueue(self, d_points, d_scalars, n, c, win_first, win_stride, stream, d_out, bases=None):
+        """gmsm_window_sums_enqueue: totals go to the device buffer d_out in stream order; returns without waiting."""
+        L = _lib.load()
+        rc = L.gmsm_window_sums_enqueue(self.gid, d_points, bases.handle if bases is not None else 0, d_scalars, n, c,
+                                        win_first, win_stride, stream or None, d_out)
+        if rc:
+            raise RuntimeError(self._error(rc))
+
+    def fold_window_sets(self, xyzz_sets, c):
+        """gmsm_fold_window_sets: (nsets, nwin, xyzz_limbs) totals of point slices -> Jacobian result."""
+        L = _lib.load()
+        xyzz_sets = np.ascontiguousarray(xyzz_sets, dtype=np.uint64)
+        nwin = self.num_windows(c)
+        nsets = xyzz_sets.size // (nwin * self.xyzz_limbs)
+        assert nsets >= 1 and xyzz_sets.size == nsets * nwin * self.xyzz_limbs
+        out = np.zeros(self.jac_limbs, dtype=np.uint64)
+        rc = L.gmsm_fold_window_sets(self.gid, c, _ptr(xyzz_sets), nsets, _ptr(out))
+        if rc:
+            raise RuntimeError(self._error(rc))
+        return out
+
     def fold_windows(self, xyzz_windows, c):
         L = _lib.load()
         xyzz_windows = np.ascontiguousarray(xyzz_windows, dtype=np.uint64)

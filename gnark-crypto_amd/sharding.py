@@ -1,5 +1,11 @@
-"""Window sharding of one MultiExp over the GPUs of a node (one process per GPU, torch.distributed; backend "nccl"
-is RCCL over xGMI on ROCm, "gloo" in the CPU tests).
+"""Sharding of one MultiExp over the GPUs of a node (one process per GPU, torch.distributed; backend "nccl" is RCCL
+over xGMI on ROCm, "gloo" in the CPU tests).  Two decompositions, both ending in ONE all-gather of a few XYZZ points:
+
+* windows: window w is owned by rank w % world, every rank holds all bases (below);
+* points:  rank r owns points [r*n/world, (r+1)*n/world) and computes all windows of its slice; window w of the whole
+  MultiExp is the sum of the ranks' totals for w (gmsm_fold_window_sets).  No replication of the bases, perfect balance;
+  measured per-rank cost on MI355X (tools/shard_model.py, BN254 G1): 2^24 on 8 ranks 3.7 ms against 4.7 ms for the
+  window decomposition, equal at 2^20 (0.80 / 0.83 ms) - `choose_mode` therefore prefers points.
 
 The reference runs one goroutine per c-bit window and collects one g1JacExtended per window on a channel
 (ecc/bn254/multiexp.go:148-209); here window w is owned by rank w % world, every rank holds all bases, and the only
@@ -61,3 +67,64 @@ def torch_all_gather(dist, device):
         dist.all_gather_into_tensor(t_out, t_in)
         return t_out.cpu().numpy().view(np.uint64).reshape((world,) + tuple(buf.shape))
     return fn
+
+
+# ---------------------------------------------------------------- device-resident exchange + point sharding
+def point_slice(n, rank, world):
+    """Points [lo, hi) owned by `rank` in the point decomposition."""
+    return rank * n // world, (rank + 1) * n // world
+
+
+def choose_mode(n, world):
+    """points unless the slices get so small that a rank would not even fill its buckets (tools/shard_model.py)."""
+    return "points" if n // max(1, world) >= (1 << 14) else "windows"
+
+
+def shard_plan(group, n, rank, world, mode="auto", c=None):
+    """Everything a rank needs to know about its piece: returns a dict with mode, c, nwin, the point range [lo, hi), the
+    window range (win_first, win_stride) and `rows` = window totals each rank contributes to the all-gather."""
+    if mode == "auto":
+        mode = choose_mode(n, world)
+    if mode == "points":
+        biggest = max(point_slice(n, r, world)[1] - point_slice(n, r, world)[0] for r in range(world))
+        c = c or group.default_window_bits(max(1, biggest))  # one c for every slice: the totals must line up
+        nwin = group.num_windows(c)
+        lo, hi = point_slice(n, rank, world)
+        return dict(mode=mode, c=c, nwin=nwin, lo=lo, hi=hi, win_first=0, win_stride=1, rows=nwin)
+    if mode != "windows":
+        raise ValueError("mode must be auto, windows or points")
+    c = c or group.default_window_bits(n)
+    nwin = group.num_windows(c)
+    return dict(mode=mode, c=c, nwin=nwin, lo=0, hi=n, win_first=rank, win_stride=world, rows=slots_per_rank(nwin, world))
+
+
+class Exchange:
+    """The one collective of a sharded MultiExp, on buffers that live where the totals are produced: `local`
+    (rows x xyzz_limbs int64; the engine writes this rank's window totals straight into it with
+    gmsm_window_sums_enqueue) is all-gathered into `gathered`; only the gathered block crosses to the host."""
+
+    def __init__(self, dist, device, rows, xyzz_limbs):
+        import torch
+        self.dist, self.world = dist, dist.get_world_size()
+        self.rows, self.limbs = rows, xyzz_limbs
+        self.local = torch.zeros((rows, xyzz_limbs), dtype=torch.int64, device=device)
+        self.gathered = torch.zeros((self.world * rows, xyzz_limbs), dtype=torch.int64, device=device)
+
+    def gather(self):
+        """-> (world, rows, xyzz_limbs) uint64 on the host, identical on every rank."""
+        self.dist.all_gather_into_tensor(self.gathered, self.local)  # ordered after the producer on the current stream
+        return self.gathered.cpu().numpy().view(np.uint64).reshape(self.world, self.rows, self.limbs)
+
+
+def sharded_multiexp_exchange(group, plan, enqueue_fn, exchange):
+    """One sharded MultiExp with device-resident totals.
+
+    plan         from shard_plan
+    enqueue_fn   (plan, local_tensor) -> None: makes this rank's totals appear in local_tensor[:nlocal] in stream order
+                 (GPU: gmsm_window_sums_enqueue into local_tensor.data_ptr(); the CPU tests fill it from the oracle)
+    Returns the Jacobian result (identical on every rank)."""
+    enqueue_fn(plan, exchange.local)
+    gathered = exchange.gather()
+    if plan["mode"] == "points":
+        return group.fold_window_sets(gathered, plan["c"])
+    return group.fold_windows(unpack_gathered(gathered, plan["nwin"], exchange.world, group.xyzz_limbs), plan["c"])

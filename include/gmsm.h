@@ -115,6 +115,14 @@ unsigned gmsm_default_window_bits(int group, size_t n);            /* the engine
 unsigned gmsm_num_windows(int group, unsigned c);                  /* computeNbChunks, multiexp.go:681 */
 int gmsm_window_sums_device(int group, const void *d_points, const void *d_scalars, size_t n, unsigned c,
                             unsigned win_first, unsigned win_stride, void *hip_stream, uint64_t *out_xyzz);
+/* The same pipeline without the copy-back: the nwin_local totals are written to the DEVICE buffer d_out_xyzz in stream
+ * order and the call returns without waiting (the next step is an RCCL all-gather on the same stream). Bases: d_points
+ * (Go layout) or, when bases_handle != 0, the registered bases (d_points ignored). */
+int gmsm_window_sums_enqueue(int group, const void *d_points, uint64_t bases_handle, const void *d_scalars, size_t n,
+                             unsigned c, unsigned win_first, unsigned win_stride, void *hip_stream, void *d_out_xyzz);
+/* Point-sharded variant of the fold: xyzz_sets = nsets x nwin window totals, one set per point slice (every slice
+ * decomposed with the same c). Window w = sum over the sets (g1JacExtended.add, g1.go:736), then the Horner fold. */
+int gmsm_fold_window_sets(int group, unsigned c, const uint64_t *xyzz_sets, unsigned nsets, uint64_t *out_jac);
 /* Horner fold of all nwin = gmsm_num_windows(group,c) window totals (msmReduceChunk, multiexp.go:302-315) -> Jacobian */
 int gmsm_fold_windows(int group, unsigned c, const uint64_t *xyzz_windows, uint64_t *out_jac);
 /* FromJacobian (g1.go:150-166) */

@@ -43,8 +43,27 @@ def _worker(rank, world, port, curve, which, c, n, q):
         def window_sums(c_, first, stride):
             return np.stack([o.process_chunk(max(c_, lastc), pts, digits[w]) for w in range(first, o.nb_chunks(c_), stride)])
 
+        expected = o.msm_affine(pts, sc, c=c)
         jac = sharding.sharded_multiexp(g, window_sums, c, rank, world, sharding.torch_all_gather(dist, torch.device("cpu")))
-        ok = bool((g.jac_to_affine(jac) == o.msm_affine(pts, sc, c=c)).all())
+        ok = bool((g.jac_to_affine(jac) == expected).all())
+
+        # the path bench.py runs on N GPUs: totals written into the exchange buffer, one all_gather_into_tensor, fold;
+        # both decompositions (here the oracle stands in for gmsm_window_sums_enqueue)
+        for mode in ("windows", "points"):
+            plan = sharding.shard_plan(g, n, rank, world, mode, c=c)
+            ex = sharding.Exchange(dist, torch.device("cpu"), plan["rows"], g.xyzz_limbs)
+
+            def enqueue(plan_, local):
+                lo, hi = plan_["lo"], plan_["hi"]
+                dg = o.partition_scalars(sc[lo:hi], plan_["c"])
+                rows = [o.process_chunk(max(plan_["c"], lastc), pts[lo:hi], dg[w])
+                        for w in range(plan_["win_first"], plan_["nwin"], plan_["win_stride"])]
+                for i, row in enumerate(rows):
+                    local[i] = torch.from_numpy(np.ascontiguousarray(row).view(np.int64))
+
+            for _ in range(2):  # the buffers are reused call after call
+                jac2 = sharding.sharded_multiexp_exchange(g, plan, enqueue, ex)
+                ok = ok and bool((g.jac_to_affine(jac2) == expected).all())
         q.put((rank, ok, None))
         dist.barrier()
         dist.destroy_process_group()
@@ -66,6 +85,31 @@ def test_window_sharded_multiexp_gloo_world2(curve, which, c):
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok, _ in results), results
+
+
+def test_shard_plans_cover_everything():
+    """Every (point, window) pair is owned by exactly one rank in both decompositions; all ranks agree on c."""
+    import importlib
+    gm = importlib.import_module("gnark-crypto_amd")
+    sharding = importlib.import_module("gnark-crypto_amd.sharding")
+    g = gm.G1Jac("bn254")
+    for n in (1, 7, 1000, (1 << 20) + 3):
+        for world in (1, 2, 3, 8):
+            for mode in ("windows", "points", "auto"):
+                plans = [sharding.shard_plan(g, n, r, world, mode) for r in range(world)]
+                assert len({(p["c"], p["nwin"], p["rows"], p["mode"]) for p in plans}) == 1
+                nwin = plans[0]["nwin"]
+                cover = np.zeros((min(n, 64), nwin), dtype=np.int64)  # the first points are enough to see the pattern
+                pts_owned = 0
+                for p in plans:
+                    wins = list(range(p["win_first"], nwin, p["win_stride"]))
+                    assert len(wins) <= p["rows"]
+                    lo, hi = p["lo"], min(p["hi"], cover.shape[0])
+                    if hi > lo:
+                        cover[lo:hi][:, wins] += 1
+                    pts_owned += (p["hi"] - p["lo"]) * len(wins)
+                assert (cover == 1).all()
+                assert pts_owned == n * nwin
 
 
 def test_sharding_layout():

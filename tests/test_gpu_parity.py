@@ -374,6 +374,51 @@ def test_resident_bases_prefix_multiexp(gm, oracle_mod, curve, which):
         rb.release()
 
 
+@pytest.mark.parametrize("curve,which", [("bn254", "g1"), ("bls12_381", "g2"), ("bw6_761", "g1")])
+@pytest.mark.parametrize("mode", ["windows", "points"])
+def test_sharded_exchange_pieces_on_one_gpu(gm, oracle_mod, curve, which, mode):
+    """What bench.py runs on N GPUs, rank by rank on one GPU: gmsm_window_sums_enqueue leaves each rank's totals in a device
+    buffer (no copy-back), the buffers are concatenated exactly as all_gather_into_tensor does, and the host folds them
+    (window decomposition: gmsm_fold_windows; point decomposition: gmsm_fold_window_sets). World sizes 1, 2, 3, 8 with an
+    n that does not divide evenly, host bases and registered slices, must all equal the oracle."""
+    import importlib
+    import torch
+    sharding = importlib.import_module("gnark-crypto_amd.sharding")
+    g = _group(gm, curve, which)
+    o = oracle_mod.Oracle(curve, which)
+    n = 4099
+    rng = rng_for(23, g.gid)
+    pts = o.gen_points(n, 2024, 9, nthreads=4)
+    pts[5] = 0
+    sc = random_scalars(rng, g.curve, n)
+    sc[17] = 0
+    expected = o.msm_affine(pts, sc, nthreads=4)
+    d_pts = torch.from_numpy(pts.view(np.int64)).cuda()
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    for world in (1, 2, 3, 8):
+        for use_resident in (False, True):
+            plans = [sharding.shard_plan(g, n, r, world, mode) for r in range(world)]
+            rows = plans[0]["rows"]
+            gathered = torch.zeros((world * rows, g.xyzz_limbs), dtype=torch.int64, device="cuda")
+            handles = []
+            for r, p in enumerate(plans):
+                lo, hi = p["lo"], p["hi"]
+                rb = g.register_bases(d_points=d_pts[lo:hi].data_ptr(), n=hi - lo) if use_resident else None
+                handles.append(rb)
+                g.window_sums_enqueue(d_pts[lo:hi].data_ptr(), d_sc[lo:hi].data_ptr(), hi - lo, p["c"], p["win_first"],
+                                      p["win_stride"], stream, gathered[r * rows:(r + 1) * rows].data_ptr(), bases=rb)
+            host = gathered.cpu().numpy().view(np.uint64).reshape(world, rows, g.xyzz_limbs)
+            for rb in handles:
+                if rb is not None:
+                    rb.release()
+            if mode == "points":
+                jac = g.fold_window_sets(host, plans[0]["c"])
+            else:
+                jac = g.fold_windows(sharding.unpack_gathered(host, plans[0]["nwin"], world, g.xyzz_limbs), plans[0]["c"])
+            assert (g.jac_to_affine(jac) == expected).all(), (world, use_resident)
+
+
 @pytest.mark.parametrize("curve,which", [("bn254", "g1"), ("bls12_381", "g2")])
 def test_two_multiexp_in_flight(gm, oracle_mod, curve, which):
     """gmsm_multiexp_bases_submit / gmsm_multiexp_collect: two MultiExp calls over the same resident bases in flight on
