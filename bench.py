@@ -212,7 +212,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline(g, pts, sc, jac, args.curve, args.group))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

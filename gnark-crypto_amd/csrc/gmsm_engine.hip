@@ -221,11 +221,10 @@ GMSM_EXPORT int gmsm_multiexp_bases_submit(uint64_t handle, const void *d_scalar
     HIP_TRY(hipSetDevice(ctx->device));
     Workspace *ws = ctx->free_workspace();
     if (!ws) return fail(GMSM_ERR_ARG, "two MultiExp calls are already in flight: collect one first");
-    if (hip_stream) {  // the scalars are produced on the caller's stream: order our stream behind it
-        if (!ws->dep) HIP_TRY(hipEventCreateWithFlags(&ws->dep, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(ws->dep, (hipStream_t)hip_stream));
-        HIP_TRY(hipStreamWaitEvent(ws->stream, ws->dep, 0));
-    }
+    // the scalars are produced on the caller's stream (NULL = the default stream): order our stream behind it
+    if (!ws->dep) HIP_TRY(hipEventCreateWithFlags(&ws->dep, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ws->dep, (hipStream_t)hip_stream));
+    HIP_TRY(hipStreamWaitEvent(ws->stream, ws->dep, 0));
     if ((rc = vt->submit(*ctx, *ws, d_scalars, n_scalars, rb))) return rc;
     ws->pending = true;
     ws->pending_group = rb->group;
@@ -300,8 +299,10 @@ GMSM_EXPORT int gmsm_window_sums_enqueue(int group, const void *d_points, uint64
     if (rb && ctx->device != rb->device) return fail(GMSM_ERR_ARG, "bases were registered on another device");
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
-    return vt->window_sums_enqueue(*ctx, d_points, d_scalars, n, c, win_first, win_stride,
-                                   hip_stream ? (hipStream_t)hip_stream : ctx->stream, d_out_xyzz, rb);
+    // hip_stream is used as given: NULL is the device's default (null) stream, which is what the consumer of d_out_xyzz
+    // is ordered against when it runs there too - not the engine's private stream.
+    return vt->window_sums_enqueue(*ctx, d_points, d_scalars, n, c, win_first, win_stride, (hipStream_t)hip_stream,
+                                   d_out_xyzz, rb);
 }
 
 GMSM_EXPORT int gmsm_fold_window_sets(int group, unsigned c, const uint64_t *xyzz_sets, unsigned nsets, uint64_t *out_jac) {

@@ -100,8 +100,8 @@ int gmsm_multiexp_bases_device(uint64_t handle, const void *d_scalars, size_t n_
  *      submit launches the whole device pipeline for device-resident scalars over registered bases and returns without
  *      waiting; collect waits, folds the windows and writes the Jacobian result. At most two tickets may be outstanding
  *      per device (a third submit returns GMSM_ERR_ARG); d_scalars must stay valid until its ticket is collected.
- *      hip_stream: the stream the scalars were produced on (the pipeline is ordered after it), or NULL if they are
- *      already complete. The sort/accumulate of one call overlaps the latency-bound bucket reduction, copy-back and
+ *      hip_stream: the stream the scalars were produced on (NULL = the default stream); the pipeline is ordered
+ *      after the work already queued there. The sort/accumulate of one call overlaps the latency-bound bucket reduction, copy-back and
  *      host fold of the other. ---- */
 int gmsm_multiexp_bases_submit(uint64_t handle, const void *d_scalars, size_t n_scalars, void *hip_stream,
                                uint64_t *out_ticket);
@@ -116,7 +116,8 @@ unsigned gmsm_num_windows(int group, unsigned c);                  /* computeNbC
 int gmsm_window_sums_device(int group, const void *d_points, const void *d_scalars, size_t n, unsigned c,
                             unsigned win_first, unsigned win_stride, void *hip_stream, uint64_t *out_xyzz);
 /* The same pipeline without the copy-back: the nwin_local totals are written to the DEVICE buffer d_out_xyzz in stream
- * order and the call returns without waiting (the next step is an RCCL all-gather on the same stream). Bases: d_points
+ * order and the call returns without waiting (the next step is an RCCL all-gather on the same stream; here hip_stream
+ * NULL means the device's default stream, not an engine-private one). Bases: d_points
  * (Go layout) or, when bases_handle != 0, the registered bases (d_points ignored). */
 int gmsm_window_sums_enqueue(int group, const void *d_points, uint64_t bases_handle, const void *d_scalars, size_t n,
                              unsigned c, unsigned win_first, unsigned win_stride, void *hip_stream, void *d_out_xyzz);
