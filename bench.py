@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--logn", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-entry", action="store_true", help="skip the PCIe-inclusive (host buffer) measurements")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the two-in-flight (submit/collect) measurement")
     ap.add_argument("--shard", default="auto", choices=["auto", "windows", "points"],
                     help="N>1: decomposition of the one MultiExp over the ranks (gnark-crypto_amd/sharding.py)")
@@ -175,6 +176,29 @@ def main():
         if resident is None:
             rb2.release()
 
+    # PCIe-inclusive rates of the drop-in entries (SURVEY.md §8(d) "cold" / "warm-bases"): host buffers in, result out.
+    # Reported beside the headline number, never as `value`.
+    host_entry = None
+    if not sharded and rank == 0 and not args.no_host_entry:
+        def median_ms(fn, reps=5):
+            fn()
+            ts = []
+            for _ in range(reps):
+                t_ = time.perf_counter()
+                fn()
+                ts.append((time.perf_counter() - t_) * 1e3)
+            return sorted(ts)[len(ts) // 2]
+        cfg = gm.MultiExpConfig()
+        cold = median_ms(lambda: g.MultiExp(pts, sc, cfg))
+        rb3 = resident or g.register_bases(d_points=d_pts.data_ptr(), n=n)
+        warm = median_ms(lambda: rb3.MultiExp(sc, cfg))
+        if resident is None:
+            rb3.release()
+        host_entry = {"cold_ms": round(cold, 3), "cold_msm_per_s": round(1e3 / cold, 2),
+                      "warm_bases_ms": round(warm, 3), "warm_bases_msm_per_s": round(1e3 / warm, 2),
+                      "note": "cold: bases+scalars copied from pageable host memory every call (gmsm_<curve>_g1_multiexp); "
+                              "warm-bases: registered bases, scalars copied every call (gmsm_multiexp_bases); median of 5"}
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = args.steps / dt
@@ -203,6 +227,7 @@ def main():
             "points_per_s": value * n,
             "stage_ms": stages,
             "pipelined": pipelined,
+            "host_entry": host_entry,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": measured_traffic(args, world), "kernel": "k_accumulate_seg",
                          "algorithmic_bytes_per_launch": algorithmic_bytes, "avg_launch_ms": acc_ms},

@@ -22,7 +22,7 @@ GROUP_IDS = {
 # every symbol include/gmsm.h declares (tests/test_abi.py checks the built library exports all of them)
 ABI_SYMBOLS = [
     "gmsm_bn254_g1_multiexp", "gmsm_bn254_g2_multiexp", "gmsm_bls12_381_g1_multiexp", "gmsm_bls12_381_g2_multiexp",
-    "gmsm_bw6_761_g1_multiexp", "gmsm_bw6_761_g2_multiexp", "gmsm_multiexp", "gmsm_multiexp_affine",
+    "gmsm_bw6_761_g1_multiexp", "gmsm_bw6_761_g2_multiexp", "gmsm_multiexp", "gmsm_multiexp_affine", "gmsm_fold",
     "gmsm_multiexp_device", "gmsm_bases_register", "gmsm_bases_release", "gmsm_multiexp_bases",
     "gmsm_multiexp_bases_device", "gmsm_multiexp_bases_submit", "gmsm_multiexp_collect", "gmsm_default_window_bits", "gmsm_num_windows", "gmsm_window_sums_device",
     "gmsm_window_sums_enqueue", "gmsm_fold_window_sets", "gmsm_fold_windows", "gmsm_jac_to_affine", "gmsm_affine_limbs", "gmsm_scalar_limbs", "gmsm_debug_decompose",
@@ -66,6 +66,8 @@ def load():
     L.gmsm_multiexp.argtypes = [ctypes.c_int, u64p, sz, u64p, sz, ctypes.c_int, u64p]
     L.gmsm_multiexp_affine.restype = ctypes.c_int
     L.gmsm_multiexp_affine.argtypes = [ctypes.c_int, u64p, sz, u64p, sz, ctypes.c_int, u64p]
+    L.gmsm_fold.restype = ctypes.c_int
+    L.gmsm_fold.argtypes = [ctypes.c_int, u64p, sz, u64p, ctypes.c_int, u64p]
     L.gmsm_multiexp_device.restype = ctypes.c_int
     L.gmsm_multiexp_device.argtypes = [ctypes.c_int, vp, vp, sz, vp, u64p]
     L.gmsm_bases_register.restype = ctypes.c_int

@@ -199,6 +199,7 @@ struct GroupVTable {
                                unsigned win_first, unsigned win_stride, hipStream_t stream, void *d_out_xyzz,
                                const ResidentBases *resident);
     void (*fold_sets)(const uint64_t *xyzz_sets, unsigned nsets, unsigned c, uint64_t *out_jac);
+    int (*fold_points)(const uint64_t *points, size_t n, const uint64_t *coeff, int nb_tasks, uint64_t *out_jac);
 };
 
 }  // namespace gmsm

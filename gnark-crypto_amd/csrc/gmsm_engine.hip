@@ -107,6 +107,13 @@ GMSM_EXPORT int gmsm_multiexp_affine(int group, const uint64_t *points, size_t n
     return GMSM_OK;
 }
 
+GMSM_EXPORT int gmsm_fold(int group, const uint64_t *points, size_t n_points, const uint64_t *combination_coeff,
+                          int nb_tasks, uint64_t *out_jac) {
+    VT_OR_FAIL(group);
+    if (!combination_coeff) return fail(GMSM_ERR_ARG, "combination_coeff is null");
+    return vt->fold_points(points, n_points, combination_coeff, nb_tasks, out_jac);
+}
+
 GMSM_EXPORT int gmsm_multiexp_device(int group, const void *d_points, const void *d_scalars, size_t n, void *hip_stream,
                                      uint64_t *out_jac) {
     VT_OR_FAIL(group);

@@ -258,10 +258,13 @@ struct Group {
             red_attr_done = true;
         }
         timer.mark(STAGE_REDUCE);
+        // level 1 doubles its S_blk log2span times in an otherwise idle wave (256-thread blocks only): level 2 then has no
+        // serial doubling tail (11 of its 20 steps at c = 16)
+        const uint32_t prescale = (RED_TPB >= 256 && env_uint("GMSM_PRESCALE", 1)) ? log2span : 0u;
         hipLaunchKernelGGL((k_reduce1<Ops, RED_TPB>), dim3(nblocks1, nw), dim3(RED_TPB), 2 * RED_TPB * sizeof(OpsElem), stream,
-                           ws.buckets.ptr, NB, log2L, ws.partials.ptr, reduce_starts);
+                           ws.buckets.ptr, NB, log2L, ws.partials.ptr, reduce_starts, prescale);
         hipLaunchKernelGGL((k_reduce2<Ops, RED2_TPB>), dim3(nw), dim3(RED2_TPB), 2 * RED2_TPB * sizeof(OpsElem), stream,
-                           ws.partials.ptr, nblocks1, log2span, ws.totals.ptr);
+                           ws.partials.ptr, nblocks1, log2span - prescale, ws.totals.ptr);
         timer.mark(STAGE_END);
         HIP_TRY(hipGetLastError());
         if (d_out)
@@ -411,6 +414,19 @@ struct Group {
         if (rc) return rc;
         *out = fold(totals.data(), ws.pending_c);
         return GMSM_OK;
+    }
+
+    // (*G1Jac).Fold (multiexp.go:331-340): scalars 1, g, g^2, ... (Montgomery fr products on the host), then MultiExp.
+    static int fold_host(const uint64_t *points, size_t n, const uint64_t *coeff, int nb_tasks, J *out) {
+        using Fr = Fp<FrP>;
+        std::vector<Fr> scalars(n);
+        Fr g, s = Fr::one();
+        memcpy(&g, coeff, sizeof g);
+        for (size_t i = 0; i < n; ++i) {
+            scalars[i] = s;
+            s = fp_mul(s, g);
+        }
+        return multiexp_host(points, n, reinterpret_cast<const uint64_t *>(scalars.data()), n, nb_tasks, out);
     }
 
     static int multiexp_host(const uint64_t *points, size_t n_points, const uint64_t *scalars, size_t n_scalars,
@@ -664,6 +680,13 @@ struct VTableOf {
         typename G::J j = G::fold_sets(reinterpret_cast<const typename G::Ext *>(xyzz_sets), nsets, c);
         memcpy(out_jac, &j, sizeof j);
     }
+    static int fold_points(const uint64_t *points, size_t n, const uint64_t *coeff, int nb_tasks, uint64_t *out_jac) {
+        typename G::J j;
+        int rc = G::fold_host(points, n, coeff, nb_tasks, &j);
+        if (rc) return rc;
+        memcpy(out_jac, &j, sizeof j);
+        return GMSM_OK;
+    }
     static int submit(Context &ctx, Workspace &ws, const void *d_scalars, size_t n, const ResidentBases *resident) {
         return G::multiexp_submit(ctx, ws, d_scalars, n, resident);
     }
@@ -731,7 +754,7 @@ struct VTableOf {
         static const GroupVTable vt = {G::FR_BITS,      G::AFF_BYTES,   G::SCALAR_BYTES, sizeof(typename G::J),
                                        sizeof(typename G::Ext), &multiexp_host, &multiexp_device, &window_sums,
                                        &fold,           &jac_to_affine, &debug_decompose, &debug_field_op,
-                                       &debug_group_op, &generate_points, &register_bases, &submit, &collect, &window_sums_enqueue, &fold_sets};
+                                       &debug_group_op, &generate_points, &register_bases, &submit, &collect, &window_sums_enqueue, &fold_sets, &fold_points};
         return &vt;
     }
 };

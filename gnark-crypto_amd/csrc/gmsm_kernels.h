@@ -576,9 +576,13 @@ __global__ void __launch_bounds__(256) k_fixup_level(uint32_t nbuckets, const vo
 //   finish  (log2L + 1)     thread 0: U = 2^log2L * U, then W += U
 // Identity:  sum_{k in [base, base+T*L)} (k-base+1) B_k = sum_t W_t + L * sum_{t>=1} Suf_t.
 // `active` (power of two, 2 <= active <= TPB): threads t >= active hold infinity.
+// prescale > 0 (level 1 only, TPB >= 256): the block's S is also needed multiplied by the width of the level-2 spans,
+// 2^prescale. Those doublings used to be level 2's serial tail (11 of its 20 steps at c = 16); here thread 64 - whose
+// wave has nothing left to do after the first tree step - performs them while the trees and the finish run, and S_out
+// of THAT thread is the scaled sum. prescale must not exceed the log2(active) - 1 + log2L + 1 steps that remain.
 template <class A, int TPB, class LoadFn>
 __device__ __forceinline__ void reduce_program(LoadFn load_bucket, uint32_t L, typename A::Elem run, typename A::Elem tot,
-                                               uint32_t log2L, uint32_t active, typename A::Elem *lds,
+                                               uint32_t log2L, uint32_t active, uint32_t prescale, typename A::Elem *lds,
                                                typename A::Elem &S_out, typename A::Elem &W_out) {
     using E = typename A::Elem;
     const uint32_t t = threadIdx.x;
@@ -590,11 +594,21 @@ __device__ __forceinline__ void reduce_program(LoadFn load_bucket, uint32_t L, t
     const bool upper = t >= TPB / 2;
     const uint32_t tt = upper ? t - TPB / 2 : t;
     E suf = A::infinity(), mine = A::infinity();
+    constexpr uint32_t DOUBLER = 64;
+    const bool doubler = TPB >= 256 && prescale != 0 && t == DOUBLER;
+    uint32_t dbl_left = prescale;
 #pragma nounroll
     for (uint32_t s = 0; s < total; ++s) {
         E X = A::infinity(), Y = A::infinity();
         int dest = -1;  // 0 run, 1 tot, 2 suf, 3 mine
         bool do_dbl = false;
+        if (doubler && s > n_serial + n_scan) {  // from the second tree step on this thread's registers are free
+            if (s == n_serial + n_scan + 1) suf = ldsA[TPB - 1];  // S, parked there by thread 0 (below)
+            if (dbl_left > 0) {
+                do_dbl = true;
+                --dbl_left;
+            }
+        }
         if (s < n_serial) {
             if ((s & 1u) == 0) {
                 X = run;
@@ -643,7 +657,7 @@ __device__ __forceinline__ void reduce_program(LoadFn load_bucket, uint32_t L, t
                 }
             }
             if (step < log2L) {
-                do_dbl = (t == 0);
+                do_dbl = do_dbl || (t == 0);
             } else if (t == 0) {
                 X = tot;
                 Y = suf;
@@ -662,10 +676,13 @@ __device__ __forceinline__ void reduce_program(LoadFn load_bucket, uint32_t L, t
             mine = X;
             E *arr = upper ? ldsB : ldsA;
             if (tt < (active >> 1)) arr[tt] = mine;
+            // first tree step: slot TPB-1 has been consumed, park S there for the doubler
+            if (TPB >= 256 && prescale != 0 && t == 0 && s == n_serial + n_scan) ldsA[TPB - 1] = suf;
         }
         __syncthreads();
     }
     W_out = tot;  // meaningful in thread 0
+    if (doubler) S_out = suf;  // 2^prescale * S
 }
 
 // grid = (nblocks1, nwin_local), block = TPB threads, each thread L = 2^log2L buckets.
@@ -673,7 +690,8 @@ __device__ __forceinline__ void reduce_program(LoadFn load_bucket, uint32_t L, t
 template <class A, int TPB>
 __global__ void __launch_bounds__(TPB) k_reduce1(const void *__restrict__ buckets, uint32_t nbuckets, uint32_t log2L,
                                                  void *__restrict__ out1,
-                                                 const uint32_t *__restrict__ starts /* null: every bucket is stored */) {
+                                                 const uint32_t *__restrict__ starts /* null: every bucket is stored */,
+                                                 uint32_t prescale /* S_blk is stored as 2^prescale * S_blk */) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     using E = typename A::Elem;
     E *lds = reinterpret_cast<E *>(lds_raw);
@@ -688,11 +706,9 @@ __global__ void __launch_bounds__(TPB) k_reduce1(const void *__restrict__ bucket
         return present ? A::load(buckets, (size_t)k * nbuckets + b) : A::infinity();
     };
     E S_out = A::infinity(), W_out = A::infinity();
-    reduce_program<A, TPB>(load_bucket, L, A::infinity(), A::infinity(), log2L, (uint32_t)TPB, lds, S_out, W_out);
-    if (t == 0) {
-        A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 0, S_out);
-        A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 1, W_out);
-    }
+    reduce_program<A, TPB>(load_bucket, L, A::infinity(), A::infinity(), log2L, (uint32_t)TPB, prescale, lds, S_out, W_out);
+    if (t == (prescale != 0 && TPB >= 256 ? 64u : 0u)) A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 0, S_out);
+    if (t == 0) A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 1, W_out);
 }
 
 // grid = nwin_local, block = TPB >= nblocks1 threads. Thread j holds level-1 block j: (S_j, W_j) covering
@@ -713,7 +729,7 @@ __global__ void __launch_bounds__(TPB) k_reduce2(const void *__restrict__ in1, u
     uint32_t active = 2;
     while (active < nblocks1) active <<= 1;
     auto no_buckets = [&](uint32_t) -> E { return A::infinity(); };
-    reduce_program<A, TPB>(no_buckets, 0u, S, W, log2span, active, lds, S_out, W_out);
+    reduce_program<A, TPB>(no_buckets, 0u, S, W, log2span, active, 0u, lds, S_out, W_out);
     if (t == 0) A::store_final(window_totals, k, W_out);
 }
 

@@ -67,6 +67,22 @@ class _Group:
                              int(config.NbTasks), _ptr(out))
         return (out, None) if rc == 0 else (None, self._error(rc))
 
+    def _fold_jac(self, points, combination_coeff, config):
+        """(*G1Jac).Fold (multiexp.go:331): sum_i points[i] * coeff^i; returns (jacobian_limbs, None) or (None, error)."""
+        L = _lib.load()
+        points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, self.aff_limbs)
+        coeff = np.ascontiguousarray(combination_coeff, dtype=np.uint64).reshape(self.fr_limbs)
+        out = np.zeros(self.jac_limbs, dtype=np.uint64)
+        rc = L.gmsm_fold(self.gid, _ptr(points), points.shape[0], _ptr(coeff), int(config.NbTasks), _ptr(out))
+        return (out, None) if rc == 0 else (None, self._error(rc))
+
+    def Fold(self, points, combination_coeff, config=MultiExpConfig()):
+        """Fold of the Jac types returns Jacobian limbs, of the Affine types affine limbs (multiexp.go:320-340)."""
+        jac, err = self._fold_jac(points, combination_coeff, config)
+        if err is not None:
+            return None, err
+        return (self.jac_to_affine(jac) if type(self).__name__.endswith("Affine") else jac), None
+
     def _multiexp_affine(self, points, scalars, config):
         L = _lib.load()
         points, scalars = self._check(points, scalars)

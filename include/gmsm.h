@@ -77,6 +77,11 @@ int gmsm_multiexp(int group, const uint64_t *points, size_t n_points, const uint
 int gmsm_multiexp_affine(int group, const uint64_t *points, size_t n_points, const uint64_t *scalars,
                          size_t n_scalars, int nb_tasks, uint64_t *out_affine);
 
+/* (*G1Jac).Fold / (*G2Jac).Fold (ecc/bn254/multiexp.go:331-340, G2 :657-665): sum_i points[i] * coeff^i. coeff is one
+ * fr.Element (Montgomery limbs); the powers are formed on the host exactly as the reference does, then MultiExp. */
+int gmsm_fold(int group, const uint64_t *points, size_t n_points, const uint64_t *combination_coeff, int nb_tasks,
+              uint64_t *out_jac);
+
 /* ---- device-resident entries (bases/scalars already in HBM: the SRS-resident fast path).
  *      d_points / d_scalars are device pointers with the layouts above; hip_stream is a hipStream_t (NULL = default
  *      stream); the call returns after the result has been copied back to out_jac (host memory). ---- */

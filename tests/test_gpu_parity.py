@@ -374,6 +374,35 @@ def test_resident_bases_prefix_multiexp(gm, oracle_mod, curve, which):
         rb.release()
 
 
+@pytest.mark.parametrize("curve,which", [("bn254", "g1"), ("bn254", "g2"), ("bls12_381", "g1"), ("bw6_761", "g2")])
+def test_fold_matches_reference_definition(gm, oracle_mod, curve, which):
+    """Fold (ecc/bn254/multiexp.go:320-340): sum_i points[i] * coeff^i. Expected value: the oracle's MultiExp over the
+    powers 1, g, g^2, ... built with the oracle's own fr multiplication (and cross-checked with Python integers)."""
+    g = _group(gm, curve, which)
+    o = oracle_mod.Oracle(curve, which)
+    cv = g.curve
+    Fr = oracle_mod.Field(f"{cv.name}_fr", cv.fr_limbs)
+    rng = rng_for(27, g.gid)
+    for n in (0, 1, 2, 150):
+        pts = o.gen_points(max(n, 1), 31, 7, nthreads=2)[:n]
+        coeff = random_scalars(rng, cv, 1)[0]
+        powers = np.zeros((n, cv.fr_limbs), dtype=np.uint64)
+        acc = scalars_from_ints(cv, [1])[0]
+        for i in range(n):
+            powers[i] = acc
+            acc = Fr.mul(acc, coeff)
+        if n:
+            gamma = sum(int(v) << (64 * k) for k, v in enumerate(Fr.from_mont(coeff)))
+            last = sum(int(v) << (64 * k) for k, v in enumerate(Fr.from_mont(powers[-1])))
+            assert last == pow(gamma, n - 1, cv.r)
+        expected = o.msm_affine(pts, powers) if n else np.zeros(g.aff_limbs, dtype=np.uint64)
+        aff, err = g.Fold(pts, coeff)
+        assert err is None
+        assert (aff == expected).all(), n
+    _, err = g.Fold(pts, coeff, gm.MultiExpConfig(NbTasks=1025))
+    assert err == "invalid config: config.NbTasks > 1024"
+
+
 @pytest.mark.parametrize("curve,which", [("bn254", "g1"), ("bls12_381", "g2"), ("bw6_761", "g1")])
 @pytest.mark.parametrize("mode", ["windows", "points"])
 def test_sharded_exchange_pieces_on_one_gpu(gm, oracle_mod, curve, which, mode):
