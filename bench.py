@@ -173,6 +173,31 @@ def main():
         pipelined = {"value": round(args.steps / dtp, 3), "unit": "MSM/s", "ms_per_step": round(dtp / args.steps * 1e3, 4),
                      "in_flight": 2, "equal_to_serial_result": bool((g.jac_to_affine(jac_a) == g.jac_to_affine(jac)).all()
                                                     and (g.jac_to_affine(jac_b) == g.jac_to_affine(jac)).all())}
+        # the same through the plain blocking entry from two caller threads (what two goroutines calling MultiExp get:
+        # BenchmarkManyMultiExpG1Reference, ecc/bn254/multiexp_test.go:385-415); ctypes drops the GIL during the call
+        import threading
+
+        def caller(k, out, slot):
+            for _ in range(k):
+                out[slot] = rb2.multiexp_device(d_sc.data_ptr(), n, stream)
+
+        def run_two_callers(k):
+            res = [None, None]
+            th = [threading.Thread(target=caller, args=(k - k // 2, res, 0)), threading.Thread(target=caller, args=(k // 2, res, 1))]
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+            return res
+        run_two_callers(4)
+        barrier()
+        tc0 = time.perf_counter()
+        res2 = run_two_callers(args.steps)
+        barrier()
+        dtc = time.perf_counter() - tc0
+        pipelined["two_blocking_callers"] = {
+            "value": round(args.steps / dtc, 3), "unit": "MSM/s", "ms_per_step": round(dtc / args.steps * 1e3, 4),
+            "equal_to_serial_result": bool(all(r is None or (g.jac_to_affine(r) == g.jac_to_affine(jac)).all() for r in res2))}
         if resident is None:
             rb2.release()
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -61,6 +62,8 @@ struct Workspace {
     hipEvent_t events[10] = {nullptr};  // stage boundaries when profiling is on
     void *pinned = nullptr;             // pinned host buffer for the window totals
     size_t pinned_cap = 0;
+    DeviceBuffer h2d_points, h2d_scalars;  // staging of the host-pointer entries
+    bool busy = false;  // leased to a call (Context::acquire / release)
     // state of a submitted, not yet collected call
     bool pending = false;
     int pending_group = -1;
@@ -82,13 +85,14 @@ struct Workspace {
     }
 };
 
+// One per device. Calls lease one of the two workspaces for their duration; the context lock protects nothing but the
+// lease table, so two callers (two goroutines calling MultiExp, or the submit/collect pair) really overlap on the GPU:
+// each runs on its workspace's stream, and the host-side wait, copy-back and fold of one happen while the other computes.
 struct Context {
     std::mutex mu;
+    std::condition_variable cv;
     int device = -1;
-    hipStream_t stream = nullptr;  // = ws[0].stream: used when the caller passes no stream
-    DeviceBuffer points, scalars;  // staging for the host-pointer entries
     Workspace ws[2];
-    Workspace *free_workspace() { return !ws[0].pending ? &ws[0] : !ws[1].pending ? &ws[1] : nullptr; }
     int num_cus = 256;
     int init(int dev) {
         device = dev;
@@ -97,10 +101,73 @@ struct Context {
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
         num_cus = prop.multiProcessorCount;
         for (auto &w : ws) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
-        stream = ws[0].stream;
         return GMSM_OK;
     }
+    // Kernels that need more than the default 64 KiB of dynamic LDS: raise the limit once per kernel on this device.
+    std::mutex attr_mu;
+    std::vector<const void *> lds_allowed;
+    int allow_lds(const void *kernel, int bytes) {
+        std::lock_guard<std::mutex> lk(attr_mu);
+        for (const void *k : lds_allowed)
+            if (k == kernel) return GMSM_OK;
+        HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        lds_allowed.push_back(kernel);
+        return GMSM_OK;
+    }
+    // wait = false: nullptr when both workspaces are leased
+    Workspace *acquire(bool wait) {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            for (auto &w : ws)
+                if (!w.busy) {
+                    w.busy = true;
+                    return &w;
+                }
+            if (!wait) return nullptr;
+            // both leased: wait for a blocking call to finish - unless both leases are submitted tickets, which only
+            // gmsm_multiexp_collect can end (possibly from this very thread: waiting would deadlock)
+            if (ws[0].pending && ws[1].pending) return nullptr;
+            cv.wait(lk);
+        }
+    }
+    void release(Workspace *w) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            w->busy = false;
+            w->pending = false;
+        }
+        cv.notify_one();
+    }
 };
+
+struct Lease {
+    Context &ctx;
+    Workspace *w;
+    Lease(Context &c, bool wait = true) : ctx(c), w(c.acquire(wait)) {}
+    ~Lease() {
+        if (w) ctx.release(w);
+    }
+    Workspace *keep() {  // the lease outlives this object (submit -> collect)
+        Workspace *x = w;
+        w = nullptr;
+        return x;
+    }
+    Lease(const Lease &) = delete;
+    Lease &operator=(const Lease &) = delete;
+};
+
+#define GMSM_LEASE_OR_FAIL(name, context)                                                                    \
+    Lease name(context);                                                                                     \
+    if (!name.w) return fail(GMSM_ERR_ARG, "two submitted MultiExp calls are waiting for gmsm_multiexp_collect")
+
+// Orders the workspace's private stream after everything queued so far on the caller's stream (NULL = the device's
+// default stream): inputs produced there are complete before the pipeline reads them.
+static inline int order_after(Workspace &ws, hipStream_t caller) {
+    if (!ws.dep) HIP_TRY(hipEventCreateWithFlags(&ws.dep, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ws.dep, caller));
+    HIP_TRY(hipStreamWaitEvent(ws.stream, ws.dep, 0));
+    return GMSM_OK;
+}
 
 // Per-stage device timing (HIP events on the stream the kernels are launched on). Off by default; bench.py switches
 // it on to obtain the dominant kernel's duration for the roofline record.
@@ -200,6 +267,8 @@ struct GroupVTable {
                                const ResidentBases *resident);
     void (*fold_sets)(const uint64_t *xyzz_sets, unsigned nsets, unsigned c, uint64_t *out_jac);
     int (*fold_points)(const uint64_t *points, size_t n, const uint64_t *coeff, int nb_tasks, uint64_t *out_jac);
+    int (*multiexp_bases_host)(Context &ctx, const uint64_t *scalars, size_t n, uint64_t *out_jac,
+                               const ResidentBases *resident);
 };
 
 }  // namespace gmsm

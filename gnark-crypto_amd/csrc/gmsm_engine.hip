@@ -120,10 +120,8 @@ GMSM_EXPORT int gmsm_multiexp_device(int group, const void *d_points, const void
     Context *ctx;
     int rc = get_context(&ctx);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
-    return vt->multiexp_device(*ctx, d_points, d_scalars, n, hip_stream ? (hipStream_t)hip_stream : ctx->stream, out_jac,
-                               nullptr);
+    return vt->multiexp_device(*ctx, d_points, d_scalars, n, (hipStream_t)hip_stream, out_jac, nullptr);
 }
 
 // ------------------------------------------------------------------ resident bases
@@ -144,18 +142,21 @@ GMSM_EXPORT int gmsm_bases_register(int group, const uint64_t *points, const voi
     Context *ctx;
     int rc = get_context(&ctx);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
+    GMSM_LEASE_OR_FAIL(lease, *ctx);
+    Workspace &ws = *lease.w;
     const void *src = d_points;
     if (points && n) {
-        if ((rc = ctx->points.ensure(n * vt->aff_bytes))) return rc;
-        HIP_TRY(hipMemcpyAsync(ctx->points.ptr, points, n * vt->aff_bytes, hipMemcpyHostToDevice, ctx->stream));
-        src = ctx->points.ptr;
+        if ((rc = ws.h2d_points.ensure(n * vt->aff_bytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(ws.h2d_points.ptr, points, n * vt->aff_bytes, hipMemcpyHostToDevice, ws.stream));
+        src = ws.h2d_points.ptr;
+    } else if (n) {
+        HIP_TRY(hipDeviceSynchronize());  // d_points may still be being written on a stream we do not know
     }
     ResidentBases *rb = new ResidentBases();
     rb->group = group;
     rb->device = ctx->device;
-    rc = vt->register_bases(*ctx, src, n, ctx->stream, rb);
+    rc = vt->register_bases(*ctx, src, n, ws.stream, rb);
     if (rc) {
         delete rb;
         return rc;
@@ -189,16 +190,9 @@ static int multiexp_bases_impl(uint64_t handle, const uint64_t *scalars, const v
     int rc = get_context(&ctx);
     if (rc) return rc;
     if (ctx->device != rb->device) return fail(GMSM_ERR_ARG, "bases were registered on another device");
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-    const void *dsc = d_scalars;
-    if (scalars && n) {
-        if ((rc = ctx->scalars.ensure(n * vt->scalar_bytes))) return rc;
-        HIP_TRY(hipMemcpyAsync(ctx->scalars.ptr, scalars, n * vt->scalar_bytes, hipMemcpyHostToDevice, stream));
-        dsc = ctx->scalars.ptr;
-    }
-    return vt->multiexp_device(*ctx, nullptr, dsc, n, stream, out_jac, rb);
+    if (scalars && n) return vt->multiexp_bases_host(*ctx, scalars, n, out_jac, rb);
+    return vt->multiexp_device(*ctx, nullptr, d_scalars, n, (hipStream_t)hip_stream, out_jac, rb);
 }
 
 GMSM_EXPORT int gmsm_multiexp_bases(uint64_t handle, const uint64_t *scalars, size_t n_scalars, int nb_tasks,
@@ -224,18 +218,20 @@ GMSM_EXPORT int gmsm_multiexp_bases_submit(uint64_t handle, const void *d_scalar
     int rc = get_context(&ctx);
     if (rc) return rc;
     if (ctx->device != rb->device) return fail(GMSM_ERR_ARG, "bases were registered on another device");
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
-    Workspace *ws = ctx->free_workspace();
+    Lease lease(*ctx, /*wait=*/false);
+    Workspace *ws = lease.w;
     if (!ws) return fail(GMSM_ERR_ARG, "two MultiExp calls are already in flight: collect one first");
     // the scalars are produced on the caller's stream (NULL = the default stream): order our stream behind it
-    if (!ws->dep) HIP_TRY(hipEventCreateWithFlags(&ws->dep, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(ws->dep, (hipStream_t)hip_stream));
-    HIP_TRY(hipStreamWaitEvent(ws->stream, ws->dep, 0));
+    if ((rc = order_after(*ws, (hipStream_t)hip_stream))) return rc;
     if ((rc = vt->submit(*ctx, *ws, d_scalars, n_scalars, rb))) return rc;
-    ws->pending = true;
-    ws->pending_group = rb->group;
-    ++ws->pending_gen;
+    lease.keep();  // released by gmsm_multiexp_collect
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        ws->pending = true;
+        ws->pending_group = rb->group;
+        ++ws->pending_gen;
+    }
     *out_ticket = ((uint64_t)ctx->device << 40) | ((uint64_t)(ws->pending_gen & 0xffffffffu) << 8) | (uint64_t)(ws - ctx->ws + 1);
     return GMSM_OK;
 }
@@ -254,14 +250,14 @@ GMSM_EXPORT int gmsm_multiexp_collect(uint64_t ticket, uint64_t *out_jac) {
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         if (!ws.pending || ws.pending_gen != gen) return fail(GMSM_ERR_ARG, "unknown MultiExp ticket (already collected?)");
+        ws.pending = false;  // claimed by this call; the workspace stays leased (busy) until the fold is done
         vt = vtable(ws.pending_group);
     }
     // The slot stays `pending` while we wait and fold, so nobody else touches it; the context lock is not held and the
     // other slot can be submitted to meanwhile.
     (void)hipSetDevice(ctx->device);
     int rc = vt->collect(ws, out_jac);
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    ws.pending = false;
+    ctx->release(&ws);
     return rc;
 }
 
@@ -282,10 +278,8 @@ GMSM_EXPORT int gmsm_window_sums_device(int group, const void *d_points, const v
     Context *ctx;
     int rc = get_context(&ctx);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
-    return vt->window_sums(*ctx, d_points, d_scalars, n, c, win_first, win_stride,
-                           hip_stream ? (hipStream_t)hip_stream : ctx->stream, out_xyzz, nullptr);
+    return vt->window_sums(*ctx, d_points, d_scalars, n, c, win_first, win_stride, (hipStream_t)hip_stream, out_xyzz, nullptr);
 }
 
 GMSM_EXPORT int gmsm_window_sums_enqueue(int group, const void *d_points, uint64_t bases_handle, const void *d_scalars,
@@ -304,7 +298,6 @@ GMSM_EXPORT int gmsm_window_sums_enqueue(int group, const void *d_points, uint64
     int rc = get_context(&ctx);
     if (rc) return rc;
     if (rb && ctx->device != rb->device) return fail(GMSM_ERR_ARG, "bases were registered on another device");
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     // hip_stream is used as given: NULL is the device's default (null) stream, which is what the consumer of d_out_xyzz
     // is ordered against when it runs there too - not the engine's private stream.

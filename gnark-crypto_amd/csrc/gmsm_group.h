@@ -59,14 +59,14 @@ struct Group {
     // Runs the device pipeline for the windows of `plan`; host_xyzz receives plan.nwin_local window totals.
     // d_points: Go-layout affine bases on the device, or nullptr when `resident` (bases already rewritten into the lazy
     // domain by register_bases) is given.
-    static int window_sums(Context &ctx, const void *d_points, const void *d_scalars, size_t n, const WindowPlan &plan,
-                           hipStream_t stream, Ext *host_xyzz, const ResidentBases *resident = nullptr) {
-        Workspace *free_ws = ctx.free_workspace();
-        if (!free_ws) return fail(GMSM_ERR_ARG, "two submitted MultiExp calls are waiting for gmsm_multiexp_collect");
-        Workspace &ws = *free_ws;
-        int rc = enqueue_window_sums(ctx, ws, d_points, d_scalars, n, plan, stream, resident);
+    // `ws` is leased by the caller; the pipeline runs on the workspace's own stream, ordered after `caller_stream`.
+    static int window_sums(Context &ctx, Workspace &ws, const void *d_points, const void *d_scalars, size_t n,
+                           const WindowPlan &plan, hipStream_t caller_stream, Ext *host_xyzz,
+                           const ResidentBases *resident = nullptr) {
+        int rc = order_after(ws, caller_stream);
         if (rc) return rc;
-        return collect_window_sums(ws, stream, plan.nwin_local, host_xyzz);
+        if ((rc = enqueue_window_sums(ctx, ws, d_points, d_scalars, n, plan, ws.stream, resident))) return rc;
+        return collect_window_sums(ws, ws.stream, plan.nwin_local, host_xyzz);
     }
 
     // Waits for the pipeline enqueued on `stream` and hands out the window totals (pinned buffer -> host_xyzz).
@@ -169,13 +169,9 @@ struct Group {
             uint32_t *bh = (uint32_t *)ws.blockhist.ptr, *part_base = (uint32_t *)ws.counts.ptr;
             uint32_t *part_pop = part_base + (size_t)nw * (nparts + 1);
             uint32_t *parted = (uint32_t *)ws.parted.ptr;
-            static bool attr2_done = false;
-            if (!attr2_done) {
-                HIP_TRY(hipFuncSetAttribute((const void *)k_part_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                HIP_TRY(hipFuncSetAttribute((const void *)k_part_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-                HIP_TRY(hipFuncSetAttribute((const void *)k_fine_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr2_done = true;
-            }
+            if ((rc = ctx.allow_lds((const void *)k_part_hist, 160 * 1024))) return rc;
+            if ((rc = ctx.allow_lds((const void *)k_part_scatter, 152 * 1024))) return rc;
+            if ((rc = ctx.allow_lds((const void *)k_fine_sort, 160 * 1024))) return rc;
             timer.mark(STAGE_HIST);
             hipLaunchKernelGGL(k_part_hist, dim3(pchunks, nw), dim3(1024), (size_t)nparts * 4, stream, digits, n, nparts, fbits,
                                pchunk_len, bh);
@@ -249,14 +245,8 @@ struct Group {
                                parts2, flags2, pb2, 1u, ws.buckets.ptr, long_flag);
         }
         // 4. bucket reduction -> window totals
-        static bool red_attr_done = false;
-        if (!red_attr_done) {
-            HIP_TRY(hipFuncSetAttribute((const void *)k_reduce1<Ops, RED_TPB>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)(2 * RED_TPB * sizeof(OpsElem))));
-            HIP_TRY(hipFuncSetAttribute((const void *)k_reduce2<Ops, RED2_TPB>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)(2 * RED2_TPB * sizeof(OpsElem))));
-            red_attr_done = true;
-        }
+        if ((rc = ctx.allow_lds((const void *)k_reduce1<Ops, RED_TPB>, (int)(2 * RED_TPB * sizeof(OpsElem))))) return rc;
+        if ((rc = ctx.allow_lds((const void *)k_reduce2<Ops, RED2_TPB>, (int)(2 * RED2_TPB * sizeof(OpsElem))))) return rc;
         timer.mark(STAGE_REDUCE);
         // level 1 doubles its S_blk log2span times in an otherwise idle wave (256-thread blocks only): level 2 then has no
         // serial doubling tail (11 of its 20 steps at c = 16)
@@ -386,12 +376,12 @@ struct Group {
         return GMSM_OK;
     }
 
-    static int multiexp_device(Context &ctx, const void *d_points, const void *d_scalars, size_t n, hipStream_t stream,
-                               J *out, const ResidentBases *resident = nullptr) {
+    static int multiexp_device(Context &ctx, Workspace &ws, const void *d_points, const void *d_scalars, size_t n,
+                               hipStream_t caller_stream, J *out, const ResidentBases *resident = nullptr) {
         const unsigned c = choose_c(FR_BITS, n);
         WindowPlan plan = make_plan(c, 0, 1);
         std::vector<Ext> totals(plan.nwin_total);
-        int rc = window_sums(ctx, d_points, d_scalars, n, plan, stream, totals.data(), resident);
+        int rc = window_sums(ctx, ws, d_points, d_scalars, n, plan, caller_stream, totals.data(), resident);
         if (rc) return rc;
         *out = fold(totals.data(), c);
         return GMSM_OK;
@@ -437,18 +427,19 @@ struct Group {
         Context *ctx;
         int rc = get_context(&ctx);
         if (rc) return rc;
-        std::lock_guard<std::mutex> lk(ctx->mu);
         HIP_TRY(hipSetDevice(ctx->device));
         const size_t n = n_points;
         if (n == 0) {
             *out = J{F::one(), F::one(), F::zero()};
             return GMSM_OK;
         }
-        if ((rc = ctx->points.ensure(n * AFF_BYTES))) return rc;
-        if ((rc = ctx->scalars.ensure(n * SCALAR_BYTES))) return rc;
-        HIP_TRY(hipMemcpyAsync(ctx->points.ptr, points, n * AFF_BYTES, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(ctx->scalars.ptr, scalars, n * SCALAR_BYTES, hipMemcpyHostToDevice, ctx->stream));
-        return multiexp_device(*ctx, ctx->points.ptr, ctx->scalars.ptr, n, ctx->stream, out);
+        GMSM_LEASE_OR_FAIL(lease, *ctx);
+        Workspace &ws = *lease.w;
+        if ((rc = ws.h2d_points.ensure(n * AFF_BYTES))) return rc;
+        if ((rc = ws.h2d_scalars.ensure(n * SCALAR_BYTES))) return rc;
+        HIP_TRY(hipMemcpyAsync(ws.h2d_points.ptr, points, n * AFF_BYTES, hipMemcpyHostToDevice, ws.stream));
+        HIP_TRY(hipMemcpyAsync(ws.h2d_scalars.ptr, scalars, n * SCALAR_BYTES, hipMemcpyHostToDevice, ws.stream));
+        return multiexp_device(*ctx, ws, ws.h2d_points.ptr, ws.h2d_scalars.ptr, n, ws.stream, out);
     }
 };
 
@@ -561,8 +552,9 @@ static int run_elementwise(size_t in_bytes_a, const void *a, size_t in_bytes_b, 
     Context *ctx;
     int rc = get_context(&ctx);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
+    GMSM_LEASE_OR_FAIL(lease, *ctx);
+    hipStream_t stream = lease.w->stream;
     void *da = nullptr, *db = nullptr, *dout = nullptr;
     HIP_TRY(hipMalloc(&da, in_bytes_a));
     HIP_TRY(hipMemcpy(da, a, in_bytes_a, hipMemcpyHostToDevice));
@@ -571,9 +563,9 @@ static int run_elementwise(size_t in_bytes_a, const void *a, size_t in_bytes_b, 
         HIP_TRY(hipMemcpy(db, b, in_bytes_b, hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMalloc(&dout, out_bytes));
-    launch(da, db, dout, ctx->stream);
+    launch(da, db, dout, stream);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipMemcpy(out, dout, out_bytes, hipMemcpyDeviceToHost));
     (void)hipFree(da);
     if (db) (void)hipFree(db);
@@ -616,18 +608,19 @@ static int debug_decompose_impl(const uint64_t *scalars, size_t n, unsigned c, u
     Context *ctx;
     int rc = get_context(&ctx);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     WindowPlan plan = G::make_plan(c, 0, 1);
     if (n == 0) return GMSM_OK;
-    if ((rc = ctx->scalars.ensure(n * G::SCALAR_BYTES))) return rc;
-    if ((rc = ctx->ws[0].digits.ensure((size_t)plan.nwin_total * n * 4))) return rc;
-    HIP_TRY(hipMemcpy(ctx->scalars.ptr, scalars, n * G::SCALAR_BYTES, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL((k_decompose<typename G::FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const uint32_t *)ctx->scalars.ptr, n, plan, (uint32_t *)ctx->ws[0].digits.ptr, (const uint8_t *)nullptr);
+    GMSM_LEASE_OR_FAIL(lease, *ctx);
+    Workspace &ws = *lease.w;
+    if ((rc = ws.h2d_scalars.ensure(n * G::SCALAR_BYTES))) return rc;
+    if ((rc = ws.digits.ensure((size_t)plan.nwin_total * n * 4))) return rc;
+    HIP_TRY(hipMemcpyAsync(ws.h2d_scalars.ptr, scalars, n * G::SCALAR_BYTES, hipMemcpyHostToDevice, ws.stream));
+    hipLaunchKernelGGL((k_decompose<typename G::FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ws.stream,
+                       (const uint32_t *)ws.h2d_scalars.ptr, n, plan, (uint32_t *)ws.digits.ptr, (const uint8_t *)nullptr);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipMemcpy(out_digits, ctx->ws[0].digits.ptr, (size_t)plan.nwin_total * n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(out_digits, ws.digits.ptr, (size_t)plan.nwin_total * n * 4, hipMemcpyDeviceToHost, ws.stream));
+    HIP_TRY(hipStreamSynchronize(ws.stream));
     return GMSM_OK;
 }
 
@@ -649,9 +642,22 @@ struct VTableOf {
         typename G::J j;
         if (n == 0) j = typename G::J{G::F::one(), G::F::one(), G::F::zero()};
         else {
-            int rc = G::multiexp_device(ctx, d_points, d_scalars, n, stream, &j, resident);
+            GMSM_LEASE_OR_FAIL(lease, ctx);
+            int rc = G::multiexp_device(ctx, *lease.w, d_points, d_scalars, n, stream, &j, resident);
             if (rc) return rc;
         }
+        memcpy(out_jac, &j, sizeof j);
+        return GMSM_OK;
+    }
+    static int multiexp_bases_host(Context &ctx, const uint64_t *scalars, size_t n, uint64_t *out_jac,
+                                   const ResidentBases *resident) {
+        GMSM_LEASE_OR_FAIL(lease, ctx);
+        Workspace &ws = *lease.w;
+        int rc = ws.h2d_scalars.ensure(n * G::SCALAR_BYTES);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(ws.h2d_scalars.ptr, scalars, n * G::SCALAR_BYTES, hipMemcpyHostToDevice, ws.stream));
+        typename G::J j;
+        if ((rc = G::multiexp_device(ctx, ws, nullptr, ws.h2d_scalars.ptr, n, ws.stream, &j, resident))) return rc;
         memcpy(out_jac, &j, sizeof j);
         return GMSM_OK;
     }
@@ -659,8 +665,9 @@ struct VTableOf {
                            unsigned win_first, unsigned win_stride, hipStream_t stream, uint64_t *out_xyzz,
                            const ResidentBases *resident) {
         WindowPlan plan = G::make_plan(c, win_first, win_stride);
-        return G::window_sums(ctx, d_points, d_scalars, n, plan, stream, reinterpret_cast<typename G::Ext *>(out_xyzz),
-                              resident);
+        GMSM_LEASE_OR_FAIL(lease, ctx);
+        return G::window_sums(ctx, *lease.w, d_points, d_scalars, n, plan, stream,
+                              reinterpret_cast<typename G::Ext *>(out_xyzz), resident);
     }
     static int register_bases(Context &ctx, const void *d_points, size_t n, hipStream_t stream, ResidentBases *out) {
         return G::register_bases(ctx, d_points, n, stream, out);
@@ -669,8 +676,10 @@ struct VTableOf {
                                    unsigned win_first, unsigned win_stride, hipStream_t stream, void *d_out_xyzz,
                                    const ResidentBases *resident) {
         WindowPlan plan = G::make_plan(c, win_first, win_stride);
-        Workspace *ws = ctx.free_workspace();
-        if (!ws) return fail(GMSM_ERR_ARG, "two submitted MultiExp calls are waiting for gmsm_multiexp_collect");
+        // leased for the duration of this call only: the work it leaves in flight is protected by stream order
+        // (Workspace::last_use), not by the lease
+        GMSM_LEASE_OR_FAIL(lease, ctx);
+        Workspace *ws = lease.w;
         int rc = G::enqueue_window_sums(ctx, *ws, d_points, d_scalars, n, plan, stream, resident, d_out_xyzz);
         ws->uncollected = ws->pending_timed;  // nobody waits for this call: its stage events are read by the next one
         ws->pending_timed = false;
@@ -754,7 +763,7 @@ struct VTableOf {
         static const GroupVTable vt = {G::FR_BITS,      G::AFF_BYTES,   G::SCALAR_BYTES, sizeof(typename G::J),
                                        sizeof(typename G::Ext), &multiexp_host, &multiexp_device, &window_sums,
                                        &fold,           &jac_to_affine, &debug_decompose, &debug_field_op,
-                                       &debug_group_op, &generate_points, &register_bases, &submit, &collect, &window_sums_enqueue, &fold_sets, &fold_points};
+                                       &debug_group_op, &generate_points, &register_bases, &submit, &collect, &window_sums_enqueue, &fold_sets, &fold_points, &multiexp_bases_host};
         return &vt;
     }
 };

@@ -83,8 +83,12 @@ int gmsm_fold(int group, const uint64_t *points, size_t n_points, const uint64_t
               uint64_t *out_jac);
 
 /* ---- device-resident entries (bases/scalars already in HBM: the SRS-resident fast path).
- *      d_points / d_scalars are device pointers with the layouts above; hip_stream is a hipStream_t (NULL = default
- *      stream); the call returns after the result has been copied back to out_jac (host memory). ---- */
+ *      d_points / d_scalars are device pointers with the layouts above; hip_stream is the hipStream_t the inputs were
+ *      produced on (NULL = default stream): the engine runs on a private stream ordered after the work queued there;
+ *      the call returns after the result has been copied back to out_jac (host memory).
+ *      Concurrency (all blocking entries): any number of threads may call at once; per device two calls are in flight
+ *      at a time on two workspaces/streams - the sort and accumulation of one overlap the latency-bound reduction,
+ *      copy-back and host fold of the other - further callers wait their turn. ---- */
 int gmsm_multiexp_device(int group, const void *d_points, const void *d_scalars, size_t n, void *hip_stream,
                          uint64_t *out_jac);
 
