@@ -155,7 +155,10 @@ struct Group {
             uint32_t log2n = 0;
             while (((size_t)1 << log2n) < n) ++log2n;
             const uint32_t lidx = log2n + 1;  // bits of (index << 1 | negate)
-            int fb = 14 + (int)log2NB - (int)log2n;
+            // target partition population 2^part_log2 (measured, BN254 G1: 2^13 is best up to 2^21 points - more
+            // workgroups for the fine pass; 2^15 from 2^24 on - 128-byte runs out of the coarse pass)
+            const uint32_t part_log2 = env_uint("GMSM_PART_LOG2", log2n <= 21 ? 13 : log2n >= 24 ? 15 : 14);
+            int fb = (int)part_log2 + (int)log2NB - (int)log2n;
             if (fb > (int)log2NB) fb = (int)log2NB;
             if (fb < 0) fb = 0;
             if (fb + lidx > 32) fb = 32 - lidx;
@@ -186,7 +189,8 @@ struct Group {
             // staging slots of the fine pass: up to 96 KiB next to the 2^fbits counters; larger partitions go direct
             const size_t fine_cnt_bytes = (size_t)4 << fbits;
             const uint32_t stage_cap = fine_cnt_bytes >= 156 * 1024 ? 0u
-                                       : (uint32_t)std::min<size_t>(24576, (156 * 1024 - fine_cnt_bytes) / 4);
+                                       : (uint32_t)std::min<size_t>(env_uint("GMSM_STAGE_CAP", part_log2 >= 15 ? 39000 : 24576),
+                                                                  (156 * 1024 - fine_cnt_bytes) / 4);
             hipLaunchKernelGGL(k_fine_sort, dim3(nparts, nw), dim3(1024), ((size_t)4 << fbits) + (size_t)stage_cap * 4, stream,
                                parted, n, NB, fbits, lidx, part_base, sorted, starts, stage_cap);
         }
