@@ -198,6 +198,19 @@ def main():
         pipelined["two_blocking_callers"] = {
             "value": round(args.steps / dtc, 3), "unit": "MSM/s", "ms_per_step": round(dtc / args.steps * 1e3, 4),
             "equal_to_serial_result": bool(all(r is None or (g.jac_to_affine(r) == g.jac_to_affine(jac)).all() for r in res2))}
+        # k MultiExp in ONE blocking call with the scalars on the HOST (gmsm_multiexp_bases_batch): the copy of vector
+        # i+1 overlaps the accumulation of vector i, so this rate includes the 32 B/scalar over PCIe
+        kb = 8
+        sc_batch = np.ascontiguousarray(np.broadcast_to(sc, (kb,) + sc.shape))
+        rb2.MultiExpBatch(scalars=sc_batch[:2])
+        tb0 = time.perf_counter()
+        jb, errb = rb2.MultiExpBatch(scalars=sc_batch)
+        dtb = time.perf_counter() - tb0
+        assert errb is None
+        pipelined["batch_call_host_scalars"] = {
+            "value": round(kb / dtb, 3), "unit": "MSM/s", "ms_per_step": round(dtb / kb * 1e3, 4), "k": kb,
+            "equal_to_serial_result": bool(all((g.jac_to_affine(j_) == g.jac_to_affine(jac)).all() for j_ in jb))}
+        del sc_batch
         if resident is None:
             rb2.release()
 

@@ -236,6 +236,66 @@ GMSM_EXPORT int gmsm_multiexp_bases_submit(uint64_t handle, const void *d_scalar
     return GMSM_OK;
 }
 
+// k MultiExp over the same registered bases, one scalar vector each (kzg.Commit over many polynomials with one SRS,
+// ecc/bn254/kzg/kzg.go:159-176, 246-300): a single blocking call that keeps two of them in flight. With host scalars
+// the copy of vector i+1 runs while vector i is being accumulated.
+GMSM_EXPORT int gmsm_multiexp_bases_batch(uint64_t handle, const uint64_t *scalars, const void *d_scalars, size_t n,
+                                          size_t k, void *hip_stream, uint64_t *out_jac) {
+    ResidentBases *rb = lookup_bases(handle);
+    if (!rb) return fail(GMSM_ERR_ARG, "unknown bases handle");
+    const GroupVTable *vt = vtable(rb->group);
+    if (n > rb->n) return fail(GMSM_ERR_LEN, "len(points) != len(scalars)");
+    if (k == 0) return GMSM_OK;
+    if (n && (scalars == nullptr) == (d_scalars == nullptr))
+        return fail(GMSM_ERR_ARG, "gmsm_multiexp_bases_batch: give exactly one of scalars (host) / d_scalars (device)");
+    Context *ctx;
+    int rc = get_context(&ctx);
+    if (rc) return rc;
+    if (ctx->device != rb->device) return fail(GMSM_ERR_ARG, "bases were registered on another device");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t jl = vt->jac_bytes / 8, sb = vt->scalar_bytes * n;
+    if (n == 0) {
+        for (size_t i = 0; i < k; ++i)
+            if ((rc = vt->multiexp_device(*ctx, nullptr, nullptr, 0, nullptr, out_jac + i * jl, rb))) return rc;
+        return GMSM_OK;
+    }
+    Workspace *w[2] = {ctx->acquire(true), nullptr};
+    if (!w[0]) return fail(GMSM_ERR_ARG, "two submitted MultiExp calls are waiting for gmsm_multiexp_collect");
+    w[1] = ctx->acquire(false);  // a concurrent caller may hold it: then this batch runs one call at a time
+    const size_t nws = w[1] ? 2 : 1;
+    size_t submitted = 0, collected = 0;
+    rc = GMSM_OK;
+    while (rc == GMSM_OK && collected < k) {
+        while (rc == GMSM_OK && submitted < k && submitted - collected < nws) {
+            Workspace &ws = *w[submitted % nws];
+            const void *dsc;
+            if (scalars) {
+                if ((rc = ws.h2d_scalars.ensure(sb))) break;
+                hipError_t e = hipMemcpyAsync(ws.h2d_scalars.ptr, (const char *)scalars + submitted * sb, sb,
+                                              hipMemcpyHostToDevice, ws.stream);
+                if (e != hipSuccess) {
+                    rc = fail(GMSM_ERR_DEVICE, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
+                    break;
+                }
+                dsc = ws.h2d_scalars.ptr;
+            } else {
+                if ((rc = order_after(ws, (hipStream_t)hip_stream))) break;
+                dsc = (const char *)d_scalars + submitted * sb;
+            }
+            if ((rc = vt->submit(*ctx, ws, dsc, n, rb))) break;
+            ++submitted;
+        }
+        if (rc) break;
+        rc = vt->collect(*w[collected % nws], out_jac + collected * jl);
+        ++collected;
+    }
+    for (size_t i = 0; i < nws; ++i) {
+        (void)hipStreamSynchronize(w[i]->stream);  // nothing of this call is left running on a released workspace
+        ctx->release(w[i]);
+    }
+    return rc;
+}
+
 GMSM_EXPORT int gmsm_multiexp_collect(uint64_t ticket, uint64_t *out_jac) {
     const unsigned slot = (unsigned)(ticket & 0xff), dev = (unsigned)(ticket >> 40);
     const uint32_t gen = (uint32_t)(ticket >> 8);

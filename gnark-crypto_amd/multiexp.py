@@ -225,6 +225,20 @@ class ResidentBases:
             raise RuntimeError(self.group._error(rc))
         return out
 
+    def MultiExpBatch(self, scalars=None, d_scalars=None, n=None, k=None, stream=0):
+        """gmsm_multiexp_bases_batch: k MultiExp over bases[:n], one per scalar vector; scalars is a (k, n, fr_limbs) host
+        array or d_scalars a device pointer to the same layout. Returns ((k, jac_limbs) array, None) or (None, error)."""
+        L = _lib.load()
+        g = self.group
+        if scalars is not None:
+            scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+            k, n = scalars.shape[0], scalars.shape[1]
+            scalars = scalars.reshape(k, n, g.fr_limbs)
+        out = np.zeros((k, g.jac_limbs), dtype=np.uint64)
+        rc = L.gmsm_multiexp_bases_batch(self.handle, _ptr(scalars) if scalars is not None and scalars.size else None,
+                                         d_scalars, n, k, stream or None, _ptr(out))
+        return (out, None) if rc == 0 else (None, g._error(rc))
+
     def submit(self, d_scalars, n, stream=0):
         """gmsm_multiexp_bases_submit: launch MultiExp(bases[:n], d_scalars) without waiting; returns a ticket."""
         import ctypes

@@ -115,6 +115,12 @@ int gmsm_multiexp_bases_device(uint64_t handle, const void *d_scalars, size_t n_
 int gmsm_multiexp_bases_submit(uint64_t handle, const void *d_scalars, size_t n_scalars, void *hip_stream,
                                uint64_t *out_ticket);
 int gmsm_multiexp_collect(uint64_t ticket, uint64_t *out_jac);
+/* k MultiExp over the same registered bases in one blocking call (one commitment per polynomial with a fixed SRS:
+ * kzg.Commit, ecc/bn254/kzg/kzg.go:159-176; BatchOpenSinglePoint :246): scalars = k x n fr.Element, contiguous, either on
+ * the host (`scalars`) or on the device (`d_scalars`, produced on hip_stream); out_jac = k Jacobian results. Two of
+ * the k calls are in flight at a time; host scalars of vector i+1 are copied while vector i is being accumulated. */
+int gmsm_multiexp_bases_batch(uint64_t handle, const uint64_t *scalars, const void *d_scalars, size_t n, size_t k,
+                              void *hip_stream, uint64_t *out_jac);
 
 /* ---- window-sharded pieces (multi-GPU: windows win_first, win_first+win_stride, ... of the c-bit decomposition are
  *      handled by this device; the tiny per-window totals are exchanged by the caller, e.g. one RCCL all-gather).

@@ -374,6 +374,41 @@ def test_resident_bases_prefix_multiexp(gm, oracle_mod, curve, which):
         rb.release()
 
 
+@pytest.mark.parametrize("curve,which", [("bn254", "g1"), ("bls12_381", "g2")])
+def test_batch_of_multiexp_over_resident_bases(gm, oracle_mod, curve, which):
+    """gmsm_multiexp_bases_batch: k scalar vectors over one registered base set (kzg.Commit of k polynomials with one SRS,
+    ecc/bn254/kzg/kzg.go:159-176) from host and from device memory; every result equals the oracle's MultiExp."""
+    import torch
+    g = _group(gm, curve, which)
+    o = oracle_mod.Oracle(curve, which)
+    nb, n, k = 5000, 4097, 5
+    rng = rng_for(33, g.gid)
+    pts = o.gen_points(nb, 7001, 13, nthreads=4)
+    sc = np.stack([random_scalars(rng, g.curve, n) for _ in range(k)])
+    sc[2] = 0                      # one all-zero vector -> infinity
+    sc[3, :100] = sc[3, 100:200]   # repeated scalars
+    expected = [o.msm_affine(pts[:n], sc[i]) for i in range(k)]
+    rb = g.register_bases(points=pts)
+    try:
+        jacs, err = rb.MultiExpBatch(scalars=sc)
+        assert err is None
+        for i in range(k):
+            assert (g.jac_to_affine(jacs[i]) == expected[i]).all(), i
+        d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+        jacs, err = rb.MultiExpBatch(d_scalars=d_sc.data_ptr(), n=n, k=k, stream=torch.cuda.current_stream().cuda_stream)
+        assert err is None
+        for i in range(k):
+            assert (g.jac_to_affine(jacs[i]) == expected[i]).all(), i
+        jacs, err = rb.MultiExpBatch(scalars=sc[:1])     # k = 1
+        assert err is None and (g.jac_to_affine(jacs[0]) == expected[0]).all()
+        jacs, err = rb.MultiExpBatch(scalars=np.zeros((2, 0, g.fr_limbs), dtype=np.uint64))  # n = 0
+        assert err is None and (g.jac_to_affine(jacs[1]) == 0).all()
+        _, err = rb.MultiExpBatch(scalars=np.zeros((1, nb + 1, g.fr_limbs), dtype=np.uint64))
+        assert err == "len(points) != len(scalars)"
+    finally:
+        rb.release()
+
+
 @pytest.mark.parametrize("curve,which", [("bn254", "g1"), ("bn254", "g2"), ("bls12_381", "g1"), ("bw6_761", "g2")])
 def test_fold_matches_reference_definition(gm, oracle_mod, curve, which):
     """Fold (ecc/bn254/multiexp.go:320-340): sum_i points[i] * coeff^i. Expected value: the oracle's MultiExp over the
