@@ -144,9 +144,41 @@ struct Group {
             upoints = ws.upoints.ptr;
             skip = (const uint8_t *)ws.skip.ptr;
         }
-        // 1. signed-digit decomposition
-        hipLaunchKernelGGL((k_decompose<FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                           (const uint32_t *)d_scalars, n, plan, digits, skip);
+        // geometry of the segmented accumulation and of the chain fixup (needed early: the grouping kernels clear the
+        // long-chain flags on their way)
+        // entry-parallel segmented accumulation: seg entries per thread, >= ~4 waves per SIMD when n allows
+        uint32_t seg = env_uint("GMSM_SEG", 0);
+        if (seg == 0) {
+            // every thread does the same work, so the launch should be a whole number of resident "rounds":
+            // capacity = CUs x 3 workgroups (160 VGPRs -> 3 waves/SIMD) x 256 threads
+            const size_t capacity = (size_t)ctx.num_cus * AccWaves<U>::value * 256;
+            const size_t SEG_MAX = env_uint("GMSM_SEGMAX", 512);  // measured: 512 best at 2^24, 256 at 2^22
+            for (size_t r = 1;; ++r) {
+                size_t s = ((size_t)nw * n + r * capacity - 1) / (r * capacity);
+                if (s <= SEG_MAX) {
+                    // nw*ceil(n/s) threads must not exceed r*capacity: round s up until it holds
+                    while (s < SEG_MAX && (size_t)nw * ((n + s - 1) / s) > r * capacity) ++s;
+                    seg = (uint32_t)std::max<size_t>(s, 32);
+                    break;
+                }
+            }
+        }
+        const uint32_t tpw = (uint32_t)((n + seg - 1) / seg);  // threads per window (upper bound: <= n entries)
+        // chain fixup: short chains in place, long ones through two hierarchical levels (no-ops unless flagged)
+        const uint32_t span1 = 64;
+        const uint32_t t1 = (tpw + span1 - 1) / span1;  // level-1 outputs per window
+        const uint32_t span2 = t1;                      // level 2: one thread per window closes everything
+        const size_t lvl_parts = ((size_t)nw * t1 + nw) * 2 * REC;
+        if ((rc = ws.seg_lvl.ensure(lvl_parts + ((size_t)nw * t1 * 2 + (size_t)nw * 3) * 4 + 256))) return rc;
+        char *lvl = (char *)ws.seg_lvl.ptr;
+        void *parts1 = lvl;
+        void *parts2 = lvl + (size_t)nw * t1 * 2 * REC;  // nw * 2 records
+        uint32_t *flags1 = (uint32_t *)(lvl + lvl_parts);
+        uint32_t *pb1 = flags1 + (size_t)nw * t1;
+        uint32_t *flags2 = pb1 + (size_t)nw * t1;
+        uint32_t *pb2 = flags2 + nw;
+        uint32_t *long_flag = pb2 + nw;
+        // 1. signed-digit decomposition: first launch of the grouping block below
         // 2. group point references by bucket
         {
             // fine buckets per partition: ~16 K references per partition for uniform scalars
@@ -175,13 +207,17 @@ struct Group {
             if ((rc = ctx.allow_lds((const void *)k_part_hist, 160 * 1024))) return rc;
             if ((rc = ctx.allow_lds((const void *)k_part_scatter, 152 * 1024))) return rc;
             if ((rc = ctx.allow_lds((const void *)k_fine_sort, 160 * 1024))) return rc;
+            // (A decomposition fused with this histogram was measured and dropped: one workgroup per 16 K-scalar chunk
+            // leaves 3/4 of the CUs idle at 2^20, and at 2^24 it only breaks even.)
+            hipLaunchKernelGGL((k_decompose<FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                               (const uint32_t *)d_scalars, n, plan, digits, skip);
             timer.mark(STAGE_HIST);
-            hipLaunchKernelGGL(k_part_hist, dim3(pchunks, nw), dim3(1024), (size_t)nparts * 4, stream, digits, n, nparts, fbits,
-                               pchunk_len, bh);
+            hipLaunchKernelGGL(k_part_hist, dim3(pchunks, nw), dim3(1024), (size_t)nparts * 4, stream, digits, n, nparts,
+                               fbits, pchunk_len, bh);
             timer.mark(STAGE_SCAN);
-            hipLaunchKernelGGL(k_part_colscan, dim3((nparts + 255) / 256, nw), dim3(256), 0, stream, bh, pchunks, nparts,
+            hipLaunchKernelGGL(k_part_colscan, dim3((nparts + 31) / 32, nw), dim3(256), 0, stream, bh, pchunks, nparts,
                                part_pop);
-            hipLaunchKernelGGL(k_part_rowscan, dim3(nw), dim3(1024), 0, stream, part_pop, nparts, part_base);
+            hipLaunchKernelGGL(k_part_rowscan, dim3(nw), dim3(1024), 0, stream, part_pop, nparts, part_base, long_flag);
             timer.mark(STAGE_SCATTER);
             hipLaunchKernelGGL(k_part_scatter, dim3(pchunks, nw), dim3(1024),
                                (size_t)nparts * 8 + (size_t)PART_CHUNK * 6, stream, digits, n, nparts, fbits, lidx, pchunk_len,
@@ -198,24 +234,6 @@ struct Group {
         timer.mark(STAGE_ACCUMULATE);
         const uint32_t *reduce_starts = starts;  // empty buckets are never written: the reduction consults starts[]
         {
-            // entry-parallel segmented accumulation: seg entries per thread, >= ~4 waves per SIMD when n allows
-            uint32_t seg = env_uint("GMSM_SEG", 0);
-            if (seg == 0) {
-                // every thread does the same work, so the launch should be a whole number of resident "rounds":
-                // capacity = CUs x 3 workgroups (160 VGPRs -> 3 waves/SIMD) x 256 threads
-                const size_t capacity = (size_t)ctx.num_cus * AccWaves<U>::value * 256;
-                const size_t SEG_MAX = env_uint("GMSM_SEGMAX", 512);  // measured: 512 best at 2^24, 256 at 2^22
-                for (size_t r = 1;; ++r) {
-                    size_t s = ((size_t)nw * n + r * capacity - 1) / (r * capacity);
-                    if (s <= SEG_MAX) {
-                        // nw*ceil(n/s) threads must not exceed r*capacity: round s up until it holds
-                        while (s < SEG_MAX && (size_t)nw * ((n + s - 1) / s) > r * capacity) ++s;
-                        seg = (uint32_t)std::max<size_t>(s, 32);
-                        break;
-                    }
-                }
-            }
-            const uint32_t tpw = (uint32_t)((n + seg - 1) / seg);  // threads per window (upper bound: <= n entries)
             if ((rc = ws.seg_partials.ensure((size_t)nw * tpw * 2 * REC))) return rc;
             if ((rc = ws.seg_flags.ensure((size_t)nw * tpw * 4))) return rc;
             if ((rc = ws.seg_bucket.ensure((size_t)nw * tpw * 4))) return rc;
@@ -223,21 +241,6 @@ struct Group {
                                upoints, n, NB, seg, starts, sorted, ws.buckets.ptr, ws.seg_partials.ptr,
                                (uint32_t *)ws.seg_flags.ptr, (uint32_t *)ws.seg_bucket.ptr, tpw);
             timer.mark(STAGE_FIXUP);
-            // chain fixup: short chains in place, long ones through two hierarchical levels (no-ops unless flagged)
-            const uint32_t span1 = 64;
-            const uint32_t t1 = (tpw + span1 - 1) / span1;  // level-1 outputs per window
-            const uint32_t span2 = t1;                      // level 2: one thread per window closes everything
-            const size_t lvl_parts = ((size_t)nw * t1 + nw) * 2 * REC;
-            if ((rc = ws.seg_lvl.ensure(lvl_parts + ((size_t)nw * t1 * 2 + (size_t)nw * 3) * 4 + 256))) return rc;
-            char *lvl = (char *)ws.seg_lvl.ptr;
-            void *parts1 = lvl;
-            void *parts2 = lvl + (size_t)nw * t1 * 2 * REC;  // nw * 2 records
-            uint32_t *flags1 = (uint32_t *)(lvl + lvl_parts);
-            uint32_t *pb1 = flags1 + (size_t)nw * t1;
-            uint32_t *flags2 = pb1 + (size_t)nw * t1;
-            uint32_t *pb2 = flags2 + nw;
-            uint32_t *long_flag = pb2 + nw;
-            HIP_TRY(hipMemsetAsync(long_flag, 0, (size_t)nw * 4, stream));
             hipLaunchKernelGGL((k_fixup_seg<Ops>), dim3((tpw + 255) / 256, nw), dim3(256), 0, stream, NB,
                                ws.seg_partials.ptr, (const uint32_t *)ws.seg_flags.ptr,
                                (const uint32_t *)ws.seg_bucket.ptr, tpw, ws.buckets.ptr, long_flag);

@@ -163,27 +163,42 @@ static __global__ void __launch_bounds__(1024) k_part_hist(const uint32_t *__res
     for (uint32_t p = threadIdx.x; p < nparts; p += blockDim.x) out[p] = lds_cnt[p];
 }
 
-// grid = (ceil(nparts/256), nwin): one thread per (window, partition) turns the per-chunk counts into exclusive prefixes
-// over the chunks (in place) and emits the partition population.
+// grid = (ceil(nparts/32), nwin), block = 256 = 32 partitions x 8 chunk segments: turns the per-chunk counts of every
+// (window, partition) into exclusive prefixes over the chunks (in place) and emits the partition population. Each
+// thread sums its segment of the chunks, the 8 segment sums of a partition are combined through LDS, then the segment
+// is rewritten with running prefixes. Adjacent lanes work on adjacent partitions (128-byte rows of blockhist).
 static __global__ void __launch_bounds__(256) k_part_colscan(uint32_t *__restrict__ blockhist, uint32_t nchunks, uint32_t nparts,
                                                              uint32_t *__restrict__ part_pop) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
-    if (p >= nparts) return;
+    __shared__ uint32_t seg_sum[8][32];
+    const uint32_t lane = threadIdx.x & 31u, s = threadIdx.x >> 5, k = blockIdx.y;
+    const uint32_t p = blockIdx.x * 32u + lane;
+    const uint32_t per = (nchunks + 7u) / 8u;
+    const uint32_t c0 = s * per < nchunks ? s * per : nchunks;
+    const uint32_t c1 = c0 + per < nchunks ? c0 + per : nchunks;
     uint32_t *bh = blockhist + (size_t)k * nchunks * nparts + p;
+    uint32_t mine = 0;
+    if (p < nparts)
+        for (uint32_t ch = c0; ch < c1; ++ch) mine += bh[(size_t)ch * nparts];
+    seg_sum[s][lane] = mine;
+    __syncthreads();
+    if (p >= nparts) return;
     uint32_t run = 0;
-    for (uint32_t ch = 0; ch < nchunks; ++ch) {
+    for (uint32_t q = 0; q < s; ++q) run += seg_sum[q][lane];
+    for (uint32_t ch = c0; ch < c1; ++ch) {
         const uint32_t v = bh[(size_t)ch * nparts];
         bh[(size_t)ch * nparts] = run;
         run += v;
     }
-    part_pop[(size_t)k * nparts + p] = run;
+    if (s == 7u) part_pop[(size_t)k * nparts + p] = run;
 }
 
 // grid = nwin, block = 1024: exclusive scan of the partition populations -> part_base[k][0..nparts]
 static __global__ void __launch_bounds__(1024) k_part_rowscan(const uint32_t *__restrict__ part_pop, uint32_t nparts,
-                                                              uint32_t *__restrict__ part_base) {
+                                                              uint32_t *__restrict__ part_base,
+                                                              uint32_t *__restrict__ clear_flag /* [nwin], may be null */) {
     __shared__ uint32_t sums[1024];
     const uint32_t k = blockIdx.x, t = threadIdx.x, T = blockDim.x;
+    if (clear_flag != nullptr && t == 0) clear_flag[k] = 0;  // the window's long-chain flag (k_fixup_seg raises it)
     const uint32_t *pp = part_pop + (size_t)k * nparts;
     uint32_t *pb = part_base + (size_t)k * (nparts + 1);
     const uint32_t per = (nparts + T - 1) / T;
