@@ -25,7 +25,8 @@ ABI_SYMBOLS = [
     "gmsm_bw6_761_g1_multiexp", "gmsm_bw6_761_g2_multiexp", "gmsm_multiexp", "gmsm_multiexp_affine", "gmsm_fold",
     "gmsm_multiexp_device", "gmsm_bases_register", "gmsm_bases_release", "gmsm_multiexp_bases",
     "gmsm_multiexp_bases_device", "gmsm_multiexp_bases_submit", "gmsm_multiexp_collect", "gmsm_multiexp_bases_batch", "gmsm_default_window_bits", "gmsm_num_windows", "gmsm_window_sums_device",
-    "gmsm_window_sums_enqueue", "gmsm_fold_window_sets", "gmsm_fold_windows", "gmsm_jac_to_affine", "gmsm_affine_limbs", "gmsm_scalar_limbs", "gmsm_debug_decompose",
+    "gmsm_window_sums_enqueue", "gmsm_fold_window_sets", "gmsm_fold_windows", "gmsm_batch_scalar_mul", "gmsm_batch_scalar_mul_device",
+    "gmsm_batch_jac_to_affine", "gmsm_jac_to_affine", "gmsm_affine_limbs", "gmsm_scalar_limbs", "gmsm_debug_decompose",
     "gmsm_debug_field_op", "gmsm_debug_group_op", "gmsm_generate_points", "gmsm_set_profiling", "gmsm_get_stage_times",
     "gmsm_device_count", "gmsm_set_device", "gmsm_last_error",
     "gmsm_version",
@@ -95,6 +96,12 @@ def load():
                                            ctypes.c_uint, vp, vp]
     L.gmsm_fold_window_sets.restype = ctypes.c_int
     L.gmsm_fold_window_sets.argtypes = [ctypes.c_int, ctypes.c_uint, u64p, ctypes.c_uint, u64p]
+    L.gmsm_batch_scalar_mul.restype = ctypes.c_int
+    L.gmsm_batch_scalar_mul.argtypes = [ctypes.c_int, u64p, u64p, sz, u64p]
+    L.gmsm_batch_scalar_mul_device.restype = ctypes.c_int
+    L.gmsm_batch_scalar_mul_device.argtypes = [ctypes.c_int, u64p, vp, sz, vp, vp]
+    L.gmsm_batch_jac_to_affine.restype = ctypes.c_int
+    L.gmsm_batch_jac_to_affine.argtypes = [ctypes.c_int, u64p, sz, u64p]
     L.gmsm_fold_windows.restype = ctypes.c_int
     L.gmsm_fold_windows.argtypes = [ctypes.c_int, ctypes.c_uint, u64p, u64p]
     L.gmsm_jac_to_affine.restype = ctypes.c_int

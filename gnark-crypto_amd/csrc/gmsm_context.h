@@ -269,6 +269,9 @@ struct GroupVTable {
     int (*fold_points)(const uint64_t *points, size_t n, const uint64_t *coeff, int nb_tasks, uint64_t *out_jac);
     int (*multiexp_bases_host)(Context &ctx, const uint64_t *scalars, size_t n, uint64_t *out_jac,
                                const ResidentBases *resident);
+    int (*batch_scalar_mul)(Context &ctx, const uint64_t *base, const uint64_t *scalars, const void *d_scalars, size_t n,
+                            hipStream_t caller_stream, uint64_t *out, void *d_out);
+    int (*batch_jac_to_affine)(Context &ctx, const uint64_t *jac, size_t n, uint64_t *out);
 };
 
 }  // namespace gmsm

@@ -321,6 +321,40 @@ GMSM_EXPORT int gmsm_multiexp_collect(uint64_t ticket, uint64_t *out_jac) {
     return rc;
 }
 
+// ------------------------------------------------------------------ fixed-base batch
+GMSM_EXPORT int gmsm_batch_scalar_mul(int group, const uint64_t *base_affine, const uint64_t *scalars, size_t n,
+                                      uint64_t *out_affine) {
+    VT_OR_FAIL(group);
+    if (!base_affine || (n && (!scalars || !out_affine))) return fail(GMSM_ERR_ARG, "gmsm_batch_scalar_mul: null argument");
+    Context *ctx;
+    int rc = get_context(&ctx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return vt->batch_scalar_mul(*ctx, base_affine, scalars, nullptr, n, nullptr, out_affine, nullptr);
+}
+
+GMSM_EXPORT int gmsm_batch_scalar_mul_device(int group, const uint64_t *base_affine, const void *d_scalars, size_t n,
+                                             void *hip_stream, void *d_out_affine) {
+    VT_OR_FAIL(group);
+    if (!base_affine || (n && (!d_scalars || !d_out_affine)))
+        return fail(GMSM_ERR_ARG, "gmsm_batch_scalar_mul_device: null argument");
+    Context *ctx;
+    int rc = get_context(&ctx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return vt->batch_scalar_mul(*ctx, base_affine, nullptr, d_scalars, n, (hipStream_t)hip_stream, nullptr, d_out_affine);
+}
+
+GMSM_EXPORT int gmsm_batch_jac_to_affine(int group, const uint64_t *jac, size_t n, uint64_t *out_affine) {
+    VT_OR_FAIL(group);
+    if (n && (!jac || !out_affine)) return fail(GMSM_ERR_ARG, "gmsm_batch_jac_to_affine: null argument");
+    Context *ctx;
+    int rc = get_context(&ctx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return vt->batch_jac_to_affine(*ctx, jac, n, out_affine);
+}
+
 GMSM_EXPORT unsigned gmsm_default_window_bits(int group, size_t n) {
     const GroupVTable *vt = vtable(group);
     return vt ? choose_c(vt->fr_bits, n) : 0;

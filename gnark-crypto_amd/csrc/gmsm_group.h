@@ -10,6 +10,7 @@
 
 #include "gmsm_context.h"
 #include "gmsm_kernels.h"
+#include "gmsm_fixedbase.h"
 
 namespace gmsm {
 
@@ -366,6 +367,99 @@ struct Group {
         for (auto &t : th) t.join();
     }
 
+    // ---- N3: fixed-base batch scalar multiplication / batch normalisation (gmsm_fixedbase.h) ----
+    // table[j][d-1] = d * 2^(c*j) * base for every window j and d = 1..nb (host, threads over windows), Go layout.
+    static void build_fixed_base_table(const Aff &base, const WindowPlan &plan, int nthreads, std::vector<Aff> &table) {
+        const uint32_t nwin = plan.nwin_total, nb = plan.nbuckets;
+        table.resize((size_t)nwin * nb);
+        std::vector<Aff> win_base(nwin);  // 2^(c*j) * base
+        {
+            std::vector<Ext> wb(nwin);
+            Ext cur = Ext::infinity();
+            xyzz_add_mixed(cur, base, false);
+            for (uint32_t j = 0; j < nwin; ++j) {
+                wb[j] = cur;
+                for (uint32_t l = 0; l < plan.c; ++l) cur = xyzz_double(cur);
+            }
+            std::vector<F> scr(nwin);
+            batch_to_affine(win_base.data(), wb.data(), nwin, scr.data());
+        }
+        if (nthreads < 1) nthreads = 1;
+        if ((uint32_t)nthreads > nwin) nthreads = (int)nwin;
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; ++t)
+            th.emplace_back([&, t] {
+                std::vector<Ext> row(nb);
+                std::vector<F> scr(nb);
+                for (uint32_t j = (uint32_t)t; j < nwin; j += (uint32_t)nthreads) {
+                    Ext cur = Ext::infinity();
+                    for (uint32_t d = 0; d < nb; ++d) {
+                        xyzz_add_mixed(cur, win_base[j], false);
+                        row[d] = cur;
+                    }
+                    batch_to_affine(table.data() + (size_t)j * nb, row.data(), nb, scr.data());
+                }
+            });
+        for (auto &x : th) x.join();
+    }
+
+    // recs (lazy XYZZ records, n of them, already on the device in ws.buckets) -> d_out affine; K records per thread
+    static int normalize_records(Workspace &ws, size_t n, void *d_out) {
+        int rc;
+        if ((rc = ws.partials.ensure(n * sizeof(U)))) return rc;
+        constexpr int K = 32;
+        const size_t threads = (n + K - 1) / K;
+        hipLaunchKernelGGL((k_batch_normalize<U, INLINE_OPS, K>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, ws.stream,
+                           ws.buckets.ptr, n, (U *)ws.partials.ptr, d_out);
+        HIP_TRY(hipGetLastError());
+        return GMSM_OK;
+    }
+
+    // BatchScalarMultiplicationG1 (g1.go:1039): out[i] = scalars[i] * base, affine. d_scalars/d_out on the device.
+    static int batch_scalar_mul(Context &ctx, Workspace &ws, const uint64_t *base_limbs, const void *d_scalars, size_t n,
+                                void *d_out) {
+        if (n == 0) return GMSM_OK;
+        Aff base;
+        memcpy(&base, base_limbs, sizeof base);
+        if (base.is_infinity()) {
+            HIP_TRY(hipMemsetAsync(d_out, 0, n * AFF_BYTES, ws.stream));
+            return GMSM_OK;
+        }
+        // table size against additions per scalar: 2^7 x 32 windows up to 2^21 scalars, 2^10 x 24 beyond (BN254)
+        const unsigned c = env_uint("GMSM_FB_C", n < ((size_t)1 << 21) ? 8 : 11);
+        if (c < 2 || c > 14) return fail(GMSM_ERR_ARG, "GMSM_FB_C out of range (2..14)");
+        const WindowPlan plan = make_plan(c, 0, 1);
+        std::vector<Aff> table;
+        build_fixed_base_table(base, plan, (int)std::min<unsigned>(16, std::thread::hardware_concurrency()), table);
+        int rc;
+        const size_t tn = table.size();
+        if ((rc = ws.h2d_points.ensure(tn * AFF_BYTES))) return rc;
+        if ((rc = ws.upoints.ensure(tn * AFF_BYTES))) return rc;
+        if ((rc = ws.skip.ensure(tn))) return rc;
+        if ((rc = ws.buckets.ensure(n * sizeof(XYZZL<U>)))) return rc;
+        HIP_TRY(hipMemcpyAsync(ws.h2d_points.ptr, table.data(), tn * AFF_BYTES, hipMemcpyHostToDevice, ws.stream));
+        hipLaunchKernelGGL((k_convert_points<U>), dim3((unsigned)((tn + 255) / 256)), dim3(256), 0, ws.stream,
+                           ws.h2d_points.ptr, tn, ws.upoints.ptr, (uint8_t *)ws.skip.ptr);
+        hipLaunchKernelGGL((k_fixed_base<U, FrP, INLINE_OPS>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ws.stream,
+                           (const uint32_t *)d_scalars, n, plan, ws.upoints.ptr, ws.buckets.ptr);
+        HIP_TRY(hipGetLastError());
+        if ((rc = normalize_records(ws, n, d_out))) return rc;
+        HIP_TRY(hipStreamSynchronize(ws.stream));  // `table` (pageable host memory) must outlive the copy
+        (void)ctx;
+        return GMSM_OK;
+    }
+
+    // BatchJacobianToAffineG1 (g1.go:989): d_jac = n Go-layout Jacobian points on the device -> d_out affine
+    static int batch_jac_to_affine(Workspace &ws, const void *d_jac, size_t n, void *d_out) {
+        if (n == 0) return GMSM_OK;
+        int rc;
+        if ((rc = ws.buckets.ensure(n * sizeof(XYZZL<U>)))) return rc;
+        hipLaunchKernelGGL((k_jac_to_recs<U, INLINE_OPS>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ws.stream, d_jac, n,
+                           ws.buckets.ptr);
+        HIP_TRY(hipGetLastError());
+        return normalize_records(ws, n, d_out);
+    }
+
     // Rewrites n Go-layout bases (device memory) into the lazy domain once; the result serves any number of MultiExp
     // calls over a prefix of the bases (kzg.Commit over pk.G1[:len(p)], ecc/bn254/kzg/kzg.go:159-176).
     static int register_bases(Context &ctx, const void *d_points, size_t n, hipStream_t stream, ResidentBases *out) {
@@ -703,6 +797,42 @@ struct VTableOf {
         memcpy(out_jac, &j, sizeof j);
         return GMSM_OK;
     }
+    // host or device scalars / results; exactly one of each pair is given
+    static int batch_scalar_mul(Context &ctx, const uint64_t *base, const uint64_t *scalars, const void *d_scalars, size_t n,
+                                hipStream_t caller_stream, uint64_t *out, void *d_out) {
+        GMSM_LEASE_OR_FAIL(lease, ctx);
+        Workspace &ws = *lease.w;
+        int rc = order_after(ws, caller_stream);
+        if (rc) return rc;
+        const void *dsc = d_scalars;
+        if (scalars && n) {
+            if ((rc = ws.h2d_scalars.ensure(n * G::SCALAR_BYTES))) return rc;
+            HIP_TRY(hipMemcpyAsync(ws.h2d_scalars.ptr, scalars, n * G::SCALAR_BYTES, hipMemcpyHostToDevice, ws.stream));
+            dsc = ws.h2d_scalars.ptr;
+        }
+        void *dres = d_out;
+        if (out && n) {
+            if ((rc = ws.parted.ensure(n * G::AFF_BYTES))) return rc;
+            dres = ws.parted.ptr;
+        }
+        if ((rc = G::batch_scalar_mul(ctx, ws, base, dsc, n, dres))) return rc;
+        if (out && n) HIP_TRY(hipMemcpyAsync(out, dres, n * G::AFF_BYTES, hipMemcpyDeviceToHost, ws.stream));
+        HIP_TRY(hipStreamSynchronize(ws.stream));
+        return GMSM_OK;
+    }
+    static int batch_jac_to_affine(Context &ctx, const uint64_t *jac, size_t n, uint64_t *out) {
+        if (n == 0) return GMSM_OK;
+        GMSM_LEASE_OR_FAIL(lease, ctx);
+        Workspace &ws = *lease.w;
+        int rc;
+        if ((rc = ws.h2d_points.ensure(n * sizeof(typename G::J)))) return rc;
+        if ((rc = ws.parted.ensure(n * G::AFF_BYTES))) return rc;
+        HIP_TRY(hipMemcpyAsync(ws.h2d_points.ptr, jac, n * sizeof(typename G::J), hipMemcpyHostToDevice, ws.stream));
+        if ((rc = G::batch_jac_to_affine(ws, ws.h2d_points.ptr, n, ws.parted.ptr))) return rc;
+        HIP_TRY(hipMemcpyAsync(out, ws.parted.ptr, n * G::AFF_BYTES, hipMemcpyDeviceToHost, ws.stream));
+        HIP_TRY(hipStreamSynchronize(ws.stream));
+        return GMSM_OK;
+    }
     static int submit(Context &ctx, Workspace &ws, const void *d_scalars, size_t n, const ResidentBases *resident) {
         return G::multiexp_submit(ctx, ws, d_scalars, n, resident);
     }
@@ -770,7 +900,7 @@ struct VTableOf {
         static const GroupVTable vt = {G::FR_BITS,      G::AFF_BYTES,   G::SCALAR_BYTES, sizeof(typename G::J),
                                        sizeof(typename G::Ext), &multiexp_host, &multiexp_device, &window_sums,
                                        &fold,           &jac_to_affine, &debug_decompose, &debug_field_op,
-                                       &debug_group_op, &generate_points, &register_bases, &submit, &collect, &window_sums_enqueue, &fold_sets, &fold_points, &multiexp_bases_host};
+                                       &debug_group_op, &generate_points, &register_bases, &submit, &collect, &window_sums_enqueue, &fold_sets, &fold_points, &multiexp_bases_host, &batch_scalar_mul, &batch_jac_to_affine};
         return &vt;
     }
 };

@@ -130,6 +130,35 @@ class _Group:
         return out
 
     # ---- resident bases (device-resident SRS): register once, then MultiExp over any prefix with scalars only
+    def BatchScalarMultiplication(self, base, scalars):
+        """BatchScalarMultiplicationG1/G2 (ecc/bn254/g1.go:1039): affine scalars[i] * base for every i."""
+        L = _lib.load()
+        base = np.ascontiguousarray(base, dtype=np.uint64).reshape(self.aff_limbs)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, self.fr_limbs)
+        out = np.zeros((scalars.shape[0], self.aff_limbs), dtype=np.uint64)
+        rc = L.gmsm_batch_scalar_mul(self.gid, _ptr(base), _ptr(scalars), scalars.shape[0], _ptr(out))
+        if rc:
+            raise RuntimeError(self._error(rc))
+        return out
+
+    def batch_scalar_mul_device(self, base, d_scalars, n, d_out, stream=0):
+        """Same with scalars and results in device memory (d_out: n affine points, Go layout)."""
+        L = _lib.load()
+        base = np.ascontiguousarray(base, dtype=np.uint64).reshape(self.aff_limbs)
+        rc = L.gmsm_batch_scalar_mul_device(self.gid, _ptr(base), d_scalars, n, stream or None, d_out)
+        if rc:
+            raise RuntimeError(self._error(rc))
+
+    def BatchJacobianToAffine(self, jac_points):
+        """BatchJacobianToAffineG1 (ecc/bn254/g1.go:989): n Jacobian points -> n affine points, Z = 0 -> (0, 0)."""
+        L = _lib.load()
+        jac_points = np.ascontiguousarray(jac_points, dtype=np.uint64).reshape(-1, self.jac_limbs)
+        out = np.zeros((jac_points.shape[0], self.aff_limbs), dtype=np.uint64)
+        rc = L.gmsm_batch_jac_to_affine(self.gid, _ptr(jac_points), jac_points.shape[0], _ptr(out))
+        if rc:
+            raise RuntimeError(self._error(rc))
+        return out
+
     def register_bases(self, points=None, d_points=None, n=None):
         """Upload (host `points`) or adopt (`d_points` device pointer, n points) the bases; returns a ResidentBases."""
         L = _lib.load()

@@ -122,6 +122,18 @@ int gmsm_multiexp_collect(uint64_t ticket, uint64_t *out_jac);
 int gmsm_multiexp_bases_batch(uint64_t handle, const uint64_t *scalars, const void *d_scalars, size_t n, size_t k,
                               void *hip_stream, uint64_t *out_jac);
 
+/* ---- fixed-base batch: BatchScalarMultiplicationG1/G2 (ecc/bn254/g1.go:1039-1118; the step that
+ *      builds an SRS, kzg.NewSRS) and BatchJacobianToAffineG1 (g1.go:989-1035). out[i] = scalars[i] * base in affine
+ *      coordinates (unique, so results are bit-comparable); scalars are Montgomery fr.Element as everywhere else.
+ *      On the device every scalar costs nwin mixed additions from a table of all windows' multiples (no doublings), then
+ *      one shared inversion per 32 results. The _device variant reads d_scalars (produced on hip_stream) and writes
+ *      n Go-layout affine points to d_out_affine; it returns when they are complete. ---- */
+int gmsm_batch_scalar_mul(int group, const uint64_t *base_affine, const uint64_t *scalars, size_t n, uint64_t *out_affine);
+int gmsm_batch_scalar_mul_device(int group, const uint64_t *base_affine, const void *d_scalars, size_t n, void *hip_stream,
+                                 void *d_out_affine);
+/* jac = n x {X, Y, Z} (Go G1Jac/G2Jac layout), Z = 0 -> (0, 0) */
+int gmsm_batch_jac_to_affine(int group, const uint64_t *jac, size_t n, uint64_t *out_affine);
+
 /* ---- window-sharded pieces (multi-GPU: windows win_first, win_first+win_stride, ... of the c-bit decomposition are
  *      handled by this device; the tiny per-window totals are exchanged by the caller, e.g. one RCCL all-gather).
  *      out_xyzz (host) receives nwin_local x {X,Y,ZZ,ZZZ} extended-Jacobian window totals

@@ -587,3 +587,66 @@ def test_concurrent_multiexp_calls(gm, oracle_mod):
     for j in range(3):
         aff, err = results[j]
         assert err is None and (aff == jobs[j][2]).all(), j
+
+
+# ------------------------------------------------------------------ N3: fixed-base batch
+@pytest.mark.parametrize("curve,which", [("bn254", "g1"), ("bn254", "g2"), ("bls12_381", "g1"), ("bls12_381", "g2"),
+                                         ("bw6_761", "g1")])
+def test_batch_scalar_multiplication(gm, oracle_mod, curve, which):
+    """BatchScalarMultiplicationG1/G2 (ecc/bn254/g1.go:1039-1118) on the device: scalars k0 + i*k1 against the oracle's
+    incremental point generator, random and edge scalars (0, 1, 2, r-1, 2^c-1 patterns) against the oracle's
+    double-and-add, a non-generator base, and the point at infinity as base."""
+    g = _group(gm, curve, which)
+    o = oracle_mod.Oracle(curve, which)
+    cv = g.curve
+    n = 3000 if which == "g1" else 700
+    k0, k1 = 0x1234567 + (cv.r >> 3), 0x9e3779b97f4a7c15
+    ks = [(k0 + i * k1) % cv.r for i in range(n)]
+    sc = scalars_from_ints(cv, ks)
+    expected = o.gen_points(n, k0, k1, nthreads=4)
+    got = g.BatchScalarMultiplication(o.generator, sc)
+    assert (got == expected).all()
+    # edge and random scalars on another base
+    base = expected[7]
+    rng = rng_for(41, g.gid)
+    edge = [0, 1, 2, cv.r - 1, cv.r - 2, 255, 256, 127, 128, 129, (1 << 64) - 1, 1 << 64, (1 << 200) + 1]
+    rnd = [int.from_bytes(rng.bytes(48), "little") % cv.r for _ in range(40)]
+    vals = edge + rnd
+    got = g.BatchScalarMultiplication(base, scalars_from_ints(cv, vals))
+    for i, k in enumerate(vals):
+        exp = o.jac_to_affine(o.scalar_mul(base, k)) if k else np.zeros(g.aff_limbs, dtype=np.uint64)
+        assert (got[i] == exp).all(), (i, hex(k))
+    # infinity base, empty batch
+    assert (g.BatchScalarMultiplication(np.zeros(g.aff_limbs, dtype=np.uint64), sc[:10]) == 0).all()
+    assert g.BatchScalarMultiplication(base, sc[:0]).shape == (0, g.aff_limbs)
+
+
+def test_batch_scalar_multiplication_large_table(gm, oracle_mod, monkeypatch):
+    """The larger table (c = 11, chosen from 2^21 scalars on) on a size the oracle checks in seconds."""
+    monkeypatch.setenv("GMSM_FB_C", "11")
+    g = _group(gm, "bn254", "g1")
+    o = oracle_mod.Oracle("bn254", "g1")
+    n = 20000
+    k0, k1 = 77, (1 << 250) + 12345
+    sc = scalars_from_ints(g.curve, [(k0 + i * k1) % g.curve.r for i in range(n)])
+    assert (g.BatchScalarMultiplication(o.generator, sc) == o.gen_points(n, k0, k1, nthreads=4)).all()
+
+
+@pytest.mark.parametrize("curve,which", [("bn254", "g1"), ("bls12_381", "g2"), ("bw6_761", "g1")])
+def test_batch_jacobian_to_affine(gm, oracle_mod, curve, which):
+    """BatchJacobianToAffineG1 (ecc/bn254/g1.go:989-1035): Jacobian points with non-trivial Z (outputs of the oracle's
+    double-and-add), with infinities (Z = 0) sprinkled in, against the oracle's FromJacobian one by one."""
+    g = _group(gm, curve, which)
+    o = oracle_mod.Oracle(curve, which)
+    rng = rng_for(43, g.gid)
+    n = 150
+    jac = np.zeros((n, g.jac_limbs), dtype=np.uint64)
+    for i in range(n):
+        if i % 17 == 5:
+            continue  # infinity: Z = 0 (X, Y arbitrary)
+        jac[i] = o.scalar_mul(o.generator, int.from_bytes(rng.bytes(40), "little") % g.curve.r)
+    jac[5, : g.jac_limbs // 3] = 7  # garbage X with Z = 0 must still give (0, 0)
+    got = g.BatchJacobianToAffine(jac)
+    for i in range(n):
+        assert (got[i] == o.jac_to_affine(jac[i])).all(), i
+    assert g.BatchJacobianToAffine(jac[:0]).shape == (0, g.aff_limbs)
