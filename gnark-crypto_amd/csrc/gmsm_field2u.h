@@ -101,6 +101,9 @@ struct Fp2U {
     FpU<P> a0, a1;
 };
 
+template <class U> struct IsLazyPrimeField { static constexpr bool value = false; };
+template <class P> struct IsLazyPrimeField<FpU<P>> { static constexpr bool value = true; };
+
 // ---- the "lz_" interface the generic group law is written against (both element types) ----
 template <bool INL, class P> GMSM_HD FpU<P> lz_mul(const FpU<P> &a, const FpU<P> &b) { return fmul<INL>(a, b); }
 template <bool INL, class P> GMSM_HD FpU<P> lz_sqr(const FpU<P> &a) { return fsqr<INL>(a); }

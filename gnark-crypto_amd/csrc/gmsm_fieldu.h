@@ -26,6 +26,7 @@ namespace gmsm {
 
 template <class P>
 struct FpU {
+    using Params = P;
     static constexpr int L = P::UL;
     static constexpr int W = P::UW;
     static constexpr uint32_t MASK = (1u << P::UW) - 1u;

@@ -44,6 +44,7 @@ struct Group {
     static_assert(2 * (sizeof(XYZZ<F>) > 256 ? 128 : 256) * sizeof(OpsElem) <= 160 * 1024, "reduction LDS budget");
     static constexpr int RED_TPB = sizeof(XYZZ<F>) > 256 ? 128 : 256;  // 2*TPB*sizeof(Elem) of LDS must fit 160 KiB
     static constexpr int RED2_TPB = 64;
+    static constexpr bool QUAD_REDUCE = IsLazyPrimeField<U>::value && INLINE_OPS;  // BN254 G1, BLS12-381 G1
 
     static WindowPlan make_plan(unsigned c, unsigned win_first, unsigned win_stride) {
         WindowPlan p;
@@ -261,8 +262,21 @@ struct Group {
         const uint32_t prescale = (RED_TPB >= 256 && env_uint("GMSM_PRESCALE", 1)) ? log2span : 0u;
         hipLaunchKernelGGL((k_reduce1<Ops, RED_TPB>), dim3(nblocks1, nw), dim3(RED_TPB), 2 * RED_TPB * sizeof(OpsElem), stream,
                            ws.buckets.ptr, NB, log2L, ws.partials.ptr, reduce_starts, prescale);
-        hipLaunchKernelGGL((k_reduce2<Ops, RED2_TPB>), dim3(nw), dim3(RED2_TPB), 2 * RED2_TPB * sizeof(OpsElem), stream,
-                           ws.partials.ptr, nblocks1, log2span - prescale, ws.totals.ptr);
+        if constexpr (QUAD_REDUCE) {
+            // prime-field groups: level 2 on quads of lanes (4 lanes share the products of one addition)
+            uint32_t active = 2;
+            while (active < nblocks1) active <<= 1;
+            if (env_uint("GMSM_QUAD", 1)) {
+                hipLaunchKernelGGL((k_reduce2_quad<typename U::Params>), dim3(nw), dim3(4 * active), active * sizeof(OpsElem),
+                                   stream, ws.partials.ptr, nblocks1, log2span - prescale, active, ws.totals.ptr);
+            } else {
+                hipLaunchKernelGGL((k_reduce2<Ops, RED2_TPB>), dim3(nw), dim3(RED2_TPB), 2 * RED2_TPB * sizeof(OpsElem), stream,
+                                   ws.partials.ptr, nblocks1, log2span - prescale, ws.totals.ptr);
+            }
+        } else {
+            hipLaunchKernelGGL((k_reduce2<Ops, RED2_TPB>), dim3(nw), dim3(RED2_TPB), 2 * RED2_TPB * sizeof(OpsElem), stream,
+                               ws.partials.ptr, nblocks1, log2span - prescale, ws.totals.ptr);
+        }
         timer.mark(STAGE_END);
         HIP_TRY(hipGetLastError());
         if (d_out)

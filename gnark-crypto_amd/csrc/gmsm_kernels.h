@@ -748,4 +748,114 @@ __global__ void __launch_bounds__(TPB) k_reduce2(const void *__restrict__ in1, u
     if (t == 0) A::store_final(window_totals, k, W_out);
 }
 
+// ------------------------------------------------------------------ lane-cooperative addition (prime-field groups)
+// The latency-bound tail of the bucket reduction runs ONE wave per SIMD whose dependent multiplies cannot hide each
+// other's latency: an XYZZ addition (12 M + 2 S, add-2008-s, g1.go:736-788) takes ~8.6 us there. Its 14 products fall
+// into 4 dependency levels of <= 4 independent products, so 4 adjacent lanes (a "quad") that hold the SAME two
+// operands each compute one product per level and exchange the results with ds_bpermute: 4 multiply-times instead of
+// 14. Same formulas, same operand bounds as add_u (gmsm_curveu.h), squares taken as plain products. All control flow
+// is uniform inside a quad (every lane sees identical data).
+template <class P>
+__device__ __forceinline__ FpU<P> quad_pick(uint32_t r, const FpU<P> &a0, const FpU<P> &a1, const FpU<P> &a2,
+                                            const FpU<P> &a3) {
+    FpU<P> o;
+#pragma unroll
+    for (int i = 0; i < P::UL; ++i) {
+        const uint32_t lo = (r & 1u) ? a1.l[i] : a0.l[i];
+        const uint32_t hi = (r & 1u) ? a3.l[i] : a2.l[i];
+        o.l[i] = (r & 2u) ? hi : lo;
+    }
+    return o;
+}
+template <class P>
+__device__ __forceinline__ void quad_gather(const FpU<P> &mine, uint32_t lane, FpU<P> &g0, FpU<P> &g1, FpU<P> &g2, FpU<P> &g3) {
+    const int base = (int)(lane & ~3u);
+#pragma unroll
+    for (int i = 0; i < P::UL; ++i) {
+        g0.l[i] = (uint32_t)__shfl((int)mine.l[i], base + 0, 64);
+        g1.l[i] = (uint32_t)__shfl((int)mine.l[i], base + 1, 64);
+        g2.l[i] = (uint32_t)__shfl((int)mine.l[i], base + 2, 64);
+        g3.l[i] = (uint32_t)__shfl((int)mine.l[i], base + 3, 64);
+    }
+}
+
+// p += q on a quad; `lane` = lane index inside the wavefront. Every lane of the quad passes the same p, q and gets the
+// same result.
+template <class P>
+__device__ __forceinline__ void add_u_quad(XYZZU<P> &p, bool &pinf, const XYZZU<P> &q, bool qinf, uint32_t lane) {
+    if (qinf) return;
+    if (pinf) {
+        p = q;
+        pinf = false;
+        return;
+    }
+    const uint32_t r = lane & 3u;
+    FpU<P> g0, g1, g2, g3;
+    // level 1: U2 = q.x p.zz, U1 = p.x q.zz, S2 = q.y p.zzz, S1 = p.y q.zzz                     (each < 2)
+    quad_gather(fpu_mul(quad_pick(r, q.x, p.x, q.y, p.y), quad_pick(r, p.zz, q.zz, p.zzz, q.zzz)), lane, g0, g1, g2, g3);
+    const FpU<P> U1 = g1, S1 = g3;
+    const FpU<P> A = fpu_sub<P, 4>(g0, g1);   // < 6
+    const FpU<P> B = fpu_sub<P, 4>(g2, g3);   // < 6
+    // level 2: PP = A^2, BB = B^2, T1 = p.zz q.zz, T2 = p.zzz q.zzz                              (each < 2)
+    quad_gather(fpu_mul(quad_pick(r, A, B, p.zz, p.zzz), quad_pick(r, A, B, q.zz, q.zzz)), lane, g0, g1, g2, g3);
+    const FpU<P> PP = g0, BB = g1, T1 = g2, T2 = g3;
+    if (fpu_prod_is_zero(PP)) {  // same x: P + P or P - P (rare) -> the one-lane code, redundantly on the four lanes
+        add_u<P, false>(p, pinf, q, qinf);
+        return;
+    }
+    // level 3: PPP = A PP, Q = U1 PP, ZZ3 = T1 PP (lane 3 repeats lane 2)
+    quad_gather(fpu_mul(quad_pick(r, A, U1, T1, T1), PP), lane, g0, g1, g2, g3);
+    const FpU<P> PPP = g0, Q = g1, ZZ3 = g2;
+    const FpU<P> X3 = fpu_sub<P, 4>(fpu_sub<P, 4>(BB, PPP), fpu_dbl(Q));  // < 2 + 4 + 4
+    // level 4: V = S1 PPP, ZZZ3 = T2 PPP, Y' = (Q - X3) B (lane 3 repeats lane 0)
+    quad_gather(fpu_mul(quad_pick(r, S1, T2, fpu_sub<P, 16>(Q, X3), S1), quad_pick(r, PPP, PPP, B, PPP)), lane, g0, g1, g2, g3);
+    p.y = fpu_sub<P, 4>(g2, g0);  // < 6
+    p.x = X3;
+    p.zz = ZZ3;
+    p.zzz = g1;
+}
+
+// Level 2 of the bucket reduction on quads (prime-field groups): grid = nwin_local, block = 4 * active threads
+// (active = power of two >= nblocks1, <= 64). Quad j holds level-1 block j: (S_j, W_j), S_j already multiplied by the
+// span when level 1 prescaled it. window_total = sum_j W_j + 2^log2span * sum_{j>=1} Suf_j, Suf = suffix sums of S:
+// suffix scan (log2 active steps), one step W_j + Suf_j, tree (log2 active steps), doublings only if log2span != 0.
+template <class P>
+__global__ void __launch_bounds__(256) k_reduce2_quad(const void *__restrict__ in1, uint32_t nblocks1, uint32_t log2span,
+                                                      uint32_t active, void *__restrict__ window_totals) {
+    using U = FpU<P>;
+    using E = UnsatElem<U>;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    E *lds = reinterpret_cast<E *>(lds_raw);  // [active]
+    const uint32_t k = blockIdx.x, t = threadIdx.x, j = t >> 2, lane = t & 63u;
+    E S = unsat_infinity<U>(), W = unsat_infinity<U>();
+    if (j < nblocks1) {
+        S = unsat_load<U>(in1, ((size_t)k * nblocks1 + j) * 2 + 0);
+        W = unsat_load<U>(in1, ((size_t)k * nblocks1 + j) * 2 + 1);
+    }
+    // inclusive suffix scan of S over the quads
+    for (uint32_t d = 1; d < active; d <<= 1) {
+        if ((t & 3u) == 0) lds[j] = S;
+        __syncthreads();
+        E Y = unsat_infinity<U>();
+        if (j + d < active) Y = lds[j + d];
+        __syncthreads();
+        add_u_quad<P>(S.v, S.inf, Y.v, Y.inf, lane);
+    }
+    // U-part of quad j: Suf_j for j >= 1, scaled by what is left of the span
+    if (j == 0) S = unsat_infinity<U>();
+    for (uint32_t s = 0; s < log2span; ++s)
+        if (!S.inf) S.v = double_u<P, false>(S.v);
+    add_u_quad<P>(W.v, W.inf, S.v, S.inf, lane);
+    // tree over the quads
+    for (uint32_t d = active >> 1; d >= 1; d >>= 1) {
+        if ((t & 3u) == 0) lds[j] = W;
+        __syncthreads();
+        E Y = unsat_infinity<U>();
+        if (j < d) Y = lds[j + d];
+        __syncthreads();
+        add_u_quad<P>(W.v, W.inf, Y.v, Y.inf, lane);
+    }
+    if (t == 0) unsat_store_final<U, false>(window_totals, k, W);
+}
+
 }  // namespace gmsm
