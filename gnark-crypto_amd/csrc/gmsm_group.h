@@ -257,25 +257,28 @@ struct Group {
         if ((rc = ctx.allow_lds((const void *)k_reduce1<Ops, RED_TPB>, (int)(2 * RED_TPB * sizeof(OpsElem))))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_reduce2<Ops, RED2_TPB>, (int)(2 * RED2_TPB * sizeof(OpsElem))))) return rc;
         timer.mark(STAGE_REDUCE);
-        // level 1 doubles its S_blk log2span times in an otherwise idle wave (256-thread blocks only): level 2 then has no
-        // serial doubling tail (11 of its 20 steps at c = 16)
-        const uint32_t prescale = (RED_TPB >= 256 && env_uint("GMSM_PRESCALE", 1)) ? log2span : 0u;
-        hipLaunchKernelGGL((k_reduce1<Ops, RED_TPB>), dim3(nblocks1, nw), dim3(RED_TPB), 2 * RED_TPB * sizeof(OpsElem), stream,
-                           ws.buckets.ptr, NB, log2L, ws.partials.ptr, reduce_starts, prescale);
-        if constexpr (QUAD_REDUCE) {
-            // prime-field groups: level 2 on quads of lanes (4 lanes share the products of one addition)
-            uint32_t active = 2;
-            while (active < nblocks1) active <<= 1;
-            if (env_uint("GMSM_QUAD", 1)) {
-                hipLaunchKernelGGL((k_reduce2_quad<typename U::Params>), dim3(nw), dim3(4 * active), active * sizeof(OpsElem),
-                                   stream, ws.partials.ptr, nblocks1, log2span - prescale, active, ws.totals.ptr);
-            } else {
+        {
+            // level 1 doubles its S_blk log2span times in an otherwise idle wave (256-thread blocks only): level 2 then has
+            // no serial doubling tail (11 of its 20 steps at c = 16)
+            const uint32_t prescale = (RED_TPB >= 256 && env_uint("GMSM_PRESCALE", 1)) ? log2span : 0u;
+            hipLaunchKernelGGL((k_reduce1<Ops, RED_TPB>), dim3(nblocks1, nw), dim3(RED_TPB), 2 * RED_TPB * sizeof(OpsElem), stream,
+                               ws.buckets.ptr, NB, log2L, ws.partials.ptr, reduce_starts, prescale);
+            bool l2 = false;
+            if constexpr (QUAD_REDUCE) {
+                // prime-field groups: level 2 on quads of lanes (4 lanes share the products of one addition). Level 1 stays
+                // on single lanes: a quad version needs 4x the lanes at ~230 VGPRs each, i.e. several rounds of
+                // workgroups per CU - measured 0.57 ms against 0.37 ms.
+                if (env_uint("GMSM_QUAD", 1) >= 1) {
+                    uint32_t active = 2;
+                    while (active < nblocks1) active <<= 1;
+                    hipLaunchKernelGGL((k_reduce2_quad<typename U::Params>), dim3(nw), dim3(4 * active), active * sizeof(OpsElem),
+                                       stream, ws.partials.ptr, nblocks1, log2span - prescale, active, ws.totals.ptr);
+                    l2 = true;
+                }
+            }
+            if (!l2)
                 hipLaunchKernelGGL((k_reduce2<Ops, RED2_TPB>), dim3(nw), dim3(RED2_TPB), 2 * RED2_TPB * sizeof(OpsElem), stream,
                                    ws.partials.ptr, nblocks1, log2span - prescale, ws.totals.ptr);
-            }
-        } else {
-            hipLaunchKernelGGL((k_reduce2<Ops, RED2_TPB>), dim3(nw), dim3(RED2_TPB), 2 * RED2_TPB * sizeof(OpsElem), stream,
-                               ws.partials.ptr, nblocks1, log2span - prescale, ws.totals.ptr);
         }
         timer.mark(STAGE_END);
         HIP_TRY(hipGetLastError());
