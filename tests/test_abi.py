@@ -90,3 +90,27 @@ def test_generate_points_matches_oracle(gm, oracle_mod, curve, which):
     a = g.generate_points(2500, 0xABCDEF, 0x1234567, nthreads=3)
     b = o.gen_points(2500, 0xABCDEF, 0x1234567, nthreads=2)
     assert (a == b).all()
+
+
+def test_c_client_links_and_fails_loudly_without_a_gpu(gm, tmp_path):
+    """The plain-C client of include/gmsm.h (tests/c/abi_client.c, the stand-in for the cgo stub) compiles as C, links
+    against libgmsm.so alone and - on a machine without a HIP device - gets GMSM_ERR_DEVICE with the no-fallback message
+    instead of a CPU result."""
+    import os
+    import subprocess
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "gnark-crypto_amd", "csrc")
+    exe = str(tmp_path / "abi_client")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-O1", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c", "abi_client.c"), "-o", exe, "-L", libdir, "-lgmsm",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the functional run of the client is tests/test_gpu_parity.py::test_c_client_through_the_abi")
+    fin = str(tmp_path / "in.bin")
+    with open(fin, "wb") as f:
+        np.array([2, 8, 4], dtype=np.uint64).tofile(f)
+        np.zeros(2 * 8 + 2 * 4, dtype=np.uint64).tofile(f)
+    r = subprocess.run([exe, "0", fin, str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1, (r.returncode, r.stderr)
+    assert "no CPU fallback" in r.stderr

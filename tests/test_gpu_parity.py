@@ -650,3 +650,39 @@ def test_batch_jacobian_to_affine(gm, oracle_mod, curve, which):
     for i in range(n):
         assert (got[i] == o.jac_to_affine(jac[i])).all(), i
     assert g.BatchJacobianToAffine(jac[:0]).shape == (0, g.aff_limbs)
+
+
+# ------------------------------------------------------------------ the boundary from plain C (what cgo would bind)
+@pytest.mark.parametrize("curve,which", [("bn254", "g1"), ("bls12_381", "g2"), ("bw6_761", "g1")])
+def test_c_client_through_the_abi(gm, oracle_mod, curve, which, tmp_path):
+    """tests/c/abi_client.c is compiled with gcc against include/gmsm.h and linked to libgmsm.so only - no Python, no torch
+    in the process: the per-curve drop-in symbol, gmsm_multiexp_affine and the registered-bases entry must all return the
+    oracle's affine point; the two argument errors must come back as the documented codes."""
+    import os
+    import subprocess
+    g = _group(gm, curve, which)
+    o = oracle_mod.Oracle(curve, which)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "gnark-crypto_amd", "csrc")
+    exe = str(tmp_path / "abi_client")
+    subprocess.run(["gcc", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", "abi_client.c"), "-o", exe,
+                    "-L", libdir, "-lgmsm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    n = 2500
+    rng = rng_for(51, g.gid)
+    pts = o.gen_points(n, 4711, 3, nthreads=4)
+    pts[100] = 0
+    sc = random_scalars(rng, g.curve, n)
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        np.array([n, g.aff_limbs, g.fr_limbs], dtype=np.uint64).tofile(f)
+        pts.tofile(f)
+        sc.tofile(f)
+    env = dict(os.environ)
+    env.pop("GMSM_LIB", None)
+    r = subprocess.run([exe, str(g.gid), fin, fout], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stderr)
+    out = np.fromfile(fout, dtype=np.uint64)
+    expected = o.msm_affine(pts, sc, nthreads=4)
+    for i in range(3):
+        assert (out[i * g.aff_limbs:(i + 1) * g.aff_limbs] == expected).all(), i
+    assert out[3 * g.aff_limbs] == gm._lib.GMSM_ERR_LEN and out[3 * g.aff_limbs + 1] == gm._lib.GMSM_ERR_CONFIG
