@@ -44,7 +44,7 @@ struct Group {
     static_assert(2 * (sizeof(XYZZ<F>) > 256 ? 128 : 256) * sizeof(OpsElem) <= 160 * 1024, "reduction LDS budget");
     static constexpr int RED_TPB = sizeof(XYZZ<F>) > 256 ? 128 : 256;  // 2*TPB*sizeof(Elem) of LDS must fit 160 KiB
     static constexpr int RED2_TPB = 64;
-    static constexpr bool QUAD_REDUCE = IsLazyPrimeField<U>::value && INLINE_OPS;  // BN254 G1, BLS12-381 G1
+    static constexpr bool QUAD_REDUCE = true;  // level 2 of the reduction on lane quads (GMSM_QUAD=0 switches it off)
 
     static WindowPlan make_plan(unsigned c, unsigned win_first, unsigned win_stride) {
         WindowPlan p;
@@ -265,13 +265,13 @@ struct Group {
                                ws.buckets.ptr, NB, log2L, ws.partials.ptr, reduce_starts, prescale);
             bool l2 = false;
             if constexpr (QUAD_REDUCE) {
-                // prime-field groups: level 2 on quads of lanes (4 lanes share the products of one addition). Level 1 stays
+                // level 2 on quads of lanes (4 lanes share the products of one addition). Level 1 stays
                 // on single lanes: a quad version needs 4x the lanes at ~230 VGPRs each, i.e. several rounds of
                 // workgroups per CU - measured 0.57 ms against 0.37 ms.
                 if (env_uint("GMSM_QUAD", 1) >= 1) {
                     uint32_t active = 2;
                     while (active < nblocks1) active <<= 1;
-                    hipLaunchKernelGGL((k_reduce2_quad<typename U::Params>), dim3(nw), dim3(4 * active), active * sizeof(OpsElem),
+                    hipLaunchKernelGGL((k_reduce2_quad<U, INLINE_OPS>), dim3(nw), dim3(4 * active), active * sizeof(OpsElem),
                                        stream, ws.partials.ptr, nblocks1, log2span - prescale, active, ws.totals.ptr);
                     l2 = true;
                 }

@@ -748,13 +748,13 @@ __global__ void __launch_bounds__(TPB) k_reduce2(const void *__restrict__ in1, u
     if (t == 0) A::store_final(window_totals, k, W_out);
 }
 
-// ------------------------------------------------------------------ lane-cooperative addition (prime-field groups)
+// ------------------------------------------------------------------ lane-cooperative addition
 // The latency-bound tail of the bucket reduction runs ONE wave per SIMD whose dependent multiplies cannot hide each
-// other's latency: an XYZZ addition (12 M + 2 S, add-2008-s, g1.go:736-788) takes ~8.6 us there. Its 14 products fall
-// into 4 dependency levels of <= 4 independent products, so 4 adjacent lanes (a "quad") that hold the SAME two
-// operands each compute one product per level and exchange the results with ds_bpermute: 4 multiply-times instead of
-// 14. Same formulas, same operand bounds as add_u (gmsm_curveu.h), squares taken as plain products. All control flow
-// is uniform inside a quad (every lane sees identical data).
+// other's latency: an XYZZ addition (12 M + 2 S, add-2008-s, g1.go:736-788) takes ~8.6 us there for BN254 G1 and ~50 us
+// over Fp2. Its 14 products fall into 4 dependency levels of <= 4 independent products, so 4 adjacent lanes (a "quad")
+// that hold the SAME two operands each compute one product per level and exchange the results with ds_bpermute: 4
+// multiply-times instead of 14. Same formulas and operand classes as add_u / add_g (gmsm_curveu.h), squares taken as
+// plain products. All control flow is uniform inside a quad (every lane sees identical data).
 template <class P>
 __device__ __forceinline__ FpU<P> quad_pick(uint32_t r, const FpU<P> &a0, const FpU<P> &a1, const FpU<P> &a2,
                                             const FpU<P> &a3) {
@@ -768,6 +768,11 @@ __device__ __forceinline__ FpU<P> quad_pick(uint32_t r, const FpU<P> &a0, const 
     return o;
 }
 template <class P>
+__device__ __forceinline__ Fp2U<P> quad_pick(uint32_t r, const Fp2U<P> &a0, const Fp2U<P> &a1, const Fp2U<P> &a2,
+                                             const Fp2U<P> &a3) {
+    return Fp2U<P>{quad_pick(r, a0.a0, a1.a0, a2.a0, a3.a0), quad_pick(r, a0.a1, a1.a1, a2.a1, a3.a1)};
+}
+template <class P>
 __device__ __forceinline__ void quad_gather(const FpU<P> &mine, uint32_t lane, FpU<P> &g0, FpU<P> &g1, FpU<P> &g2, FpU<P> &g3) {
     const int base = (int)(lane & ~3u);
 #pragma unroll
@@ -778,11 +783,17 @@ __device__ __forceinline__ void quad_gather(const FpU<P> &mine, uint32_t lane, F
         g3.l[i] = (uint32_t)__shfl((int)mine.l[i], base + 3, 64);
     }
 }
+template <class P>
+__device__ __forceinline__ void quad_gather(const Fp2U<P> &mine, uint32_t lane, Fp2U<P> &g0, Fp2U<P> &g1, Fp2U<P> &g2,
+                                            Fp2U<P> &g3) {
+    quad_gather(mine.a0, lane, g0.a0, g1.a0, g2.a0, g3.a0);
+    quad_gather(mine.a1, lane, g0.a1, g1.a1, g2.a1, g3.a1);
+}
 
 // p += q on a quad; `lane` = lane index inside the wavefront. Every lane of the quad passes the same p, q and gets the
-// same result.
-template <class P>
-__device__ __forceinline__ void add_u_quad(XYZZU<P> &p, bool &pinf, const XYZZU<P> &q, bool qinf, uint32_t lane) {
+// same result. Prime field: the bound-tracked formulas of add_u.
+template <bool INL, class P>
+__device__ __forceinline__ void lz_padd_quad(XYZZL<FpU<P>> &p, bool &pinf, const XYZZL<FpU<P>> &q, bool qinf, uint32_t lane) {
     if (qinf) return;
     if (pinf) {
         p = q;
@@ -792,37 +803,105 @@ __device__ __forceinline__ void add_u_quad(XYZZU<P> &p, bool &pinf, const XYZZU<
     const uint32_t r = lane & 3u;
     FpU<P> g0, g1, g2, g3;
     // level 1: U2 = q.x p.zz, U1 = p.x q.zz, S2 = q.y p.zzz, S1 = p.y q.zzz                     (each < 2)
-    quad_gather(fpu_mul(quad_pick(r, q.x, p.x, q.y, p.y), quad_pick(r, p.zz, q.zz, p.zzz, q.zzz)), lane, g0, g1, g2, g3);
+    quad_gather(fmul<INL>(quad_pick(r, q.x, p.x, q.y, p.y), quad_pick(r, p.zz, q.zz, p.zzz, q.zzz)), lane, g0, g1, g2, g3);
     const FpU<P> U1 = g1, S1 = g3;
     const FpU<P> A = fpu_sub<P, 4>(g0, g1);   // < 6
     const FpU<P> B = fpu_sub<P, 4>(g2, g3);   // < 6
     // level 2: PP = A^2, BB = B^2, T1 = p.zz q.zz, T2 = p.zzz q.zzz                              (each < 2)
-    quad_gather(fpu_mul(quad_pick(r, A, B, p.zz, p.zzz), quad_pick(r, A, B, q.zz, q.zzz)), lane, g0, g1, g2, g3);
+    quad_gather(fmul<INL>(quad_pick(r, A, B, p.zz, p.zzz), quad_pick(r, A, B, q.zz, q.zzz)), lane, g0, g1, g2, g3);
     const FpU<P> PP = g0, BB = g1, T1 = g2, T2 = g3;
     if (fpu_prod_is_zero(PP)) {  // same x: P + P or P - P (rare) -> the one-lane code, redundantly on the four lanes
         add_u<P, false>(p, pinf, q, qinf);
         return;
     }
     // level 3: PPP = A PP, Q = U1 PP, ZZ3 = T1 PP (lane 3 repeats lane 2)
-    quad_gather(fpu_mul(quad_pick(r, A, U1, T1, T1), PP), lane, g0, g1, g2, g3);
+    quad_gather(fmul<INL>(quad_pick(r, A, U1, T1, T1), PP), lane, g0, g1, g2, g3);
     const FpU<P> PPP = g0, Q = g1, ZZ3 = g2;
     const FpU<P> X3 = fpu_sub<P, 4>(fpu_sub<P, 4>(BB, PPP), fpu_dbl(Q));  // < 2 + 4 + 4
     // level 4: V = S1 PPP, ZZZ3 = T2 PPP, Y' = (Q - X3) B (lane 3 repeats lane 0)
-    quad_gather(fpu_mul(quad_pick(r, S1, T2, fpu_sub<P, 16>(Q, X3), S1), quad_pick(r, PPP, PPP, B, PPP)), lane, g0, g1, g2, g3);
+    quad_gather(fmul<INL>(quad_pick(r, S1, T2, fpu_sub<P, 16>(Q, X3), S1), quad_pick(r, PPP, PPP, B, PPP)), lane, g0, g1, g2, g3);
     p.y = fpu_sub<P, 4>(g2, g0);  // < 6
     p.x = X3;
     p.zz = ZZ3;
     p.zzz = g1;
 }
+// Fp2 (reduced class [0,4q)): the formulas of add_g.
+template <bool INL, class P>
+__device__ __forceinline__ void lz_padd_quad(XYZZL<Fp2U<P>> &p, bool &pinf, const XYZZL<Fp2U<P>> &q, bool qinf, uint32_t lane) {
+    using U = Fp2U<P>;
+    if (qinf) return;
+    if (pinf) {
+        p = q;
+        pinf = false;
+        return;
+    }
+    const uint32_t r = lane & 3u;
+    U g0, g1, g2, g3;
+    quad_gather(lz_mul<INL>(quad_pick(r, q.x, p.x, q.y, p.y), quad_pick(r, p.zz, q.zz, p.zzz, q.zzz)), lane, g0, g1, g2, g3);
+    const U U1 = g1, S1 = g3;
+    const U A = lz_sub(g0, g1), B = lz_sub(g2, g3);
+    if (lz_is_zero(A)) {
+        add_g<U, false>(p, pinf, q, qinf);
+        return;
+    }
+    quad_gather(lz_mul<INL>(quad_pick(r, A, B, p.zz, p.zzz), quad_pick(r, A, B, q.zz, q.zzz)), lane, g0, g1, g2, g3);
+    const U PP = g0, BB = g1, T1 = g2, T2 = g3;
+    quad_gather(lz_mul<INL>(quad_pick(r, A, U1, T1, T1), PP), lane, g0, g1, g2, g3);
+    const U PPP = g0, Q = g1, ZZ3 = g2;
+    const U X3 = lz_sub(lz_sub(BB, PPP), lz_dbl(Q));
+    quad_gather(lz_mul<INL>(quad_pick(r, S1, T2, lz_sub(Q, X3), S1), quad_pick(r, PPP, PPP, B, PPP)), lane, g0, g1, g2, g3);
+    p.y = lz_sub(g2, g0);
+    p.x = X3;
+    p.zz = ZZ3;
+    p.zzz = g1;
+}
 
-// Level 2 of the bucket reduction on quads (prime-field groups): grid = nwin_local, block = 4 * active threads
-// (active = power of two >= nblocks1, <= 64). Quad j holds level-1 block j: (S_j, W_j), S_j already multiplied by the
-// span when level 1 prescaled it. window_total = sum_j W_j + 2^log2span * sum_{j>=1} Suf_j, Suf = suffix sums of S:
-// suffix scan (log2 active steps), one step W_j + Suf_j, tree (log2 active steps), doublings only if log2span != 0.
-template <class P>
+// r = [2]q on a quad (dbl-2008-s-1, a = 0; same operands as double_u / double_g): 9 products in 3 levels.
+template <bool INL, class P>
+__device__ __forceinline__ XYZZL<FpU<P>> lz_pdbl_quad(const XYZZL<FpU<P>> &q, uint32_t lane) {
+    const uint32_t r = lane & 3u;
+    FpU<P> g0, g1, g2, g3;
+    const FpU<P> Uy = fpu_dbl(q.y);  // < 14
+    quad_gather(fmul<INL>(quad_pick(r, Uy, q.x, Uy, q.x), quad_pick(r, Uy, q.x, Uy, q.x)), lane, g0, g1, g2, g3);  // V, XX
+    const FpU<P> V = g0, XX = g1;
+    const FpU<P> M = fpu_add(fpu_add(XX, XX), XX);  // < 6
+    quad_gather(fmul<INL>(quad_pick(r, Uy, q.x, V, M), quad_pick(r, V, V, q.zz, M)), lane, g0, g1, g2, g3);  // W, S, ZZ3, M^2
+    const FpU<P> W = g0, S = g1, ZZ3 = g2;
+    XYZZL<FpU<P>> o;
+    o.x = fpu_sub<P, 4>(g3, fpu_dbl(S));  // < 6
+    quad_gather(fmul<INL>(quad_pick(r, W, W, fpu_sub<P, 16>(S, o.x), W), quad_pick(r, q.y, q.zzz, M, q.y)), lane, g0, g1, g2, g3);
+    o.y = fpu_sub<P, 4>(g2, g0);  // < 6
+    o.zz = ZZ3;
+    o.zzz = g1;
+    return o;
+}
+template <bool INL, class P>
+__device__ __forceinline__ XYZZL<Fp2U<P>> lz_pdbl_quad(const XYZZL<Fp2U<P>> &q, uint32_t lane) {
+    using U = Fp2U<P>;
+    const uint32_t r = lane & 3u;
+    U g0, g1, g2, g3;
+    const U Uy = lz_dbl(q.y);
+    quad_gather(lz_mul<INL>(quad_pick(r, Uy, q.x, Uy, q.x), quad_pick(r, Uy, q.x, Uy, q.x)), lane, g0, g1, g2, g3);
+    const U V = g0, XX = g1;
+    const U M = lz_add(lz_dbl(XX), XX);
+    quad_gather(lz_mul<INL>(quad_pick(r, Uy, q.x, V, M), quad_pick(r, V, V, q.zz, M)), lane, g0, g1, g2, g3);
+    const U W = g0, S = g1, ZZ3 = g2;
+    XYZZL<U> o;
+    o.x = lz_sub(g3, lz_dbl(S));
+    quad_gather(lz_mul<INL>(quad_pick(r, W, W, lz_sub(S, o.x), W), quad_pick(r, q.y, q.zzz, M, q.y)), lane, g0, g1, g2, g3);
+    o.y = lz_sub(g2, g0);
+    o.zz = ZZ3;
+    o.zzz = g1;
+    return o;
+}
+
+// Level 2 of the bucket reduction on quads: grid = nwin_local, block = 4 * active threads (active = power of two >=
+// nblocks1, <= 64). Quad j holds level-1 block j: (S_j, W_j), S_j already multiplied by the span when level 1 prescaled
+// it. window_total = sum_j W_j + 2^log2span * sum_{j>=1} Suf_j, Suf = suffix sums of S: suffix scan (log2 active quad
+// steps), quad doublings only if log2span != 0, one step W_j + Suf_j, tree (log2 active steps).
+template <class U, bool INL>
 __global__ void __launch_bounds__(256) k_reduce2_quad(const void *__restrict__ in1, uint32_t nblocks1, uint32_t log2span,
                                                       uint32_t active, void *__restrict__ window_totals) {
-    using U = FpU<P>;
     using E = UnsatElem<U>;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     E *lds = reinterpret_cast<E *>(lds_raw);  // [active]
@@ -833,27 +912,30 @@ __global__ void __launch_bounds__(256) k_reduce2_quad(const void *__restrict__ i
         W = unsat_load<U>(in1, ((size_t)k * nblocks1 + j) * 2 + 1);
     }
     // inclusive suffix scan of S over the quads
+#pragma nounroll
     for (uint32_t d = 1; d < active; d <<= 1) {
         if ((t & 3u) == 0) lds[j] = S;
         __syncthreads();
         E Y = unsat_infinity<U>();
         if (j + d < active) Y = lds[j + d];
         __syncthreads();
-        add_u_quad<P>(S.v, S.inf, Y.v, Y.inf, lane);
+        lz_padd_quad<INL>(S.v, S.inf, Y.v, Y.inf, lane);
     }
     // U-part of quad j: Suf_j for j >= 1, scaled by what is left of the span
     if (j == 0) S = unsat_infinity<U>();
+#pragma nounroll
     for (uint32_t s = 0; s < log2span; ++s)
-        if (!S.inf) S.v = double_u<P, false>(S.v);
-    add_u_quad<P>(W.v, W.inf, S.v, S.inf, lane);
+        if (!S.inf) S.v = lz_pdbl_quad<INL>(S.v, lane);
+    lz_padd_quad<INL>(W.v, W.inf, S.v, S.inf, lane);
     // tree over the quads
+#pragma nounroll
     for (uint32_t d = active >> 1; d >= 1; d >>= 1) {
         if ((t & 3u) == 0) lds[j] = W;
         __syncthreads();
         E Y = unsat_infinity<U>();
         if (j < d) Y = lds[j + d];
         __syncthreads();
-        add_u_quad<P>(W.v, W.inf, Y.v, Y.inf, lane);
+        lz_padd_quad<INL>(W.v, W.inf, Y.v, Y.inf, lane);
     }
     if (t == 0) unsat_store_final<U, false>(window_totals, k, W);
 }
