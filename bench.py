@@ -272,6 +272,10 @@ def main():
             "int_roofline": {"achieved_mulmod_per_s": mulmods_per_s, "peak_mulmod_per_s": int_peak,
                              "measured_peak_mulmod_per_s": 174e9, "frac": mulmods_per_s / int_peak},
         }
+        if sharded:
+            # the sharded result against the same MultiExp computed by this rank alone (after the timed region)
+            single = g.multiexp_device(d_pts.data_ptr(), d_sc.data_ptr(), n, stream)
+            out["equal_to_single_gpu_result"] = bool((g.jac_to_affine(single) == g.jac_to_affine(jac)).all())
         if world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline(g, pts, sc, jac, args.curve, args.group))
         print(json.dumps(out), flush=True)
