@@ -589,6 +589,118 @@ def test_concurrent_multiexp_calls(gm, oracle_mod):
         assert err is None and (aff == jobs[j][2]).all(), j
 
 
+def test_mixed_entries_from_many_threads(gm, oracle_mod):
+    """Five OS threads hammer one device at once through DIFFERENT entries and groups - host-pointer MultiExp (BN254 G1),
+    registered bases with host scalars (BLS12-381 G1), the device entry (BN254 G2), a submit/collect pipeline and the
+    fixed-base batch - while another thread toggles the stage profiler. Two workspaces are shared by all of them (leases);
+    every single result must be the oracle's."""
+    import threading
+    import torch
+    errors = []
+    lib = gm._lib.load()
+
+    def check(name, got, want):
+        if not (np.asarray(got) == np.asarray(want)).all():
+            errors.append(name)
+
+    def host_g1():
+        g, o = gm.G1Affine("bn254"), oracle_mod.Oracle("bn254", "g1")
+        for it in range(6):
+            n = 1500 + 700 * it
+            pts = o.gen_points(n, 11 + it, 3)
+            sc = random_scalars(rng_for(61, it), g.curve, n)
+            aff, err = g.MultiExp(pts, sc)
+            if err is not None:
+                errors.append("host_g1 " + err)
+            else:
+                check(f"host_g1 {it}", aff, o.msm_affine(pts, sc))
+
+    def resident_bls():
+        g, o = gm.G1Affine("bls12_381"), oracle_mod.Oracle("bls12_381", "g1")
+        pts = o.gen_points(4000, 5, 9)
+        rb = g.register_bases(points=pts)
+        try:
+            for it in range(6):
+                m = 4000 - 555 * it
+                sc = random_scalars(rng_for(62, it), g.curve, m)
+                jac, err = rb.MultiExp(sc)
+                if err is not None:
+                    errors.append("resident_bls " + err)
+                else:
+                    check(f"resident_bls {it}", g.jac_to_affine(jac), o.msm_affine(pts[:m], sc))
+        finally:
+            rb.release()
+
+    def device_g2():
+        g, o = gm.G2Affine("bn254"), oracle_mod.Oracle("bn254", "g2")
+        n = 1200
+        pts = o.gen_points(n, 21, 4)
+        d_pts = torch.from_numpy(pts.view(np.int64)).cuda()
+        for it in range(5):
+            sc = random_scalars(rng_for(63, it), g.curve, n)
+            d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+            torch.cuda.synchronize()
+            jac = g.multiexp_device(d_pts.data_ptr(), d_sc.data_ptr(), n)
+            check(f"device_g2 {it}", g.jac_to_affine(jac), o.msm_affine(pts, sc))
+
+    def pipeline_g1():
+        g, o = gm.G1Affine("bn254"), oracle_mod.Oracle("bn254", "g1")
+        n = 5000
+        pts = o.gen_points(n, 31, 7)
+        rb = g.register_bases(points=pts)
+        try:
+            scs = [random_scalars(rng_for(64, it), g.curve, n) for it in range(6)]
+            d = [torch.from_numpy(sc.view(np.int64)).cuda() for sc in scs]
+            torch.cuda.synchronize()
+            prev, got = None, []
+            for it in range(6):
+                while True:  # both workspaces may be leased by the other threads for a moment
+                    try:
+                        t = rb.submit(d[it].data_ptr(), n)
+                        break
+                    except RuntimeError:
+                        if prev is not None:
+                            got.append(rb.collect(prev))
+                            prev = None
+                if prev is not None:
+                    got.append(rb.collect(prev))
+                prev = t
+            got.append(rb.collect(prev))
+            for it, jac in enumerate(got):
+                check(f"pipeline_g1 {it}", g.jac_to_affine(jac), o.msm_affine(pts, scs[it]))
+        finally:
+            rb.release()
+
+    def fixed_base():
+        g, o = gm.G1Affine("bn254"), oracle_mod.Oracle("bn254", "g1")
+        for it in range(4):
+            n = 800 + 100 * it
+            sc = scalars_from_ints(g.curve, [(5 + it + i * 977) % g.curve.r for i in range(n)])
+            check(f"fixed_base {it}", g.BatchScalarMultiplication(o.generator, sc), o.gen_points(n, 5 + it, 977))
+
+    stop = threading.Event()
+
+    def profiler():
+        while not stop.is_set():
+            lib.gmsm_set_profiling(1)
+            stop.wait(0.01)
+            lib.gmsm_set_profiling(0)
+            stop.wait(0.01)
+
+    workers = [threading.Thread(target=f) for f in (host_g1, resident_bls, device_g2, pipeline_g1, fixed_base)]
+    prof = threading.Thread(target=profiler)
+    prof.start()
+    for t in workers:
+        t.start()
+    for t in workers:
+        t.join(timeout=600)
+    stop.set()
+    prof.join()
+    lib.gmsm_set_profiling(0)
+    assert not any(t.is_alive() for t in workers), "a worker thread is stuck"
+    assert errors == [], errors
+
+
 # ------------------------------------------------------------------ N3: fixed-base batch
 @pytest.mark.parametrize("curve,which", [("bn254", "g1"), ("bn254", "g2"), ("bls12_381", "g1"), ("bls12_381", "g2"),
                                          ("bw6_761", "g1")])
