@@ -4,11 +4,19 @@
 
 namespace gmsm {
 
+// Error text: per thread (like errno), plus the most recent one of the process - a cgo caller's goroutine may be moved to
+// another OS thread between the failing call and gmsm_last_error().
 static thread_local std::string g_last_error;
+static std::mutex g_any_error_mu;
+static std::string g_any_error;
 static thread_local int g_device = 0;
 
 int fail(int code, const std::string &msg) {
     g_last_error = msg;
+    {
+        std::lock_guard<std::mutex> lk(g_any_error_mu);
+        g_any_error = msg;
+    }
     return code;
 }
 
@@ -485,7 +493,13 @@ GMSM_EXPORT int gmsm_set_device(int device) {
     return GMSM_OK;
 }
 
-GMSM_EXPORT const char *gmsm_last_error(void) { return g_last_error.c_str(); }
+GMSM_EXPORT const char *gmsm_last_error(void) {
+    if (g_last_error.empty()) {  // this thread never failed: hand out the process-wide text (copied, so it stays valid)
+        std::lock_guard<std::mutex> lk(g_any_error_mu);
+        g_last_error = g_any_error;
+    }
+    return g_last_error.c_str();
+}
 GMSM_EXPORT const char *gmsm_version(void) { return "gmsm 0.1 (gfx950)"; }
 
 }  // extern "C"

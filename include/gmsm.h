@@ -186,7 +186,9 @@ int gmsm_get_stage_times(double *out_ms, int max_stages, unsigned long *out_call
 
 int gmsm_device_count(void);
 int gmsm_set_device(int device);          /* device used by subsequent calls of this thread (default 0) */
-const char *gmsm_last_error(void);        /* thread-local text of the last failure */
+/* text of the calling thread's last failure; a thread that never failed gets the most recent failure of the process
+ * (a cgo caller may be rescheduled onto another OS thread between the failing call and this one) */
+const char *gmsm_last_error(void);
 const char *gmsm_version(void);
 
 #ifdef __cplusplus
