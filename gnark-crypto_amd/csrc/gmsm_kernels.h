@@ -500,17 +500,26 @@ __global__ void __launch_bounds__(256) k_fixup_seg(uint32_t nbuckets, const void
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
     if (t >= threads_per_win) return;
     const size_t base = (size_t)k * threads_per_win;
-    if (!(pflags[base + t] & SegFlags::HAS_P1)) return;
+    // The usual chain is P1[t] + P0[t+1]: fetch all of it (and the destination) before looking at any flag, so that the
+    // four dependent memory round trips of the straightforward walk overlap.
+    const uint32_t f0 = pflags[base + t];
+    const bool has_next = t + 1 < threads_per_win;
+    uint32_t f = has_next ? pflags[base + t + 1] : 0u;
     typename A::Elem acc = A::load(partials, (base + t) * 2 + 1);
+    typename A::Elem q = A::load(partials, (base + (has_next ? t + 1 : t)) * 2 + 0);
+    const uint32_t dest = pbucket[base + t];
+    if (!(f0 & SegFlags::HAS_P1)) return;
     bool closed = false;
     for (uint32_t u = t + 1; u < threads_per_win && u <= t + MAXWALK; ++u) {
-        const uint32_t f = pflags[base + u];
+        if (u != t + 1) {
+            f = pflags[base + u];
+            if (f & SegFlags::HAS_P0) q = A::load(partials, (base + u) * 2 + 0);
+        }
         if (!(f & SegFlags::HAS_P0)) { closed = true; break; }
-        typename A::Elem q = A::load(partials, (base + u) * 2 + 0);
         A::add(acc, q);
         if (!(f & SegFlags::P0_OPEN_RIGHT)) { closed = true; break; }
     }
-    if (closed) A::store(buckets, (size_t)k * nbuckets + pbucket[base + t], acc);
+    if (closed) A::store(buckets, (size_t)k * nbuckets + dest, acc);
     else long_flag[k] = 1u;  // benign race: every writer stores 1
 }
 
