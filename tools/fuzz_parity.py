@@ -1,0 +1,76 @@
+"""Randomised parity sweep (not part of the pytest suites): many sizes, scalar distributions and entry points against the
+oracle. usage: python tools/fuzz_parity.py [seconds] [curve] [g1|g2]"""
+import importlib
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+sys.path.insert(0, "oracle")
+sys.path.insert(0, "tests")
+gm = importlib.import_module("gnark-crypto_amd")
+
+
+def main():
+    import oracle
+    from conftest import random_scalars, scalars_from_ints
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    curve, which = (sys.argv[2], sys.argv[3]) if len(sys.argv) > 3 else ("bn254", "g1")
+    g = (gm.G1Affine if which == "g1" else gm.G2Affine)(curve)
+    o = oracle.Oracle(curve, which)
+    rng = np.random.default_rng(20260924)
+    nmax = 1 << 17
+    pts_all = o.gen_points(nmax, 99, 5, nthreads=8)
+    rb = g.register_bases(points=pts_all)
+    t0 = time.time()
+    cases = bad = 0
+    while time.time() - t0 < budget:
+        n = int(rng.choice([rng.integers(1, 64), rng.integers(64, 5000), rng.integers(5000, nmax)]))
+        kind = int(rng.integers(0, 6))
+        if kind == 0:
+            sc = random_scalars(rng, g.curve, n)
+        elif kind == 1:  # small values
+            sc = scalars_from_ints(g.curve, [int(x) for x in rng.integers(0, 1 << 20, size=n)])
+        elif kind == 2:  # few distinct values
+            vals = [int.from_bytes(rng.bytes(32), "little") % g.curve.r for _ in range(3)]
+            sc = scalars_from_ints(g.curve, [vals[int(i)] for i in rng.integers(0, 3, size=n)])
+        elif kind == 3:  # all equal
+            v = int.from_bytes(rng.bytes(32), "little") % g.curve.r
+            sc = scalars_from_ints(g.curve, [v] * n)
+        elif kind == 4:  # sparse: mostly zero
+            sc = random_scalars(rng, g.curve, n)
+            sc[rng.random(n) < 0.9] = 0
+        else:  # powers of two and r - small
+            sc = scalars_from_ints(g.curve, [(1 << int(e)) % g.curve.r if e >= 0 else g.curve.r + int(e)
+                                             for e in rng.integers(-5, g.curve.fr_bits, size=n)])
+        pts = pts_all[:n]
+        want = o.msm_affine(pts, sc, nthreads=8)
+        entry = int(rng.integers(0, 4))
+        if entry == 0:
+            got, err = g.MultiExp(pts, sc)
+            assert err is None
+        elif entry == 1:
+            jac, err = rb.MultiExp(sc)
+            assert err is None
+            got = g.jac_to_affine(jac)
+        elif entry == 2:
+            d = torch.from_numpy(sc.view(np.int64)).cuda()
+            torch.cuda.synchronize()
+            got = g.jac_to_affine(rb.collect(rb.submit(d.data_ptr(), n)))
+        else:
+            jacs, err = rb.MultiExpBatch(scalars=np.stack([sc, sc]))
+            assert err is None
+            got = g.jac_to_affine(jacs[1])
+        cases += 1
+        if not (got == want).all():
+            bad += 1
+            print("MISMATCH", dict(n=n, kind=kind, entry=entry), flush=True)
+    rb.release()
+    print(f"{curve} {which}: {cases} cases, {bad} mismatches", flush=True)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
