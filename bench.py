@@ -258,8 +258,9 @@ def main():
         out = {
             "metric": "G1 MSM/sec (BN254)" if (args.curve, args.group) == ("bn254", "g1") else f"{args.group.upper()} MSM/sec ({args.curve})", "value": value, "unit": "MSM/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "u32 limbs (256-bit Montgomery)", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"{args.curve.upper()} {args.group.upper()} MultiExp 2^{args.logn} points, bases+scalars resident in HBM",
+                       "arithmetic": f"{g.curve.p.bit_length()}-bit Montgomery field on 32-bit words (lazy 28/29-bit limbs, v_mad_u64_u32)",
                        "points": n, "window_bits": c, "windows": nwin, "resident_bases": resident is not None,
                        "parallelism": "single GPU" if not sharded else f"{plan['mode']}-sharded x{world} + one RCCL all-gather"},
             "points_per_s": value * n,
