@@ -4,8 +4,8 @@ over xGMI on ROCm, "gloo" in the CPU tests).  Two decompositions, both ending in
 * windows: window w is owned by rank w % world, every rank holds all bases (below);
 * points:  rank r owns points [r*n/world, (r+1)*n/world) and computes all windows of its slice; window w of the whole
   MultiExp is the sum of the ranks' totals for w (gmsm_fold_window_sets).  No replication of the bases, perfect balance;
-  measured per-rank cost on MI355X (tools/shard_model.py, BN254 G1): 2^24 on 8 ranks 3.7 ms against 4.7 ms for the
-  window decomposition, equal at 2^20 (0.80 / 0.83 ms) - `choose_mode` therefore prefers points.
+  measured per-rank cost on MI355X (tools/shard_model.py, BN254 G1): 2^24 on 8 ranks 3.5 ms against 4.2 ms for the
+  window decomposition; at 2^20 the window decomposition is ahead (0.64 / 0.70 ms) - see `choose_mode`.
 
 The reference runs one goroutine per c-bit window and collects one g1JacExtended per window on a channel
 (ecc/bn254/multiexp.go:148-209); here window w is owned by rank w % world, every rank holds all bases, and the only
@@ -76,8 +76,11 @@ def point_slice(n, rank, world):
 
 
 def choose_mode(n, world):
-    """points unless the slices get so small that a rank would not even fill its buckets (tools/shard_model.py)."""
-    return "points" if n // max(1, world) >= (1 << 14) else "windows"
+    """Measured per-rank cost (tools/shard_model.py, BN254 G1, ms; windows / points):
+         2^20:  N=2 1.22 / 1.27   N=4 0.83 / 0.88   N=8 0.64 / 0.70     (a rank with few windows runs a shorter
+         2^24:  N=2 13.1 / 12.7   N=4 7.29 / 6.63   N=8 4.17 / 3.48      reduction; its fold needs no per-rank sums)
+    points once a rank's slice reaches 2^20 points (no replicated base rewrite / decomposition), windows below."""
+    return "points" if n // max(1, world) >= (1 << 20) else "windows"
 
 
 def shard_plan(group, n, rank, world, mode="auto", c=None):
