@@ -50,6 +50,13 @@ def main():
     ap.add_argument("--group", default="g1", help="exploration only: g1 | g2")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout. Native libraries write there too (RCCL prints a version banner to the C
+    # stdout when the process exits, libdrm complains about amdgpu.ids): keep a private handle on the real stdout for the
+    # JSON line and point file descriptor 1 at stderr for everything else.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -279,7 +286,7 @@ def main():
             out["equal_to_single_gpu_result"] = bool((g.jac_to_affine(single) == g.jac_to_affine(jac)).all())
         if world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline(g, pts, sc, jac, args.curve, args.group))
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
