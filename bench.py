@@ -57,6 +57,7 @@ def main():
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between the ranks of a node
     import torch
     import torch.distributed as dist
 
