@@ -28,7 +28,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-STAGES = ["decompose", "histogram", "scans", "scatter", "accumulate", "fixup", "reduce"]
+STAGES = ["decompose", "histogram", "scans", "scatter", "accumulate", "fixup", "reduce", "wait_prev_group"]
 
 
 def main():
@@ -150,6 +150,8 @@ def main():
     stage_ms = (_ctypes_double * len(STAGES))()
     calls = _ctypes_ulong(0)
     lib.gmsm_get_stage_times(stage_ms, len(STAGES), _byref(calls))
+    stage_launches = (_ctypes_ulong * len(STAGES))()
+    lib.gmsm_get_stage_launches(stage_launches, len(STAGES))
     lib.gmsm_set_profiling(0)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -250,17 +252,20 @@ def main():
         value = args.steps / dt
         ncalls = max(1, calls.value)
         stages = {name: stage_ms[i] / ncalls for i, name in enumerate(STAGES)}
-        acc_ms = stages["accumulate"]
+        # one MultiExp = several k_accumulate_seg launches (window groups, overlapped with each other's grouping and
+        # reduction): per-launch figures are averages over the launches
+        acc_launches = max(1, stage_launches[STAGES.index("accumulate")] // ncalls)
+        acc_ms = stages["accumulate"] / acc_launches
         bytes_per_point = 8 * (g.aff_limbs + g.fr_limbs)  # affine point + scalar (BN254 G1: 96 B)
         # this rank's share of the (point, window) pairs: all windows of its slice, or its windows of all points
         my_pairs = (plan["hi"] - plan["lo"]) * len(range(plan["win_first"], nwin, plan["win_stride"])) if sharded else n * nwin
-        algorithmic_bytes = bytes_per_point * n * my_pairs / (n * nwin)
+        algorithmic_bytes = bytes_per_point * n * my_pairs / (n * nwin) / acc_launches
         achieved = algorithmic_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
         # integer roofline of the same kernel: 10 field products per mixed add (8M+2S, g1.go:822), n*(windows of this
         # rank) mixed adds; one lazy 9x29-bit Montgomery product = 171 v_mad_u64_u32/v_mul_lo_u32 + 18 v_lshrrev_b64, all
         # 4 cycles / wave64 / SIMD (tools/ubench_valu.hip): issue peak = 1024 SIMD * 64 lanes * 2.4 GHz / (189 * 4)
         # = 208e9 products/s at the nominal clock; tools/ubench_fpmul.hip measures 174-177e9 on the chip.
-        madds = my_pairs
+        madds = my_pairs / acc_launches
         mulmods_per_s = madds * 10 / (acc_ms * 1e-3) if acc_ms > 0 else 0.0
         int_peak = 1024 * 64 * 2.4e9 / (189 * 4)
         out = {
@@ -277,7 +282,8 @@ def main():
             "host_entry": host_entry,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": measured_traffic(args, world), "kernel": "k_accumulate_seg",
-                         "algorithmic_bytes_per_launch": algorithmic_bytes, "avg_launch_ms": acc_ms},
+                         "algorithmic_bytes_per_launch": algorithmic_bytes, "avg_launch_ms": acc_ms,
+                         "launches_per_msm": acc_launches},
             "int_roofline": {"achieved_mulmod_per_s": mulmods_per_s, "peak_mulmod_per_s": int_peak,
                              "measured_peak_mulmod_per_s": 174e9, "frac": mulmods_per_s / int_peak},
         }

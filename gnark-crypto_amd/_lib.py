@@ -28,6 +28,7 @@ ABI_SYMBOLS = [
     "gmsm_window_sums_enqueue", "gmsm_fold_window_sets", "gmsm_fold_windows", "gmsm_batch_scalar_mul", "gmsm_batch_scalar_mul_device",
     "gmsm_batch_jac_to_affine", "gmsm_jac_to_affine", "gmsm_affine_limbs", "gmsm_scalar_limbs", "gmsm_debug_decompose",
     "gmsm_debug_field_op", "gmsm_debug_group_op", "gmsm_generate_points", "gmsm_set_profiling", "gmsm_get_stage_times",
+    "gmsm_get_stage_launches",
     "gmsm_device_count", "gmsm_set_device", "gmsm_last_error",
     "gmsm_version",
 ]
@@ -122,6 +123,8 @@ def load():
     L.gmsm_set_profiling.argtypes = [ctypes.c_int]
     L.gmsm_get_stage_times.restype = ctypes.c_int
     L.gmsm_get_stage_times.argtypes = [vp, ctypes.c_int, vp]
+    L.gmsm_get_stage_launches.restype = ctypes.c_int
+    L.gmsm_get_stage_launches.argtypes = [vp, ctypes.c_int]
     L.gmsm_device_count.restype = ctypes.c_int
     L.gmsm_set_device.restype = ctypes.c_int
     L.gmsm_set_device.argtypes = [ctypes.c_int]

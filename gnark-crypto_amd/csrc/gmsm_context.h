@@ -5,8 +5,10 @@
 
 #include <cstdlib>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/gmsm.h"
@@ -40,11 +42,27 @@ struct DeviceBuffer {
 };
 
 // Bases rewritten once into the lazy Montgomery domain and kept in HBM (gmsm_bases_register): the resident-SRS path.
+// Shared ownership (std::shared_ptr): the handle table holds one reference, every call and every outstanding ticket
+// holds another for as long as it may touch the buffers; gmsm_bases_release only drops the table's reference and the
+// last owner frees the device memory.
 struct ResidentBases {
     int group = -1;
     int device = -1;
     size_t n = 0;
     DeviceBuffer upoints, skip;
+    ResidentBases() = default;
+    ResidentBases(const ResidentBases &) = delete;
+    ResidentBases &operator=(const ResidentBases &) = delete;
+    ~ResidentBases() {
+        if (!upoints.ptr && !skip.ptr) return;
+        int prev = 0;
+        (void)hipGetDevice(&prev);
+        if (device >= 0) (void)hipSetDevice(device);
+        (void)hipDeviceSynchronize();  // an enqueue-only call may still be reading the bases
+        if (upoints.ptr) (void)hipFree(upoints.ptr);
+        if (skip.ptr) (void)hipFree(skip.ptr);
+        (void)hipSetDevice(prev);
+    }
 };
 
 
@@ -59,7 +77,12 @@ struct Workspace {
     DeviceBuffer seg_partials, seg_flags, seg_bucket;  // split-bucket partial sums of the segmented accumulation
     DeviceBuffer parted;         // coarse-partitioned references (two-level grouping)
     DeviceBuffer digits, sorted, blockhist, counts, starts, buckets, partials, totals;
-    hipEvent_t events[10] = {nullptr};  // stage boundaries when profiling is on
+    static constexpr int MAX_PIECES = 4;   // window groups of one call (enqueue_window_sums): alternate between the streams
+    hipStream_t stream2 = nullptr;         // second stream of a call: the pieces' pipelines overlap each other
+    hipEvent_t events[MAX_PIECES][12] = {{nullptr}};  // stage boundaries per piece when profiling is on
+    int timed_pieces = 0;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // inputs ready -> stream2; stream2 done -> main stream
+    hipEvent_t ev_acc[MAX_PIECES] = {nullptr};        // accumulation kernel of piece p finished (piece p+1 waits for it)
     void *pinned = nullptr;             // pinned host buffer for the window totals
     size_t pinned_cap = 0;
     DeviceBuffer h2d_points, h2d_scalars;  // staging of the host-pointer entries
@@ -70,6 +93,8 @@ struct Workspace {
     unsigned pending_c = 0;
     uint32_t pending_nw = 0;
     uint32_t pending_gen = 0;   // ticket generation: a stale or repeated ticket is refused
+    std::shared_ptr<ResidentBases> bases_ref;  // keeps the registered bases of the call in flight on this workspace alive
+    std::thread::id pending_owner;  // thread that submitted the ticket (it cannot collect while it waits for a lease)
     hipEvent_t dep = nullptr;   // orders the workspace stream after the caller's stream (scalars produced there)
     bool uncollected = false;          // stage events of an enqueue-only call not yet added to the profile
     hipEvent_t last_use = nullptr;     // recorded after the last call enqueued on this workspace ...
@@ -100,7 +125,13 @@ struct Context {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
         num_cus = prop.multiProcessorCount;
-        for (auto &w : ws) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+        for (auto &w : ws) {
+            HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&w.stream2, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming));
+            for (auto &e : w.ev_acc) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
         return GMSM_OK;
     }
     // Kernels that need more than the default 64 KiB of dynamic LDS: raise the limit once per kernel on this device.
@@ -114,9 +145,13 @@ struct Context {
         lds_allowed.push_back(kernel);
         return GMSM_OK;
     }
-    // wait = false: nullptr when both workspaces are leased
+    // wait = false: nullptr when both workspaces are leased.
+    // wait = true: blocks until a workspace is free. The one case that cannot be waited out: both leases are submitted
+    // tickets (only gmsm_multiexp_collect ends those) and the calling thread itself holds one of them - it would be
+    // waiting for its own collect. Tickets of other threads are waited for like any other lease.
     Workspace *acquire(bool wait) {
         std::unique_lock<std::mutex> lk(mu);
+        const std::thread::id self = std::this_thread::get_id();
         for (;;) {
             for (auto &w : ws)
                 if (!w.busy) {
@@ -124,9 +159,7 @@ struct Context {
                     return &w;
                 }
             if (!wait) return nullptr;
-            // both leased: wait for a blocking call to finish - unless both leases are submitted tickets, which only
-            // gmsm_multiexp_collect can end (possibly from this very thread: waiting would deadlock)
-            if (ws[0].pending && ws[1].pending) return nullptr;
+            if (ws[0].pending && ws[1].pending && (ws[0].pending_owner == self || ws[1].pending_owner == self)) return nullptr;
             cv.wait(lk);
         }
     }
@@ -136,14 +169,19 @@ struct Context {
             w->busy = false;
             w->pending = false;
         }
-        cv.notify_one();
+        cv.notify_all();
     }
 };
 
 struct Lease {
     Context &ctx;
     Workspace *w;
-    Lease(Context &c, bool wait = true) : ctx(c), w(c.acquire(wait)) {}
+    // A workspace can still be busy with work that an enqueue-only call (gmsm_window_sums_enqueue) left in flight on the
+    // caller's stream after giving its lease back: whoever leases it next orders the workspace's own stream behind that
+    // work before touching any scratch buffer (entries that run on another stream do the same through begin_use).
+    Lease(Context &c, bool wait = true) : ctx(c), w(c.acquire(wait)) {
+        if (w && w->last_use && w->last_stream != w->stream) (void)hipStreamWaitEvent(w->stream, w->last_use, 0);
+    }
     ~Lease() {
         if (w) ctx.release(w);
     }
@@ -169,9 +207,25 @@ static inline int order_after(Workspace &ws, hipStream_t caller) {
     return GMSM_OK;
 }
 
-// Per-stage device timing (HIP events on the stream the kernels are launched on). Off by default; bench.py switches
-// it on to obtain the dominant kernel's duration for the roofline record.
-enum Stage {
+// Scratch of a workspace is reused by every call that leases it; calls may run on different streams (the workspace's
+// own, or the caller's for the enqueue-only entry). begin_use orders `stream` behind the last work enqueued on the
+// workspace, end_use publishes the end of this call's work.
+static inline int begin_use(Workspace &ws, hipStream_t stream) {
+    if (ws.last_use && ws.last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, ws.last_use, 0));
+    return GMSM_OK;
+}
+static inline int end_use(Workspace &ws, hipStream_t stream) {
+    if (!ws.last_use) HIP_TRY(hipEventCreateWithFlags(&ws.last_use, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ws.last_use, stream));
+    ws.last_stream = stream;
+    return GMSM_OK;
+}
+
+// Per-stage device timing (HIP events on the streams the kernels are launched on). Off by default; bench.py switches
+// it on to obtain the dominant kernel's duration for the roofline record. One call runs as up to MAX_PIECES window
+// groups ("pieces") whose pipelines overlap on two streams, so the stage sums exceed the wall time of the call.
+// Order of the events inside one piece (T_ prefix); the ABI (gmsm_get_stage_times) keeps its historical indices:
+enum Stage {  // ABI index
     STAGE_DECOMPOSE = 0,
     STAGE_HIST,
     STAGE_SCAN,
@@ -179,35 +233,47 @@ enum Stage {
     STAGE_ACCUMULATE,  // k_accumulate_seg alone: the dominant kernel of the roofline record
     STAGE_FIXUP,
     STAGE_REDUCE,
-    STAGE_END,
-    STAGE_COUNT = STAGE_END
+    STAGE_WAIT,        // a piece's stream idle until the previous piece's accumulation kernel has finished
+    STAGE_COUNT
 };
+enum TimedEvent { T_DECOMPOSE = 0, T_HIST, T_SCAN, T_SCATTER, T_WAIT, T_ACCUMULATE, T_FIXUP, T_REDUCE, T_END };
+static constexpr int T_TO_STAGE[T_END] = {STAGE_DECOMPOSE, STAGE_HIST, STAGE_SCAN, STAGE_SCATTER,
+                                          STAGE_WAIT,      STAGE_ACCUMULATE, STAGE_FIXUP, STAGE_REDUCE};
 
 bool profiling_enabled();
-void record_stage_times(const float *ms);  // adds one call's stage durations to the thread-independent accumulators
+// adds one call's stage durations (and the number of kernel instances behind each) to the process-wide accumulators
+void record_stage_times(const float *ms, const unsigned *launches);
 
 struct StageTimer {
     Workspace &ws;
-    hipStream_t stream;
     bool on;
-    StageTimer(Workspace &w, hipStream_t s) : ws(w), stream(s), on(profiling_enabled()) {
-        if (on && !ws.events[0])
-            for (int i = 0; i <= STAGE_END; ++i) (void)hipEventCreate(&ws.events[i]);
+    explicit StageTimer(Workspace &w) : ws(w), on(profiling_enabled()) {
+        if (on && !ws.events[0][0])
+            for (auto &row : ws.events)
+                for (int i = 0; i <= T_END; ++i) (void)hipEventCreate(&row[i]);
     }
-    void mark(int stage) {
-        if (on) (void)hipEventRecord(ws.events[stage], stream);
+    void mark(int piece, int ev, hipStream_t stream) {
+        if (on) (void)hipEventRecord(ws.events[piece][ev], stream);
     }
-    static void collect(Workspace &ws) {  // call after the stream has been synchronised
-        float ms[STAGE_COUNT];
-        for (int i = 0; i < STAGE_COUNT; ++i) {
-            ms[i] = 0.f;
-            (void)hipEventElapsedTime(&ms[i], ws.events[i], ws.events[i + 1]);
-        }
-        record_stage_times(ms);
+    static void collect(Workspace &ws) {  // call after the streams have been synchronised
+        float ms[STAGE_COUNT] = {0};
+        unsigned launches[STAGE_COUNT] = {0};
+        for (int p = 0; p < ws.timed_pieces; ++p)
+            for (int i = (p == 0 ? T_DECOMPOSE : T_HIST); i < T_END; ++i) {
+                float t = 0.f;
+                if (hipEventElapsedTime(&t, ws.events[p][i], ws.events[p][i + 1]) != hipSuccess) continue;
+                ms[T_TO_STAGE[i]] += t;
+                ++launches[T_TO_STAGE[i]];
+            }
+        record_stage_times(ms, launches);
     }
 };
 
 int get_context(Context **out);  // context of the calling thread's device (gmsm_set_device), created on first use
+int get_context_for(int device, Context **out);
+// Context of the device that owns the device pointer `p` (the calling thread's device when p is null or unknown to
+// the runtime): the device-pointer entries do not depend on which OS thread the caller happens to run on.
+int get_context_of_pointer(const void *p, Context **out);
 
 
 // ------------------------------------------------------------------ window geometry
@@ -264,7 +330,7 @@ struct GroupVTable {
     int (*collect)(Workspace &ws, uint64_t *out_jac);
     int (*window_sums_enqueue)(Context &ctx, const void *d_points, const void *d_scalars, size_t n, unsigned c,
                                unsigned win_first, unsigned win_stride, hipStream_t stream, void *d_out_xyzz,
-                               const ResidentBases *resident);
+                               const std::shared_ptr<ResidentBases> &resident);
     void (*fold_sets)(const uint64_t *xyzz_sets, unsigned nsets, unsigned c, uint64_t *out_jac);
     int (*fold_points)(const uint64_t *points, size_t n, const uint64_t *coeff, int nb_tasks, uint64_t *out_jac);
     int (*multiexp_bases_host)(Context &ctx, const uint64_t *scalars, size_t n, uint64_t *out_jac,

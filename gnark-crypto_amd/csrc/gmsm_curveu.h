@@ -295,13 +295,23 @@ __device__ __forceinline__ UnsatElem<U> unsat_load(const void *base, size_t i) {
 
 template <class U>
 __device__ __forceinline__ void lazy_store(void *base, size_t i, const XYZZL<U> &v, bool inf) {
-    XYZZL<U> m = v;
-    if (inf) {
-        uint32_t *w = reinterpret_cast<uint32_t *>(&m.zz);
+    // x, y, zzz go out as they are; zz is ANDed with an all-ones / all-zero mask (infinity <=> zz limbs all zero): no
+    // copy of the 4 x sizeof(U) record is built in registers - this sits on the bucket-boundary path of the hot loop
+    static_assert(sizeof(U) % 4 == 0 && sizeof(XYZZL<U>) % 16 == 0, "record layout");
+    constexpr int UW = (int)(sizeof(U) / 4);
+    const uint32_t keep = inf ? 0u : 0xffffffffu;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(&v);
+    uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(base) + i * sizeof(XYZZL<U>));
 #pragma unroll
-        for (int k = 0; k < (int)(sizeof(U) / 4); ++k) w[k] = 0;
+    for (int q = 0; q < (int)(sizeof(XYZZL<U>) / 16); ++q) {
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int word = 4 * q + j;
+            o[j] = (word >= 2 * UW && word < 3 * UW) ? (w[word] & keep) : w[word];
+        }
+        dst[q] = make_uint4(o[0], o[1], o[2], o[3]);
     }
-    policy_store<XYZZL<U>>(base, i, m);
 }
 
 // canonical saturated XYZZ for the host (window totals)

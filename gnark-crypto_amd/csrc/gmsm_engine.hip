@@ -1,5 +1,7 @@
 // libgmsm.so -- C ABI (include/gmsm.h), per-device contexts and dispatch to the per-group pipelines (gmsm_group.h).
 // There is no CPU fallback: every compute entry needs a usable gfx950 device and fails loudly otherwise.
+#include <atomic>
+
 #include "gmsm_context.h"
 
 namespace gmsm {
@@ -9,7 +11,11 @@ namespace gmsm {
 static thread_local std::string g_last_error;
 static std::mutex g_any_error_mu;
 static std::string g_any_error;
-static thread_local int g_device = 0;
+// Device selection: gmsm_set_device sets the calling thread's device AND the process-wide default that threads which
+// never called it inherit (a goroutine that selected a device and was then moved to a fresh OS thread still gets it).
+// Entries that receive device pointers use the device that owns the pointer instead.
+static thread_local int g_device = -1;
+static std::atomic<int> g_default_device{0};
 
 int fail(int code, const std::string &msg) {
     g_last_error = msg;
@@ -21,40 +27,56 @@ int fail(int code, const std::string &msg) {
 }
 
 static std::mutex g_prof_mu;
-static bool g_profiling = false;
+static std::atomic<bool> g_profiling{false};
 static double g_stage_ms[STAGE_COUNT] = {0};
+static unsigned long g_stage_launches[STAGE_COUNT] = {0};
 static unsigned long g_stage_calls = 0;
 
-bool profiling_enabled() { return g_profiling; }
-void record_stage_times(const float *ms) {
+bool profiling_enabled() { return g_profiling.load(std::memory_order_relaxed); }
+void record_stage_times(const float *ms, const unsigned *launches) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (int i = 0; i < STAGE_COUNT; ++i) g_stage_ms[i] += ms[i];
+    for (int i = 0; i < STAGE_COUNT; ++i) {
+        g_stage_ms[i] += ms[i];
+        g_stage_launches[i] += launches[i];
+    }
     ++g_stage_calls;
 }
 
 static std::mutex g_ctx_mu;
 static std::vector<Context *> g_ctx;
 
-int get_context(Context **out) {
+int get_context_for(int device, Context **out) {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
         return fail(GMSM_ERR_DEVICE, std::string("no usable HIP device (hipGetDeviceCount: ") + hipGetErrorString(e) +
                                          "); libgmsm has no CPU fallback");
-    if (g_device < 0 || g_device >= ndev) return fail(GMSM_ERR_DEVICE, "gmsm_set_device: device index out of range");
+    if (device < 0 || device >= ndev) return fail(GMSM_ERR_DEVICE, "gmsm_set_device: device index out of range");
     if ((int)g_ctx.size() < ndev) g_ctx.resize(ndev, nullptr);
-    if (!g_ctx[g_device]) {
+    if (!g_ctx[device]) {
         Context *c = new Context();
-        int rc = c->init(g_device);
+        int rc = c->init(device);
         if (rc != GMSM_OK) {
             delete c;
             return rc;
         }
-        g_ctx[g_device] = c;
+        g_ctx[device] = c;
     }
-    *out = g_ctx[g_device];
+    *out = g_ctx[device];
     return GMSM_OK;
+}
+
+int get_context(Context **out) { return get_context_for(g_device >= 0 ? g_device : g_default_device.load(), out); }
+
+int get_context_of_pointer(const void *p, Context **out) {
+    if (p) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type == hipMemoryTypeDevice)
+            return get_context_for(attr.device, out);
+        (void)hipGetLastError();  // not a pointer the runtime knows: fall back to the thread's device
+    }
+    return get_context(out);
 }
 
 const GroupVTable *gmsm_vtable_bn254_g1();
@@ -126,17 +148,20 @@ GMSM_EXPORT int gmsm_multiexp_device(int group, const void *d_points, const void
                                      uint64_t *out_jac) {
     VT_OR_FAIL(group);
     Context *ctx;
-    int rc = get_context(&ctx);
+    int rc = get_context_of_pointer(d_scalars ? d_scalars : d_points, &ctx);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
     return vt->multiexp_device(*ctx, d_points, d_scalars, n, (hipStream_t)hip_stream, out_jac, nullptr);
 }
 
 // ------------------------------------------------------------------ resident bases
+using BasesRef = std::shared_ptr<ResidentBases>;
 static std::mutex g_bases_mu;
-static std::vector<ResidentBases *> g_bases;  // handle = index + 1
+static std::vector<BasesRef> g_bases;  // handle = index + 1
 
-static ResidentBases *lookup_bases(uint64_t handle) {
+// The returned reference keeps the bases alive for the caller's whole call (or ticket) even if another thread releases
+// the handle meanwhile.
+static BasesRef lookup_bases(uint64_t handle) {
     std::lock_guard<std::mutex> lk(g_bases_mu);
     if (handle == 0 || handle > g_bases.size()) return nullptr;
     return g_bases[handle - 1];
@@ -145,10 +170,11 @@ static ResidentBases *lookup_bases(uint64_t handle) {
 GMSM_EXPORT int gmsm_bases_register(int group, const uint64_t *points, const void *d_points, size_t n,
                                     uint64_t *out_handle) {
     VT_OR_FAIL(group);
+    if (!out_handle) return fail(GMSM_ERR_ARG, "gmsm_bases_register: out_handle is null");
     if ((points == nullptr) == (d_points == nullptr) && n)
         return fail(GMSM_ERR_ARG, "gmsm_bases_register: give exactly one of points (host) / d_points (device)");
     Context *ctx;
-    int rc = get_context(&ctx);
+    int rc = get_context_of_pointer(d_points, &ctx);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
     GMSM_LEASE_OR_FAIL(lease, *ctx);
@@ -161,14 +187,11 @@ GMSM_EXPORT int gmsm_bases_register(int group, const uint64_t *points, const voi
     } else if (n) {
         HIP_TRY(hipDeviceSynchronize());  // d_points may still be being written on a stream we do not know
     }
-    ResidentBases *rb = new ResidentBases();
+    BasesRef rb = std::make_shared<ResidentBases>();
     rb->group = group;
     rb->device = ctx->device;
-    rc = vt->register_bases(*ctx, src, n, ws.stream, rb);
-    if (rc) {
-        delete rb;
-        return rc;
-    }
+    rc = vt->register_bases(*ctx, src, n, ws.stream, rb.get());
+    if (rc) return rc;  // ~ResidentBases frees whatever was allocated
     std::lock_guard<std::mutex> lk2(g_bases_mu);
     g_bases.push_back(rb);
     *out_handle = g_bases.size();
@@ -176,31 +199,29 @@ GMSM_EXPORT int gmsm_bases_register(int group, const uint64_t *points, const voi
 }
 
 GMSM_EXPORT int gmsm_bases_release(uint64_t handle) {
-    std::lock_guard<std::mutex> lk(g_bases_mu);
-    if (handle == 0 || handle > g_bases.size() || !g_bases[handle - 1]) return fail(GMSM_ERR_ARG, "unknown bases handle");
-    ResidentBases *rb = g_bases[handle - 1];
-    g_bases[handle - 1] = nullptr;
-    (void)hipSetDevice(rb->device);
-    if (rb->upoints.ptr) (void)hipFree(rb->upoints.ptr);
-    if (rb->skip.ptr) (void)hipFree(rb->skip.ptr);
-    delete rb;
+    BasesRef rb;
+    {
+        std::lock_guard<std::mutex> lk(g_bases_mu);
+        if (handle == 0 || handle > g_bases.size() || !g_bases[handle - 1]) return fail(GMSM_ERR_ARG, "unknown bases handle");
+        rb.swap(g_bases[handle - 1]);
+    }
+    // calls and tickets that are still using the bases hold their own references; the memory goes with the last one
     return GMSM_OK;
 }
 
 static int multiexp_bases_impl(uint64_t handle, const uint64_t *scalars, const void *d_scalars, size_t n, int nb_tasks,
                                void *hip_stream, uint64_t *out_jac) {
-    ResidentBases *rb = lookup_bases(handle);
+    BasesRef rb = lookup_bases(handle);
     if (!rb) return fail(GMSM_ERR_ARG, "unknown bases handle");
     const GroupVTable *vt = vtable(rb->group);
     if (n > rb->n) return fail(GMSM_ERR_LEN, "len(points) != len(scalars)");  // more scalars than registered bases
     if (nb_tasks > 1024) return fail(GMSM_ERR_CONFIG, "invalid config: config.NbTasks > 1024");
     Context *ctx;
-    int rc = get_context(&ctx);
+    int rc = get_context_for(rb->device, &ctx);  // the bases decide the device, not the calling thread
     if (rc) return rc;
-    if (ctx->device != rb->device) return fail(GMSM_ERR_ARG, "bases were registered on another device");
     HIP_TRY(hipSetDevice(ctx->device));
-    if (scalars && n) return vt->multiexp_bases_host(*ctx, scalars, n, out_jac, rb);
-    return vt->multiexp_device(*ctx, nullptr, d_scalars, n, (hipStream_t)hip_stream, out_jac, rb);
+    if (scalars && n) return vt->multiexp_bases_host(*ctx, scalars, n, out_jac, rb.get());
+    return vt->multiexp_device(*ctx, nullptr, d_scalars, n, (hipStream_t)hip_stream, out_jac, rb.get());
 }
 
 GMSM_EXPORT int gmsm_multiexp_bases(uint64_t handle, const uint64_t *scalars, size_t n_scalars, int nb_tasks,
@@ -217,25 +238,26 @@ GMSM_EXPORT int gmsm_multiexp_bases_device(uint64_t handle, const void *d_scalar
 // ticket = device << 40 | generation << 8 | (slot + 1)
 GMSM_EXPORT int gmsm_multiexp_bases_submit(uint64_t handle, const void *d_scalars, size_t n_scalars, void *hip_stream,
                                            uint64_t *out_ticket) {
-    ResidentBases *rb = lookup_bases(handle);
+    BasesRef rb = lookup_bases(handle);
     if (!rb) return fail(GMSM_ERR_ARG, "unknown bases handle");
     if (!out_ticket) return fail(GMSM_ERR_ARG, "out_ticket is null");
     const GroupVTable *vt = vtable(rb->group);
     if (n_scalars > rb->n) return fail(GMSM_ERR_LEN, "len(points) != len(scalars)");
     Context *ctx;
-    int rc = get_context(&ctx);
+    int rc = get_context_for(rb->device, &ctx);
     if (rc) return rc;
-    if (ctx->device != rb->device) return fail(GMSM_ERR_ARG, "bases were registered on another device");
     HIP_TRY(hipSetDevice(ctx->device));
     Lease lease(*ctx, /*wait=*/false);
     Workspace *ws = lease.w;
     if (!ws) return fail(GMSM_ERR_ARG, "two MultiExp calls are already in flight: collect one first");
     // the scalars are produced on the caller's stream (NULL = the default stream): order our stream behind it
     if ((rc = order_after(*ws, (hipStream_t)hip_stream))) return rc;
-    if ((rc = vt->submit(*ctx, *ws, d_scalars, n_scalars, rb))) return rc;
+    if ((rc = vt->submit(*ctx, *ws, d_scalars, n_scalars, rb.get()))) return rc;
     lease.keep();  // released by gmsm_multiexp_collect
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
+        ws->bases_ref = rb;  // the ticket owns a reference until it is collected
+        ws->pending_owner = std::this_thread::get_id();
         ws->pending = true;
         ws->pending_group = rb->group;
         ++ws->pending_gen;
@@ -249,7 +271,7 @@ GMSM_EXPORT int gmsm_multiexp_bases_submit(uint64_t handle, const void *d_scalar
 // the copy of vector i+1 runs while vector i is being accumulated.
 GMSM_EXPORT int gmsm_multiexp_bases_batch(uint64_t handle, const uint64_t *scalars, const void *d_scalars, size_t n,
                                           size_t k, void *hip_stream, uint64_t *out_jac) {
-    ResidentBases *rb = lookup_bases(handle);
+    BasesRef rb = lookup_bases(handle);
     if (!rb) return fail(GMSM_ERR_ARG, "unknown bases handle");
     const GroupVTable *vt = vtable(rb->group);
     if (n > rb->n) return fail(GMSM_ERR_LEN, "len(points) != len(scalars)");
@@ -257,14 +279,13 @@ GMSM_EXPORT int gmsm_multiexp_bases_batch(uint64_t handle, const uint64_t *scala
     if (n && (scalars == nullptr) == (d_scalars == nullptr))
         return fail(GMSM_ERR_ARG, "gmsm_multiexp_bases_batch: give exactly one of scalars (host) / d_scalars (device)");
     Context *ctx;
-    int rc = get_context(&ctx);
+    int rc = get_context_for(rb->device, &ctx);
     if (rc) return rc;
-    if (ctx->device != rb->device) return fail(GMSM_ERR_ARG, "bases were registered on another device");
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t jl = vt->jac_bytes / 8, sb = vt->scalar_bytes * n;
     if (n == 0) {
         for (size_t i = 0; i < k; ++i)
-            if ((rc = vt->multiexp_device(*ctx, nullptr, nullptr, 0, nullptr, out_jac + i * jl, rb))) return rc;
+            if ((rc = vt->multiexp_device(*ctx, nullptr, nullptr, 0, nullptr, out_jac + i * jl, rb.get()))) return rc;
         return GMSM_OK;
     }
     Workspace *w[2] = {ctx->acquire(true), nullptr};
@@ -290,7 +311,7 @@ GMSM_EXPORT int gmsm_multiexp_bases_batch(uint64_t handle, const uint64_t *scala
                 if ((rc = order_after(ws, (hipStream_t)hip_stream))) break;
                 dsc = (const char *)d_scalars + submitted * sb;
             }
-            if ((rc = vt->submit(*ctx, ws, dsc, n, rb))) break;
+            if ((rc = vt->submit(*ctx, ws, dsc, n, rb.get()))) break;
             ++submitted;
         }
         if (rc) break;
@@ -325,6 +346,7 @@ GMSM_EXPORT int gmsm_multiexp_collect(uint64_t ticket, uint64_t *out_jac) {
     // other slot can be submitted to meanwhile.
     (void)hipSetDevice(ctx->device);
     int rc = vt->collect(ws, out_jac);
+    ws.bases_ref.reset();
     ctx->release(&ws);
     return rc;
 }
@@ -347,7 +369,7 @@ GMSM_EXPORT int gmsm_batch_scalar_mul_device(int group, const uint64_t *base_aff
     if (!base_affine || (n && (!d_scalars || !d_out_affine)))
         return fail(GMSM_ERR_ARG, "gmsm_batch_scalar_mul_device: null argument");
     Context *ctx;
-    int rc = get_context(&ctx);
+    int rc = get_context_of_pointer(d_scalars, &ctx);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
     return vt->batch_scalar_mul(*ctx, base_affine, nullptr, d_scalars, n, (hipStream_t)hip_stream, nullptr, d_out_affine);
@@ -378,7 +400,7 @@ GMSM_EXPORT int gmsm_window_sums_device(int group, const void *d_points, const v
     VT_OR_FAIL(group);
     if (c < 2 || c > 16) return fail(GMSM_ERR_ARG, "c out of range (2..16)");
     Context *ctx;
-    int rc = get_context(&ctx);
+    int rc = get_context_of_pointer(d_scalars, &ctx);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
     return vt->window_sums(*ctx, d_points, d_scalars, n, c, win_first, win_stride, (hipStream_t)hip_stream, out_xyzz, nullptr);
@@ -390,21 +412,20 @@ GMSM_EXPORT int gmsm_window_sums_enqueue(int group, const void *d_points, uint64
     VT_OR_FAIL(group);
     if (c < 2 || c > 16) return fail(GMSM_ERR_ARG, "c out of range (2..16)");
     if (!d_out_xyzz) return fail(GMSM_ERR_ARG, "d_out_xyzz is null");
-    ResidentBases *rb = nullptr;
+    BasesRef rb;
     if (bases_handle) {
         rb = lookup_bases(bases_handle);
         if (!rb || rb->group != group) return fail(GMSM_ERR_ARG, "unknown bases handle");
         if (n > rb->n) return fail(GMSM_ERR_LEN, "len(points) != len(scalars)");
     }
     Context *ctx;
-    int rc = get_context(&ctx);
+    int rc = rb ? get_context_for(rb->device, &ctx) : get_context_of_pointer(d_out_xyzz, &ctx);
     if (rc) return rc;
-    if (rb && ctx->device != rb->device) return fail(GMSM_ERR_ARG, "bases were registered on another device");
     HIP_TRY(hipSetDevice(ctx->device));
     // hip_stream is used as given: NULL is the device's default (null) stream, which is what the consumer of d_out_xyzz
     // is ordered against when it runs there too - not the engine's private stream.
     return vt->window_sums_enqueue(*ctx, d_points, d_scalars, n, c, win_first, win_stride, (hipStream_t)hip_stream,
-                                   d_out_xyzz, rb);
+                                   d_out_xyzz, rb);  // the workspace keeps the reference while the work is in flight
 }
 
 GMSM_EXPORT int gmsm_fold_window_sets(int group, unsigned c, const uint64_t *xyzz_sets, unsigned nsets, uint64_t *out_jac) {
@@ -467,8 +488,11 @@ GMSM_EXPORT int gmsm_generate_points(int group, const uint64_t *base_affine, con
 
 GMSM_EXPORT void gmsm_set_profiling(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_profiling = on != 0;
-    for (int i = 0; i < STAGE_COUNT; ++i) g_stage_ms[i] = 0;
+    g_profiling.store(on != 0);
+    for (int i = 0; i < STAGE_COUNT; ++i) {
+        g_stage_ms[i] = 0;
+        g_stage_launches[i] = 0;
+    }
     g_stage_calls = 0;
 }
 
@@ -477,6 +501,13 @@ GMSM_EXPORT int gmsm_get_stage_times(double *out_ms, int max_stages, unsigned lo
     int n = max_stages < (int)STAGE_COUNT ? max_stages : (int)STAGE_COUNT;
     for (int i = 0; i < n; ++i) out_ms[i] = g_stage_ms[i];
     if (out_calls) *out_calls = g_stage_calls;
+    return n;
+}
+
+GMSM_EXPORT int gmsm_get_stage_launches(unsigned long *out_launches, int max_stages) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int n = max_stages < (int)STAGE_COUNT ? max_stages : (int)STAGE_COUNT;
+    for (int i = 0; i < n; ++i) out_launches[i] = g_stage_launches[i];
     return n;
 }
 
@@ -490,6 +521,7 @@ GMSM_EXPORT int gmsm_set_device(int device) {
     int n = gmsm_device_count();
     if (device < 0 || device >= n) return fail(GMSM_ERR_DEVICE, "gmsm_set_device: no such device");
     g_device = device;
+    g_default_device.store(device);
     return GMSM_OK;
 }
 

@@ -64,10 +64,11 @@ struct Group {
     // `ws` is leased by the caller; the pipeline runs on the workspace's own stream, ordered after `caller_stream`.
     static int window_sums(Context &ctx, Workspace &ws, const void *d_points, const void *d_scalars, size_t n,
                            const WindowPlan &plan, hipStream_t caller_stream, Ext *host_xyzz,
-                           const ResidentBases *resident = nullptr) {
+                           const ResidentBases *resident = nullptr, size_t resident_offset = 0) {
         int rc = order_after(ws, caller_stream);
         if (rc) return rc;
-        if ((rc = enqueue_window_sums(ctx, ws, d_points, d_scalars, n, plan, ws.stream, resident))) return rc;
+        if ((rc = enqueue_window_sums(ctx, ws, d_points, d_scalars, n, plan, ws.stream, resident, nullptr, resident_offset)))
+            return rc;
         return collect_window_sums(ws, ws.stream, plan.nwin_local, host_xyzz);
     }
 
@@ -81,21 +82,85 @@ struct Group {
         return GMSM_OK;
     }
 
-    // Launches every kernel of one MultiExp on `stream` and queues the copy of the window totals into ws.pinned; does
-    // not wait. All scratch comes from `ws`, so two workspaces can be in flight on two streams.
+    // floor(r / 2^shift) for the scalar-field modulus r (the largest value a top window can hold, before the carry)
+    static uint64_t fr_modulus_shifted(unsigned shift) {
+        uint64_t v = 0;
+        for (int b = 62; b >= 0; --b) {
+            const unsigned bit = shift + (unsigned)b;
+            if (bit < 32u * FrP::N && ((FrP::Q[bit >> 5] >> (bit & 31)) & 1u)) v |= (uint64_t)1 << b;
+        }
+        return v;
+    }
+    // largest digit code k_decompose can emit for this plan (multiexp.go:779-800): decides uint16 vs uint32 digit arrays
+    static uint64_t max_digit_code(const WindowPlan &plan) {
+        const uint64_t low = ((uint64_t)1 << plan.c) - 1;
+        const unsigned top_shift = (plan.nwin_total - 1) * plan.c;
+        const uint64_t top = top_shift >= 63 + 32u * FrP::N ? 0 : ((fr_modulus_shifted(top_shift) + 1) << 1);
+        return plan.nwin_total > 1 ? std::max(low, top) : top;
+    }
+
+    // One window group ("piece") of a call: windows [k0, k0 + nw) of the call's local windows, with its own accumulation
+    // and reduction geometry and its offsets into the per-thread / per-block scratch arrays.
+    struct Piece {
+        uint32_t k0, nw;
+        uint32_t seg, tpw, t1;                 // accumulation: entries per thread, threads per window, level-1 fixup outputs
+        uint32_t log2L, nblocks1, log2span;    // reduction
+        size_t off_thr, off_t1, off_blk;       // sums of nw*tpw, nw*t1, nw*nblocks1 over the earlier pieces
+    };
+
+    // How the call's windows are cut into pieces. The pieces run the same pipeline (group, accumulate, fix up, reduce)
+    // on alternating streams with their accumulation kernels chained by events, the idea being that the memory-bound
+    // grouping of piece p+1 and the latency-bound reduction of piece p-1 run underneath the accumulation of piece p.
+    // MEASURED (MI355X, BN254 G1, profiles/r02_split_ab.log): it does not pay. One piece 2.12 ms at 2^20, two 2.31-2.36,
+    // three 2.57-2.78; 2^24: 24.4 against 25.9-26.1. The reduction is not idle time that other work can fill: its lone
+    // wave per SIMD already issues at 84 % of the multiplier peak (tools/ubench_fpmul.hip, one block per CU), so
+    // co-resident accumulation waves only take issue slots away from it, and its 256-register workgroups cannot be
+    // placed at all until a CU has drained two thirds of its accumulation waves. The default is therefore ONE piece;
+    // GMSM_SPLIT=2..4 keeps the experiment reproducible.
+    static int plan_pieces(uint32_t nw, size_t n, uint32_t *sizes) {
+        uint32_t want = env_uint("GMSM_SPLIT", 0);
+        if (want == 0) want = 1;
+        if (want > (uint32_t)Workspace::MAX_PIECES) want = Workspace::MAX_PIECES;
+        if (want > nw) want = nw;
+        if (want <= 1) {
+            sizes[0] = nw;
+            return 1;
+        }
+        // last piece: GMSM_SPLIT_LAST sixteenths of the windows (default 1/4), the rest spread evenly, larger pieces first
+        const uint32_t last16 = env_uint("GMSM_SPLIT_LAST", 4);
+        uint32_t last = std::max<uint32_t>(1, nw * last16 / 16);
+        if (last > nw - (want - 1)) last = nw - (want - 1);
+        uint32_t rest = nw - last;
+        for (uint32_t p = 0; p + 1 < want; ++p) {
+            const uint32_t left = want - 1 - p;
+            sizes[p] = (rest + left - 1) / left;
+            rest -= sizes[p];
+        }
+        sizes[want - 1] = last;
+        (void)n;
+        return (int)want;
+    }
+
+    // Launches every kernel of one MultiExp and queues the copy of the window totals into ws.pinned; does not wait.
+    // `stream` carries the call (inputs are ready there; the totals are complete there); the workspace's second stream
+    // runs every other piece and is joined back before the copy. All scratch comes from `ws`, so two workspaces can be in
+    // flight at once.
     // d_out != nullptr: the totals stay on the device (copied to d_out in stream order) instead of going to ws.pinned.
     static int enqueue_window_sums(Context &ctx, Workspace &ws, const void *d_points, const void *d_scalars, size_t n,
                                    const WindowPlan &plan, hipStream_t stream, const ResidentBases *resident,
-                                   void *d_out = nullptr) {
+                                   void *d_out = nullptr, size_t resident_offset = 0 /* first registered base used */) {
         const uint32_t nw = plan.nwin_local;
         ws.pending_timed = false;
         if (nw == 0) return GMSM_OK;
         if (ws.uncollected) {  // stage events of an enqueue-only call (nobody waited for it): pick them up now
-            if (hipEventQuery(ws.events[STAGE_END]) == hipSuccess) StageTimer::collect(ws);
+            bool done = ws.timed_pieces > 0;
+            for (int p = 0; p < ws.timed_pieces; ++p) done = done && hipEventQuery(ws.events[p][T_END]) == hipSuccess;
+            if (done) StageTimer::collect(ws);
             ws.uncollected = false;
         }
         // The workspace may still be in use by work enqueued earlier on another stream: order behind it.
-        if (ws.last_use && ws.last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, ws.last_use, 0));
+        int rc;
+        if ((rc = begin_use(ws, stream))) return rc;
         if (n == 0) {
             int rc0 = ws.ensure_pinned((size_t)nw * sizeof(Ext));
             if (rc0) return rc0;
@@ -109,44 +174,143 @@ struct Group {
         }
         if (n >= ((size_t)1 << 31)) return fail(GMSM_ERR_ARG, "n must be < 2^31");
         const uint32_t NB = plan.nbuckets;
-        // reduction geometry
-        // buckets per level-1 thread, L = 2^log2L: as few as possible (the per-thread running sum is a serial chain) while
-        // all level-1 workgroups of the call are resident at once - one per CU, every one of them runs a single wave per
-        // SIMD - and level 2 gets at most RED2_TPB of them per window. Measured: BN254/BLS12-381 G1 and BN254 G2 L = 8,
-        // BLS12-381 G2 L = 16 (-24 % reduction time against L = 8), BW6-761 (24 windows) L = 32 (-15 %).
-        const auto blocks1 = [&](uint32_t l2) { return ((size_t)NB + ((size_t)RED_TPB << l2) - 1) / ((size_t)RED_TPB << l2); };
-        uint32_t log2L = env_uint("GMSM_LOG2L", 0);
-        if (log2L == 0) {
-            log2L = 1;
-            while ((size_t)nw * blocks1(log2L) > (size_t)ctx.num_cus && blocks1(log2L) > 1) ++log2L;
-        }
-        while (blocks1(log2L) > (size_t)RED2_TPB) ++log2L;
-        const uint32_t nblocks1 = (uint32_t)(((size_t)NB + ((size_t)RED_TPB << log2L) - 1) / ((size_t)RED_TPB << log2L));
-        uint32_t log2span = log2L;
-        for (int t = RED_TPB; t > 1; t >>= 1) ++log2span;
-
-        int rc;
-        if ((rc = ws.digits.ensure((size_t)nw * n * 4))) return rc;
-        if ((rc = ws.sorted.ensure((size_t)nw * n * 4))) return rc;
-        if ((rc = ws.starts.ensure((size_t)nw * (NB + 1) * 4))) return rc;
         constexpr size_t REC = sizeof(typename Ops::Mem);  // bucket / partial record (lazy representation on the fast path)
         static_assert(sizeof(typename Ops::Mem) == sizeof(typename OpsNI::Mem), "one record format per group");
+
+        // ---- pieces and their geometry
+        uint32_t psize[Workspace::MAX_PIECES];
+        const int npieces = plan_pieces(nw, n, psize);
+        Piece pc[Workspace::MAX_PIECES];
+        const uint32_t span1 = 64;  // chain fixup: short chains in place, long ones through two hierarchical levels
+        {
+            uint32_t k0 = 0;
+            size_t off_thr = 0, off_t1 = 0, off_blk = 0;
+            for (int p = 0; p < npieces; ++p) {
+                Piece &q = pc[p];
+                q.k0 = k0;
+                q.nw = psize[p];
+                // reduction: buckets per level-1 thread, L = 2^log2L: as few as possible (the per-thread running sum is a
+                // serial chain) while all level-1 workgroups of the piece are resident at once - one per CU, every one of
+                // them runs a single wave per SIMD - and level 2 gets at most RED2_TPB of them per window. Measured with
+                // whole calls: BN254/BLS12-381 G1 and BN254 G2 L = 8, BLS12-381 G2 L = 16, BW6-761 (24 windows) L = 32.
+                const auto blocks1 = [&](uint32_t l2) { return ((size_t)NB + ((size_t)RED_TPB << l2) - 1) / ((size_t)RED_TPB << l2); };
+                uint32_t log2L = env_uint("GMSM_LOG2L", 0);
+                if (log2L == 0) {
+                    log2L = 1;
+                    while ((size_t)q.nw * blocks1(log2L) > (size_t)ctx.num_cus && blocks1(log2L) > 1) ++log2L;
+                }
+                while (blocks1(log2L) > (size_t)RED2_TPB) ++log2L;
+                q.log2L = log2L;
+                q.nblocks1 = (uint32_t)blocks1(log2L);
+                q.log2span = log2L;
+                for (int t = RED_TPB; t > 1; t >>= 1) ++q.log2span;
+                // entry-parallel segmented accumulation: seg entries per thread. Every thread does the same work, so the
+                // launch should be a whole number of resident "rounds": capacity = CUs x resident workgroups x 256 threads
+                uint32_t seg = env_uint("GMSM_SEG", 0);
+                if (seg == 0) {
+                    const size_t capacity = (size_t)ctx.num_cus * AccWaves<U>::value * 256;
+                    const size_t SEG_MAX = env_uint("GMSM_SEGMAX", 512);  // measured: 512 best at 2^24, 256 at 2^22
+                    for (size_t r = 1;; ++r) {
+                        size_t sg = ((size_t)q.nw * n + r * capacity - 1) / (r * capacity);
+                        if (sg <= SEG_MAX) {
+                            // nw*ceil(n/s) threads must not exceed r*capacity: round s up until it holds
+                            while (sg < SEG_MAX && (size_t)q.nw * ((n + sg - 1) / sg) > r * capacity) ++sg;
+                            seg = (uint32_t)std::max<size_t>(sg, 32);
+                            break;
+                        }
+                    }
+                }
+                q.seg = seg;
+                q.tpw = (uint32_t)((n + seg - 1) / seg);  // threads per window (upper bound: <= n entries)
+                q.t1 = (q.tpw + span1 - 1) / span1;       // level-1 fixup outputs per window; level 2: one thread closes all
+                q.off_thr = off_thr;
+                q.off_t1 = off_t1;
+                q.off_blk = off_blk;
+                off_thr += (size_t)q.nw * q.tpw;
+                off_t1 += (size_t)q.nw * q.t1;
+                off_blk += (size_t)q.nw * q.nblocks1;
+                k0 += q.nw;
+            }
+        }
+        const Piece &lastp = pc[npieces - 1];
+        const size_t tot_thr = lastp.off_thr + (size_t)lastp.nw * lastp.tpw;
+        const size_t tot_t1 = lastp.off_t1 + (size_t)lastp.nw * lastp.t1;
+        const size_t tot_blk = lastp.off_blk + (size_t)lastp.nw * lastp.nblocks1;
+
+        // ---- grouping geometry (the same for every piece)
+        uint32_t log2NB = 0;
+        while ((1u << log2NB) < NB) ++log2NB;
+        uint32_t log2n = 0;
+        while (((size_t)1 << log2n) < n) ++log2n;
+        const uint32_t lidx = log2n + 1;  // bits of (index << 1 | negate)
+        // target partition population 2^part_log2 (measured, BN254 G1: 2^13 is best up to 2^21 points - more
+        // workgroups for the fine pass; 2^15 from 2^24 on - 128-byte runs out of the coarse pass)
+        const uint32_t part_log2 = env_uint("GMSM_PART_LOG2", log2n <= 21 ? 13 : log2n >= 24 ? 15 : 14);
+        int fb = (int)part_log2 + (int)log2NB - (int)log2n;
+        if (fb > (int)log2NB) fb = (int)log2NB;
+        if (fb < 0) fb = 0;
+        if (fb + lidx > 32) fb = 32 - lidx;
+        const uint32_t fbits = (uint32_t)fb;
+        const uint32_t nparts = NB >> fbits;
+        const uint32_t pchunks = (uint32_t)((n + PART_CHUNK - 1) / PART_CHUNK);  // chunk = one LDS staging buffer
+        const size_t pchunk_len = PART_CHUNK;
+        const size_t scatter_lds = (size_t)nparts * 8 + (size_t)PART_CHUNK * 6;
+        if (scatter_lds > 152 * 1024)
+            return fail(GMSM_ERR_ARG, "more than 2^27 points in one pipeline run: split the window sums by point range and add "
+                                      "the sets (gmsm_fold_window_sets); the MultiExp entries do this themselves");
+        // staging slots of the fine pass: up to 96 KiB next to the 2^fbits counters; larger partitions go direct
+        const size_t fine_cnt_bytes = (size_t)4 << fbits;
+        const uint32_t stage_cap = fine_cnt_bytes >= 156 * 1024 ? 0u
+                                   : (uint32_t)std::min<size_t>(env_uint("GMSM_STAGE_CAP", part_log2 >= 15 ? 39000 : 24576),
+                                                              (156 * 1024 - fine_cnt_bytes) / 4);
+        const bool d16 = max_digit_code(plan) < 65536 && env_uint("GMSM_DIGIT32", 0) == 0;
+        const size_t dsz = d16 ? 2 : 4;
+
+        // ---- scratch
+        if ((rc = ws.digits.ensure((size_t)nw * n * dsz))) return rc;
+        if ((rc = ws.sorted.ensure((size_t)nw * n * 4))) return rc;
+        if ((rc = ws.parted.ensure((size_t)nw * n * 4))) return rc;
+        if ((rc = ws.starts.ensure((size_t)nw * (NB + 1) * 4))) return rc;
         if ((rc = ws.buckets.ensure((size_t)nw * NB * REC))) return rc;
-        if ((rc = ws.partials.ensure((size_t)nw * nblocks1 * 2 * REC))) return rc;
+        if ((rc = ws.partials.ensure(tot_blk * 2 * REC))) return rc;
         if ((rc = ws.totals.ensure((size_t)nw * sizeof(Ext)))) return rc;
         if ((rc = ws.ensure_pinned((size_t)nw * sizeof(Ext)))) return rc;
+        if ((rc = ws.blockhist.ensure((size_t)nw * pchunks * nparts * 4))) return rc;
+        if ((rc = ws.counts.ensure((size_t)nw * (2 * nparts + 1) * 4))) return rc;
+        if ((rc = ws.seg_partials.ensure(tot_thr * 2 * REC))) return rc;
+        if ((rc = ws.seg_flags.ensure(tot_thr * 4))) return rc;
+        if ((rc = ws.seg_bucket.ensure(tot_thr * 4))) return rc;
+        const size_t lvl_parts = (tot_t1 + nw) * 2 * REC;
+        if ((rc = ws.seg_lvl.ensure(lvl_parts + (tot_t1 * 2 + (size_t)nw * 3) * 4 + 256))) return rc;
+        char *lvl = (char *)ws.seg_lvl.ptr;
+        char *parts1_all = lvl;                                  // [tot_t1][2] records
+        char *parts2_all = lvl + tot_t1 * 2 * REC;               // [nw][2] records
+        uint32_t *flags1_all = (uint32_t *)(lvl + lvl_parts);    // [tot_t1]
+        uint32_t *pb1_all = flags1_all + tot_t1;                 // [tot_t1]
+        uint32_t *flags2_all = pb1_all + tot_t1;                 // [nw]
+        uint32_t *pb2_all = flags2_all + nw;                     // [nw]
+        uint32_t *long_flag_all = pb2_all + nw;                  // [nw]
+        uint32_t *bh_all = (uint32_t *)ws.blockhist.ptr, *part_base_all = (uint32_t *)ws.counts.ptr;
+        uint32_t *part_pop_all = part_base_all + (size_t)nw * (nparts + 1);
 
-        uint32_t *digits = (uint32_t *)ws.digits.ptr, *sorted = (uint32_t *)ws.sorted.ptr;
-        uint32_t *starts = (uint32_t *)ws.starts.ptr;
+        if ((rc = ctx.allow_lds((const void *)k_part_hist<uint16_t>, 160 * 1024))) return rc;
+        if ((rc = ctx.allow_lds((const void *)k_part_hist<uint32_t>, 160 * 1024))) return rc;
+        if ((rc = ctx.allow_lds((const void *)k_part_scatter<uint16_t>, 152 * 1024))) return rc;
+        if ((rc = ctx.allow_lds((const void *)k_part_scatter<uint32_t>, 152 * 1024))) return rc;
+        if ((rc = ctx.allow_lds((const void *)k_fine_sort, 160 * 1024))) return rc;
+        if ((rc = ctx.allow_lds((const void *)k_reduce1<Ops, RED_TPB>, (int)(2 * RED_TPB * sizeof(OpsElem))))) return rc;
+        if ((rc = ctx.allow_lds((const void *)k_reduce2<Ops, RED2_TPB>, (int)(2 * RED2_TPB * sizeof(OpsElem))))) return rc;
 
-        StageTimer timer(ws, stream);
-        // 0. rewrite the bases into the lazy Montgomery domain + infinity flags (unless registered earlier)
-        timer.mark(STAGE_DECOMPOSE);
+        StageTimer timer(ws);
+        ws.timed_pieces = npieces;
+        // ---- 0. inputs, once for all pieces: rewrite the bases into the lazy Montgomery domain + infinity flags (unless
+        // registered earlier), signed-digit decomposition of every scalar
+        timer.mark(0, T_DECOMPOSE, stream);
         const uint8_t *skip = nullptr;
         const void *upoints = nullptr;
         if (resident) {
-            upoints = resident->upoints.ptr;
-            skip = (const uint8_t *)resident->skip.ptr;
+            upoints = (const char *)resident->upoints.ptr + resident_offset * AFF_BYTES;
+            skip = (const uint8_t *)resident->skip.ptr + resident_offset;
         } else {
             if ((rc = ws.upoints.ensure(n * AFF_BYTES))) return rc;
             if ((rc = ws.skip.ensure(n))) return rc;
@@ -155,149 +319,114 @@ struct Group {
             upoints = ws.upoints.ptr;
             skip = (const uint8_t *)ws.skip.ptr;
         }
-        // geometry of the segmented accumulation and of the chain fixup (needed early: the grouping kernels clear the
-        // long-chain flags on their way)
-        // entry-parallel segmented accumulation: seg entries per thread, >= ~4 waves per SIMD when n allows
-        uint32_t seg = env_uint("GMSM_SEG", 0);
-        if (seg == 0) {
-            // every thread does the same work, so the launch should be a whole number of resident "rounds":
-            // capacity = CUs x 3 workgroups (160 VGPRs -> 3 waves/SIMD) x 256 threads
-            const size_t capacity = (size_t)ctx.num_cus * AccWaves<U>::value * 256;
-            const size_t SEG_MAX = env_uint("GMSM_SEGMAX", 512);  // measured: 512 best at 2^24, 256 at 2^22
-            for (size_t r = 1;; ++r) {
-                size_t s = ((size_t)nw * n + r * capacity - 1) / (r * capacity);
-                if (s <= SEG_MAX) {
-                    // nw*ceil(n/s) threads must not exceed r*capacity: round s up until it holds
-                    while (s < SEG_MAX && (size_t)nw * ((n + s - 1) / s) > r * capacity) ++s;
-                    seg = (uint32_t)std::max<size_t>(s, 32);
-                    break;
-                }
-            }
+        // (A decomposition fused with the coarse histogram was measured and dropped: one workgroup per 16 K-scalar chunk
+        // leaves 3/4 of the CUs idle at 2^20, and at 2^24 it only breaks even.)
+        if (d16)
+            hipLaunchKernelGGL((k_decompose<FrP, uint16_t>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                               (const uint32_t *)d_scalars, n, plan, (uint16_t *)ws.digits.ptr, skip);
+        else
+            hipLaunchKernelGGL((k_decompose<FrP, uint32_t>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                               (const uint32_t *)d_scalars, n, plan, (uint32_t *)ws.digits.ptr, skip);
+        if (npieces > 1) {
+            HIP_TRY(hipEventRecord(ws.ev_fork, stream));
+            HIP_TRY(hipStreamWaitEvent(ws.stream2, ws.ev_fork, 0));
         }
-        const uint32_t tpw = (uint32_t)((n + seg - 1) / seg);  // threads per window (upper bound: <= n entries)
-        // chain fixup: short chains in place, long ones through two hierarchical levels (no-ops unless flagged)
-        const uint32_t span1 = 64;
-        const uint32_t t1 = (tpw + span1 - 1) / span1;  // level-1 outputs per window
-        const uint32_t span2 = t1;                      // level 2: one thread per window closes everything
-        const size_t lvl_parts = ((size_t)nw * t1 + nw) * 2 * REC;
-        if ((rc = ws.seg_lvl.ensure(lvl_parts + ((size_t)nw * t1 * 2 + (size_t)nw * 3) * 4 + 256))) return rc;
-        char *lvl = (char *)ws.seg_lvl.ptr;
-        void *parts1 = lvl;
-        void *parts2 = lvl + (size_t)nw * t1 * 2 * REC;  // nw * 2 records
-        uint32_t *flags1 = (uint32_t *)(lvl + lvl_parts);
-        uint32_t *pb1 = flags1 + (size_t)nw * t1;
-        uint32_t *flags2 = pb1 + (size_t)nw * t1;
-        uint32_t *pb2 = flags2 + nw;
-        uint32_t *long_flag = pb2 + nw;
-        // 1. signed-digit decomposition: first launch of the grouping block below
-        // 2. group point references by bucket
-        {
-            // fine buckets per partition: ~16 K references per partition for uniform scalars
-            uint32_t log2NB = 0;
-            while ((1u << log2NB) < NB) ++log2NB;
-            uint32_t log2n = 0;
-            while (((size_t)1 << log2n) < n) ++log2n;
-            const uint32_t lidx = log2n + 1;  // bits of (index << 1 | negate)
-            // target partition population 2^part_log2 (measured, BN254 G1: 2^13 is best up to 2^21 points - more
-            // workgroups for the fine pass; 2^15 from 2^24 on - 128-byte runs out of the coarse pass)
-            const uint32_t part_log2 = env_uint("GMSM_PART_LOG2", log2n <= 21 ? 13 : log2n >= 24 ? 15 : 14);
-            int fb = (int)part_log2 + (int)log2NB - (int)log2n;
-            if (fb > (int)log2NB) fb = (int)log2NB;
-            if (fb < 0) fb = 0;
-            if (fb + lidx > 32) fb = 32 - lidx;
-            const uint32_t fbits = (uint32_t)fb;
-            const uint32_t nparts = NB >> fbits;
-            const uint32_t pchunks = (uint32_t)((n + PART_CHUNK - 1) / PART_CHUNK);  // chunk = one LDS staging buffer
-            const size_t pchunk_len = PART_CHUNK;
-            if ((rc = ws.blockhist.ensure((size_t)nw * pchunks * nparts * 4))) return rc;
-            if ((rc = ws.counts.ensure((size_t)nw * (2 * nparts + 1) * 4))) return rc;
-            if ((rc = ws.parted.ensure((size_t)nw * n * 4))) return rc;
-            uint32_t *bh = (uint32_t *)ws.blockhist.ptr, *part_base = (uint32_t *)ws.counts.ptr;
-            uint32_t *part_pop = part_base + (size_t)nw * (nparts + 1);
-            uint32_t *parted = (uint32_t *)ws.parted.ptr;
-            if ((rc = ctx.allow_lds((const void *)k_part_hist, 160 * 1024))) return rc;
-            if ((rc = ctx.allow_lds((const void *)k_part_scatter, 152 * 1024))) return rc;
-            if ((rc = ctx.allow_lds((const void *)k_fine_sort, 160 * 1024))) return rc;
-            // (A decomposition fused with this histogram was measured and dropped: one workgroup per 16 K-scalar chunk
-            // leaves 3/4 of the CUs idle at 2^20, and at 2^24 it only breaks even.)
-            hipLaunchKernelGGL((k_decompose<FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                               (const uint32_t *)d_scalars, n, plan, digits, skip);
-            timer.mark(STAGE_HIST);
-            hipLaunchKernelGGL(k_part_hist, dim3(pchunks, nw), dim3(1024), (size_t)nparts * 4, stream, digits, n, nparts,
-                               fbits, pchunk_len, bh);
-            timer.mark(STAGE_SCAN);
-            hipLaunchKernelGGL(k_part_colscan, dim3((nparts + 31) / 32, nw), dim3(256), 0, stream, bh, pchunks, nparts,
-                               part_pop);
-            hipLaunchKernelGGL(k_part_rowscan, dim3(nw), dim3(1024), 0, stream, part_pop, nparts, part_base, long_flag);
-            timer.mark(STAGE_SCATTER);
-            hipLaunchKernelGGL(k_part_scatter, dim3(pchunks, nw), dim3(1024),
-                               (size_t)nparts * 8 + (size_t)PART_CHUNK * 6, stream, digits, n, nparts, fbits, lidx, pchunk_len,
-                               bh, part_base, parted);
-            // staging slots of the fine pass: up to 96 KiB next to the 2^fbits counters; larger partitions go direct
-            const size_t fine_cnt_bytes = (size_t)4 << fbits;
-            const uint32_t stage_cap = fine_cnt_bytes >= 156 * 1024 ? 0u
-                                       : (uint32_t)std::min<size_t>(env_uint("GMSM_STAGE_CAP", part_log2 >= 15 ? 39000 : 24576),
-                                                                  (156 * 1024 - fine_cnt_bytes) / 4);
-            hipLaunchKernelGGL(k_fine_sort, dim3(nparts, nw), dim3(1024), ((size_t)4 << fbits) + (size_t)stage_cap * 4, stream,
+
+        for (int p = 0; p < npieces; ++p) {
+            const Piece &q = pc[p];
+            hipStream_t st = (p & 1) ? ws.stream2 : stream;
+            const uint32_t k0 = q.k0, nwp = q.nw;
+            // this piece's slices of the window-major arrays
+            const char *digits = (const char *)ws.digits.ptr + (size_t)k0 * n * dsz;
+            uint32_t *sorted = (uint32_t *)ws.sorted.ptr + (size_t)k0 * n;
+            uint32_t *parted = (uint32_t *)ws.parted.ptr + (size_t)k0 * n;
+            uint32_t *starts = (uint32_t *)ws.starts.ptr + (size_t)k0 * (NB + 1);
+            uint32_t *bh = bh_all + (size_t)k0 * pchunks * nparts;
+            uint32_t *part_base = part_base_all + (size_t)k0 * (nparts + 1);
+            uint32_t *part_pop = part_pop_all + (size_t)k0 * nparts;
+            char *buckets = (char *)ws.buckets.ptr + (size_t)k0 * NB * REC;
+            char *seg_partials = (char *)ws.seg_partials.ptr + q.off_thr * 2 * REC;
+            uint32_t *seg_flags = (uint32_t *)ws.seg_flags.ptr + q.off_thr;
+            uint32_t *seg_bucket = (uint32_t *)ws.seg_bucket.ptr + q.off_thr;
+            char *parts1 = parts1_all + q.off_t1 * 2 * REC;
+            char *parts2 = parts2_all + (size_t)k0 * 2 * REC;
+            uint32_t *flags1 = flags1_all + q.off_t1, *pb1 = pb1_all + q.off_t1;
+            uint32_t *flags2 = flags2_all + k0, *pb2 = pb2_all + k0, *long_flag = long_flag_all + k0;
+            char *partials = (char *)ws.partials.ptr + q.off_blk * 2 * REC;
+            char *totals = (char *)ws.totals.ptr + (size_t)k0 * sizeof(Ext);
+
+            // ---- 1. group the point references of every window by bucket
+            timer.mark(p, T_HIST, st);
+            if (d16)
+                hipLaunchKernelGGL(k_part_hist<uint16_t>, dim3(pchunks, nwp), dim3(1024), (size_t)nparts * 4, st,
+                                   (const uint16_t *)digits, n, nparts, fbits, pchunk_len, bh);
+            else
+                hipLaunchKernelGGL(k_part_hist<uint32_t>, dim3(pchunks, nwp), dim3(1024), (size_t)nparts * 4, st,
+                                   (const uint32_t *)digits, n, nparts, fbits, pchunk_len, bh);
+            timer.mark(p, T_SCAN, st);
+            hipLaunchKernelGGL(k_part_colscan, dim3((nparts + 31) / 32, nwp), dim3(256), 0, st, bh, pchunks, nparts, part_pop);
+            hipLaunchKernelGGL(k_part_rowscan, dim3(nwp), dim3(1024), 0, st, part_pop, nparts, part_base, long_flag);
+            timer.mark(p, T_SCATTER, st);
+            if (d16)
+                hipLaunchKernelGGL(k_part_scatter<uint16_t>, dim3(pchunks, nwp), dim3(1024), scatter_lds, st,
+                                   (const uint16_t *)digits, n, nparts, fbits, lidx, pchunk_len, bh, part_base, parted);
+            else
+                hipLaunchKernelGGL(k_part_scatter<uint32_t>, dim3(pchunks, nwp), dim3(1024), scatter_lds, st,
+                                   (const uint32_t *)digits, n, nparts, fbits, lidx, pchunk_len, bh, part_base, parted);
+            hipLaunchKernelGGL(k_fine_sort, dim3(nparts, nwp), dim3(1024), ((size_t)4 << fbits) + (size_t)stage_cap * 4, st,
                                parted, n, NB, fbits, lidx, part_base, sorted, starts, stage_cap);
-        }
-        // 3. bucket accumulation
-        timer.mark(STAGE_ACCUMULATE);
-        const uint32_t *reduce_starts = starts;  // empty buckets are never written: the reduction consults starts[]
-        {
-            if ((rc = ws.seg_partials.ensure((size_t)nw * tpw * 2 * REC))) return rc;
-            if ((rc = ws.seg_flags.ensure((size_t)nw * tpw * 4))) return rc;
-            if ((rc = ws.seg_bucket.ensure((size_t)nw * tpw * 4))) return rc;
-            hipLaunchKernelGGL((k_accumulate_seg<U>), dim3((tpw + 255) / 256, nw), dim3(256), 0, stream,
-                               upoints, n, NB, seg, starts, sorted, ws.buckets.ptr, ws.seg_partials.ptr,
-                               (uint32_t *)ws.seg_flags.ptr, (uint32_t *)ws.seg_bucket.ptr, tpw);
-            timer.mark(STAGE_FIXUP);
-            hipLaunchKernelGGL((k_fixup_seg<Ops>), dim3((tpw + 255) / 256, nw), dim3(256), 0, stream, NB,
-                               ws.seg_partials.ptr, (const uint32_t *)ws.seg_flags.ptr,
-                               (const uint32_t *)ws.seg_bucket.ptr, tpw, ws.buckets.ptr, long_flag);
-            hipLaunchKernelGGL((k_fixup_level<OpsNI>), dim3((t1 + 255) / 256, nw), dim3(256), 0, stream, NB,
-                               ws.seg_partials.ptr, (const uint32_t *)ws.seg_flags.ptr,
-                               (const uint32_t *)ws.seg_bucket.ptr, tpw, span1, parts1, flags1, pb1, t1, ws.buckets.ptr,
-                               long_flag);
-            hipLaunchKernelGGL((k_fixup_level<OpsNI>), dim3(1, nw), dim3(256), 0, stream, NB, parts1, flags1, pb1, t1, span2,
-                               parts2, flags2, pb2, 1u, ws.buckets.ptr, long_flag);
-        }
-        // 4. bucket reduction -> window totals
-        if ((rc = ctx.allow_lds((const void *)k_reduce1<Ops, RED_TPB>, (int)(2 * RED_TPB * sizeof(OpsElem))))) return rc;
-        if ((rc = ctx.allow_lds((const void *)k_reduce2<Ops, RED2_TPB>, (int)(2 * RED2_TPB * sizeof(OpsElem))))) return rc;
-        timer.mark(STAGE_REDUCE);
-        {
-            // level 1 doubles its S_blk log2span times in an otherwise idle wave (256-thread blocks only): level 2 then has
-            // no serial doubling tail (11 of its 20 steps at c = 16)
-            const uint32_t prescale = (RED_TPB >= 256 && env_uint("GMSM_PRESCALE", 1)) ? log2span : 0u;
-            hipLaunchKernelGGL((k_reduce1<Ops, RED_TPB>), dim3(nblocks1, nw), dim3(RED_TPB), 2 * RED_TPB * sizeof(OpsElem), stream,
-                               ws.buckets.ptr, NB, log2L, ws.partials.ptr, reduce_starts, prescale);
-            bool l2 = false;
-            if constexpr (QUAD_REDUCE) {
-                // level 2 on quads of lanes (4 lanes share the products of one addition). Level 1 stays
-                // on single lanes: a quad version needs 4x the lanes at ~230 VGPRs each, i.e. several rounds of
-                // workgroups per CU - measured 0.57 ms against 0.37 ms.
-                if (env_uint("GMSM_QUAD", 1) >= 1) {
-                    uint32_t active = 2;
-                    while (active < nblocks1) active <<= 1;
-                    hipLaunchKernelGGL((k_reduce2_quad<U, INLINE_OPS>), dim3(nw), dim3(4 * active), active * sizeof(OpsElem),
-                                       stream, ws.partials.ptr, nblocks1, log2span - prescale, active, ws.totals.ptr);
-                    l2 = true;
+            // ---- 2. bucket accumulation, after the previous piece's
+            timer.mark(p, T_WAIT, st);
+            if (p > 0) HIP_TRY(hipStreamWaitEvent(st, ws.ev_acc[p - 1], 0));
+            timer.mark(p, T_ACCUMULATE, st);
+            hipLaunchKernelGGL((k_accumulate_seg<U>), dim3((q.tpw + 255) / 256, nwp), dim3(256), 0, st, upoints, n, NB, q.seg,
+                               starts, sorted, buckets, seg_partials, seg_flags, seg_bucket, q.tpw);
+            if (p + 1 < npieces) HIP_TRY(hipEventRecord(ws.ev_acc[p], st));
+            timer.mark(p, T_FIXUP, st);
+            hipLaunchKernelGGL((k_fixup_seg<Ops>), dim3((q.tpw + 255) / 256, nwp), dim3(256), 0, st, NB, seg_partials,
+                               (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets, long_flag);
+            hipLaunchKernelGGL((k_fixup_level<OpsNI>), dim3((q.t1 + 255) / 256, nwp), dim3(256), 0, st, NB, seg_partials,
+                               (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, span1, parts1, flags1, pb1, q.t1,
+                               buckets, long_flag);
+            hipLaunchKernelGGL((k_fixup_level<OpsNI>), dim3(1, nwp), dim3(256), 0, st, NB, parts1, flags1, pb1, q.t1, q.t1, parts2,
+                               flags2, pb2, 1u, buckets, long_flag);
+            // ---- 3. bucket reduction -> window totals (empty buckets are never written: the reduction consults starts[])
+            timer.mark(p, T_REDUCE, st);
+            {
+                // level 1 doubles its S_blk log2span times in an otherwise idle wave (256-thread blocks only): level 2 then
+                // has no serial doubling tail (11 of its 20 steps at c = 16)
+                const uint32_t prescale = (RED_TPB >= 256 && env_uint("GMSM_PRESCALE", 1)) ? q.log2span : 0u;
+                hipLaunchKernelGGL((k_reduce1<Ops, RED_TPB>), dim3(q.nblocks1, nwp), dim3(RED_TPB), 2 * RED_TPB * sizeof(OpsElem), st,
+                                   buckets, NB, q.log2L, partials, starts, prescale);
+                bool l2 = false;
+                if constexpr (QUAD_REDUCE) {
+                    // level 2 on quads of lanes (4 lanes share the products of one addition). Level 1 stays
+                    // on single lanes: a quad version needs 4x the lanes at ~230 VGPRs each, i.e. several rounds of
+                    // workgroups per CU - measured 0.57 ms against 0.37 ms.
+                    if (env_uint("GMSM_QUAD", 1) >= 1) {
+                        uint32_t active = 2;
+                        while (active < q.nblocks1) active <<= 1;
+                        hipLaunchKernelGGL((k_reduce2_quad<U, INLINE_OPS>), dim3(nwp), dim3(4 * active), active * sizeof(OpsElem),
+                                           st, partials, q.nblocks1, q.log2span - prescale, active, totals);
+                        l2 = true;
+                    }
                 }
+                if (!l2)
+                    hipLaunchKernelGGL((k_reduce2<Ops, RED2_TPB>), dim3(nwp), dim3(RED2_TPB), 2 * RED2_TPB * sizeof(OpsElem), st,
+                                       partials, q.nblocks1, q.log2span - prescale, totals);
             }
-            if (!l2)
-                hipLaunchKernelGGL((k_reduce2<Ops, RED2_TPB>), dim3(nw), dim3(RED2_TPB), 2 * RED2_TPB * sizeof(OpsElem), stream,
-                                   ws.partials.ptr, nblocks1, log2span - prescale, ws.totals.ptr);
+            timer.mark(p, T_END, st);
         }
-        timer.mark(STAGE_END);
         HIP_TRY(hipGetLastError());
+        if (npieces > 1) {  // everything queued on the second stream is finished before the totals leave
+            HIP_TRY(hipEventRecord(ws.ev_join, ws.stream2));
+            HIP_TRY(hipStreamWaitEvent(stream, ws.ev_join, 0));
+        }
         if (d_out)
             HIP_TRY(hipMemcpyAsync(d_out, ws.totals.ptr, (size_t)nw * sizeof(Ext), hipMemcpyDeviceToDevice, stream));
         else
             HIP_TRY(hipMemcpyAsync(ws.pinned, ws.totals.ptr, (size_t)nw * sizeof(Ext), hipMemcpyDeviceToHost, stream));
-        if (!ws.last_use) HIP_TRY(hipEventCreateWithFlags(&ws.last_use, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(ws.last_use, stream));
-        ws.last_stream = stream;
+        if ((rc = end_use(ws, stream))) return rc;
         ws.pending_timed = timer.on;
         return GMSM_OK;
     }
@@ -503,20 +632,48 @@ struct Group {
         return GMSM_OK;
     }
 
+    // Most points one pipeline run takes: the coarse partition pass keeps two 32-bit words per partition in LDS, which
+    // caps it at 2^27 references per window. Larger inputs run as consecutive point ranges whose window totals are added
+    // (the point decomposition of sharding.py, on one device). GMSM_MAX_RUN lowers the cap (tests).
+    static size_t max_run_points() {
+        const size_t cap = (size_t)1 << 27;
+        const size_t forced = env_uint("GMSM_MAX_RUN", 0);
+        return forced ? std::min(cap, forced) : cap;
+    }
+
     static int multiexp_device(Context &ctx, Workspace &ws, const void *d_points, const void *d_scalars, size_t n,
                                hipStream_t caller_stream, J *out, const ResidentBases *resident = nullptr) {
-        const unsigned c = choose_c(FR_BITS, n);
+        const size_t run = max_run_points();
+        if (n <= run) {
+            const unsigned c = choose_c(FR_BITS, n);
+            WindowPlan plan = make_plan(c, 0, 1);
+            std::vector<Ext> totals(plan.nwin_total);
+            int rc = window_sums(ctx, ws, d_points, d_scalars, n, plan, caller_stream, totals.data(), resident);
+            if (rc) return rc;
+            *out = fold(totals.data(), c);
+            return GMSM_OK;
+        }
+        const unsigned nruns = (unsigned)((n + run - 1) / run);
+        const size_t per = (n + nruns - 1) / nruns;
+        const unsigned c = choose_c(FR_BITS, per);  // one c for every range: the totals must line up
         WindowPlan plan = make_plan(c, 0, 1);
-        std::vector<Ext> totals(plan.nwin_total);
-        int rc = window_sums(ctx, ws, d_points, d_scalars, n, plan, caller_stream, totals.data(), resident);
-        if (rc) return rc;
-        *out = fold(totals.data(), c);
+        std::vector<Ext> sets((size_t)nruns * plan.nwin_total);
+        for (unsigned r = 0; r < nruns; ++r) {
+            const size_t lo = (size_t)r * per, len = std::min(per, n - lo);
+            const void *dp = d_points ? (const char *)d_points + lo * AFF_BYTES : nullptr;
+            int rc = window_sums(ctx, ws, dp, (const char *)d_scalars + lo * SCALAR_BYTES, len, plan, caller_stream,
+                                 sets.data() + (size_t)r * plan.nwin_total, resident, lo);
+            if (rc) return rc;
+        }
+        *out = fold_sets(sets.data(), nruns, c);
         return GMSM_OK;
     }
 
     // Asynchronous pair (gmsm_multiexp_bases_submit / gmsm_multiexp_collect): submit launches the whole device pipeline
     // on the workspace's own stream and returns; collect waits for it, then folds the windows on the host.
     static int multiexp_submit(Context &ctx, Workspace &ws, const void *d_scalars, size_t n, const ResidentBases *resident) {
+        if (n > max_run_points())
+            return fail(GMSM_ERR_ARG, "submit/collect takes at most 2^27 points per ticket: use the blocking entry, which splits larger inputs");
         const unsigned c = choose_c(FR_BITS, n);
         WindowPlan plan = make_plan(c, 0, 1);
         int rc = enqueue_window_sums(ctx, ws, nullptr, d_scalars, n, plan, ws.stream, resident);
@@ -743,7 +900,7 @@ static int debug_decompose_impl(const uint64_t *scalars, size_t n, unsigned c, u
     if ((rc = ws.h2d_scalars.ensure(n * G::SCALAR_BYTES))) return rc;
     if ((rc = ws.digits.ensure((size_t)plan.nwin_total * n * 4))) return rc;
     HIP_TRY(hipMemcpyAsync(ws.h2d_scalars.ptr, scalars, n * G::SCALAR_BYTES, hipMemcpyHostToDevice, ws.stream));
-    hipLaunchKernelGGL((k_decompose<typename G::FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ws.stream,
+    hipLaunchKernelGGL((k_decompose<typename G::FrP, uint32_t>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ws.stream,
                        (const uint32_t *)ws.h2d_scalars.ptr, n, plan, (uint32_t *)ws.digits.ptr, (const uint8_t *)nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_digits, ws.digits.ptr, (size_t)plan.nwin_total * n * 4, hipMemcpyDeviceToHost, ws.stream));
@@ -801,13 +958,14 @@ struct VTableOf {
     }
     static int window_sums_enqueue(Context &ctx, const void *d_points, const void *d_scalars, size_t n, unsigned c,
                                    unsigned win_first, unsigned win_stride, hipStream_t stream, void *d_out_xyzz,
-                                   const ResidentBases *resident) {
+                                   const std::shared_ptr<ResidentBases> &resident) {
         WindowPlan plan = G::make_plan(c, win_first, win_stride);
         // leased for the duration of this call only: the work it leaves in flight is protected by stream order
-        // (Workspace::last_use), not by the lease
+        // (Workspace::last_use, honoured by whoever leases the workspace next), not by the lease
         GMSM_LEASE_OR_FAIL(lease, ctx);
         Workspace *ws = lease.w;
-        int rc = G::enqueue_window_sums(ctx, *ws, d_points, d_scalars, n, plan, stream, resident, d_out_xyzz);
+        int rc = G::enqueue_window_sums(ctx, *ws, d_points, d_scalars, n, plan, stream, resident.get(), d_out_xyzz);
+        ws->bases_ref = resident;             // alive until the next call on this workspace replaces it
         ws->uncollected = ws->pending_timed;  // nobody waits for this call: its stage events are read by the next one
         ws->pending_timed = false;
         return rc;

@@ -12,7 +12,8 @@
 //   k_reduce1/2        running-sum bucket reduction         multiexp_jacobian.go:44-52
 //   (host) fold        msmReduceChunkG1Affine               multiexp.go:302-315
 //
-// Digit code (same as the reference's uint16 digits, widened to 32 bit so c may exceed 16):
+// Digit code (the reference's uint16 digits, multiexp.go:779-800; stored as uint16 whenever every code of the call fits,
+// i.e. for all c <= 16 in scope, else uint32 - the digit arrays are the largest intermediate of the front end):
 //   0 = skip, d > 0 -> 2d, d < 0 -> 2(-d-1)+1;  bucket = (code>>1) - ((code&1)^1), negate = code&1.
 // Sorted entry: (point_index << 1) | negate.
 #pragma once
@@ -54,9 +55,9 @@ __device__ __forceinline__ void store_struct(void *base, size_t index, const T &
 
 // ------------------------------------------------------------------ scalar decomposition
 // One thread per scalar. digits is [nwin_local][n] (window-major, coalesced stores).
-template <class FrP>
+template <class FrP, class D>
 __global__ void __launch_bounds__(256) k_decompose(const uint32_t *__restrict__ scalars, size_t n, WindowPlan plan,
-                                                   uint32_t *__restrict__ digits,
+                                                   D *__restrict__ digits,
                                                    const uint8_t *__restrict__ skip /* may be null */) {
     constexpr int NR = FrP::N;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -96,7 +97,7 @@ __global__ void __launch_bounds__(256) k_decompose(const uint32_t *__restrict__ 
         }
         if (w >= plan.win_first && (w - plan.win_first) % plan.win_stride == 0) {
             const uint32_t k = (w - plan.win_first) / plan.win_stride;
-            if (k < plan.nwin_local) digits[(size_t)k * n + i] = zero ? 0u : code;
+            if (k < plan.nwin_local) digits[(size_t)k * n + i] = (D)(zero ? 0u : code);
         }
     }
 }
@@ -144,7 +145,8 @@ __device__ __forceinline__ uint32_t wave0_exclusive_scan(const uint32_t *cnt, ui
 }
 
 // grid = (nchunks, nwin). LDS: P counters. blockhist[k][chunk][p]
-static __global__ void __launch_bounds__(1024) k_part_hist(const uint32_t *__restrict__ digits, size_t n, uint32_t nparts,
+template <class D>
+__global__ void __launch_bounds__(1024) k_part_hist(const D *__restrict__ digits, size_t n, uint32_t nparts,
                                                            uint32_t fbits, size_t chunk_len,
                                                            uint32_t *__restrict__ blockhist) {
     extern __shared__ uint32_t lds_cnt[];
@@ -153,7 +155,7 @@ static __global__ void __launch_bounds__(1024) k_part_hist(const uint32_t *__res
     __syncthreads();
     const size_t lo = (size_t)chunk * chunk_len;
     const size_t hi = lo + chunk_len < n ? lo + chunk_len : n;
-    const uint32_t *d = digits + (size_t)k * n;
+    const D *d = digits + (size_t)k * n;
     for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const uint32_t code = d[i];
         if (code) atomicAdd(&lds_cnt[code_bucket(code) >> fbits], 1u);
@@ -226,7 +228,8 @@ static __global__ void __launch_bounds__(1024) k_part_rowscan(const uint32_t *__
 // consecutive addresses, so every (chunk, partition) run leaves the CU as one burst instead of trickling out 4 bytes at
 // a time over the lifetime of the workgroup (which left L2 writing back partially filled lines: 4.4 ms at 2^24).
 constexpr uint32_t PART_CHUNK = 16384;
-static __global__ void __launch_bounds__(1024) k_part_scatter(const uint32_t *__restrict__ digits, size_t n, uint32_t nparts,
+template <class D>
+__global__ void __launch_bounds__(1024) k_part_scatter(const D *__restrict__ digits, size_t n, uint32_t nparts,
                                                               uint32_t fbits, uint32_t lidx, size_t chunk_len,
                                                               const uint32_t *__restrict__ blockhist,
                                                               const uint32_t *__restrict__ part_base,
@@ -244,7 +247,7 @@ static __global__ void __launch_bounds__(1024) k_part_scatter(const uint32_t *__
     __syncthreads();
     const size_t lo = (size_t)chunk * chunk_len;
     const size_t hi = lo + chunk_len < n ? lo + chunk_len : n;
-    const uint32_t *d = digits + (size_t)k * n;
+    const D *d = digits + (size_t)k * n;
     const uint32_t fmask = (1u << fbits) - 1u;
     constexpr int PER = PART_CHUNK / 1024;  // entries per thread, kept in registers between the two passes
     uint32_t ent[PER];
@@ -435,8 +438,18 @@ __global__ void __launch_bounds__(256, AccWaves<U>::value) k_accumulate_seg(cons
         const uint32_t mid = (lo + hi) >> 1;
         if (st[mid] <= e0) lo = mid; else hi = mid;
     }
+    // Software pipeline: nothing the current addition needs is loaded in the iteration that uses it.
+    //   entry e+2      (the address of the NEXT iteration's gather) is requested now;
+    //   point of e+1   is gathered while the point of e is being added (64 B per lane; at 2^24 the 1 GiB table is HBM);
+    //   starts[b+2]    (the end of the NEXT bucket) is requested when the current bucket ends.
+    // Measured ablations (profiles/r02_accumulate_ablation.md): with the operands in registers the same additions take
+    // 1.08-1.12 ms per 2^24 (tools/ubench_madd.hip), this kernel 1.35 ms at 2^20; removing the gather, the bucket flushes
+    // and all boundary handling together only gets it to 1.28 ms. At 2^24 the gather (HBM instead of Infinity Cache)
+    // costs 12 %; requesting the entries one iteration earlier, or gathering whole 64-byte lines with four cooperating
+    // lanes through an LDS tile (9-13 % slower: spills), does not recover it.
     uint32_t b = lo;
     uint32_t bend = st[b + 1];
+    uint32_t bend2 = st[b + 2 <= nbuckets ? b + 2 : nbuckets];
     bool open_left = st[b] < e0;
     uint32_t flags = 0;
     const uint32_t *ent = sorted + (size_t)k * n;
@@ -444,6 +457,7 @@ __global__ void __launch_bounds__(256, AccWaves<U>::value) k_accumulate_seg(cons
     XYZZL<U> acc;
     bool inf = true;
     uint32_t v = ent[e0];
+    uint32_t vn = e0 + 1 < e1 ? ent[e0 + 1] : 0u;
     UAffine<U> p = load_struct<UAffine<U>>(upoints, v >> 1);
     for (uint32_t e = e0; e < e1; ++e) {
         if (e == bend) {  // the current run is complete on the right
@@ -456,16 +470,19 @@ __global__ void __launch_bounds__(256, AccWaves<U>::value) k_accumulate_seg(cons
             }
             inf = true;
             ++b;
-            while (st[b + 1] == e) ++b;  // skip empty buckets
-            bend = st[b + 1];
+            bend = bend2;
+            while (bend == e) {  // empty buckets (rare: the next bucket's end was prefetched, further ones are not)
+                ++b;
+                bend = st[b + 1];
+            }
+            bend2 = st[b + 2 <= nbuckets ? b + 2 : nbuckets];
         }
-        // prefetch the next entry's point while this one is being added
         const uint32_t vc = v;
         const UAffine<U> pc = p;
-        if (e + 1 < e1) {
-            v = ent[e + 1];
-            p = load_struct<UAffine<U>>(upoints, v >> 1);
-        }
+        const uint32_t vnn = e + 2 < e1 ? ent[e + 2] : 0u;
+        if (e + 1 < e1) p = load_struct<UAffine<U>>(upoints, vn >> 1);
+        v = vn;
+        vn = vnn;
         lz_madd<true>(acc, inf, T::unpack(pc.x), T::unpack(pc.y), (vc & 1u) != 0);
     }
     {

@@ -23,7 +23,9 @@
  *                fallback inside this library: without a usable gfx950 device every compute entry fails loudly.
  *
  * Threading: every entry point is re-entrant and may be called concurrently from any OS thread (goroutines
- * migrate); calls on one device are serialised internally on that device's context.
+ * migrate); per device two calls run at a time, further callers wait their turn.
+ * Limits: n < 2^31. One pipeline run takes up to 2^27 points; the MultiExp entries split larger inputs into point
+ * ranges themselves, gmsm_window_sums_* and gmsm_multiexp_bases_submit refuse them (GMSM_ERR_ARG).
  * Ownership: the caller owns all buffers; host pointers are not retained after return.
  */
 #ifndef GMSM_H
@@ -176,16 +178,24 @@ int gmsm_debug_group_op(int group, int op, const uint64_t *acc, const uint64_t *
  * ecc/bn254/g1.go:1039). */
 int gmsm_generate_points(int group, const uint64_t *base_affine, const uint64_t *k0, const uint64_t *k1, int klimbs,
                          size_t n, int nthreads, uint64_t *out_points);
-/* Per-stage device timing with HIP events on the launch stream. gmsm_set_profiling(1) resets and enables the
+/* Per-stage device timing with HIP events on the launch streams. gmsm_set_profiling(1) resets and enables the
  * accumulators; gmsm_get_stage_times copies the summed milliseconds of up to max_stages stages
- * (0 decompose, 1 histogram, 2 scans, 3 scatter, 4 bucket accumulation kernel, 5 split-bucket fixup, 6 bucket
- * reduction) and the number of
- * pipeline runs they cover; returns the number of stages written. */
+ * (0 base rewrite + decompose, 1 histogram, 2 scans, 3 scatter + fine sort, 4 bucket accumulation kernel, 5 split-bucket
+ * fixup, 6 bucket reduction, 7 time a window group's stream waited for the previous group's accumulation kernel) and the
+ * number of pipeline runs they cover; returns the number of stages written. One MultiExp runs as up to four window
+ * groups whose pipelines overlap on two streams, so the stage sums exceed the wall time of the call;
+ * gmsm_get_stage_launches gives how many stage instances (window groups) each sum covers - for stage 4 that is the
+ * number of k_accumulate_seg launches. */
 void gmsm_set_profiling(int on);
 int gmsm_get_stage_times(double *out_ms, int max_stages, unsigned long *out_calls);
+int gmsm_get_stage_launches(unsigned long *out_launches, int max_stages);
 
 int gmsm_device_count(void);
-int gmsm_set_device(int device);          /* device used by subsequent calls of this thread (default 0) */
+/* Device used by later calls of this thread AND process-wide default for threads that never called it (a goroutine
+ * that is moved to another OS thread keeps its device as long as the process uses one device; a process that drives
+ * several devices from several threads must pin them, runtime.LockOSThread). Entries that take device pointers or a
+ * bases handle do not depend on it: they run on the device that owns the pointer / the registered bases. */
+int gmsm_set_device(int device);
 /* text of the calling thread's last failure; a thread that never failed gets the most recent failure of the process
  * (a cgo caller may be rescheduled onto another OS thread between the failing call and this one) */
 const char *gmsm_last_error(void);
