@@ -5,16 +5,23 @@
 
 One "step" = one complete MultiExp (device-resident bases and scalars -> Jacobian result on the host) of
 n = 2^logn points.  N = 1: the whole MSM on one GPU (BASELINE config C2 at the default logn = 20).  N > 1 (launched by
-torch.distributed.run, one rank per GPU): the windows of the SAME MSM are sharded round-robin over the ranks, every
-rank holds all bases, the per-window totals are exchanged with one RCCL all-gather and folded (strong scaling of one
-MSM, as BASELINE.json's north_star describes).
+torch.distributed.run, one rank per GPU): the SAME MSM is sharded over the ranks (points or windows, sharding.py), the
+per-window totals are exchanged with one RCCL all-gather and folded (strong scaling of one MSM, as BASELINE.json's
+north_star describes).
 
 Rank 0 prints one JSON line.  Besides the contract fields it carries
-  roofline      dominant kernel (k_accumulate): algorithmic bytes per launch (96 B/point x n) / mean
-                launch duration from HIP events recorded on the launch stream inside libgmsm; peak = 8000 GB/s
+  value_cold / value_warm_bases   SURVEY.md §8(d): the same MSM through the drop-in C entries with host buffers
+                (cold: bases + scalars cross PCIe every call; warm-bases: registered bases, scalars cross PCIe)
+  roofline      dominant kernel (k_accumulate_seg): algorithmic bytes per launch (96 B/point x n) /
+                mean launch duration from HIP events recorded on the launch stream inside libgmsm; peak = 8000 GB/s
   int_roofline  the bound that actually binds: field multiplications per second against the v_mad_u64_u32 issue peak
   cpu_baseline  the oracle (C restatement of gnark-crypto's algorithm, kind "port") timed on this box's host cores
   bit_exact     GPU affine result == oracle affine result on the timed input
+  also          the other BASELINE.json configurations, timed in the same run: BN254 G1 2^24 (resident, warm-bases,
+                cold), BLS12-381 G1 and G2 2^22, BW6-761 G1 2^20; each with ms_per_step, stage_ms, roofline and a
+                closed-form bit_exact check (bases [a_i]G built on the device, expected result [sum a_i b_i]G from the
+                oracle: the shape of the reference's own MSM identity, multiexp_test.go:54-60)
+  replica_batch (--batch K) K MultiExp over the same registered bases spread over the ranks, one all-gather of results
 """
 import argparse
 import importlib
@@ -29,6 +36,161 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 STAGES = ["decompose", "histogram", "scans", "scatter", "accumulate", "fixup", "reduce", "wait_prev_group"]
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md
+
+# BASELINE.json configs beyond the headline one: (curve, group, logn, steps, host-entry legs too)
+ALSO = [("bn254", "g1", 24, 5, True), ("bls12_381", "g1", 22, 5, False), ("bls12_381", "g2", 22, 3, False),
+        ("bw6_761", "g1", 20, 3, False)]
+
+
+def uniform_scalars(rng, g, n):
+    """(n, fr_limbs) uint64: stored (Montgomery) limbs uniform in [0, r) by rejection, hence so is the scalar value."""
+    nl = g.fr_limbs
+    sc = np.zeros((n, nl), dtype=np.uint64)
+    todo = np.arange(n)
+    r_limbs = [(g.curve.r >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(nl)]
+    top_bits = g.curve.fr_bits - 64 * (nl - 1)
+    while todo.size:
+        cand = rng.integers(0, 2**64, size=(todo.size, nl), dtype=np.uint64)
+        cand[:, nl - 1] &= np.uint64((1 << top_bits) - 1)
+        lt = np.zeros(todo.size, dtype=bool)
+        eq = np.ones(todo.size, dtype=bool)
+        for i in range(nl - 1, -1, -1):
+            lt |= eq & (cand[:, i] < np.uint64(r_limbs[i]))
+            eq &= cand[:, i] == np.uint64(r_limbs[i])
+        sc[todo[lt]] = cand[lt]
+        todo = todo[~lt]
+    return sc
+
+
+class StageProfile:
+    """Per-stage device times of the calls between start() and stop() (HIP events inside libgmsm)."""
+
+    def __init__(self, lib):
+        self.lib = lib
+
+    def start(self):
+        self.lib.gmsm_set_profiling(1)
+
+    def stop(self):
+        ms = (_ct.c_double * len(STAGES))()
+        calls = _ct.c_ulong(0)
+        launches = (_ct.c_ulong * len(STAGES))()
+        self.lib.gmsm_get_stage_times(ms, len(STAGES), _ct.byref(calls))
+        self.lib.gmsm_get_stage_launches(launches, len(STAGES))
+        self.lib.gmsm_set_profiling(0)
+        ncalls = max(1, calls.value)
+        stages = {name: ms[i] / ncalls for i, name in enumerate(STAGES)}
+        acc_launches = max(1, launches[STAGES.index("accumulate")] // ncalls)
+        return stages, acc_launches
+
+
+def roofline_record(g, n, pairs_share, stages, acc_launches, traffic):
+    """roofline + int_roofline of k_accumulate_seg.  pairs_share = this rank's fraction of the n*nwin (point, window)
+    pairs; one MultiExp may run several launches (window groups): per-launch figures are averages."""
+    acc_ms = stages["accumulate"] / acc_launches
+    bytes_per_point = 8 * (g.aff_limbs + g.fr_limbs)  # SURVEY.md §8(d): affine point + scalar (BN254 G1: 96 B)
+    algorithmic_bytes = bytes_per_point * n * pairs_share / acc_launches
+    achieved = algorithmic_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": traffic, "kernel": "k_accumulate_seg", "algorithmic_bytes_per_launch": algorithmic_bytes,
+            "avg_launch_ms": acc_ms, "launches_per_msm": acc_launches}
+
+
+def int_roofline_record(madds, acc_ms_total):
+    """Integer roofline of the BN254 accumulation: 10 lazy products per mixed add (8M+2S, g1.go:822); one 9x29-bit
+    product = 171 v_mad_u64_u32/v_mul_lo_u32 + 18 v_lshrrev_b64, 4 cycles / wave64 / SIMD each (tools/ubench_valu.hip):
+    issue peak = 1024 SIMDs * 64 lanes * 2.4 GHz / (189 * 4) = 208e9 products/s at the nominal clock; the chip sustains
+    what tools/ubench_fpmul.hip measured (profiles/peaks_r02.json) at its DVFS clock."""
+    mulmods_per_s = madds * 10 / (acc_ms_total * 1e-3) if acc_ms_total > 0 else 0.0
+    int_peak = 1024 * 64 * 2.4e9 / (189 * 4)
+    measured = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "peaks_r02.json")) as f:
+            measured = json.load(f)["lazy_mul_9x29_per_s"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return {"achieved_mulmod_per_s": mulmods_per_s, "peak_mulmod_per_s": int_peak, "measured_peak_mulmod_per_s": measured,
+            "frac": mulmods_per_s / int_peak, "frac_of_measured": (mulmods_per_s / measured) if measured else None}
+
+
+def measured_traffic(curve, group, logn, world):
+    """HBM/fabric bytes per k_accumulate_seg launch from the committed rocprofv3 PMC passes of THIS round's build
+    (FETCH_SIZE + WRITE_SIZE, separate passes; profiles/traffic_r02.json, keyed curve_group_logn).  Counters cannot be
+    read from inside the timed run, so this is the profiled value for the same workload - or None when that workload was
+    not profiled."""
+    if world != 1:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_r02.json")) as f:
+            return json.load(f)["k_accumulate_seg"].get(f"{curve}_{group}_{logn}")
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def median_ms(fn, reps=5):
+    fn()
+    ts = []
+    for _ in range(reps):
+        t_ = time.perf_counter()
+        fn()
+        ts.append((time.perf_counter() - t_) * 1e3)
+    return sorted(ts)[len(ts) // 2]
+
+
+def also_config(gm, lib, torch, curve, group, logn, steps, host_legs):
+    """One of the other BASELINE.json configurations on this GPU: bases [a_i]G built ON the device (fixed-base batch,
+    gmsm_batch_scalar_mul_device), uniform scalars b_i, K timed MultiExp calls over resident inputs, and the closed form
+    [sum a_i b_i]G from the oracle as the bit-exactness check."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle  # test infrastructure: here only the checker
+    g = (gm.G1Jac if group == "g1" else gm.G2Jac)(curve)
+    n = 1 << logn
+    rng = np.random.default_rng([0x6D736D, logn, len(curve), 1 if group == "g2" else 0])
+    a = uniform_scalars(rng, g, n)
+    b = uniform_scalars(rng, g, n)
+    d_a = torch.from_numpy(a.view(np.int64)).cuda()
+    d_b = torch.from_numpy(b.view(np.int64)).cuda()
+    d_pts = torch.empty((n, g.aff_limbs), dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    g.batch_scalar_mul_device(g.generator, d_a.data_ptr(), n, d_pts.data_ptr(), stream)
+    del d_a
+    c = g.default_window_bits(n)
+    nwin = g.num_windows(c)
+    jac = g.multiexp_device(d_pts.data_ptr(), d_b.data_ptr(), n, stream)  # warm-up (allocations, LDS attributes)
+    prof = StageProfile(lib)
+    prof.start()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        jac = g.multiexp_device(d_pts.data_ptr(), d_b.data_ptr(), n, stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stages, acc_launches = prof.stop()
+    out = {"workload": f"{curve.upper()} {group.upper()} MultiExp 2^{logn} points, bases+scalars resident in HBM",
+           "value": steps / dt, "unit": "MSM/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "window_bits": c,
+           "windows": nwin, "stage_ms": stages,
+           "roofline": roofline_record(g, n, 1.0, stages, acc_launches, measured_traffic(curve, group, logn, 1))}
+    if host_legs:
+        pts_host = d_pts.cpu().numpy().view(np.uint64)
+        cfg = gm.MultiExpConfig()
+        rb = g.register_bases(d_points=d_pts.data_ptr(), n=n)
+        warm = median_ms(lambda: rb.MultiExp(b, cfg), reps=3)
+        jw, _ = rb.MultiExp(b, cfg)
+        rb.release()
+        cold = median_ms(lambda: g.MultiExp(pts_host, b, cfg), reps=3)
+        jc, _ = g.MultiExp(pts_host, b, cfg)
+        out.update({"value_warm_bases": 1e3 / warm, "warm_bases_ms": warm, "value_cold": 1e3 / cold, "cold_ms": cold,
+                    "host_entries_equal_resident": bool((g.jac_to_affine(jw) == g.jac_to_affine(jac)).all()
+                                                        and (g.jac_to_affine(jc) == g.jac_to_affine(jac)).all())})
+        del pts_host
+    t0 = time.perf_counter()
+    expected = oracle.Oracle(curve, group).fixed_base_msm_affine(a, b)
+    out["bit_exact"] = bool((g.jac_to_affine(jac) == expected).all())
+    out["bit_exact_check"] = f"closed form [sum a_i b_i]G via the oracle ({time.perf_counter() - t0:.1f} s on one host core)"
+    del d_pts, d_b
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -40,12 +202,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-entry", action="store_true", help="skip the PCIe-inclusive (host buffer) measurements")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the two-in-flight (submit/collect) measurement")
+    ap.add_argument("--no-also", action="store_true", help="skip the other BASELINE.json configurations")
     ap.add_argument("--shard", default="auto", choices=["auto", "windows", "points"],
                     help="N>1: decomposition of the one MultiExp over the ranks (gnark-crypto_amd/sharding.py)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N>1 code path (RCCL process group, device-side all-gather) even with one rank")
     ap.add_argument("--resident", action="store_true",
                     help="register the bases once (gmsm_bases_register) and time MultiExp over the resident form")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="also time K MultiExp over the same registered bases spread over the ranks (replica mode)")
     ap.add_argument("--curve", default="bn254", help="exploration only: bn254 | bls12_381 | bw6_761")
     ap.add_argument("--group", default="g1", help="exploration only: g1 | g2")
     args = ap.parse_args()
@@ -78,26 +243,11 @@ def main():
     g = (gm.G1Jac if args.group == "g1" else gm.G2Jac)(args.curve)
     n = 1 << args.logn
 
-    # synthetic, deterministic, on-curve inputs: P_i = [k0 + i*k1] G; scalars uniform (stored limbs
-    # uniform in [0, r) by rejection)
+    # synthetic, deterministic, on-curve inputs: P_i = [k0 + i*k1] G; scalars uniform
     rng = np.random.default_rng([0x6D736D, args.logn])
     k0, k1 = int(rng.integers(1, 2**62)), int(rng.integers(1, 2**62))
     pts = g.generate_points(n, k0, k1)
-    nl = g.fr_limbs
-    sc = np.zeros((n, nl), dtype=np.uint64)
-    todo = np.arange(n)
-    r_limbs = [(g.curve.r >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(nl)]
-    top_bits = g.curve.fr_bits - 64 * (nl - 1)
-    while todo.size:
-        cand = rng.integers(0, 2**64, size=(todo.size, nl), dtype=np.uint64)
-        cand[:, nl - 1] &= np.uint64((1 << top_bits) - 1)
-        lt = np.zeros(todo.size, dtype=bool)
-        eq = np.ones(todo.size, dtype=bool)
-        for i in range(nl - 1, -1, -1):
-            lt |= eq & (cand[:, i] < np.uint64(r_limbs[i]))
-            eq &= cand[:, i] == np.uint64(r_limbs[i])
-        sc[todo[lt]] = cand[lt]
-        todo = todo[~lt]
+    sc = uniform_scalars(rng, g, n)
 
     d_pts = torch.from_numpy(pts.view(np.int64)).cuda()
     d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
@@ -140,19 +290,15 @@ def main():
 
     for _ in range(args.warmup):
         jac = step()
-    lib.gmsm_set_profiling(1)
+    prof = StageProfile(lib)
+    prof.start()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         jac = step()
     barrier()
     dt = time.perf_counter() - t0
-    stage_ms = (_ctypes_double * len(STAGES))()
-    calls = _ctypes_ulong(0)
-    lib.gmsm_get_stage_times(stage_ms, len(STAGES), _byref(calls))
-    stage_launches = (_ctypes_ulong * len(STAGES))()
-    lib.gmsm_get_stage_launches(stage_launches, len(STAGES))
-    lib.gmsm_set_profiling(0)
+    stages, acc_launches = prof.stop()
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -224,18 +370,40 @@ def main():
         if resident is None:
             rb2.release()
 
+    # Replica mode (--batch K): K scalar vectors over the same registered bases, vector j on rank j % world, each rank
+    # runs its share through gmsm_multiexp_bases_batch, ONE all-gather of the K Jacobian results.
+    replica = None
+    if args.batch > 0:
+        K = args.batch
+        rbk = g.register_bases(d_points=d_pts.data_ptr(), n=n)
+        d_vecs = d_sc.unsqueeze(0).repeat(len(sharding.owned_vectors(K, rank, world)) or 1, 1, 1).contiguous()
+
+        def local_batch(mine):
+            res, err = rbk.MultiExpBatch(d_scalars=d_vecs.data_ptr(), n=n, k=len(mine), stream=stream)
+            assert err is None, err
+            return res
+        gather = (sharding.torch_all_gather(dist, torch.device("cuda", local_rank)) if dist.is_initialized()
+                  else (lambda buf: buf[None]))
+        sharding.replicated_batch(K, rank, world, g.jac_limbs, local_batch, gather)
+        barrier()
+        tr0 = time.perf_counter()
+        resk = sharding.replicated_batch(K, rank, world, g.jac_limbs, local_batch, gather)
+        barrier()
+        dtr = time.perf_counter() - tr0
+        if world > 1:
+            tmax = torch.tensor([dtr], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dtr = float(tmax.item())
+        replica = {"k": K, "value": K / dtr, "unit": "MSM/s", "ms_per_msm": dtr / K * 1e3, "n_gpus": world,
+                   "scaling": "weak over K (every vector is a whole MultiExp on one GPU; no data-path collective)",
+                   "equal_to_serial_result": bool(all((g.jac_to_affine(r_) == g.jac_to_affine(jac)).all() for r_ in resk))}
+        rbk.release()
+        del d_vecs
+
     # PCIe-inclusive rates of the drop-in entries (SURVEY.md §8(d) "cold" / "warm-bases"): host buffers in, result out.
-    # Reported beside the headline number, never as `value`.
+    # First-class fields beside `value`, never instead of it.
     host_entry = None
     if not sharded and rank == 0 and not args.no_host_entry:
-        def median_ms(fn, reps=5):
-            fn()
-            ts = []
-            for _ in range(reps):
-                t_ = time.perf_counter()
-                fn()
-                ts.append((time.perf_counter() - t_) * 1e3)
-            return sorted(ts)[len(ts) // 2]
         cfg = gm.MultiExpConfig()
         cold = median_ms(lambda: g.MultiExp(pts, sc, cfg))
         rb3 = resident or g.register_bases(d_points=d_pts.data_ptr(), n=n)
@@ -250,42 +418,27 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = args.steps / dt
-        ncalls = max(1, calls.value)
-        stages = {name: stage_ms[i] / ncalls for i, name in enumerate(STAGES)}
-        # one MultiExp = several k_accumulate_seg launches (window groups, overlapped with each other's grouping and
-        # reduction): per-launch figures are averages over the launches
-        acc_launches = max(1, stage_launches[STAGES.index("accumulate")] // ncalls)
-        acc_ms = stages["accumulate"] / acc_launches
-        bytes_per_point = 8 * (g.aff_limbs + g.fr_limbs)  # affine point + scalar (BN254 G1: 96 B)
         # this rank's share of the (point, window) pairs: all windows of its slice, or its windows of all points
         my_pairs = (plan["hi"] - plan["lo"]) * len(range(plan["win_first"], nwin, plan["win_stride"])) if sharded else n * nwin
-        algorithmic_bytes = bytes_per_point * n * my_pairs / (n * nwin) / acc_launches
-        achieved = algorithmic_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
-        # integer roofline of the same kernel: 10 field products per mixed add (8M+2S, g1.go:822), n*(windows of this
-        # rank) mixed adds; one lazy 9x29-bit Montgomery product = 171 v_mad_u64_u32/v_mul_lo_u32 + 18 v_lshrrev_b64, all
-        # 4 cycles / wave64 / SIMD (tools/ubench_valu.hip): issue peak = 1024 SIMD * 64 lanes * 2.4 GHz / (189 * 4)
-        # = 208e9 products/s at the nominal clock; tools/ubench_fpmul.hip measures 174-177e9 on the chip.
-        madds = my_pairs / acc_launches
-        mulmods_per_s = madds * 10 / (acc_ms * 1e-3) if acc_ms > 0 else 0.0
-        int_peak = 1024 * 64 * 2.4e9 / (189 * 4)
         out = {
-            "metric": "G1 MSM/sec (BN254)" if (args.curve, args.group) == ("bn254", "g1") else f"{args.group.upper()} MSM/sec ({args.curve})", "value": value, "unit": "MSM/s", "n_gpus": world, "steps": args.steps,
+            "metric": "G1 MSM/sec (BN254)" if (args.curve, args.group) == ("bn254", "g1") else f"{args.group.upper()} MSM/sec ({args.curve})",
+            "value": value, "unit": "MSM/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"{args.curve.upper()} {args.group.upper()} MultiExp 2^{args.logn} points, bases+scalars resident in HBM",
                        "arithmetic": f"{g.curve.p.bit_length()}-bit Montgomery field on 32-bit words (lazy 28/29-bit limbs, v_mad_u64_u32)",
                        "points": n, "window_bits": c, "windows": nwin, "resident_bases": resident is not None,
                        "parallelism": "single GPU" if not sharded else f"{plan['mode']}-sharded x{world} + one RCCL all-gather"},
+            "value_cold": host_entry["cold_msm_per_s"] if host_entry else None,
+            "value_warm_bases": host_entry["warm_bases_msm_per_s"] if host_entry else None,
             "points_per_s": value * n,
             "stage_ms": stages,
             "pipelined": pipelined,
             "host_entry": host_entry,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": measured_traffic(args, world), "kernel": "k_accumulate_seg",
-                         "algorithmic_bytes_per_launch": algorithmic_bytes, "avg_launch_ms": acc_ms,
-                         "launches_per_msm": acc_launches},
-            "int_roofline": {"achieved_mulmod_per_s": mulmods_per_s, "peak_mulmod_per_s": int_peak,
-                             "measured_peak_mulmod_per_s": 174e9, "frac": mulmods_per_s / int_peak},
+            "replica_batch": replica,
+            "roofline": roofline_record(g, n, my_pairs / (n * nwin), stages, acc_launches,
+                                        measured_traffic(args.curve, args.group, args.logn, world)),
+            "int_roofline": int_roofline_record(my_pairs, stages["accumulate"]),
         }
         if sharded:
             # the sharded result against the same MultiExp computed by this rank alone (after the timed region)
@@ -293,23 +446,15 @@ def main():
             out["equal_to_single_gpu_result"] = bool((g.jac_to_affine(single) == g.jac_to_affine(jac)).all())
         if world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline(g, pts, sc, jac, args.curve, args.group))
+        if world == 1 and not sharded and not args.no_also:
+            del d_pts, d_sc, pts
+            torch.cuda.empty_cache()
+            out["also"] = [also_config(gm, lib, torch, *cfg_) for cfg_ in ALSO
+                           if (cfg_[0], cfg_[1], cfg_[2]) != (args.curve, args.group, args.logn)]
         print(json.dumps(out), file=json_out, flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
-
-
-def measured_traffic(args, world):
-    """HBM/fabric bytes per k_accumulate_seg launch from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
-    profiles/traffic_r01.json); counters cannot be read from inside the timed run, so this is the profiled value for
-    the same workload, or None when the workload was not profiled."""
-    if world != 1 or (args.curve, args.group) != ("bn254", "g1"):
-        return None
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic_r01.json")) as f:
-            return json.load(f)["k_accumulate_seg"].get(str(args.logn))
-    except (OSError, KeyError, ValueError):
-        return None
 
 
 def effective_cpus():
@@ -327,8 +472,7 @@ def effective_cpus():
 
 def cpu_baseline(g, pts, sc, gpu_jac, curve="bn254", group="g1"):
     """The oracle = C restatement of gnark-crypto's MultiExp (bestC, split recursion, one task per (leaf, window),
-    extended-Jacobian buckets; the batch-affine bucket variant is off), on all host cores.  Bounded: repeats whole
-    MSMs until ~10 s have elapsed (at least 1)."""
+    extended-Jacobian buckets), on all host cores.  Bounded: repeats whole MSMs until ~10 s have elapsed (at least 1)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle  # test infrastructure, used here only as the reported baseline and the checker
     o = oracle.Oracle(curve, group)
@@ -346,16 +490,12 @@ def cpu_baseline(g, pts, sc, gpu_jac, curve="bn254", group="g1"):
         "cpu_baseline": {"value": reps / t_total, "unit": "MSM/s", "cores": cores, "kind": "port",
                          "threads": threads,
                          "sample": f"{reps} full MSM(s) of the same 2^{int(np.log2(len(pts)))} input, {t_total:.1f} s total; "
-                                   "C restatement of gnark-crypto's algorithm (ext-Jacobian buckets, batch-affine off)"},
+                                   + getattr(oracle, "BASELINE_NOTE", "C restatement of gnark-crypto's algorithm (ext-Jacobian buckets, batch-affine off)")},
         "bit_exact": exact,
     }
 
 
 import ctypes as _ct  # noqa: E402
-
-_ctypes_double = _ct.c_double
-_ctypes_ulong = _ct.c_ulong
-_byref = _ct.byref
 
 if __name__ == "__main__":
     main()

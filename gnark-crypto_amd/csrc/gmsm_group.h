@@ -703,6 +703,85 @@ struct Group {
         return multiexp_host(points, n, reinterpret_cast<const uint64_t *>(scalars.data()), n, nb_tasks, out);
     }
 
+    // Number of point ranges a host-buffer MultiExp is cut into so that the H2D copy of range k+1 runs under the
+    // pipeline of range k (two workspaces, two streams; the ranges' window totals are added on the host, fold_sets).
+    // A range pays the size-independent part of the pipeline again (~0.6 ms: reduction chain, dependent launches), so
+    // small inputs stay whole. Model with T(2^18..2^22) = 0.96 / 1.25 / 2.05 / 3.6 / 6.9 ms and 56 GB/s (96 B/point cold,
+    // 32 B/point with registered bases): cold - 2 ranges from 2^20, ranges of 2^21 from 2^22 on (2^24: 32 ms against
+    // 55 ms serial, PCIe floor 27 ms); registered bases - 2 ranges from 2^20, ranges of 2^22 from 2^23 on. Measured at
+    // 2^20 (profiles/r02_host_ranges.log): cold 3.99 / 3.31 / 3.94 ms with 1 / 2 / 4 ranges, registered bases 2.70 / 2.53 /
+    // 3.11. GMSM_HOST_RANGES overrides.
+    static unsigned host_ranges(size_t n, bool with_points) {
+        const unsigned forced = env_uint("GMSM_HOST_RANGES", 0);
+        if (forced) return (unsigned)std::min<size_t>(forced, std::max<size_t>(1, n));
+        if (with_points) {
+            if (n < ((size_t)1 << 20)) return 1;
+            if (n < ((size_t)1 << 22)) return 2;
+            return (unsigned)std::min<size_t>(64, n >> 21);
+        }
+        if (n < ((size_t)1 << 20)) return 1;
+        if (n < ((size_t)1 << 23)) return 2;  // measured at 2^20: 2.70 -> 2.53 ms (profiles/r02_host_ranges.log)
+        return (unsigned)std::min<size_t>(64, n >> 22);
+    }
+
+    // MultiExp with the scalars (and, unless `resident`, the points) in host memory. `first` is leased by the caller;
+    // a second workspace is borrowed when one is free, otherwise the ranges run one after the other.
+    static int multiexp_from_host(Context &ctx, Workspace &first, const uint64_t *points, const ResidentBases *resident,
+                                  const uint64_t *scalars, size_t n, J *out) {
+        unsigned nr = host_ranges(n, points != nullptr);
+        const size_t run = max_run_points();
+        if ((n + nr - 1) / nr > run) nr = (unsigned)((n + run - 1) / run);
+        const size_t per = (n + nr - 1) / nr;
+        nr = (unsigned)((n + per - 1) / per);
+        const unsigned c = choose_c(FR_BITS, per);  // one c for every range: the totals must line up
+        WindowPlan plan = make_plan(c, 0, 1);
+        const uint32_t nw = plan.nwin_total;
+        Workspace *w[2] = {&first, nr > 1 ? ctx.acquire(false) : nullptr};
+        const unsigned nws = w[1] ? 2 : 1;
+        std::vector<Ext> sets((size_t)nr * nw);
+        int rc = GMSM_OK;
+        unsigned submitted = 0, collected = 0;
+        while (rc == GMSM_OK && collected < nr) {
+            while (rc == GMSM_OK && submitted < nr && submitted - collected < nws) {
+                Workspace &ws = *w[submitted % nws];
+                const size_t lo = (size_t)submitted * per, len = std::min(per, n - lo);
+                const void *dp = nullptr;
+                // hipMemcpyAsync from pageable memory returns when the caller's buffer has been consumed; the kernels
+                // queued behind it do not wait for the host, so range k computes while range k+1 is being copied
+                if ((rc = ws.h2d_scalars.ensure(len * SCALAR_BYTES))) break;
+                if (hipMemcpyAsync(ws.h2d_scalars.ptr, (const char *)scalars + lo * SCALAR_BYTES, len * SCALAR_BYTES,
+                                   hipMemcpyHostToDevice, ws.stream) != hipSuccess) {
+                    rc = fail(GMSM_ERR_DEVICE, "hipMemcpyAsync(scalars) failed");
+                    break;
+                }
+                if (points) {
+                    if ((rc = ws.h2d_points.ensure(len * AFF_BYTES))) break;
+                    if (hipMemcpyAsync(ws.h2d_points.ptr, (const char *)points + lo * AFF_BYTES, len * AFF_BYTES,
+                                       hipMemcpyHostToDevice, ws.stream) != hipSuccess) {
+                        rc = fail(GMSM_ERR_DEVICE, "hipMemcpyAsync(points) failed");
+                        break;
+                    }
+                    dp = ws.h2d_points.ptr;
+                }
+                if ((rc = enqueue_window_sums(ctx, ws, dp, ws.h2d_scalars.ptr, len, plan, ws.stream, resident, nullptr, lo))) break;
+                ++submitted;
+            }
+            if (rc) break;
+            rc = collect_window_sums(*w[collected % nws], w[collected % nws]->stream, nw, sets.data() + (size_t)collected * nw);
+            ++collected;
+        }
+        if (w[1]) {
+            (void)hipStreamSynchronize(w[1]->stream);  // nothing of this call is left running on the borrowed workspace
+            ctx.release(w[1]);
+        }
+        if (rc) {
+            (void)hipStreamSynchronize(first.stream);
+            return rc;
+        }
+        *out = nr == 1 ? fold(sets.data(), c) : fold_sets(sets.data(), nr, c);
+        return GMSM_OK;
+    }
+
     static int multiexp_host(const uint64_t *points, size_t n_points, const uint64_t *scalars, size_t n_scalars,
                              int nb_tasks, J *out) {
         // argument checks of (*G1Jac).MultiExp, multiexp.go:61-71
@@ -718,12 +797,7 @@ struct Group {
             return GMSM_OK;
         }
         GMSM_LEASE_OR_FAIL(lease, *ctx);
-        Workspace &ws = *lease.w;
-        if ((rc = ws.h2d_points.ensure(n * AFF_BYTES))) return rc;
-        if ((rc = ws.h2d_scalars.ensure(n * SCALAR_BYTES))) return rc;
-        HIP_TRY(hipMemcpyAsync(ws.h2d_points.ptr, points, n * AFF_BYTES, hipMemcpyHostToDevice, ws.stream));
-        HIP_TRY(hipMemcpyAsync(ws.h2d_scalars.ptr, scalars, n * SCALAR_BYTES, hipMemcpyHostToDevice, ws.stream));
-        return multiexp_device(*ctx, ws, ws.h2d_points.ptr, ws.h2d_scalars.ptr, n, ws.stream, out);
+        return multiexp_from_host(*ctx, *lease.w, points, nullptr, scalars, n, out);
     }
 };
 
@@ -936,12 +1010,9 @@ struct VTableOf {
     static int multiexp_bases_host(Context &ctx, const uint64_t *scalars, size_t n, uint64_t *out_jac,
                                    const ResidentBases *resident) {
         GMSM_LEASE_OR_FAIL(lease, ctx);
-        Workspace &ws = *lease.w;
-        int rc = ws.h2d_scalars.ensure(n * G::SCALAR_BYTES);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(ws.h2d_scalars.ptr, scalars, n * G::SCALAR_BYTES, hipMemcpyHostToDevice, ws.stream));
         typename G::J j;
-        if ((rc = G::multiexp_device(ctx, ws, nullptr, ws.h2d_scalars.ptr, n, ws.stream, &j, resident))) return rc;
+        int rc = G::multiexp_from_host(ctx, *lease.w, nullptr, resident, scalars, n, &j);
+        if (rc) return rc;
         memcpy(out_jac, &j, sizeof j);
         return GMSM_OK;
     }

@@ -131,3 +131,40 @@ def sharded_multiexp_exchange(group, plan, enqueue_fn, exchange):
     if plan["mode"] == "points":
         return group.fold_window_sets(gathered, plan["c"])
     return group.fold_windows(unpack_gathered(gathered, plan["nwin"], exchange.world, group.xyzz_limbs), plan["c"])
+
+
+# ---------------------------------------------------------------- replicas: k MultiExp over the same bases on N ranks
+# The callers that issue many MultiExp over one SRS (one kzg.Commit per polynomial, ecc/bn254/kzg/kzg.go:159-176;
+# BatchOpenSinglePoint :246; the folded commitments of BatchVerifyMultiPoints :405-520) need no sharding of a single
+# MSM at all: every rank registers the bases once, scalar vector j belongs to rank j % world, each rank runs its vectors
+# through gmsm_multiexp_bases_batch (two in flight), and the only collective is ONE all-gather of the k Jacobian results.
+def batch_owner(j, world):
+    return j % world
+
+
+def batch_slots(k, world):
+    return (k + world - 1) // world
+
+
+def owned_vectors(k, rank, world):
+    return list(range(rank, k, world))
+
+
+def replicated_batch(k, rank, world, jac_limbs, local_batch_fn, all_gather_fn):
+    """k independent MultiExp, vector j on rank j % world.
+
+    local_batch_fn   list of owned vector indices -> (len, jac_limbs) uint64 Jacobian results of those vectors
+                     (GPU: ResidentBases.MultiExpBatch over this rank's copy of the bases; CPU tests: the oracle)
+    all_gather_fn    (slots, jac_limbs) uint64 -> (world, slots, jac_limbs) uint64, identical on every rank
+    Returns the (k, jac_limbs) results in vector order on every rank."""
+    mine = owned_vectors(k, rank, world)
+    slots = batch_slots(k, world)
+    local = np.zeros((slots, jac_limbs), dtype=np.uint64)
+    if mine:
+        res = np.asarray(local_batch_fn(mine), dtype=np.uint64).reshape(len(mine), jac_limbs)
+        local[: len(mine)] = res
+    gathered = np.asarray(all_gather_fn(local), dtype=np.uint64).reshape(world, slots, jac_limbs)
+    out = np.zeros((k, jac_limbs), dtype=np.uint64)
+    for j in range(k):
+        out[j] = gathered[batch_owner(j, world), j // world]
+    return out

@@ -188,7 +188,13 @@
 #define PRIME_FIELD_API(F)                                                                                                  \
     FIELD_API(F)                                                                                                            \
     EXPORT void oracle_##F##_from_mont(const uint64_t *a, uint64_t *z) { F##_t t = *(const F##_t *)a; F##_from_mont(&t); *(F##_t *)z = t; } \
-    EXPORT void oracle_##F##_to_mont(const uint64_t *a, uint64_t *z) { F##_to_mont((F##_t *)z, (const F##_t *)a); }
+    EXPORT void oracle_##F##_to_mont(const uint64_t *a, uint64_t *z) { F##_to_mont((F##_t *)z, (const F##_t *)a); }     \
+    /* z = sum_i a[i]*b[i] (Montgomery products, so z is the Montgomery form of sum a_i b_i): closed-form check of an   \
+     * MSM over bases [a_i]G with scalars b_i, whose result must be [sum a_i b_i]G */                                        \
+    EXPORT void oracle_##F##_dot(const uint64_t *a, const uint64_t *b, size_t n, uint64_t *z) {                             \
+        F##_t acc, t; F##_set_zero(&acc);                                                                                   \
+        for (size_t i = 0; i < n; ++i) { F##_mul(&t, (const F##_t *)a + i, (const F##_t *)b + i); F##_add(&acc, &acc, &t); } \
+        *(F##_t *)z = acc; }
 
 PRIME_FIELD_API(bn254_fp)
 PRIME_FIELD_API(bn254_fr)

@@ -64,6 +64,17 @@ class Field:
     def dbl(self, a): return self._un("dbl", a)
     def sqr(self, a): return self._un("sqr", a)
     def inv(self, a): return self._un("inv", a)
+    def dot(self, a, b):
+        """sum_i a[i]*b[i] over (n, limbs) Montgomery arrays -> Montgomery limbs of the sum of products."""
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, self.limbs)
+        b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, self.limbs)
+        assert a.shape == b.shape
+        z = np.zeros(self.limbs, dtype=np.uint64)
+        f = getattr(self.L, f"oracle_{self.name}_dot")
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        f(_p(a), _p(b), a.shape[0], _p(z))
+        return z
+
     def from_mont(self, a): return self._un("from_mont", a)
     def to_mont(self, a): return self._un("to_mont", a)
 
@@ -209,6 +220,14 @@ class Oracle:
         out = np.zeros(self.jac_limbs, dtype=np.uint64)
         self._fn("scalar_mul")(_p(np.ascontiguousarray(a, dtype=np.uint64)), _p(kl), nl, _p(out))
         return out
+
+    def fixed_base_msm_affine(self, a_mont, b_mont):
+        """Affine limbs of [sum_i a_i b_i] G for Montgomery scalar arrays a, b: the closed form of
+        MultiExp({[a_i]G}, {b_i}) (same shape as the reference's sum i^2 identity, multiexp_test.go:54-60)."""
+        fr = Field(f"{self.curve.name}_fr", self.fr_limbs)
+        k_limbs = fr.from_mont(fr.dot(a_mont, b_mont))
+        k = sum(int(v) << (64 * i) for i, v in enumerate(k_limbs))
+        return self.jac_to_affine(self.scalar_mul(self.generator, k))
 
     def gen_points(self, n, k0, k1, nthreads=1, base=None):
         """points[i] = [k0 + i*k1] * base  (base defaults to the group generator), affine Montgomery limbs."""

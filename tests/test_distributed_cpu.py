@@ -71,6 +71,59 @@ def _worker(rank, world, port, curve, which, c, n, q):
         q.put((rank, False, repr(e)))
 
 
+def _batch_worker(rank, world, port, k, n, q):
+    """Replica mode: k scalar vectors over the same bases, vector j on rank j % world, one all-gather of k results."""
+    try:
+        import importlib
+        for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        import torch.distributed as dist
+        import torch
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        gm = importlib.import_module("gnark-crypto_amd")
+        sharding = importlib.import_module("gnark-crypto_amd.sharding")
+        import oracle
+        from conftest import random_scalars, rng_for
+        g = gm.G1Jac("bn254")
+        o = oracle.Oracle("bn254", "g1")
+        pts = o.gen_points(n, 5, 11)
+        vectors = [random_scalars(rng_for(77, j), g.curve, n) for j in range(k)]
+        computed = []
+
+        def local_batch(mine):
+            computed.extend(mine)
+            return np.stack([o.multiexp(pts, vectors[j])[1] for j in mine])
+
+        res = sharding.replicated_batch(k, rank, world, g.jac_limbs, local_batch,
+                                        sharding.torch_all_gather(dist, torch.device("cpu")))
+        ok = computed == list(range(rank, k, world))  # every rank only computed its own vectors
+        for j in range(k):
+            ok = ok and bool((g.jac_to_affine(res[j]) == o.msm_affine(pts, vectors[j])).all())
+        q.put((rank, ok, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        q.put((rank, False, repr(e)))
+
+
+@pytest.mark.parametrize("k", [1, 5])
+def test_replicated_batch_gloo_world2(k):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_batch_worker, args=(r, world, port, k, 150, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in results), results
+
+
 @pytest.mark.parametrize("curve,which,c", [("bn254", "g1", 16), ("bn254", "g1", 11), ("bls12_381", "g2", 13)])
 def test_window_sharded_multiexp_gloo_world2(curve, which, c):
     import torch.multiprocessing as mp
