@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GMSM_LIB") or os.path.join(CSRC, "libgmsm.so")  # GMSM_LIB: A/B builds
 
-GMSM_OK, GMSM_ERR_LEN, GMSM_ERR_CONFIG, GMSM_ERR_DEVICE, GMSM_ERR_ARG = 0, 1, 2, 3, 4
+GMSM_OK, GMSM_ERR_LEN, GMSM_ERR_CONFIG, GMSM_ERR_DEVICE, GMSM_ERR_ARG, GMSM_ERR_POINT = 0, 1, 2, 3, 4, 5
 
 GROUP_IDS = {
     ("bn254", "g1"): 0, ("bn254", "g2"): 1,
@@ -28,7 +28,8 @@ ABI_SYMBOLS = [
     "gmsm_window_sums_enqueue", "gmsm_fold_window_sets", "gmsm_fold_windows", "gmsm_batch_scalar_mul", "gmsm_batch_scalar_mul_device",
     "gmsm_batch_jac_to_affine", "gmsm_jac_to_affine", "gmsm_affine_limbs", "gmsm_scalar_limbs", "gmsm_debug_decompose",
     "gmsm_debug_field_op", "gmsm_debug_group_op", "gmsm_generate_points", "gmsm_set_profiling", "gmsm_get_stage_times",
-    "gmsm_get_stage_launches",
+    "gmsm_get_stage_launches", "gmsm_points_from_raw", "gmsm_points_validate", "gmsm_bases_register_raw",
+    "gmsm_bases_register_dump",
     "gmsm_device_count", "gmsm_set_device", "gmsm_last_error",
     "gmsm_version",
 ]
@@ -123,6 +124,16 @@ def load():
     L.gmsm_set_profiling.argtypes = [ctypes.c_int]
     L.gmsm_get_stage_times.restype = ctypes.c_int
     L.gmsm_get_stage_times.argtypes = [vp, ctypes.c_int, vp]
+    i64p = ctypes.POINTER(ctypes.c_int64)
+    L.gmsm_points_from_raw.restype = ctypes.c_int
+    L.gmsm_points_from_raw.argtypes = [ctypes.c_int, vp, sz, ctypes.c_int, u64p, vp, i64p]
+    L.gmsm_points_validate.restype = ctypes.c_int
+    L.gmsm_points_validate.argtypes = [ctypes.c_int, u64p, vp, sz, ctypes.c_int, i64p]
+    L.gmsm_bases_register_raw.restype = ctypes.c_int
+    L.gmsm_bases_register_raw.argtypes = [ctypes.c_int, vp, sz, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), i64p]
+    L.gmsm_bases_register_dump.restype = ctypes.c_int
+    L.gmsm_bases_register_dump.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, sz, ctypes.c_int,
+                                           ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(sz), i64p]
     L.gmsm_get_stage_launches.restype = ctypes.c_int
     L.gmsm_get_stage_launches.argtypes = [vp, ctypes.c_int]
     L.gmsm_device_count.restype = ctypes.c_int

@@ -86,6 +86,7 @@ struct Workspace {
     void *pinned = nullptr;             // pinned host buffer for the window totals
     size_t pinned_cap = 0;
     DeviceBuffer h2d_points, h2d_scalars;  // staging of the host-pointer entries
+    DeviceBuffer raw_bytes, flagword;      // point ingest: wire-format bytes, first-offender word
     bool busy = false;  // leased to a call (Context::acquire / release)
     // state of a submitted, not yet collected call
     bool pending = false;
@@ -276,6 +277,27 @@ int get_context_for(int device, Context **out);
 int get_context_of_pointer(const void *p, Context **out);
 
 
+// ------------------------------------------------------------------ point ingest status (gmsm_ingest.h)
+enum PointStatus : uint32_t {
+    PT_OK = 0,
+    PT_BAD_FLAG = 1,        // compressed or undefined metadata bits
+    PT_BAD_INFINITY = 2,    // infinity flag with non-zero payload (ErrInvalidInfinityEncoding, marshal.go:36)
+    PT_NOT_CANONICAL = 3,   // a coordinate >= q (SetBytesCanonical, fp/element.go)
+    PT_NOT_ON_CURVE = 4,
+    PT_NOT_IN_SUBGROUP = 5
+};
+
+static inline const char *point_status_text(uint32_t s) {
+    switch (s) {
+        case PT_BAD_FLAG: return "invalid point encoding (compressed or undefined flag bits; the raw ingest takes RawBytes output)";
+        case PT_BAD_INFINITY: return "invalid infinity point encoding";
+        case PT_NOT_CANONICAL: return "invalid fp.Element encoding (coordinate not below the modulus)";
+        case PT_NOT_ON_CURVE: return "invalid point: not on the curve";
+        case PT_NOT_IN_SUBGROUP: return "invalid point: subgroup check failed";
+        default: return "ok";
+    }
+}
+
 // ------------------------------------------------------------------ window geometry
 static inline unsigned num_windows(unsigned fr_bits, unsigned c) { return (fr_bits + c - 1) / c; }  // multiexp.go:681
 static inline unsigned last_c(unsigned fr_bits, unsigned c) {                                         // multiexp.go:690
@@ -338,6 +360,9 @@ struct GroupVTable {
     int (*batch_scalar_mul)(Context &ctx, const uint64_t *base, const uint64_t *scalars, const void *d_scalars, size_t n,
                             hipStream_t caller_stream, uint64_t *out, void *d_out);
     int (*batch_jac_to_affine)(Context &ctx, const uint64_t *jac, size_t n, uint64_t *out);
+    int (*decode_raw)(Workspace &ws, const void *d_raw, size_t n, int level, void *d_out, long long *bad_index,
+                      uint32_t *status);
+    int (*validate_points)(Workspace &ws, const void *d_points, size_t n, int level, long long *bad_index, uint32_t *status);
 };
 
 }  // namespace gmsm

@@ -1,6 +1,7 @@
 // libgmsm.so -- C ABI (include/gmsm.h), per-device contexts and dispatch to the per-group pipelines (gmsm_group.h).
 // There is no CPU fallback: every compute entry needs a usable gfx950 device and fails loudly otherwise.
 #include <atomic>
+#include <cstdio>
 
 #include "gmsm_context.h"
 
@@ -195,6 +196,204 @@ GMSM_EXPORT int gmsm_bases_register(int group, const uint64_t *points, const voi
     std::lock_guard<std::mutex> lk2(g_bases_mu);
     g_bases.push_back(rb);
     *out_handle = g_bases.size();
+    return GMSM_OK;
+}
+
+// ------------------------------------------------------------------ point ingest
+static int point_error(const char *what, long long index, uint32_t status) {
+    return fail(GMSM_ERR_POINT, std::string(what) + ": point " + std::to_string(index) + ": " + point_status_text(status));
+}
+
+static int register_device_points(const GroupVTable *vt, Context *ctx, Workspace &ws, int group, const void *d_points,
+                                  size_t n, uint64_t *out_handle) {
+    BasesRef rb = std::make_shared<ResidentBases>();
+    rb->group = group;
+    rb->device = ctx->device;
+    int rc = vt->register_bases(*ctx, d_points, n, ws.stream, rb.get());
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk2(g_bases_mu);
+    g_bases.push_back(rb);
+    *out_handle = g_bases.size();
+    return GMSM_OK;
+}
+
+GMSM_EXPORT int gmsm_points_from_raw(int group, const uint8_t *raw, size_t n, int check, uint64_t *out_affine,
+                                     void *d_out_affine, int64_t *bad_index) {
+    VT_OR_FAIL(group);
+    if (!bad_index) return fail(GMSM_ERR_ARG, "gmsm_points_from_raw: bad_index is null");
+    *bad_index = -1;
+    if (n && (!raw || (!out_affine && !d_out_affine))) return fail(GMSM_ERR_ARG, "gmsm_points_from_raw: null argument");
+    if (n == 0) return GMSM_OK;
+    Context *ctx;
+    int rc = get_context_of_pointer(d_out_affine, &ctx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    GMSM_LEASE_OR_FAIL(lease, *ctx);
+    Workspace &ws = *lease.w;
+    const size_t bytes = n * vt->aff_bytes;
+    if ((rc = ws.raw_bytes.ensure(bytes))) return rc;
+    void *d_out = d_out_affine;
+    if (!d_out) {
+        if ((rc = ws.h2d_points.ensure(bytes))) return rc;
+        d_out = ws.h2d_points.ptr;
+    }
+    HIP_TRY(hipMemcpyAsync(ws.raw_bytes.ptr, raw, bytes, hipMemcpyHostToDevice, ws.stream));
+    long long bad = -1;
+    uint32_t status = 0;
+    if ((rc = vt->decode_raw(ws, ws.raw_bytes.ptr, n, check, d_out, &bad, &status))) return rc;
+    if (out_affine) {
+        HIP_TRY(hipMemcpyAsync(out_affine, d_out, bytes, hipMemcpyDeviceToHost, ws.stream));
+        HIP_TRY(hipStreamSynchronize(ws.stream));
+    }
+    if (bad >= 0) {
+        *bad_index = bad;
+        return point_error("gmsm_points_from_raw", bad, status);
+    }
+    return GMSM_OK;
+}
+
+GMSM_EXPORT int gmsm_points_validate(int group, const uint64_t *points, const void *d_points, size_t n, int check,
+                                     int64_t *bad_index) {
+    VT_OR_FAIL(group);
+    if (!bad_index) return fail(GMSM_ERR_ARG, "gmsm_points_validate: bad_index is null");
+    *bad_index = -1;
+    if (n && (points == nullptr) == (d_points == nullptr))
+        return fail(GMSM_ERR_ARG, "gmsm_points_validate: give exactly one of points (host) / d_points (device)");
+    if (n == 0 || check <= 0) return GMSM_OK;
+    Context *ctx;
+    int rc = get_context_of_pointer(d_points, &ctx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    GMSM_LEASE_OR_FAIL(lease, *ctx);
+    Workspace &ws = *lease.w;
+    const void *src = d_points;
+    if (points) {
+        if ((rc = ws.h2d_points.ensure(n * vt->aff_bytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(ws.h2d_points.ptr, points, n * vt->aff_bytes, hipMemcpyHostToDevice, ws.stream));
+        src = ws.h2d_points.ptr;
+    } else {
+        HIP_TRY(hipDeviceSynchronize());  // d_points may still be being written on a stream we do not know
+    }
+    long long bad = -1;
+    uint32_t status = 0;
+    if ((rc = vt->validate_points(ws, src, n, check, &bad, &status))) return rc;
+    if (bad >= 0) {
+        *bad_index = bad;
+        return point_error("gmsm_points_validate", bad, status);
+    }
+    return GMSM_OK;
+}
+
+GMSM_EXPORT int gmsm_bases_register_raw(int group, const uint8_t *raw, size_t n, int check, uint64_t *out_handle,
+                                        int64_t *bad_index) {
+    VT_OR_FAIL(group);
+    if (!out_handle || !bad_index) return fail(GMSM_ERR_ARG, "gmsm_bases_register_raw: null argument");
+    *bad_index = -1;
+    if (n && !raw) return fail(GMSM_ERR_ARG, "gmsm_bases_register_raw: raw is null");
+    Context *ctx;
+    int rc = get_context(&ctx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    GMSM_LEASE_OR_FAIL(lease, *ctx);
+    Workspace &ws = *lease.w;
+    const size_t bytes = n * vt->aff_bytes;
+    if (n) {
+        if ((rc = ws.raw_bytes.ensure(bytes))) return rc;
+        if ((rc = ws.h2d_points.ensure(bytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(ws.raw_bytes.ptr, raw, bytes, hipMemcpyHostToDevice, ws.stream));
+        long long bad = -1;
+        uint32_t status = 0;
+        if ((rc = vt->decode_raw(ws, ws.raw_bytes.ptr, n, check, ws.h2d_points.ptr, &bad, &status))) return rc;
+        if (bad >= 0) {
+            *bad_index = bad;
+            return point_error("gmsm_bases_register_raw", bad, status);
+        }
+    }
+    return register_device_points(vt, ctx, ws, group, ws.h2d_points.ptr, n, out_handle);
+}
+
+GMSM_EXPORT int gmsm_bases_register_dump(int group, const char *path, uint64_t offset, int expect_marker, size_t max_points,
+                                         int check, uint64_t *out_handle, size_t *out_n, int64_t *bad_index) {
+    VT_OR_FAIL(group);
+    if (!path || !out_handle || !out_n || !bad_index) return fail(GMSM_ERR_ARG, "gmsm_bases_register_dump: null argument");
+    *bad_index = -1;
+    *out_n = 0;
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(GMSM_ERR_ARG, std::string("gmsm_bases_register_dump: cannot open ") + path);
+    struct Closer {
+        FILE *f;
+        ~Closer() { fclose(f); }
+    } closer{f};
+    if (fseeko(f, (off_t)offset, SEEK_SET) != 0) return fail(GMSM_ERR_ARG, "gmsm_bases_register_dump: bad offset");
+    uint64_t word = 0;
+    if (expect_marker) {  // unsafe.ReadMarker, utils/unsafe/dump_slice.go:91-103
+        if (fread(&word, 8, 1, f) != 1) return fail(GMSM_ERR_ARG, "gmsm_bases_register_dump: short read (marker)");
+        if (word != 0xdeadbeefull)
+            return fail(GMSM_ERR_ARG, "marker mismatch: dump was not written on the same architecture");
+    }
+    if (fread(&word, 8, 1, f) != 1) return fail(GMSM_ERR_ARG, "gmsm_bases_register_dump: short read (length)");
+    size_t n = (size_t)word;
+    if (max_points && n > max_points) n = max_points;  // ReadSlice's maxElements
+    if (n >= ((size_t)1 << 31)) return fail(GMSM_ERR_ARG, "gmsm_bases_register_dump: more than 2^31 points");
+    Context *ctx;
+    int rc = get_context(&ctx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    GMSM_LEASE_OR_FAIL(lease, *ctx);
+    Workspace &ws = *lease.w;
+    const size_t bytes = n * vt->aff_bytes;
+    if (n) {
+        if ((rc = ws.h2d_points.ensure(bytes))) return rc;
+        // file -> two pinned buffers -> HBM: the read of chunk k+1 runs while chunk k crosses PCIe
+        constexpr size_t CHUNK = (size_t)32 << 20;
+        void *pin[2] = {nullptr, nullptr};
+        hipEvent_t done[2] = {nullptr, nullptr};
+        auto cleanup = [&]() {
+            for (int i = 0; i < 2; ++i) {
+                if (done[i]) (void)hipEventDestroy(done[i]);
+                if (pin[i]) (void)hipHostFree(pin[i]);
+            }
+        };
+        for (int i = 0; i < 2; ++i) {
+            if (hipHostMalloc(&pin[i], CHUNK, hipHostMallocDefault) != hipSuccess ||
+                hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess) {
+                cleanup();
+                return fail(GMSM_ERR_DEVICE, "gmsm_bases_register_dump: cannot allocate pinned staging buffers");
+            }
+        }
+        size_t pos = 0;
+        for (unsigned k = 0; pos < bytes; ++k) {
+            const size_t len = std::min(CHUNK, bytes - pos);
+            const int b = (int)(k & 1u);
+            if (k >= 2) (void)hipEventSynchronize(done[b]);
+            if (fread(pin[b], 1, len, f) != len) {
+                (void)hipStreamSynchronize(ws.stream);
+                cleanup();
+                return fail(GMSM_ERR_ARG, "gmsm_bases_register_dump: short read (points)");
+            }
+            hipError_t e = hipMemcpyAsync((char *)ws.h2d_points.ptr + pos, pin[b], len, hipMemcpyHostToDevice, ws.stream);
+            if (e == hipSuccess) e = hipEventRecord(done[b], ws.stream);
+            if (e != hipSuccess) {
+                (void)hipStreamSynchronize(ws.stream);
+                cleanup();
+                return fail(GMSM_ERR_DEVICE, std::string("gmsm_bases_register_dump: ") + hipGetErrorString(e));
+            }
+            pos += len;
+        }
+        (void)hipStreamSynchronize(ws.stream);
+        cleanup();
+        if (check > 0) {
+            long long bad = -1;
+            uint32_t status = 0;
+            if ((rc = vt->validate_points(ws, ws.h2d_points.ptr, n, check, &bad, &status))) return rc;
+            if (bad >= 0) {
+                *bad_index = bad;
+                return point_error("gmsm_bases_register_dump", bad, status);
+            }
+        }
+    }
+    if ((rc = register_device_points(vt, ctx, ws, group, ws.h2d_points.ptr, n, out_handle))) return rc;
+    *out_n = n;
     return GMSM_OK;
 }
 

@@ -11,6 +11,7 @@
 #include "gmsm_context.h"
 #include "gmsm_kernels.h"
 #include "gmsm_fixedbase.h"
+#include "gmsm_ingest.h"
 
 namespace gmsm {
 
@@ -19,10 +20,12 @@ template <class T> struct LazyOf;
 template <class P> struct LazyOf<Fp<P>> { using type = FpU<P>; };
 template <class P> struct LazyOf<Fp2<P>> { using type = Fp2U<P>; };
 
-template <class F_, class FrP_>
+template <class F_, class FrP_, class Consts_, bool NEEDS_TORSION_>
 struct Group {
     using F = F_;
     using FrP = FrP_;
+    using Consts = Consts_;                                   // curve coefficient, wire-format flag bits (gmsm_params32.h)
+    static constexpr bool NEEDS_TORSION = NEEDS_TORSION_;     // cofactor != 1: subgroup check beyond the curve equation
     using Aff = Affine<F>;
     using Ext = XYZZ<F>;
     using J = Jac<F>;
@@ -632,6 +635,45 @@ struct Group {
         return GMSM_OK;
     }
 
+    // ---- N4: point ingest (gmsm_ingest.h). Results of the checks come back through one 64-bit word:
+    // (index << 3 | PointStatus) of the first offending point, all ones when every point passed.
+    static int read_first_bad(Workspace &ws, long long *bad_index, uint32_t *status) {
+        unsigned long long v = 0;
+        HIP_TRY(hipMemcpyAsync(&v, ws.flagword.ptr, 8, hipMemcpyDeviceToHost, ws.stream));
+        HIP_TRY(hipStreamSynchronize(ws.stream));
+        if (v == ~0ull) {
+            *bad_index = -1;
+            *status = PT_OK;
+        } else {
+            *bad_index = (long long)(v >> 3);
+            *status = (uint32_t)(v & 7u);
+        }
+        return GMSM_OK;
+    }
+    // d_raw: n wire-format points on the device -> d_out: n Go-layout affine points (Montgomery)
+    static int decode_raw(Workspace &ws, const void *d_raw, size_t n, int level, void *d_out, long long *bad_index,
+                          uint32_t *status) {
+        int rc;
+        if ((rc = ws.flagword.ensure(8))) return rc;
+        HIP_TRY(hipMemsetAsync(ws.flagword.ptr, 0xff, 8, ws.stream));
+        if (n)
+            hipLaunchKernelGGL((k_decode_raw<F, FrP, Consts, NEEDS_TORSION>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0,
+                               ws.stream, (const uint8_t *)d_raw, n, level, (Aff *)d_out, (unsigned long long *)ws.flagword.ptr);
+        HIP_TRY(hipGetLastError());
+        return read_first_bad(ws, bad_index, status);
+    }
+    static int validate_points(Workspace &ws, const void *d_points, size_t n, int level, long long *bad_index,
+                               uint32_t *status) {
+        int rc;
+        if ((rc = ws.flagword.ensure(8))) return rc;
+        HIP_TRY(hipMemsetAsync(ws.flagword.ptr, 0xff, 8, ws.stream));
+        if (n && level > 0)
+            hipLaunchKernelGGL((k_validate_points<F, FrP, Consts, NEEDS_TORSION>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0,
+                               ws.stream, (const Aff *)d_points, n, level, (unsigned long long *)ws.flagword.ptr);
+        HIP_TRY(hipGetLastError());
+        return read_first_bad(ws, bad_index, status);
+    }
+
     // Most points one pipeline run takes: the coarse partition pass keeps two 32-bit words per partition in LDS, which
     // caps it at 2^27 references per window. Larger inputs run as consecutive point ranges whose window totals are added
     // (the point decomposition of sharding.py, on one device). GMSM_MAX_RUN lowers the cap (tests).
@@ -1091,6 +1133,14 @@ struct VTableOf {
     static int submit(Context &ctx, Workspace &ws, const void *d_scalars, size_t n, const ResidentBases *resident) {
         return G::multiexp_submit(ctx, ws, d_scalars, n, resident);
     }
+    static int decode_raw(Workspace &ws, const void *d_raw, size_t n, int level, void *d_out, long long *bad_index,
+                          uint32_t *status) {
+        return G::decode_raw(ws, d_raw, n, level, d_out, bad_index, status);
+    }
+    static int validate_points(Workspace &ws, const void *d_points, size_t n, int level, long long *bad_index,
+                               uint32_t *status) {
+        return G::validate_points(ws, d_points, n, level, bad_index, status);
+    }
     static int collect(Workspace &ws, uint64_t *out_jac) {
         typename G::J j;
         int rc = G::multiexp_collect(ws, &j);
@@ -1155,7 +1205,7 @@ struct VTableOf {
         static const GroupVTable vt = {G::FR_BITS,      G::AFF_BYTES,   G::SCALAR_BYTES, sizeof(typename G::J),
                                        sizeof(typename G::Ext), &multiexp_host, &multiexp_device, &window_sums,
                                        &fold,           &jac_to_affine, &debug_decompose, &debug_field_op,
-                                       &debug_group_op, &generate_points, &register_bases, &submit, &collect, &window_sums_enqueue, &fold_sets, &fold_points, &multiexp_bases_host, &batch_scalar_mul, &batch_jac_to_affine};
+                                       &debug_group_op, &generate_points, &register_bases, &submit, &collect, &window_sums_enqueue, &fold_sets, &fold_points, &multiexp_bases_host, &batch_scalar_mul, &batch_jac_to_affine, &decode_raw, &validate_points};
         return &vt;
     }
 };

@@ -173,6 +173,75 @@ class _Group:
             raise RuntimeError(self._error(rc))
         return ResidentBases(self, handle.value, n)
 
+    # ---- point ingest: wire format / raw dumps -> validated limbs, on the device
+    @property
+    def raw_point_bytes(self):
+        """SizeOfG1AffineUncompressed / SizeOfG2AffineUncompressed (marshal.go): equals the in-memory size."""
+        return 8 * self.aff_limbs
+
+    def DecodeRaw(self, buf, subgroup_check=True, on_curve_check=True):
+        """n uncompressed points (the bytes of RawBytes(), ecc/bn254/marshal.go:826) -> ((n, aff_limbs) Montgomery limbs,
+        None) or (None, error text); the Decoder's checks (marshal.go:250-275) run on the device.  The failing index is
+        the number after 'point' in the error text."""
+        L = _lib.load()
+        raw = np.frombuffer(bytes(buf), dtype=np.uint8) if not isinstance(buf, np.ndarray) else np.ascontiguousarray(buf, dtype=np.uint8)
+        if raw.size % self.raw_point_bytes:
+            return None, "short buffer"  # io.ErrShortBuffer
+        n = raw.size // self.raw_point_bytes
+        out = np.zeros((n, self.aff_limbs), dtype=np.uint64)
+        bad = _lib.ctypes.c_int64(-1)
+        check = 2 if subgroup_check else (1 if on_curve_check else 0)
+        rc = L.gmsm_points_from_raw(self.gid, _ptr(raw), n, check, _ptr(out), None, _lib.ctypes.byref(bad))
+        return (out, None) if rc == 0 else (None, self._error(rc))
+
+    def DecodeSlice(self, buf, subgroup_check=True):
+        """What Decoder.Decode(&[]G1Affine) reads (marshal.go:220-280): uint32 big-endian length, then the points - here
+        all in the raw (uncompressed) encoding an Encoder with RawEncoding() writes (marshal.go:418, :586-640)."""
+        b = bytes(buf)
+        if len(b) < 4:
+            return None, "short buffer"
+        n = int.from_bytes(b[:4], "big")
+        if len(b) < 4 + n * self.raw_point_bytes:
+            return None, "short buffer"
+        return self.DecodeRaw(b[4:4 + n * self.raw_point_bytes], subgroup_check)
+
+    def ValidatePoints(self, points=None, d_points=None, n=None, subgroup_check=True):
+        """IsOnCurve / IsInSubGroup over a whole vector of limb-form points (host array or device pointer): returns
+        (True, None) or (False, error text)."""
+        L = _lib.load()
+        bad = _lib.ctypes.c_int64(-1)
+        if points is not None:
+            points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, self.aff_limbs)
+            rc = L.gmsm_points_validate(self.gid, _ptr(points), None, points.shape[0], 2 if subgroup_check else 1,
+                                        _lib.ctypes.byref(bad))
+        else:
+            rc = L.gmsm_points_validate(self.gid, None, d_points, n, 2 if subgroup_check else 1, _lib.ctypes.byref(bad))
+        return (True, None) if rc == 0 else (False, self._error(rc))
+
+    def register_bases_raw(self, buf, subgroup_check=True):
+        """Decode + validate + register in one call: returns (ResidentBases, None) or (None, error text)."""
+        L = _lib.load()
+        raw = np.frombuffer(bytes(buf), dtype=np.uint8) if not isinstance(buf, np.ndarray) else np.ascontiguousarray(buf, dtype=np.uint8)
+        if raw.size % self.raw_point_bytes:
+            return None, "short buffer"
+        n = raw.size // self.raw_point_bytes
+        handle = _lib.ctypes.c_uint64(0)
+        bad = _lib.ctypes.c_int64(-1)
+        rc = L.gmsm_bases_register_raw(self.gid, _ptr(raw), n, 2 if subgroup_check else 0, _lib.ctypes.byref(handle),
+                                       _lib.ctypes.byref(bad))
+        return (ResidentBases(self, handle.value, n), None) if rc == 0 else (None, self._error(rc))
+
+    def register_bases_dump(self, path, offset=0, expect_marker=True, max_points=0, check=0):
+        """kzg.SRS.ReadDump's point part (ecc/bn254/kzg/marshal.go:98-113; utils/unsafe/dump_slice.go:35-76) straight
+        into HBM: marker, uint64 length, raw []G1Affine memory.  Returns (ResidentBases, None) or (None, error text)."""
+        L = _lib.load()
+        handle = _lib.ctypes.c_uint64(0)
+        n = _lib.ctypes.c_size_t(0)
+        bad = _lib.ctypes.c_int64(-1)
+        rc = L.gmsm_bases_register_dump(self.gid, str(path).encode(), offset, 1 if expect_marker else 0, max_points, check,
+                                        _lib.ctypes.byref(handle), _lib.ctypes.byref(n), _lib.ctypes.byref(bad))
+        return (ResidentBases(self, handle.value, n.value), None) if rc == 0 else (None, self._error(rc))
+
     def default_window_bits(self, n):
         return int(_lib.load().gmsm_default_window_bits(self.gid, n))
 

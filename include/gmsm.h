@@ -43,6 +43,7 @@ extern "C" {
 #define GMSM_ERR_CONFIG 2
 #define GMSM_ERR_DEVICE 3
 #define GMSM_ERR_ARG 4
+#define GMSM_ERR_POINT 5 /* a point failed decoding / validation; *bad_index has its position, gmsm_last_error() why */
 
 /* group ids for the generic entry points */
 enum gmsm_group {
@@ -135,6 +136,32 @@ int gmsm_batch_scalar_mul_device(int group, const uint64_t *base_affine, const v
                                  void *d_out_affine);
 /* jac = n x {X, Y, Z} (Go G1Jac/G2Jac layout), Z = 0 -> (0, 0) */
 int gmsm_batch_jac_to_affine(int group, const uint64_t *jac, size_t n, uint64_t *out_affine);
+
+/* ---- point ingest: the step before the MSM - points arrive as bytes and must become validated
+ *      Montgomery limbs in HBM.  `check`: 0 decode only, 1 + on the curve, 2 + in the r-torsion (the Decoder's default,
+ *      ecc/bn254/marshal.go:250-275; membership is decided as "on the curve and [r]P = infinity", the predicate the
+ *      reference's endomorphism-based IsInSubGroup computes).  On a bad point the call returns GMSM_ERR_POINT,
+ *      *bad_index is the first offender and gmsm_last_error() carries the reference's error text; otherwise *bad_index = -1.
+ *
+ *      gmsm_points_from_raw: raw = n points in the uncompressed wire format of (*G1Affine).RawBytes() /
+ *      Encoder(RawEncoding()) (marshal.go:826, G2 :1078; bls12-381/marshal.go:855): big-endian, regular (non-Montgomery)
+ *      form, X | Y (Fp2: A1 | A0), metadata in the top bits of the first byte, n * gmsm_affine_limbs(group) * 8 bytes in
+ *      total.  Compressed encodings are refused.  Decoded points go to out_affine (host) and/or d_out_affine (device);
+ *      give at least one.
+ *      gmsm_points_validate: the same checks over points that are already Go-layout limbs (host or device).
+ *      gmsm_bases_register_raw: decode + check + register in one call (the SRS never exists on the host in limb form).
+ *      gmsm_bases_register_dump: an SRS dump written by kzg.SRS.WriteDump (ecc/bn254/kzg/marshal.go:65-95) ends in
+ *      unsafe.WriteMarker + unsafe.WriteSlice(pk.G1) = u64 0xdeadbeef | u64 length | raw []G1Affine memory
+ *      (utils/unsafe/dump_slice.go:16-32, :80).  `offset` is the byte position of the marker (expect_marker != 0) or of
+ *      the length word; at most max_points (0 = all) are loaded, like ReadDump's maxPkPoints.  The file is streamed
+ *      through pinned buffers straight into HBM and registered; *out_n receives the number of bases.  ReadDump validates
+ *      nothing; check > 0 runs the validation kernel over the loaded points. ---- */
+int gmsm_points_from_raw(int group, const uint8_t *raw, size_t n, int check, uint64_t *out_affine, void *d_out_affine,
+                         int64_t *bad_index);
+int gmsm_points_validate(int group, const uint64_t *points, const void *d_points, size_t n, int check, int64_t *bad_index);
+int gmsm_bases_register_raw(int group, const uint8_t *raw, size_t n, int check, uint64_t *out_handle, int64_t *bad_index);
+int gmsm_bases_register_dump(int group, const char *path, uint64_t offset, int expect_marker, size_t max_points, int check,
+                             uint64_t *out_handle, size_t *out_n, int64_t *bad_index);
 
 /* ---- window-sharded pieces (multi-GPU: windows win_first, win_first+win_stride, ... of the c-bit decomposition are
  *      handled by this device; the tiny per-window totals are exchanged by the caller, e.g. one RCCL all-gather).

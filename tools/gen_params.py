@@ -122,6 +122,41 @@ def unsat_block(q, n64):
     return out
 
 
+def fp2_inv(a0, a1, p):
+    """(a0 + a1 u)^-1 in Fp[u]/(u^2+1)."""
+    t = pow(a0 * a0 + a1 * a1, -1, p)
+    return a0 * t % p, (-a1 * t) % p
+
+
+def group_consts(c):
+    """Curve coefficient b of y^2 = x^3 + b for G1 and for the twist G2 lives on, Montgomery form, 32-bit words
+    (Fp2: a0 then a1), and the flag bits of the point encoding (ecc/<curve>/marshal.go, const block at the top).
+    Twists: BN254 3/(9+u) (D-type, bn254.go:105-109), BLS12-381 4(1+u) (M-type, bls12-381.go:100-104), BW6-761 G2 over Fp:
+    y^2 = x^3 + 4 (bw6-761.go:93-96)."""
+    R = c.fp_R
+    n64 = c.fp_limbs
+    words = lambda v: limbs32(v % c.p * R % c.p, n64)
+    b1 = words(c.b)
+    if c.name == "bn254":
+        i0, i1 = fp2_inv(9, 1, c.p)
+        b2 = words(3 * i0) + words(3 * i1)
+        flag_bits, inf_flag = 2, -1      # infinity = every byte zero under the "uncompressed" flag (marshal.go:826-834)
+    elif c.name == "bls12_381":
+        b2 = words(4) + words(4)
+        flag_bits, inf_flag = 3, 0b010   # mUncompressedInfinity (bls12-381/marshal.go:27-34)
+    else:
+        b2 = words(4)
+        flag_bits, inf_flag = 3, 0b010   # bw6-761/marshal.go:25-35
+    out = ""
+    for gname, b in (("g1", b1), ("g2", b2)):
+        out += f"struct {c.name}_{gname}_consts {{\n"
+        out += f"    static constexpr uint32_t B[{len(b)}] = {{" + ", ".join(f"0x{x:08x}u" for x in b) + "};  /* curve coefficient, Montgomery */\n"
+        out += f"    static constexpr int RAW_FLAG_BITS = {flag_bits};      /* metadata bits on top of the first byte */\n"
+        out += f"    static constexpr int RAW_INFINITY_FLAG = {inf_flag};  /* flag value of an uncompressed point at infinity; -1: none */\n"
+        out += "};\n"
+    return out
+
+
 def render_cxx():
     s = "/* GENERATED by tools/gen_params.py -- do not edit. 32-bit-limb constexpr parameters for the HIP kernels.\n"
     s += " * Same numbers as gmsm_params.h (reference: ecc/<curve>/fp/element.go:44-74), split into 32-bit words. */\n"
@@ -129,6 +164,7 @@ def render_cxx():
     for c in curves.CURVES.values():
         s += cxx_field(f"{c.name}_fp", c.p, c.fp_limbs)
         s += cxx_field(f"{c.name}_fr", c.r, c.fr_limbs)
+        s += group_consts(c)
         s += "\n"
     s += "}  // namespace gmsm\n"
     return s
