@@ -486,9 +486,10 @@ def cpu_baseline(g, pts, sc, gpu_jac, curve="bn254", group="g1"):
         reps += 1
         assert err == 0
     exact = bool((o.jac_to_affine(jac) == g.jac_to_affine(gpu_jac)).all())
+    mul_ns = oracle.Field(f"{curve}_fp", g.curve.fp_limbs).mul_ns()
     return {
         "cpu_baseline": {"value": reps / t_total, "unit": "MSM/s", "cores": cores, "kind": "port",
-                         "threads": threads,
+                         "threads": threads, "base_field_mul_ns": round(mul_ns, 1), "batch_affine": True,
                          "sample": f"{reps} full MSM(s) of the same 2^{int(np.log2(len(pts)))} input, {t_total:.1f} s total; "
                                    + getattr(oracle, "BASELINE_NOTE", "C restatement of gnark-crypto's algorithm (ext-Jacobian buckets, batch-affine off)")},
         "bit_exact": exact,

@@ -17,8 +17,11 @@
  *   partitionScalars   multiexp.go:709-803, computeNbChunks :681, lastC :690
  *   processChunkG1Jacobian  multiexp_jacobian.go:8-61
  *   msmReduceChunkG1Affine  multiexp.go:302-315
- * The batch-affine bucket variant (multiexp_affine.go) is NOT restated: it computes the same group
- * element (that equality is what multiexp_test.go:221-272 asserts) and is a CPU-cache optimisation.
+ *   processChunkG1BatchAffine  multiexp_affine.go:24-231, batchAddG1Affine g1.go:1122-1182, selected per window by
+ *                              getChunkProcessorG1's thresholds (multiexp.go:213-299: c >= 10 and at least batchSize
+ *                              buckets hit, batchSize 80/150/200/350/400/500/640 for c = 10..16)
+ * oracle_set_batch_affine(0) forces the extended-Jacobian buckets everywhere (the two must give the same point:
+ * multiexp_test.go:221-272).
  */
 #include <stdlib.h>
 #include <pthread.h>
@@ -304,6 +307,161 @@ static void GF(process_chunk)(unsigned c_buckets, const AFF *points, const uint1
     *out = total;
 }
 
+/* ---------------------------------------------------------------- one window, batch-affine buckets */
+
+#ifndef ORACLE_BATCH_AFFINE_DEFINED
+#define ORACLE_BATCH_AFFINE_DEFINED
+static int oracle_batch_affine_on = 1;
+/* batch sizes of the generated code (multiexp_affine.go:296-340): index = c */
+static const unsigned oracle_batch_size[17] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 80, 150, 200, 350, 400, 500, 640};
+#endif
+
+/* batchAddG1Affine (g1.go:1122-1182): R[j] += P[j] for cnt independent pairs with ONE field inversion */
+static void GF(batch_add_affine)(AFF **R, const AFF *P, unsigned cnt, CFT *lambda, CFT *lambdain) {
+    if (cnt == 0) return;
+    for (unsigned j = 0; j < cnt; ++j) CFF(sub)(&lambdain[j], &P[j].x, &R[j]->x);
+    CFT acc;
+    CFF(set_one)(&lambda[0]);
+    acc = lambdain[0];
+    for (unsigned i = 1; i < cnt; ++i) {
+        lambda[i] = acc;
+        CFF(mul)(&acc, &acc, &lambdain[i]);
+    }
+    CFF(inv)(&acc, &acc);
+    for (unsigned i = cnt - 1; i > 0; --i) {
+        CFF(mul)(&lambda[i], &lambda[i], &acc);
+        CFF(mul)(&acc, &acc, &lambdain[i]);
+    }
+    lambda[0] = acc;
+    for (unsigned j = 0; j < cnt; ++j) {
+        CFT t;
+        AFF Q;
+        CFF(sub)(&t, &P[j].y, &R[j]->y);
+        CFF(mul)(&lambda[j], &lambda[j], &t);      /* lambda = (y2 - y1) / (x2 - x1) */
+        CFF(sqr)(&Q.x, &lambda[j]);
+        CFF(sub)(&Q.x, &Q.x, &R[j]->x);
+        CFF(sub)(&Q.x, &Q.x, &P[j].x);             /* x3 = lambda^2 - x1 - x2 */
+        CFF(sub)(&t, &R[j]->x, &Q.x);
+        CFF(mul)(&Q.y, &lambda[j], &t);
+        CFF(sub)(&Q.y, &Q.y, &R[j]->y);            /* y3 = lambda (x1 - x3) - y1 */
+        *R[j] = Q;
+    }
+}
+
+typedef struct { uint16_t bucket; AFF point; } GF(bop_t);
+
+/* processChunkG1BatchAffine (multiexp_affine.go:24-231). buckets_je: 2^(c_buckets-1) XYZZ (the caller's scratch, also
+ * used by the Jacobian variant); the affine buckets, batch and queue are allocated here. */
+static void GF(process_chunk_batch_affine)(unsigned c_buckets, unsigned batch, const AFF *points, const uint16_t *digits,
+                                           size_t n, XYZZ *buckets_je, XYZZ *out) {
+    const size_t nbuckets = (size_t)1 << (c_buckets - 1);
+    AFF *buckets = (AFF *)calloc(nbuckets, sizeof(AFF));         /* (0,0) = infinity */
+    uint8_t *in_batch = (uint8_t *)calloc(nbuckets, 1);          /* bitSet: bucket already part of the current batch */
+    AFF **R = (AFF **)malloc(sizeof(AFF *) * batch);
+    AFF *P = (AFF *)malloc(sizeof(AFF) * batch);
+    CFT *lambda = (CFT *)malloc(sizeof(CFT) * batch), *lambdain = (CFT *)malloc(sizeof(CFT) * batch);
+    GF(bop_t) *queue = (GF(bop_t) *)malloc(sizeof(GF(bop_t)) * batch);
+    unsigned cnt = 0, qid = 0;
+    for (size_t k = 0; k < nbuckets; ++k) GF(xyzz_set_infinity)(&buckets_je[k]);
+
+#define ORACLE_EXECUTE_AND_RESET()                                                   \
+    do {                                                                             \
+        GF(batch_add_affine)(R, P, cnt, lambda, lambdain);                           \
+        for (unsigned q_ = 0; q_ < cnt; ++q_) in_batch[R[q_] - buckets] = 0;          \
+        cnt = 0;                                                                     \
+    } while (0)
+
+    for (size_t i = 0; i < n; ++i) {
+        const uint16_t digit = digits[i];
+        if (digit == 0 || GF(aff_is_infinity)(&points[i])) continue;
+        uint16_t bid = (uint16_t)(digit >> 1);
+        const int is_add = (digit & 1) == 0;
+        if (is_add) bid -= 1;
+        AFF pt = points[i];
+        if (!is_add) CFF(neg)(&pt.y, &pt.y);
+        if (in_batch[bid]) {  /* conflict: queue it (multiexp_affine.go:181-197) */
+            queue[qid].bucket = bid;
+            queue[qid].point = pt;
+            ++qid;
+            if (qid == batch - 1) {  /* queue full: flush into the extended-Jacobian buckets */
+                for (unsigned q = 0; q < qid; ++q) GF(xyzz_add_mixed)(&buckets_je[queue[q].bucket], &queue[q].point, 0);
+                qid = 0;
+            }
+            continue;
+        }
+        /* add(): special cases first (multiexp_affine.go:113-149); pt already carries the sign */
+        AFF *BK = &buckets[bid];
+        if (GF(aff_is_infinity)(BK)) { *BK = pt; continue; }
+        if (CFF(equal)(&BK->x, &pt.x)) {
+            if (CFF(equal)(&BK->y, &pt.y)) GF(xyzz_add_mixed)(&buckets_je[bid], &pt, 0);  /* P + P: rare, other bucket set */
+            else { CFF(set_zero)(&BK->x); CFF(set_zero)(&BK->y); }                          /* P - P */
+            continue;
+        }
+        in_batch[bid] = 1;
+        R[cnt] = BK;
+        P[cnt] = pt;
+        ++cnt;
+        if (cnt == batch) {
+            ORACLE_EXECUTE_AND_RESET();
+            /* processTopQueue (multiexp_affine.go:158-169) */
+            while (qid > 0) {
+                GF(bop_t) *op = &queue[qid - 1];
+                if (in_batch[op->bucket]) break;
+                AFF *B2 = &buckets[op->bucket];
+                if (GF(aff_is_infinity)(B2)) *B2 = op->point;
+                else if (CFF(equal)(&B2->x, &op->point.x)) {
+                    if (CFF(equal)(&B2->y, &op->point.y)) GF(xyzz_add_mixed)(&buckets_je[op->bucket], &op->point, 0);
+                    else { CFF(set_zero)(&B2->x); CFF(set_zero)(&B2->y); }
+                } else {
+                    in_batch[op->bucket] = 1;
+                    R[cnt] = B2;
+                    P[cnt] = op->point;
+                    ++cnt;
+                }
+                --qid;
+            }
+        }
+    }
+    ORACLE_EXECUTE_AND_RESET();
+    for (unsigned q = 0; q < qid; ++q) GF(xyzz_add_mixed)(&buckets_je[queue[q].bucket], &queue[q].point, 0);
+#undef ORACLE_EXECUTE_AND_RESET
+    /* total = bucket[0] + 2 bucket[1] + ... (multiexp_affine.go:207-218) */
+    XYZZ running, total;
+    GF(xyzz_set_infinity)(&running);
+    GF(xyzz_set_infinity)(&total);
+    for (size_t k = nbuckets; k-- > 0;) {
+        GF(xyzz_add_mixed)(&running, &buckets[k], 0);
+        if (!GF(xyzz_is_infinity)(&buckets_je[k])) GF(xyzz_add)(&running, &buckets_je[k]);
+        GF(xyzz_add)(&total, &running);
+    }
+    *out = total;
+    free(buckets); free(in_batch); free(R); free(P); free(lambda); free(lambdain); free(queue);
+}
+
+/* getChunkProcessorG1 (multiexp.go:213-299): batch-affine buckets for c >= 10 when at least batchSize distinct
+ * buckets of the window are hit (chunkStat.nbBucketFilled, multiexp.go:811-838), extended-Jacobian otherwise. */
+static void GF(process_chunk_auto)(unsigned c, unsigned c_buckets, const AFF *points, const uint16_t *digits, size_t n,
+                                   XYZZ *buckets, XYZZ *out) {
+    const unsigned batch = (oracle_batch_affine_on && c >= 10 && c <= 16) ? oracle_batch_size[c] : 0;
+    if (batch) {
+        const size_t nbuckets = (size_t)1 << (c_buckets - 1);
+        uint8_t *hit = (uint8_t *)calloc(nbuckets, 1);
+        size_t nz = 0;
+        for (size_t i = 0; i < n && nz < batch; ++i) {
+            const uint16_t d = digits[i];
+            if (d == 0) continue;
+            const size_t b = (d & 1) ? (size_t)(d >> 1) : (size_t)(d >> 1) - 1;
+            if (!hit[b]) { hit[b] = 1; ++nz; }
+        }
+        free(hit);
+        if (nz >= batch) {
+            GF(process_chunk_batch_affine)(c_buckets, batch, points, digits, n, buckets, out);
+            return;
+        }
+    }
+    GF(process_chunk)(c_buckets, points, digits, n, buckets, out);
+}
+
 typedef struct {
     unsigned c;        /* digit window width */
     unsigned c_alloc;  /* bucket arrays hold 2^(c_alloc-1) entries: max(c, lastC(c)) */
@@ -344,7 +502,7 @@ static void *GF(chunk_worker)(void *arg) {
         /* the reference sizes the top window's bucket array from lastC(c) (multiexp.go:182-184); every worker
          * here gets 2^(max(c,lastC)-1) buckets, unused high buckets stay at infinity and cost only adds of
          * infinity in the reduction (no effect on the value). */
-        GF(process_chunk)(job->c_alloc, job->points, job->digits + (size_t)j * job->n, job->n, buckets, &job->totals[j]);
+        GF(process_chunk_auto)(job->c, job->c_alloc, job->points, job->digits + (size_t)j * job->n, job->n, buckets, &job->totals[j]);
     }
     free(buckets);
     return NULL;
@@ -520,7 +678,7 @@ static void *GF(pool_chunks)(void *arg) {
         while (t >= plan->leaves[l].nb) { t -= plan->leaves[l].nb; ++l; }
         GF(leaf_t) *lf = &plan->leaves[l];
         unsigned j = lf->nb - 1 - (unsigned)t;
-        GF(process_chunk)(lf->c_alloc, pool->points + lf->off, lf->digits + (size_t)j * lf->n, lf->n, buckets, &lf->totals[j]);
+        GF(process_chunk_auto)(lf->c, lf->c_alloc, pool->points + lf->off, lf->digits + (size_t)j * lf->n, lf->n, buckets, &lf->totals[j]);
     }
     free(buckets);
     return NULL;

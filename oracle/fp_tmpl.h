@@ -108,8 +108,9 @@ static inline void FPF(neg)(FPT *z, const FPT *x) {
 }
 
 /* z = x*y*R^-1 mod q: CIOS, one outer iteration per limb of y (element.go:470-591).
- * t has N+1 limbs plus the overflow bit D, exactly as _mulGeneric. */
-static inline void FPF(mul)(FPT *z, const FPT *x, const FPT *y) {
+ * t has N+1 limbs plus the overflow bit D, exactly as _mulGeneric.  Kept as the cross-check of FPF(mul) below
+ * (tests/test_oracle_pinning.py compares the two on random and edge values). */
+static inline void FPF(mul_generic)(FPT *z, const FPT *x, const FPT *y) {
     uint64_t t[FP_N + 1];
     memset(t, 0, sizeof t);
     for (int i = 0; i < FP_N; ++i) {
@@ -140,6 +141,36 @@ static inline void FPF(mul)(FPT *z, const FPT *x, const FPT *y) {
     /* moduli in scope: t[N] == 0 here (spare bits), result < 2q */
     for (int i = 0; i < FP_N; ++i) z->l[i] = t[i];
     if (t[FP_N] || !FPF(lt_modulus)(z->l)) FPF(sub_q)(z->l);
+}
+
+/* z = x*y*R^-1 mod q, the "no-carry" interleaving the reference's Mul uses for these moduli (top word of q below
+ * 2^63 and not all ones): element_purego.go:46-213 and, as MULX/ADCX/ADOX assembly, field/asm/element_4w_amd64.s:208-304.
+ * One pass per limb of y merges the product row and the reduction row, N words of state, no overflow word.  Fully
+ * unrolled; with -mbmi2 -madx gcc emits MULX and ADC chains for the 128-bit expressions. */
+static inline void FPF(mul)(FPT *z, const FPT *x, const FPT *y) {
+    uint64_t t[FP_N];
+#pragma GCC unroll 16
+    for (int j = 0; j < FP_N; ++j) t[j] = 0;
+#pragma GCC unroll 16
+    for (int i = 0; i < FP_N; ++i) {
+        const uint64_t yi = y->l[i];
+        oracle_u128 a = (oracle_u128)x->l[0] * yi + t[0];           /* (A, t0) = t0 + x0*yi */
+        const uint64_t m = (uint64_t)a * FP_QINVNEG;
+        oracle_u128 c = (oracle_u128)m * FP_Q[0] + (uint64_t)a;      /* (C, _) = t0 + m*q0 */
+        uint64_t A = (uint64_t)(a >> 64), C = (uint64_t)(c >> 64);
+#pragma GCC unroll 16
+        for (int j = 1; j < FP_N; ++j) {
+            a = (oracle_u128)x->l[j] * yi + t[j] + A;                /* (A, tj) = tj + xj*yi + A */
+            A = (uint64_t)(a >> 64);
+            c = (oracle_u128)m * FP_Q[j] + (uint64_t)a + C;          /* (C, t[j-1]) = tj + m*qj + C */
+            t[j - 1] = (uint64_t)c;
+            C = (uint64_t)(c >> 64);
+        }
+        t[FP_N - 1] = C + A;
+    }
+#pragma GCC unroll 16
+    for (int i = 0; i < FP_N; ++i) z->l[i] = t[i];
+    if (!FPF(lt_modulus)(z->l)) FPF(sub_q)(z->l);
 }
 
 static inline void FPF(sqr)(FPT *z, const FPT *x) { FPF(mul)(z, x, x); } /* Square == Mul(x,x) value-wise */

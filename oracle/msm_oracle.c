@@ -176,6 +176,16 @@
 /* ------------------------------------------------------------------ exported C API (ctypes) */
 #define EXPORT __attribute__((visibility("default")))
 
+#include <time.h>
+#define bn254_fp_RSQ_ARR bn254_fp_rsquare
+#define bn254_fr_RSQ_ARR bn254_fr_rsquare
+#define bls12_381_fp_RSQ_ARR bls12_381_fp_rsquare
+#define bls12_381_fr_RSQ_ARR bls12_381_fr_rsquare
+#define bw6_761_fp_RSQ_ARR bw6_761_fp_rsquare
+#define bw6_761_fr_RSQ_ARR bw6_761_fr_rsquare
+/* 1 (default): windows use the batch-affine buckets where the reference would; 0: extended-Jacobian buckets everywhere */
+EXPORT void oracle_set_batch_affine(int on) { oracle_batch_affine_on = on; }
+
 #define FIELD_API(F)                                                                                                        \
     EXPORT void oracle_##F##_mul(const uint64_t *a, const uint64_t *b, uint64_t *z) { F##_mul((F##_t *)z, (const F##_t *)a, (const F##_t *)b); } \
     EXPORT void oracle_##F##_add(const uint64_t *a, const uint64_t *b, uint64_t *z) { F##_add((F##_t *)z, (const F##_t *)a, (const F##_t *)b); } \
@@ -189,6 +199,15 @@
     FIELD_API(F)                                                                                                            \
     EXPORT void oracle_##F##_from_mont(const uint64_t *a, uint64_t *z) { F##_t t = *(const F##_t *)a; F##_from_mont(&t); *(F##_t *)z = t; } \
     EXPORT void oracle_##F##_to_mont(const uint64_t *a, uint64_t *z) { F##_to_mont((F##_t *)z, (const F##_t *)a); }     \
+    /* nanoseconds per Montgomery product on this host (dependent chain of 2*iters products, one core) */             \
+    EXPORT double oracle_##F##_mul_ns(unsigned iters) {                                                                 \
+        F##_t a, b; F##_set_one(&a); memcpy(b.l, F##_RSQ_ARR, sizeof b.l);                                              \
+        struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);                                                    \
+        for (unsigned i = 0; i < iters; ++i) { F##_mul(&a, &a, &b); F##_mul(&b, &b, &a); }                              \
+        clock_gettime(CLOCK_MONOTONIC, &t1);                                                                            \
+        volatile uint64_t sink = a.l[0] ^ b.l[0]; (void)sink;                                                           \
+        return ((double)(t1.tv_sec - t0.tv_sec) * 1e9 + (double)(t1.tv_nsec - t0.tv_nsec)) / (2.0 * iters); }           \
+    EXPORT void oracle_##F##_mul_generic(const uint64_t *a, const uint64_t *b, uint64_t *z) { F##_mul_generic((F##_t *)z, (const F##_t *)a, (const F##_t *)b); } \
     /* z = sum_i a[i]*b[i] (Montgomery products, so z is the Montgomery form of sum a_i b_i): closed-form check of an   \
      * MSM over bases [a_i]G with scalars b_i, whose result must be [sum a_i b_i]G */                                        \
     EXPORT void oracle_##F##_dot(const uint64_t *a, const uint64_t *b, size_t n, uint64_t *z) {                             \

@@ -41,6 +41,15 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+def set_batch_affine(on):
+    """True (default): windows use batch-affine buckets where the reference would (multiexp.go:232-294)."""
+    lib().oracle_set_batch_affine(1 if on else 0)
+
+
+BASELINE_NOTE = ("C restatement of gnark-crypto's algorithm: no-carry Montgomery product (MULX via gcc, no hand-written "
+                 "ADX assembly), batch-affine buckets with the reference's thresholds for c >= 10, ext-Jacobian otherwise")
+
+
 class Field:
     """Prime field (e.g. 'bn254_fp') or quadratic extension ('bn254_e2') ops on Montgomery limb arrays."""
 
@@ -58,6 +67,14 @@ class Field:
         return z
 
     def mul(self, a, b): return self._bin("mul", a, b)
+    def mul_ns(self, iters=2_000_000):
+        """nanoseconds per Montgomery product of this (prime) field on the current host, one core"""
+        f = getattr(self.L, f"oracle_{self.name}_mul_ns")
+        f.restype = ctypes.c_double
+        f.argtypes = [ctypes.c_uint]
+        return float(f(iters))
+
+    def mul_generic(self, a, b): return self._bin("mul_generic", a, b)  # _mulGeneric (CIOS with the overflow word)
     def add(self, a, b): return self._bin("add", a, b)
     def sub(self, a, b): return self._bin("sub", a, b)
     def neg(self, a): return self._un("neg", a)

@@ -197,3 +197,49 @@ def test_signed_digits_reconstruct_scalar(oracle_mod, pyref_mod, curve):
             assert sum(int(signed[j, i]) << (c * j) for j in range(nwin)) == v
         assert (signed[:-1].max() <= (1 << (c - 1)) - 1) and (signed[:-1].min() >= -(1 << (c - 1)))
         assert (signed[-1] >= 0).all()                            # top window never borrows (:788-800)
+
+
+def test_no_carry_product_equals_generic_cios(oracle_mod):
+    """FPF(mul) (the reference's no-carry Mul, element_purego.go:46-213) against _mulGeneric (element.go:470-591) on
+    random and edge operands, every prime field in scope."""
+    import importlib
+    curves = importlib.import_module("gnark-crypto_amd.curves")
+    for c in curves.CURVES.values():
+        for fname, mod, limbs in ((f"{c.name}_fp", c.p, c.fp_limbs), (f"{c.name}_fr", c.r, c.fr_limbs)):
+            F = oracle_mod.Field(fname, limbs)
+            rng = rng_for(41, limbs, mod & 0xFFFF)
+            vals = random_field_limbs(rng, mod, limbs, 60)
+            edge = [0, 1, 2, mod - 1, mod - 2, (1 << (64 * limbs)) % mod, (mod + 1) // 2]
+            edge = np.array([[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(limbs)] for v in edge], dtype=np.uint64)
+            ops = np.concatenate([vals, edge])
+            for i in range(len(ops)):
+                for j in (i, (i * 7 + 3) % len(ops), len(ops) - 1 - i):
+                    assert (F.mul(ops[i], ops[j]) == F.mul_generic(ops[i], ops[j])).all()
+
+
+@pytest.mark.parametrize("curve,which", [("bn254", "g1"), ("bn254", "g2"), ("bls12_381", "g1"), ("bw6_761", "g1")])
+def test_batch_affine_buckets_equal_jacobian_buckets(oracle_mod, curve, which):
+    """multiexp_test.go:221-272: the batch-affine windows (c >= 10 with enough buckets hit) and the extended-Jacobian
+    windows must produce the same point; duplicated pairs and s/-s pairs exercise the P+P / P-P conflict handling."""
+    o = oracle_mod.Oracle(curve, which)
+    n = 3000
+    pts = o.gen_points(n, 11, 13, nthreads=4)
+    sc = random_scalars(rng_for(55, n), o.curve, n)
+    pts[10:60] = pts[1000:1050]   # the same points twice ...
+    sc[10:60] = sc[1000:1050]     # ... with the same scalars: P + P inside one bucket
+    pts[70] = 0
+    try:
+        for c in (10, 11, 13, 16):
+            if curve == "bw6_761" and c not in (10, 16):
+                continue
+            oracle_mod.set_batch_affine(True)
+            a = o.msm_affine(pts, sc, c=c, nthreads=4)
+            oracle_mod.set_batch_affine(False)
+            b = o.msm_affine(pts, sc, c=c, nthreads=4)
+            assert (a == b).all(), c
+        oracle_mod.set_batch_affine(True)
+        a = o.msm_affine(pts, sc, nthreads=4)
+        oracle_mod.set_batch_affine(False)
+        assert (a == o.msm_affine(pts, sc, nthreads=4)).all()
+    finally:
+        oracle_mod.set_batch_affine(True)
