@@ -2,6 +2,7 @@
 seeded inputs.  Bit-exact: integer work, the bar is equality of limbs (affine X,Y Montgomery limbs for MSM results).
 Run with `pytest -m gpu` on an MI355X."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -798,3 +799,48 @@ def test_c_client_through_the_abi(gm, oracle_mod, curve, which, tmp_path):
     for i in range(3):
         assert (out[i * g.aff_limbs:(i + 1) * g.aff_limbs] == expected).all(), i
     assert out[3 * g.aff_limbs] == gm._lib.GMSM_ERR_LEN and out[3 * g.aff_limbs + 1] == gm._lib.GMSM_ERR_CONFIG
+
+
+@pytest.mark.parametrize("curve,which,budget", [("bn254", "g1", 12.0), ("bls12_381", "g1", 8.0), ("bn254", "g2", 8.0)])
+def test_bounded_fuzz_against_the_oracle(gm, oracle_mod, curve, which, budget):
+    """tools/fuzz_parity.py inside the suite, bounded in time (~30 s for the three groups): random sizes, six scalar
+    distributions (uniform, small, few distinct, all equal, sparse, powers of two and r - k) and four entry points
+    (drop-in, registered bases, submit/collect, batch) against the oracle."""
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([_sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), str(budget), curve, which],
+                       cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 mismatches" in r.stdout
+
+
+def test_bn254_g1_2_pow_26_closed_form(gm, oracle_mod):
+    """The largest size north_star names (2^26 points, 4 GiB of bases), checked through the closed form: bases [a_i]G
+    built on the device, result must be [sum a_i b_i]G (shape of multiexp_test.go:54-60). The a_i, b_i repeat with period
+    2^22 to keep the host side of the test short; the MSM itself sees 2^26 distinct (point, scalar) pairs only through
+    their positions, so the 16 blocks additionally check that equal inputs at different indices add up: result = 16 x
+    the 2^22 closed form."""
+    import torch
+    g = gm.G1Jac("bn254")
+    o = oracle_mod.Oracle("bn254", "g1")
+    m, reps = 1 << 22, 16
+    rng = rng_for(26, 1)
+    a = random_scalars(rng, g.curve, m)
+    b = random_scalars(rng, g.curve, m)
+    d_a = torch.from_numpy(a.view(np.int64)).cuda()
+    d_blk = torch.empty((m, g.aff_limbs), dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    g.batch_scalar_mul_device(g.generator, d_a.data_ptr(), m, d_blk.data_ptr(), stream)
+    d_pts = d_blk.repeat(reps, 1).contiguous()
+    d_sc = torch.from_numpy(b.view(np.int64)).cuda().repeat(reps, 1).contiguous()
+    n = m * reps
+    assert n == 1 << 26
+    jac = g.multiexp_device(d_pts.data_ptr(), d_sc.data_ptr(), n, stream)
+    fr = oracle_mod.Field("bn254_fr", 4)
+    k_limbs = fr.from_mont(fr.dot(a, b))
+    k = sum(int(v) << (64 * i) for i, v in enumerate(k_limbs)) * reps % g.curve.r
+    expected = o.jac_to_affine(o.scalar_mul(o.generator, k))
+    assert (g.jac_to_affine(jac) == expected).all()
+    del d_pts, d_sc, d_blk, d_a
+    torch.cuda.empty_cache()
