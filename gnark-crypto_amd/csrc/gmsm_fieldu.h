@@ -97,6 +97,18 @@ GMSM_HD FpU<P> fpu_sub_sub2(const FpU<P> &a, const FpU<P> &b, const FpU<P> &c) {
     return r;
 }
 
+// Independent accumulator chains per product column (GMSM_MUL_NACC, set per translation unit = per group).
+// The product scan adds every partial product of a column into ONE 64-bit accumulator: a dependency chain of up to
+// 2*UL v_mad_u64_u32. Kernels that run several waves per SIMD hide it; the wide element types (28-limb BW6-761, Fp2 over
+// 14-limb BLS12-381) only fit ONE wave per SIMD and their register pressure leaves the compiler no room to interleave
+// independent columns (ISA: one chain through a single register pair), so that lone wave issues at the multiplier's
+// result latency instead of its issue rate. With NACC chains the partial products of a column alternate between NACC
+// accumulators that are summed once per column: NACC-1 extra 64-bit additions per column (3.5 % of the instructions at
+// NACC = 2, UL = 28).
+#ifndef GMSM_MUL_NACC
+#define GMSM_MUL_NACC 1
+#endif
+
 // Montgomery product a*b*2^-(L*W) mod q, product scanning. Requires limbs of a, b <= 2^(W+1) and
 // bound(a)*bound(b) <= 2^(L*W)/q * (B-1) for the output bound B (BN254: 2^261/q = 169, so 13q x 13q -> < 2q).
 // Output limbs are normalised (< 2^W), top limb holds the rest.
@@ -104,26 +116,43 @@ template <class P>
 GMSM_HD FpU<P> fpu_mul(const FpU<P> &a, const FpU<P> &b) {
     constexpr int L = P::UL, W = P::UW;
     constexpr uint32_t MASK = FpU<P>::MASK;
+    constexpr int NACC = GMSM_MUL_NACC;
     uint32_t m[L];
     FpU<P> r;
     uint64_t acc = 0;
 #pragma unroll
-    for (int k = 0; k < L; ++k) {
+    for (int k = 0; k < 2 * L - 1; ++k) {
+        uint64_t part[NACC > 1 ? NACC - 1 : 1] = {0};  // side chains of this column (chain 0 is `acc`, which carries over)
+        int t = 0;
+        const int lo = k < L ? 0 : k - L + 1, hi = k < L ? k : L - 1;
 #pragma unroll
-        for (int i = 0; i <= k; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
+        for (int i = lo; i <= hi; ++i, ++t) {
+            const uint64_t pr = (uint64_t)a.l[i] * b.l[k - i];
+            if (NACC > 1 && (t % NACC) != 0) part[(t % NACC) - 1] += pr;
+            else acc += pr;
+        }
+        // reduction row: m[i] * q[k-i] for the m's known so far (i < k, i < L) with q index k-i in [1, L)
 #pragma unroll
-        for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * P::UQ[k - i];
-        m[k] = ((uint32_t)acc * P::UQINV) & MASK;
-        acc += (uint64_t)m[k] * P::UQ[0];
-        acc >>= W;
-    }
+        for (int i = (k < L ? 0 : k - L + 1); i < (k < L ? k : L); ++i, ++t) {
+            const uint64_t pr = (uint64_t)m[i] * P::UQ[k - i];
+            if (NACC > 1 && (t % NACC) != 0) part[(t % NACC) - 1] += pr;
+            else acc += pr;
+        }
+        if (NACC > 1) {
 #pragma unroll
-    for (int k = L; k < 2 * L - 1; ++k) {
-#pragma unroll
-        for (int i = k - L + 1; i < L; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
-#pragma unroll
-        for (int i = k - L + 1; i < L; ++i) acc += (uint64_t)m[i] * P::UQ[k - i];
-        r.l[k - L] = (uint32_t)acc & MASK;
+            for (int j = 0; j < NACC - 1; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm("" : "+v"(part[j]));  // opaque to the reassociation pass, which would fold the chains back into one
+#endif
+                acc += part[j];
+            }
+        }
+        if (k < L) {
+            m[k] = ((uint32_t)acc * P::UQINV) & MASK;
+            acc += (uint64_t)m[k] * P::UQ[0];
+        } else {
+            r.l[k - L] = (uint32_t)acc & MASK;
+        }
         acc >>= W;
     }
     r.l[L - 1] = (uint32_t)acc;
@@ -135,30 +164,50 @@ template <class P>
 GMSM_HD FpU<P> fpu_sqr(const FpU<P> &a) {
     constexpr int L = P::UL, W = P::UW;
     constexpr uint32_t MASK = FpU<P>::MASK;
+    constexpr int NACC = GMSM_MUL_NACC;
     uint32_t m[L], d[L];
 #pragma unroll
     for (int i = 0; i < L; ++i) d[i] = a.l[i] << 1;
     FpU<P> r;
     uint64_t acc = 0;
 #pragma unroll
-    for (int k = 0; k < L; ++k) {
+    for (int k = 0; k < 2 * L - 1; ++k) {
+        uint64_t part[NACC > 1 ? NACC - 1 : 1] = {0};
+        int t = 0;
+        const int lo = k < L ? 0 : k - L + 1;
 #pragma unroll
-        for (int i = 0; 2 * i < k; ++i) acc += (uint64_t)d[i] * a.l[k - i];
-        if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+        for (int i = lo; 2 * i < k; ++i, ++t) {
+            const uint64_t pr = (uint64_t)d[i] * a.l[k - i];
+            if (NACC > 1 && (t % NACC) != 0) part[(t % NACC) - 1] += pr;
+            else acc += pr;
+        }
+        if ((k & 1) == 0) {
+            const uint64_t pr = (uint64_t)a.l[k / 2] * a.l[k / 2];
+            if (NACC > 1 && (t % NACC) != 0) part[(t % NACC) - 1] += pr;
+            else acc += pr;
+            ++t;
+        }
 #pragma unroll
-        for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * P::UQ[k - i];
-        m[k] = ((uint32_t)acc * P::UQINV) & MASK;
-        acc += (uint64_t)m[k] * P::UQ[0];
-        acc >>= W;
-    }
+        for (int i = (k < L ? 0 : k - L + 1); i < (k < L ? k : L); ++i, ++t) {
+            const uint64_t pr = (uint64_t)m[i] * P::UQ[k - i];
+            if (NACC > 1 && (t % NACC) != 0) part[(t % NACC) - 1] += pr;
+            else acc += pr;
+        }
+        if (NACC > 1) {
 #pragma unroll
-    for (int k = L; k < 2 * L - 1; ++k) {
-#pragma unroll
-        for (int i = k - L + 1; 2 * i < k; ++i) acc += (uint64_t)d[i] * a.l[k - i];
-        if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
-#pragma unroll
-        for (int i = k - L + 1; i < L; ++i) acc += (uint64_t)m[i] * P::UQ[k - i];
-        r.l[k - L] = (uint32_t)acc & MASK;
+            for (int j = 0; j < NACC - 1; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm("" : "+v"(part[j]));  // opaque to the reassociation pass, which would fold the chains back into one
+#endif
+                acc += part[j];
+            }
+        }
+        if (k < L) {
+            m[k] = ((uint32_t)acc * P::UQINV) & MASK;
+            acc += (uint64_t)m[k] * P::UQ[0];
+        } else {
+            r.l[k - L] = (uint32_t)acc & MASK;
+        }
         acc >>= W;
     }
     r.l[L - 1] = (uint32_t)acc;

@@ -38,7 +38,10 @@ struct Group {
     // fully inlined group operations in k_fixup_seg / k_reduce* only where one XYZZ addition is small enough (9- and
     // 14-limb prime fields); Fp2 and the 28-limb field use the out-of-line forms (a single inlined Fp2 or BW6-761
     // addition is 60-350 KB of code: instruction-cache misses and minutes of compile time)
-    static constexpr bool INLINE_OPS = sizeof(U) <= 14 * 4;
+#ifndef GMSM_INLINE_ALL_OPS
+#define GMSM_INLINE_ALL_OPS 0
+#endif
+    static constexpr bool INLINE_OPS = GMSM_INLINE_ALL_OPS || sizeof(U) <= 14 * 4;
     template <bool Fast, class Dummy = void> struct OpsSel { using type = UnsatOpsNI<U>; };
     template <class Dummy> struct OpsSel<true, Dummy> { using type = UnsatOps<U>; };
     using Ops = typename OpsSel<INLINE_OPS>::type;     // arithmetic of k_fixup_seg and the reduction kernels
@@ -208,20 +211,33 @@ struct Group {
                 q.log2span = log2L;
                 for (int t = RED_TPB; t > 1; t >>= 1) ++q.log2span;
                 // entry-parallel segmented accumulation: seg entries per thread. Every thread does the same work, so the
-                // launch should be a whole number of resident "rounds": capacity = CUs x resident workgroups x 256 threads
+                // launch should be a whole number of resident "rounds" of WORKGROUPS: the grid is (blocks per window) x
+                // (windows), so the unit is a 256-thread block per window - nw * ceil(tpw/256) blocks must not exceed
+                // rounds x (CUs x resident blocks). (Counting threads instead put 24 x 11 = 264 blocks on 256 CUs for the
+                // 24 windows of BW6-761: eight blocks ran a second round alone and the kernel took twice as long - PMC:
+                // 1056 waves, each alive for half of the kernel.) Among the round counts that keep seg <= SEG_MAX the
+                // one that fills its last round best is taken.
                 uint32_t seg = env_uint("GMSM_SEG", 0);
                 if (seg == 0) {
-                    const size_t capacity = (size_t)ctx.num_cus * AccWaves<U>::value * 256;
+                    const size_t cap_blocks = (size_t)ctx.num_cus * AccWaves<U>::value;
                     const size_t SEG_MAX = env_uint("GMSM_SEGMAX", 512);  // measured: 512 best at 2^24, 256 at 2^22
-                    for (size_t r = 1;; ++r) {
-                        size_t sg = ((size_t)q.nw * n + r * capacity - 1) / (r * capacity);
-                        if (sg <= SEG_MAX) {
-                            // nw*ceil(n/s) threads must not exceed r*capacity: round s up until it holds
-                            while (sg < SEG_MAX && (size_t)q.nw * ((n + sg - 1) / sg) > r * capacity) ++sg;
-                            seg = (uint32_t)std::max<size_t>(sg, 32);
-                            break;
+                    size_t best_seg = 0, first_r = 0;
+                    double best_fill = -1.0;
+                    for (size_t r = 1; r < 100000; ++r) {
+                        const size_t bpw = r * cap_blocks / q.nw;  // whole blocks per window in r rounds
+                        if (bpw == 0) continue;
+                        const size_t sg = std::max<size_t>((n + bpw * 256 - 1) / (bpw * 256), 32);
+                        if (sg > SEG_MAX) continue;
+                        if (!first_r) first_r = r;
+                        const size_t blocks = (size_t)q.nw * (((n + sg - 1) / sg + 255) / 256);
+                        const double fill = (double)blocks / (double)(((blocks + cap_blocks - 1) / cap_blocks) * cap_blocks);
+                        if (fill > best_fill + 1e-9) {
+                            best_fill = fill;
+                            best_seg = sg;
                         }
+                        if (fill > 0.985 || r >= first_r + 5 || sg == 32) break;
                     }
+                    seg = (uint32_t)(best_seg ? best_seg : 32);
                 }
                 q.seg = seg;
                 q.tpw = (uint32_t)((n + seg - 1) / seg);  // threads per window (upper bound: <= n entries)

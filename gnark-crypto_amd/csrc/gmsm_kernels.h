@@ -414,6 +414,10 @@ template <class U> struct AccWaves { static constexpr int value = 1; };
 template <class P> struct AccWaves<FpU<P>> { static constexpr int value = P::UL <= 9 ? GMSM_W9 : (P::UL <= 14 ? 2 : 1); };
 template <class P> struct AccWaves<Fp2U<P>> { static constexpr int value = P::UL <= 9 ? 2 : 1; };
 
+// The accumulation loop inlines its field products for every element type. (Tried for the two largest - Fp2 over 14
+// limbs, 90 KB of loop body, and 28 limbs, 130 KB, both beyond the 64 KB instruction cache: calling one shared copy of
+// the product instead is SLOWER, BW6-761 2^20 43.7 against 32.9 ms, BLS12-381 G2 2^22 55.1 against 47.0 ms - the calls
+// spill 0.5-1 KB per lane. What those kernels were missing is instruction-level parallelism, see GMSM_MUL_NACC.)
 template <class U>
 __global__ void __launch_bounds__(256, AccWaves<U>::value) k_accumulate_seg(const void *__restrict__ upoints, size_t n, uint32_t nbuckets,
                                                            uint32_t seg, const uint32_t *__restrict__ starts,
