@@ -109,9 +109,9 @@ struct Group {
     // and reduction geometry and its offsets into the per-thread / per-block scratch arrays.
     struct Piece {
         uint32_t k0, nw;
-        uint32_t seg, tpw, t1;                 // accumulation: entries per thread, threads per window, level-1 fixup outputs
+        uint32_t seg, tpw;                     // accumulation: entries per thread, threads per window
         uint32_t log2L, nblocks1, log2span;    // reduction
-        size_t off_thr, off_t1, off_blk;       // sums of nw*tpw, nw*t1, nw*nblocks1 over the earlier pieces
+        size_t off_thr, off_blk;               // sums of nw*tpw, nw*nblocks1 over the earlier pieces
     };
 
     // How the call's windows are cut into pieces. The pieces run the same pipeline (group, accumulate, fix up, reduce)
@@ -187,10 +187,9 @@ struct Group {
         uint32_t psize[Workspace::MAX_PIECES];
         const int npieces = plan_pieces(nw, n, psize);
         Piece pc[Workspace::MAX_PIECES];
-        const uint32_t span1 = 64;  // chain fixup: short chains in place, long ones through two hierarchical levels
         {
             uint32_t k0 = 0;
-            size_t off_thr = 0, off_t1 = 0, off_blk = 0;
+            size_t off_thr = 0, off_blk = 0;
             for (int p = 0; p < npieces; ++p) {
                 Piece &q = pc[p];
                 q.k0 = k0;
@@ -241,19 +240,15 @@ struct Group {
                 }
                 q.seg = seg;
                 q.tpw = (uint32_t)((n + seg - 1) / seg);  // threads per window (upper bound: <= n entries)
-                q.t1 = (q.tpw + span1 - 1) / span1;       // level-1 fixup outputs per window; level 2: one thread closes all
                 q.off_thr = off_thr;
-                q.off_t1 = off_t1;
                 q.off_blk = off_blk;
                 off_thr += (size_t)q.nw * q.tpw;
-                off_t1 += (size_t)q.nw * q.t1;
                 off_blk += (size_t)q.nw * q.nblocks1;
                 k0 += q.nw;
             }
         }
         const Piece &lastp = pc[npieces - 1];
         const size_t tot_thr = lastp.off_thr + (size_t)lastp.nw * lastp.tpw;
-        const size_t tot_t1 = lastp.off_t1 + (size_t)lastp.nw * lastp.t1;
         const size_t tot_blk = lastp.off_blk + (size_t)lastp.nw * lastp.nblocks1;
 
         // ---- grouping geometry (the same for every piece)
@@ -299,16 +294,12 @@ struct Group {
         if ((rc = ws.seg_partials.ensure(tot_thr * 2 * REC))) return rc;
         if ((rc = ws.seg_flags.ensure(tot_thr * 4))) return rc;
         if ((rc = ws.seg_bucket.ensure(tot_thr * 4))) return rc;
-        const size_t lvl_parts = (tot_t1 + nw) * 2 * REC;
-        if ((rc = ws.seg_lvl.ensure(lvl_parts + (tot_t1 * 2 + (size_t)nw * 3) * 4 + 256))) return rc;
-        char *lvl = (char *)ws.seg_lvl.ptr;
-        char *parts1_all = lvl;                                  // [tot_t1][2] records
-        char *parts2_all = lvl + tot_t1 * 2 * REC;               // [nw][2] records
-        uint32_t *flags1_all = (uint32_t *)(lvl + lvl_parts);    // [tot_t1]
-        uint32_t *pb1_all = flags1_all + tot_t1;                 // [tot_t1]
-        uint32_t *flags2_all = pb1_all + tot_t1;                 // [nw]
-        uint32_t *pb2_all = flags2_all + nw;                     // [nw]
-        uint32_t *long_flag_all = pb2_all + nw;                  // [nw]
+        // long-chain list of the fixup (k_fixup_seg appends, k_fixup_long consumes): one counter per window slot (a piece
+        // uses the slot of its first window; k_part_rowscan zeroes them) + at most one entry per FIXUP_MAXWALK threads
+        const size_t list_cap = tot_thr / FIXUP_MAXWALK + nw + 1;
+        if ((rc = ws.seg_lvl.ensure((size_t)nw * 4 + 16 + list_cap * sizeof(LongChain)))) return rc;
+        uint32_t *long_flag_all = (uint32_t *)ws.seg_lvl.ptr;                                  // [nw] counters
+        LongChain *long_list_all = (LongChain *)((char *)ws.seg_lvl.ptr + (((size_t)nw * 4 + 15) / 16) * 16);
         uint32_t *bh_all = (uint32_t *)ws.blockhist.ptr, *part_base_all = (uint32_t *)ws.counts.ptr;
         uint32_t *part_pop_all = part_base_all + (size_t)nw * (nparts + 1);
 
@@ -317,6 +308,7 @@ struct Group {
         if ((rc = ctx.allow_lds((const void *)k_part_scatter<uint16_t>, 152 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_part_scatter<uint32_t>, 152 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_fine_sort, 160 * 1024))) return rc;
+        if ((rc = ctx.allow_lds((const void *)k_fixup_long<Ops>, (int)(256 * sizeof(OpsElem))))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_reduce1<Ops, RED_TPB>, (int)(2 * RED_TPB * sizeof(OpsElem))))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_reduce2<Ops, RED2_TPB>, (int)(2 * RED2_TPB * sizeof(OpsElem))))) return rc;
 
@@ -367,10 +359,8 @@ struct Group {
             char *seg_partials = (char *)ws.seg_partials.ptr + q.off_thr * 2 * REC;
             uint32_t *seg_flags = (uint32_t *)ws.seg_flags.ptr + q.off_thr;
             uint32_t *seg_bucket = (uint32_t *)ws.seg_bucket.ptr + q.off_thr;
-            char *parts1 = parts1_all + q.off_t1 * 2 * REC;
-            char *parts2 = parts2_all + (size_t)k0 * 2 * REC;
-            uint32_t *flags1 = flags1_all + q.off_t1, *pb1 = pb1_all + q.off_t1;
-            uint32_t *flags2 = flags2_all + k0, *pb2 = pb2_all + k0, *long_flag = long_flag_all + k0;
+            uint32_t *long_flag = long_flag_all + k0;                                   // this piece's chain counter
+            LongChain *long_list = long_list_all + q.off_thr / FIXUP_MAXWALK + k0;      // disjoint slices per piece
             char *partials = (char *)ws.partials.ptr + q.off_blk * 2 * REC;
             char *totals = (char *)ws.totals.ptr + (size_t)k0 * sizeof(Ext);
 
@@ -403,12 +393,10 @@ struct Group {
             if (p + 1 < npieces) HIP_TRY(hipEventRecord(ws.ev_acc[p], st));
             timer.mark(p, T_FIXUP, st);
             hipLaunchKernelGGL((k_fixup_seg<Ops>), dim3((q.tpw + 255) / 256, nwp), dim3(256), 0, st, NB, seg_partials,
-                               (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets, long_flag);
-            hipLaunchKernelGGL((k_fixup_level<OpsNI>), dim3((q.t1 + 255) / 256, nwp), dim3(256), 0, st, NB, seg_partials,
-                               (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, span1, parts1, flags1, pb1, q.t1,
-                               buckets, long_flag);
-            hipLaunchKernelGGL((k_fixup_level<OpsNI>), dim3(1, nwp), dim3(256), 0, st, NB, parts1, flags1, pb1, q.t1, q.t1, parts2,
-                               flags2, pb2, 1u, buckets, long_flag);
+                               (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets, long_flag, long_list);
+            hipLaunchKernelGGL((k_fixup_long<Ops>), dim3(2 * ctx.num_cus), dim3(256), 256 * sizeof(OpsElem), st, NB, seg_partials,
+                               (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets,
+                               (const uint32_t *)long_flag, (const LongChain *)long_list);
             // ---- 3. bucket reduction -> window totals (empty buckets are never written: the reduction consults starts[])
             timer.mark(p, T_REDUCE, st);
             {

@@ -506,18 +506,22 @@ __global__ void __launch_bounds__(256, AccWaves<U>::value) k_accumulate_seg(cons
 }
 
 // Chain fixup. A split bucket is a chain  P1[t0], P0[t0+1], ..., P0[t1]  of partial sums of consecutive accumulation
-// threads.  k_fixup_seg: the thread that owns the chain head adds up to MAXWALK followers (random scalars: 1-3); a
-// longer chain (tiny top window, repeated scalars, every scalar equal) raises long_flag[window] and is left to
-// k_fixup_level, which re-reduces all chains of a flagged window hierarchically: each thread walks `span`
-// consecutive threads of the previous level, stores chains that close inside its span, and emits at most two open
-// partials in the same (flags, partials, pbucket) format for the next level.  The host launches two levels with
-// spans that cover any n < 2^31; a level is a no-op for windows whose flag is clear.
+// threads.  k_fixup_seg: the thread that owns the chain head adds up to MAXWALK followers (random scalars: 1-3). A
+// longer chain (a narrow top window - BW6-761's has 9 bits, 256 buckets of n/256 entries -, repeated scalars, every
+// scalar equal) is appended to a list and closed by k_fixup_long: one workgroup per chain, every thread sums a strided
+// share of the partials, then a tree over the workgroup through LDS - depth m/256 + 8 additions instead of m.
+// (Round 1 closed long chains with two hierarchical passes that were serial inside their spans: 32-link chains cost
+// BW6-761 4 ms once the accumulation ran three times as many threads.)
+struct LongChain {
+    uint32_t window, head;  // window index inside the launch, head thread (the chain's destination is pbucket[head])
+};
+constexpr uint32_t FIXUP_MAXWALK = 8;
+
 template <class A>
 __global__ void __launch_bounds__(256) k_fixup_seg(uint32_t nbuckets, const void *__restrict__ partials,
                                                    const uint32_t *__restrict__ pflags, const uint32_t *__restrict__ pbucket,
                                                    uint32_t threads_per_win, void *__restrict__ buckets,
-                                                   uint32_t *__restrict__ long_flag) {
-    constexpr uint32_t MAXWALK = 48;
+                                                   uint32_t *__restrict__ long_count, LongChain *__restrict__ long_list) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
     if (t >= threads_per_win) return;
     const size_t base = (size_t)k * threads_per_win;
@@ -530,78 +534,85 @@ __global__ void __launch_bounds__(256) k_fixup_seg(uint32_t nbuckets, const void
     typename A::Elem q = A::load(partials, (base + (has_next ? t + 1 : t)) * 2 + 0);
     const uint32_t dest = pbucket[base + t];
     if (!(f0 & SegFlags::HAS_P1)) return;
+    // length of the chain from the flags alone (no arithmetic yet): long ones are handed over untouched
     bool closed = false;
-    for (uint32_t u = t + 1; u < threads_per_win && u <= t + MAXWALK; ++u) {
+    {
+        uint32_t fu = f;
+        for (uint32_t u = t + 1; u < threads_per_win && u <= t + FIXUP_MAXWALK; ++u) {
+            if (u != t + 1) fu = pflags[base + u];
+            if (!(fu & SegFlags::HAS_P0) || !(fu & SegFlags::P0_OPEN_RIGHT)) {
+                closed = true;
+                break;
+            }
+        }
+        if (!closed && t + FIXUP_MAXWALK + 1 >= threads_per_win) closed = true;  // runs off the end of the window: short
+    }
+    if (!closed) {
+        const uint32_t slot = atomicAdd(long_count, 1u);
+        long_list[slot] = LongChain{k, t};
+        return;
+    }
+    for (uint32_t u = t + 1; u < threads_per_win; ++u) {
         if (u != t + 1) {
             f = pflags[base + u];
             if (f & SegFlags::HAS_P0) q = A::load(partials, (base + u) * 2 + 0);
         }
-        if (!(f & SegFlags::HAS_P0)) { closed = true; break; }
+        if (!(f & SegFlags::HAS_P0)) break;
         A::add(acc, q);
-        if (!(f & SegFlags::P0_OPEN_RIGHT)) { closed = true; break; }
+        if (!(f & SegFlags::P0_OPEN_RIGHT)) break;
     }
-    if (closed) A::store(buckets, (size_t)k * nbuckets + dest, acc);
-    else long_flag[k] = 1u;  // benign race: every writer stores 1
+    A::store(buckets, (size_t)k * nbuckets + dest, acc);
 }
 
-// grid = (ceil(t_out/256), nwin). Level input: t_in threads per window; output: t_out = ceil(t_in/span).
+// grid = any (grid-stride over the list), block = 256, dynamic LDS = 256 * sizeof(A::Elem).
 template <class A>
-__global__ void __launch_bounds__(256) k_fixup_level(uint32_t nbuckets, const void *__restrict__ parts_in,
-                                                     const uint32_t *__restrict__ flags_in,
-                                                     const uint32_t *__restrict__ pbucket_in, uint32_t t_in, uint32_t span,
-                                                     void *__restrict__ parts_out, uint32_t *__restrict__ flags_out,
-                                                     uint32_t *__restrict__ pbucket_out, uint32_t t_out,
-                                                     void *__restrict__ buckets, const uint32_t *__restrict__ long_flag) {
-    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
-    if (u >= t_out) return;
-    const size_t obase = (size_t)k * t_out;
-    if (!long_flag[k]) {
-        flags_out[obase + u] = 0;
-        return;
-    }
-    const size_t ibase = (size_t)k * t_in;
-    const uint32_t lo = u * span, hi = (t_in - lo > span) ? lo + span : t_in;
-    typename A::Elem acc = A::infinity();
-    bool valid = false, open_left = false;
-    uint32_t dest = 0, oflags = 0;
-    for (uint32_t t = lo; t < hi; ++t) {
-        const uint32_t f = flags_in[ibase + t];
-        if (f & SegFlags::HAS_P0) {
-            if (!valid) {  // the chain's head lies before this span
-                valid = true;
-                open_left = true;
-                acc = A::infinity();
+__global__ void __launch_bounds__(256) k_fixup_long(uint32_t nbuckets, const void *__restrict__ partials,
+                                                    const uint32_t *__restrict__ pflags, const uint32_t *__restrict__ pbucket,
+                                                    uint32_t threads_per_win, void *__restrict__ buckets,
+                                                    const uint32_t *__restrict__ long_count,
+                                                    const LongChain *__restrict__ long_list) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    using E = typename A::Elem;
+    E *lds = reinterpret_cast<E *>(lds_raw);
+    __shared__ uint32_t s_len;
+    const uint32_t tid = threadIdx.x, count = *long_count;
+    for (uint32_t c = blockIdx.x; c < count; c += gridDim.x) {
+        const LongChain lc = long_list[c];
+        const size_t base = (size_t)lc.window * threads_per_win;
+        // chain length m (head included): followers continue while they carry an open-right P0
+        if (tid == 0) s_len = 0xffffffffu;
+        __syncthreads();
+        for (uint32_t u0 = lc.head + 1; u0 < threads_per_win; u0 += 256) {
+            const uint32_t u = u0 + tid;
+            if (u < threads_per_win) {
+                const uint32_t fu = pflags[base + u];
+                if (!(fu & SegFlags::HAS_P0)) atomicMin(&s_len, u - lc.head);          // chain ended before u
+                else if (!(fu & SegFlags::P0_OPEN_RIGHT)) atomicMin(&s_len, u - lc.head + 1);  // u closes it
             }
-            typename A::Elem q = A::load(parts_in, (ibase + t) * 2 + 0);
-            A::add(acc, q);
-            if (!(f & SegFlags::P0_OPEN_RIGHT)) {  // chain closes here
-                if (open_left) {
-                    A::store(parts_out, (obase + u) * 2 + 0, acc);
-                    oflags |= SegFlags::HAS_P0;
-                } else {
-                    A::store(buckets, (size_t)k * nbuckets + dest, acc);
-                }
-                valid = false;
-            }
+            __syncthreads();
+            if (s_len != 0xffffffffu) break;
+            __syncthreads();
         }
-        if (f & SegFlags::HAS_P1) {  // a new chain starts (any previous one closed at this thread's P0)
-            acc = A::load(parts_in, (ibase + t) * 2 + 1);
-            valid = true;
-            open_left = false;
-            dest = pbucket_in[ibase + t];
+        __syncthreads();
+        const uint32_t m = s_len != 0xffffffffu ? s_len : threads_per_win - lc.head;
+        E mine = A::infinity();
+        for (uint32_t j = tid; j < m; j += 256) {
+            const E piece = j == 0 ? A::load(partials, (base + lc.head) * 2 + 1) : A::load(partials, (base + lc.head + j) * 2 + 0);
+            A::add(mine, piece);
         }
+        uint32_t active = 256;
+        while (active / 2 >= m && active > 1) active >>= 1;  // smallest power of two >= min(m, 256)
+        for (uint32_t d = active >> 1; d >= 1; d >>= 1) {
+            if (tid < 2 * d) lds[tid] = mine;
+            __syncthreads();
+            E other = A::infinity();
+            if (tid < d) other = lds[tid + d];
+            __syncthreads();
+            A::add(mine, other);
+        }
+        if (tid == 0) A::store(buckets, (size_t)lc.window * nbuckets + pbucket[base + lc.head], mine);
+        __syncthreads();
     }
-    if (valid) {  // chain continues into the next span
-        if (open_left) {
-            A::store(parts_out, (obase + u) * 2 + 0, acc);
-            oflags |= SegFlags::HAS_P0 | SegFlags::P0_OPEN_RIGHT;
-        } else {
-            A::store(parts_out, (obase + u) * 2 + 1, acc);
-            oflags |= SegFlags::HAS_P1;
-            pbucket_out[obase + u] = dest;
-        }
-    }
-    flags_out[obase + u] = oflags;
 }
 
 // ------------------------------------------------------------------ bucket reduction
