@@ -77,6 +77,7 @@ struct Workspace {
     DeviceBuffer seg_partials, seg_flags, seg_bucket;  // split-bucket partial sums of the segmented accumulation
     DeviceBuffer parted;         // coarse-partitioned references (two-level grouping)
     DeviceBuffer digits, sorted, blockhist, counts, starts, buckets, partials, totals;
+    DeviceBuffer red_pre;        // per-thread (S, W) of the split bucket reduction (k_reduce_serial -> k_reduce1)
     static constexpr int MAX_PIECES = 4;   // window groups of one call (enqueue_window_sums): alternate between the streams
     hipStream_t stream2 = nullptr;         // second stream of a call: the pieces' pipelines overlap each other
     hipEvent_t events[MAX_PIECES][12] = {{nullptr}};  // stage boundaries per piece when profiling is on

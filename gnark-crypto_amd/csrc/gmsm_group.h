@@ -50,6 +50,12 @@ struct Group {
     static_assert(2 * (sizeof(XYZZ<F>) > 256 ? 128 : 256) * sizeof(OpsElem) <= 160 * 1024, "reduction LDS budget");
     static constexpr int RED_TPB = sizeof(XYZZ<F>) > 256 ? 128 : 256;  // 2*TPB*sizeof(Elem) of LDS must fit 160 KiB
     static constexpr int RED2_TPB = 64;
+    // Every element type except the 9-limb prime field runs the serial part of reduction level 1 as its own kernel
+    // (k_reduce_serial, group law inlined, no LDS): measured reduce times fused / split - BW6-761 G1 8.87 / 6.14 ms,
+    // BLS12-381 G2 5.60 / 4.42, BN254 G2 2.60 / 1.99, BLS12-381 G1 0.98 / 0.84, BN254 G1 0.365 / 0.511 (stays fused).
+    // GMSM_SPLIT_REDUCE=0/1 overrides for A/B measurements.
+    static constexpr bool SPLIT_REDUCE_DEFAULT = sizeof(U) > 9 * 4;
+    using OpsSerial = UnsatOps<U>;
     static constexpr bool QUAD_REDUCE = true;  // level 2 of the reduction on lane quads (GMSM_QUAD=0 switches it off)
 
     static WindowPlan make_plan(unsigned c, unsigned win_first, unsigned win_stride) {
@@ -183,6 +189,7 @@ struct Group {
         constexpr size_t REC = sizeof(typename Ops::Mem);  // bucket / partial record (lazy representation on the fast path)
         static_assert(sizeof(typename Ops::Mem) == sizeof(typename OpsNI::Mem), "one record format per group");
 
+        const bool split_reduce = env_uint("GMSM_SPLIT_REDUCE", SPLIT_REDUCE_DEFAULT ? 1 : 0) != 0;
         // ---- pieces and their geometry
         uint32_t psize[Workspace::MAX_PIECES];
         const int npieces = plan_pieces(nw, n, psize);
@@ -201,8 +208,29 @@ struct Group {
                 const auto blocks1 = [&](uint32_t l2) { return ((size_t)NB + ((size_t)RED_TPB << l2) - 1) / ((size_t)RED_TPB << l2); };
                 uint32_t log2L = env_uint("GMSM_LOG2L", 0);
                 if (log2L == 0) {
-                    log2L = 1;
-                    while ((size_t)q.nw * blocks1(log2L) > (size_t)ctx.num_cus && blocks1(log2L) > 1) ++log2L;
+                    if (split_reduce) {
+                        // serial kernel: 2L dependent additions on every SIMD; combine: (2 log2 TPB + log2 L + 1) steps per
+                        // round of LDS-limited workgroups. Minimise the total number of steps.
+                        const size_t wg_per_round = std::max<size_t>(1, (size_t)ctx.num_cus * std::max<size_t>(1, (160 * 1024) / (2 * RED_TPB * sizeof(OpsElem))));
+                        uint32_t lg_tpb = 0;
+                        for (int t = RED_TPB; t > 1; t >>= 1) ++lg_tpb;
+                        size_t best = ~(size_t)0;
+                        for (uint32_t l2 = 1; l2 <= 8; ++l2) {
+                            if (blocks1(l2) > (size_t)RED2_TPB) continue;
+                            const size_t serial_threads = (size_t)q.nw * (((size_t)NB + ((size_t)1 << l2) - 1) >> l2);
+                            const size_t serial_rounds = (serial_threads + (size_t)ctx.num_cus * 256 - 1) / ((size_t)ctx.num_cus * 256);
+                            const size_t rounds = ((size_t)q.nw * blocks1(l2) + wg_per_round - 1) / wg_per_round;
+                            const size_t steps = serial_rounds * ((size_t)2 << l2) + rounds * (2 * lg_tpb + l2 + 1);
+                            if (steps < best) {
+                                best = steps;
+                                log2L = l2;
+                            }
+                        }
+                        if (log2L == 0) log2L = 8;
+                    } else {
+                        log2L = 1;
+                        while ((size_t)q.nw * blocks1(log2L) > (size_t)ctx.num_cus && blocks1(log2L) > 1) ++log2L;
+                    }
                 }
                 while (blocks1(log2L) > (size_t)RED2_TPB) ++log2L;
                 q.log2L = log2L;
@@ -287,6 +315,10 @@ struct Group {
         if ((rc = ws.starts.ensure((size_t)nw * (NB + 1) * 4))) return rc;
         if ((rc = ws.buckets.ensure((size_t)nw * NB * REC))) return rc;
         if ((rc = ws.partials.ensure(tot_blk * 2 * REC))) return rc;
+        size_t tot_pre = 0;  // (S, W) pairs of k_reduce_serial, all pieces
+        if (split_reduce)
+            for (int p = 0; p < npieces; ++p) tot_pre += (size_t)pc[p].nw * (((size_t)NB + ((size_t)1 << pc[p].log2L) - 1) >> pc[p].log2L);
+        if ((rc = ws.red_pre.ensure(tot_pre * 2 * REC))) return rc;
         if ((rc = ws.totals.ensure((size_t)nw * sizeof(Ext)))) return rc;
         if ((rc = ws.ensure_pinned((size_t)nw * sizeof(Ext)))) return rc;
         if ((rc = ws.blockhist.ensure((size_t)nw * pchunks * nparts * 4))) return rc;
@@ -343,6 +375,7 @@ struct Group {
             HIP_TRY(hipStreamWaitEvent(ws.stream2, ws.ev_fork, 0));
         }
 
+        size_t pre_off = 0;
         for (int p = 0; p < npieces; ++p) {
             const Piece &q = pc[p];
             hipStream_t st = (p & 1) ? ws.stream2 : stream;
@@ -403,8 +436,18 @@ struct Group {
                 // level 1 doubles its S_blk log2span times in an otherwise idle wave (256-thread blocks only): level 2 then
                 // has no serial doubling tail (11 of its 20 steps at c = 16)
                 const uint32_t prescale = (RED_TPB >= 256 && env_uint("GMSM_PRESCALE", 1)) ? q.log2span : 0u;
+                const void *pre = nullptr;
+                uint32_t T = 0;
+                if (split_reduce) {
+                    T = (uint32_t)(((size_t)NB + ((size_t)1 << q.log2L) - 1) >> q.log2L);
+                    char *pre_w = (char *)ws.red_pre.ptr + pre_off * 2 * REC;
+                    pre_off += (size_t)nwp * T;
+                    hipLaunchKernelGGL((k_reduce_serial<OpsSerial>), dim3((T + 255) / 256, nwp), dim3(256), 0, st, buckets, NB,
+                                       q.log2L, T, starts, pre_w);
+                    pre = pre_w;
+                }
                 hipLaunchKernelGGL((k_reduce1<Ops, RED_TPB>), dim3(q.nblocks1, nwp), dim3(RED_TPB), 2 * RED_TPB * sizeof(OpsElem), st,
-                                   buckets, NB, q.log2L, partials, starts, prescale);
+                                   buckets, NB, q.log2L, partials, starts, prescale, pre, T);
                 bool l2 = false;
                 if constexpr (QUAD_REDUCE) {
                     // level 2 on quads of lanes (4 lanes share the products of one addition). Level 1 stays

@@ -741,13 +741,45 @@ __device__ __forceinline__ void reduce_program(LoadFn load_bucket, uint32_t L, t
     if (doubler) S_out = suf;  // 2^prescale * S
 }
 
+// The serial part of level 1 as a kernel of its own (wide element types): thread g of a window owns the L = 2^log2L
+// consecutive buckets [g*L, (g+1)*L) and runs the reference's running sum over them (multiexp_jacobian.go:44-52), leaving
+// S_g = sum B_j and W_g = sum (j+1) B_j in pre[(k*T + g)*2 + {0,1}], T = ceil(nbuckets / L). Fused into k_reduce1 the
+// loop keeps four extended-Jacobian values plus the addition's temporaries alive - for a 28-limb field or Fp2 over 14
+// limbs that is over 600 registers and the kernel ran out of a 3-4 KB per lane scratch frame (BW6-761: 9.1 ms for a 4.8 ms
+// multiplier bill). Here only `run`, `tot` and the loaded bucket are live, the addition is inlined, and the launch is
+// not tied to the LDS-limited workgroups of the combine step, so it spreads over every SIMD.
+template <class A>
+__global__ void __launch_bounds__(256, 1) k_reduce_serial(const void *__restrict__ buckets, uint32_t nbuckets, uint32_t log2L,
+                                                          uint32_t T, const uint32_t *__restrict__ starts,
+                                                          void *__restrict__ pre) {
+    using E = typename A::Elem;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (g >= T) return;
+    const uint32_t L = 1u << log2L, lo = g * L;
+    const uint32_t *st = starts + (size_t)k * (nbuckets + 1);
+    E run = A::infinity(), tot = A::infinity();
+#pragma nounroll
+    for (uint32_t j = L; j-- > 0;) {
+        const uint32_t b = lo + j;
+        if (b < nbuckets && st[b + 1] > st[b]) {  // empty buckets were never written
+            const E B = A::load(buckets, (size_t)k * nbuckets + b);
+            A::add(run, B);
+        }
+        A::add(tot, run);
+    }
+    A::store(pre, ((size_t)k * T + g) * 2 + 0, run);
+    A::store(pre, ((size_t)k * T + g) * 2 + 1, tot);
+}
+
 // grid = (nblocks1, nwin_local), block = TPB threads, each thread L = 2^log2L buckets.
 // out1[(k*nblocks1 + blk)*2 + {0,1}] = (S_blk, W_blk)
+// pre != null: the threads' (S_t, W_t) were produced by k_reduce_serial (T of them per window); this kernel only combines.
 template <class A, int TPB>
 __global__ void __launch_bounds__(TPB) k_reduce1(const void *__restrict__ buckets, uint32_t nbuckets, uint32_t log2L,
                                                  void *__restrict__ out1,
                                                  const uint32_t *__restrict__ starts /* null: every bucket is stored */,
-                                                 uint32_t prescale /* S_blk is stored as 2^prescale * S_blk */) {
+                                                 uint32_t prescale /* S_blk is stored as 2^prescale * S_blk */,
+                                                 const void *__restrict__ pre, uint32_t T) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     using E = typename A::Elem;
     E *lds = reinterpret_cast<E *>(lds_raw);
@@ -762,7 +794,17 @@ __global__ void __launch_bounds__(TPB) k_reduce1(const void *__restrict__ bucket
         return present ? A::load(buckets, (size_t)k * nbuckets + b) : A::infinity();
     };
     E S_out = A::infinity(), W_out = A::infinity();
-    reduce_program<A, TPB>(load_bucket, L, A::infinity(), A::infinity(), log2L, (uint32_t)TPB, prescale, lds, S_out, W_out);
+    if (pre != nullptr) {
+        const uint32_t g = blk * TPB + t;
+        E S = A::infinity(), W = A::infinity();
+        if (g < T) {
+            S = A::load(pre, ((size_t)k * T + g) * 2 + 0);
+            W = A::load(pre, ((size_t)k * T + g) * 2 + 1);
+        }
+        reduce_program<A, TPB>(load_bucket, 0u, S, W, log2L, (uint32_t)TPB, prescale, lds, S_out, W_out);
+    } else {
+        reduce_program<A, TPB>(load_bucket, L, A::infinity(), A::infinity(), log2L, (uint32_t)TPB, prescale, lds, S_out, W_out);
+    }
     if (t == (prescale != 0 && TPB >= 256 ? 64u : 0u)) A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 0, S_out);
     if (t == 0) A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 1, W_out);
 }
