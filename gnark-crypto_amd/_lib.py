@@ -29,7 +29,8 @@ ABI_SYMBOLS = [
     "gmsm_batch_jac_to_affine", "gmsm_jac_to_affine", "gmsm_affine_limbs", "gmsm_scalar_limbs", "gmsm_debug_decompose",
     "gmsm_debug_field_op", "gmsm_debug_group_op", "gmsm_generate_points", "gmsm_set_profiling", "gmsm_get_stage_times",
     "gmsm_get_stage_launches", "gmsm_points_from_raw", "gmsm_points_validate", "gmsm_bases_register_raw",
-    "gmsm_bases_register_dump",
+    "gmsm_bases_register_dump", "gmsm_fft_domain_new", "gmsm_fft_domain_release", "gmsm_fft_domain_info", "gmsm_fft",
+    "gmsm_fft_bit_reverse",
     "gmsm_device_count", "gmsm_set_device", "gmsm_last_error",
     "gmsm_version",
 ]
@@ -134,6 +135,16 @@ def load():
     L.gmsm_bases_register_dump.restype = ctypes.c_int
     L.gmsm_bases_register_dump.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, sz, ctypes.c_int,
                                            ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(sz), i64p]
+    L.gmsm_fft_domain_new.restype = ctypes.c_int
+    L.gmsm_fft_domain_new.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
+    L.gmsm_fft_domain_release.restype = ctypes.c_int
+    L.gmsm_fft_domain_release.argtypes = [ctypes.c_uint64]
+    L.gmsm_fft_domain_info.restype = ctypes.c_int
+    L.gmsm_fft_domain_info.argtypes = [ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), u64p, u64p, u64p, u64p, u64p]
+    L.gmsm_fft.restype = ctypes.c_int
+    L.gmsm_fft.argtypes = [ctypes.c_uint64, u64p, vp, sz, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
+    L.gmsm_fft_bit_reverse.restype = ctypes.c_int
+    L.gmsm_fft_bit_reverse.argtypes = [ctypes.c_int, u64p, vp, sz, vp]
     L.gmsm_get_stage_launches.restype = ctypes.c_int
     L.gmsm_get_stage_launches.argtypes = [vp, ctypes.c_int]
     L.gmsm_device_count.restype = ctypes.c_int

@@ -66,6 +66,35 @@ struct ResidentBases {
 };
 
 
+// One fft.Domain (ecc/bn254/fr/fft/domain.go:24-60) resident on a device: the constants on the host (Montgomery limbs),
+// the twiddle and coset tables in HBM. Shared ownership like ResidentBases.
+struct FftDomain {
+    int group = -1;
+    int device = -1;
+    unsigned log2n = 0;
+    std::vector<uint64_t> generator, generator_inv, cardinality_inv, shift, shift_inv;
+    DeviceBuffer twiddles, twiddles_inv;      // w^t, w^-t for t < n/2
+    DeviceBuffer coset, coset_inv_scaled;     // u^i and u^-i / n for i < n, built by the first coset transform
+    bool coset_ready = false;
+    std::mutex mu;                            // serialises the lazy coset build and transforms that share the tables
+    FftDomain() = default;
+    FftDomain(const FftDomain &) = delete;
+    FftDomain &operator=(const FftDomain &) = delete;
+    ~FftDomain() {
+        DeviceBuffer *bufs[] = {&twiddles, &twiddles_inv, &coset, &coset_inv_scaled};
+        bool any = false;
+        for (auto *b : bufs) any = any || b->ptr;
+        if (!any) return;
+        int prev = 0;
+        (void)hipGetDevice(&prev);
+        if (device >= 0) (void)hipSetDevice(device);
+        (void)hipDeviceSynchronize();
+        for (auto *b : bufs)
+            if (b->ptr) (void)hipFree(b->ptr);
+        (void)hipSetDevice(prev);
+    }
+};
+
 // Everything one in-flight MultiExp needs on the device: scratch buffers, a pinned host buffer for the window totals, a
 // stream of its own (used when the caller gives none) and the stage events. A context owns two of them so that the
 // asynchronous entry points (gmsm_multiexp_bases_submit / _collect) can keep two MultiExp calls in flight: the sort and
@@ -364,6 +393,10 @@ struct GroupVTable {
     int (*decode_raw)(Workspace &ws, const void *d_raw, size_t n, int level, void *d_out, long long *bad_index,
                       uint32_t *status);
     int (*validate_points)(Workspace &ws, const void *d_points, size_t n, int level, long long *bad_index, uint32_t *status);
+    // fr/fft over the group's scalar field (gmsm_fft.h)
+    int (*fft_domain_new)(Context &ctx, hipStream_t stream, unsigned log2n, FftDomain *out);
+    int (*fft_run)(hipStream_t stream, FftDomain *d, void *d_a, bool inverse, bool dif, bool coset);
+    int (*fft_bit_reverse)(hipStream_t stream, void *d_a, size_t n);
 };
 
 }  // namespace gmsm

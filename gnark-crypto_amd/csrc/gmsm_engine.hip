@@ -2,6 +2,7 @@
 // There is no CPU fallback: every compute entry needs a usable gfx950 device and fails loudly otherwise.
 #include <atomic>
 #include <cstdio>
+#include <cstring>
 
 #include "gmsm_context.h"
 
@@ -548,6 +549,120 @@ GMSM_EXPORT int gmsm_multiexp_collect(uint64_t ticket, uint64_t *out_jac) {
     ws.bases_ref.reset();
     ctx->release(&ws);
     return rc;
+}
+
+// ------------------------------------------------------------------ fr/fft
+using FftRef = std::shared_ptr<FftDomain>;
+static std::mutex g_fft_mu;
+static std::vector<FftRef> g_fft;  // handle = index + 1
+
+static FftRef lookup_fft(uint64_t handle) {
+    std::lock_guard<std::mutex> lk(g_fft_mu);
+    if (handle == 0 || handle > g_fft.size()) return nullptr;
+    return g_fft[handle - 1];
+}
+
+GMSM_EXPORT int gmsm_fft_domain_new(int group, uint64_t m, uint64_t *out_handle) {
+    VT_OR_FAIL(group);
+    if (!out_handle) return fail(GMSM_ERR_ARG, "gmsm_fft_domain_new: out_handle is null");
+    unsigned log2n = 0;  // ecc.NextPowerOfTwo(m)
+    while (log2n < 63 && ((uint64_t)1 << log2n) < m) ++log2n;
+    Context *ctx;
+    int rc = get_context(&ctx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    GMSM_LEASE_OR_FAIL(lease, *ctx);
+    FftRef d = std::make_shared<FftDomain>();
+    d->group = group;
+    d->device = ctx->device;
+    if ((rc = vt->fft_domain_new(*ctx, lease.w->stream, log2n, d.get()))) return rc;
+    std::lock_guard<std::mutex> lk(g_fft_mu);
+    g_fft.push_back(d);
+    *out_handle = g_fft.size();
+    return GMSM_OK;
+}
+
+GMSM_EXPORT int gmsm_fft_domain_release(uint64_t handle) {
+    FftRef d;
+    std::lock_guard<std::mutex> lk(g_fft_mu);
+    if (handle == 0 || handle > g_fft.size() || !g_fft[handle - 1]) return fail(GMSM_ERR_ARG, "unknown fft domain handle");
+    d.swap(g_fft[handle - 1]);
+    return GMSM_OK;
+}
+
+GMSM_EXPORT int gmsm_fft_domain_info(uint64_t handle, uint64_t *cardinality, uint64_t *generator, uint64_t *generator_inv,
+                                     uint64_t *cardinality_inv, uint64_t *fr_multiplicative_gen,
+                                     uint64_t *fr_multiplicative_gen_inv) {
+    FftRef d = lookup_fft(handle);
+    if (!d) return fail(GMSM_ERR_ARG, "unknown fft domain handle");
+    if (cardinality) *cardinality = (uint64_t)1 << d->log2n;
+    auto put = [](uint64_t *dst, const std::vector<uint64_t> &src) {
+        if (dst) memcpy(dst, src.data(), src.size() * 8);
+    };
+    put(generator, d->generator);
+    put(generator_inv, d->generator_inv);
+    put(cardinality_inv, d->cardinality_inv);
+    put(fr_multiplicative_gen, d->shift);
+    put(fr_multiplicative_gen_inv, d->shift_inv);
+    return GMSM_OK;
+}
+
+GMSM_EXPORT int gmsm_fft(uint64_t handle, uint64_t *a, void *d_a, size_t n, int inverse, int decimation, int on_coset,
+                         void *hip_stream) {
+    FftRef d = lookup_fft(handle);
+    if (!d) return fail(GMSM_ERR_ARG, "unknown fft domain handle");
+    const GroupVTable *vt = vtable(d->group);
+    if (n != ((size_t)1 << d->log2n)) return fail(GMSM_ERR_LEN, "len(a) must equal the domain's cardinality");
+    if ((a == nullptr) == (d_a == nullptr)) return fail(GMSM_ERR_ARG, "gmsm_fft: give exactly one of a (host) / d_a (device)");
+    if (decimation != 0 && decimation != 1) return fail(GMSM_ERR_ARG, "gmsm_fft: decimation must be 0 (DIT) or 1 (DIF)");
+    Context *ctx;
+    int rc = get_context_for(d->device, &ctx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    GMSM_LEASE_OR_FAIL(lease, *ctx);
+    Workspace &ws = *lease.w;
+    const size_t bytes = n * vt->scalar_bytes;
+    void *dev = d_a;
+    if (a) {
+        if ((rc = ws.h2d_scalars.ensure(bytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(ws.h2d_scalars.ptr, a, bytes, hipMemcpyHostToDevice, ws.stream));
+        dev = ws.h2d_scalars.ptr;
+    } else if ((rc = order_after(ws, (hipStream_t)hip_stream))) {
+        return rc;
+    }
+    {
+        std::lock_guard<std::mutex> lk(d->mu);
+        rc = vt->fft_run(ws.stream, d.get(), dev, inverse != 0, decimation == 1, on_coset != 0);
+    }
+    if (rc) return rc;
+    if (a) HIP_TRY(hipMemcpyAsync(a, dev, bytes, hipMemcpyDeviceToHost, ws.stream));
+    HIP_TRY(hipStreamSynchronize(ws.stream));
+    return GMSM_OK;
+}
+
+GMSM_EXPORT int gmsm_fft_bit_reverse(int group, uint64_t *a, void *d_a, size_t n, void *hip_stream) {
+    VT_OR_FAIL(group);
+    if ((a == nullptr) == (d_a == nullptr) && n) return fail(GMSM_ERR_ARG, "gmsm_fft_bit_reverse: give exactly one of a / d_a");
+    if (n == 0) return GMSM_OK;
+    Context *ctx;
+    int rc = get_context_of_pointer(d_a, &ctx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    GMSM_LEASE_OR_FAIL(lease, *ctx);
+    Workspace &ws = *lease.w;
+    const size_t bytes = n * vt->scalar_bytes;
+    void *dev = d_a;
+    if (a) {
+        if ((rc = ws.h2d_scalars.ensure(bytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(ws.h2d_scalars.ptr, a, bytes, hipMemcpyHostToDevice, ws.stream));
+        dev = ws.h2d_scalars.ptr;
+    } else if ((rc = order_after(ws, (hipStream_t)hip_stream))) {
+        return rc;
+    }
+    if ((rc = vt->fft_bit_reverse(ws.stream, dev, n))) return rc;
+    if (a) HIP_TRY(hipMemcpyAsync(a, dev, bytes, hipMemcpyDeviceToHost, ws.stream));
+    HIP_TRY(hipStreamSynchronize(ws.stream));
+    return GMSM_OK;
 }
 
 // ------------------------------------------------------------------ fixed-base batch

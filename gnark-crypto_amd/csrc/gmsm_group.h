@@ -12,6 +12,7 @@
 #include "gmsm_kernels.h"
 #include "gmsm_fixedbase.h"
 #include "gmsm_ingest.h"
+#include "gmsm_fft.h"
 
 namespace gmsm {
 
@@ -1184,6 +1185,15 @@ struct VTableOf {
                           uint32_t *status) {
         return G::decode_raw(ws, d_raw, n, level, d_out, bad_index, status);
     }
+    static int fft_domain_new(Context &ctx, hipStream_t stream, unsigned log2n, FftDomain *out) {
+        return FftField<typename G::FrP>::domain_new(ctx, stream, log2n, out);
+    }
+    static int fft_run(hipStream_t stream, FftDomain *d, void *d_a, bool inverse, bool dif, bool coset) {
+        return FftField<typename G::FrP>::run(stream, d, d_a, inverse, dif, coset);
+    }
+    static int fft_bit_reverse(hipStream_t stream, void *d_a, size_t n) {
+        return FftField<typename G::FrP>::bit_reverse(stream, d_a, n);
+    }
     static int validate_points(Workspace &ws, const void *d_points, size_t n, int level, long long *bad_index,
                                uint32_t *status) {
         return G::validate_points(ws, d_points, n, level, bad_index, status);
@@ -1252,7 +1262,7 @@ struct VTableOf {
         static const GroupVTable vt = {G::FR_BITS,      G::AFF_BYTES,   G::SCALAR_BYTES, sizeof(typename G::J),
                                        sizeof(typename G::Ext), &multiexp_host, &multiexp_device, &window_sums,
                                        &fold,           &jac_to_affine, &debug_decompose, &debug_field_op,
-                                       &debug_group_op, &generate_points, &register_bases, &submit, &collect, &window_sums_enqueue, &fold_sets, &fold_points, &multiexp_bases_host, &batch_scalar_mul, &batch_jac_to_affine, &decode_raw, &validate_points};
+                                       &debug_group_op, &generate_points, &register_bases, &submit, &collect, &window_sums_enqueue, &fold_sets, &fold_points, &multiexp_bases_host, &batch_scalar_mul, &batch_jac_to_affine, &decode_raw, &validate_points, &fft_domain_new, &fft_run, &fft_bit_reverse};
         return &vt;
     }
 };

@@ -163,6 +163,24 @@ int gmsm_bases_register_raw(int group, const uint8_t *raw, size_t n, int check, 
 int gmsm_bases_register_dump(int group, const char *path, uint64_t offset, int expect_marker, size_t max_points, int check,
                              uint64_t *out_handle, size_t *out_n, int64_t *bad_index);
 
+/* ---- fr/fft: ecc/<curve>/fr/fft on the device, over the scalar field of `group`'s curve (G1 and
+ *      G2 ids of a curve name the same field).  gmsm_fft_domain_new = fft.NewDomain(m) (fr/fft/domain.go:66): cardinality
+ *      = next power of two >= m, Generator = fr.Generator(m) (fr/generator.go:18-36), coset shift = the generator of Fr^*
+ *      (domain.go:56-62; 5 / 7 / 15 for BN254 / BLS12-381 / BW6-761); twiddles live in HBM, coset tables appear with the
+ *      first coset transform.  gmsm_fft = (*Domain).FFT (inverse = 0) / FFTInverse (inverse != 0), fft.go:31-196:
+ *      decimation 0 = DIT (input bit-reversed, output natural), 1 = DIF (input natural, output bit-reversed);
+ *      on_coset = the OnCoset() option.  a: n = cardinality fr.Elements (Montgomery limbs), transformed in place, either on
+ *      the host (`a`) or on the device (`d_a`, produced on hip_stream; the call returns when the result is complete).
+ *      gmsm_fft_bit_reverse = fft.BitReverse (bitreverse.go:20).  Results are bit-identical to the reference's: every
+ *      output is a uniquely determined field element in canonical Montgomery form. ---- */
+int gmsm_fft_domain_new(int group, uint64_t m, uint64_t *out_handle);
+int gmsm_fft_domain_release(uint64_t handle);
+/* Cardinality and the domain's field constants (fr.Element limbs each; any pointer may be NULL) */
+int gmsm_fft_domain_info(uint64_t handle, uint64_t *cardinality, uint64_t *generator, uint64_t *generator_inv,
+                         uint64_t *cardinality_inv, uint64_t *fr_multiplicative_gen, uint64_t *fr_multiplicative_gen_inv);
+int gmsm_fft(uint64_t handle, uint64_t *a, void *d_a, size_t n, int inverse, int decimation, int on_coset, void *hip_stream);
+int gmsm_fft_bit_reverse(int group, uint64_t *a, void *d_a, size_t n, void *hip_stream);
+
 /* ---- window-sharded pieces (multi-GPU: windows win_first, win_first+win_stride, ... of the c-bit decomposition are
  *      handled by this device; the tiny per-window totals are exchanged by the caller, e.g. one RCCL all-gather).
  *      out_xyzz (host) receives nwin_local x {X,Y,ZZ,ZZZ} extended-Jacobian window totals

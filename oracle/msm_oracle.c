@@ -173,6 +173,35 @@
 #undef SF_BITS
 #undef G_CS
 
+/* ------------------------------------------------------------------ fr/fft (fft_tmpl.h), one instance per scalar field */
+#define SF bn254_fr
+#define SF_ROOT bn254_fr_root_of_unity
+#define SF_MAXORD BN254_FR_MAX_ORDER
+#define SF_MULTGEN bn254_fr_mult_gen
+#include "fft_tmpl.h"
+#undef SF
+#undef SF_ROOT
+#undef SF_MAXORD
+#undef SF_MULTGEN
+#define SF bls12_381_fr
+#define SF_ROOT bls12_381_fr_root_of_unity
+#define SF_MAXORD BLS12_381_FR_MAX_ORDER
+#define SF_MULTGEN bls12_381_fr_mult_gen
+#include "fft_tmpl.h"
+#undef SF
+#undef SF_ROOT
+#undef SF_MAXORD
+#undef SF_MULTGEN
+#define SF bw6_761_fr
+#define SF_ROOT bw6_761_fr_root_of_unity
+#define SF_MAXORD BW6_761_FR_MAX_ORDER
+#define SF_MULTGEN bw6_761_fr_mult_gen
+#include "fft_tmpl.h"
+#undef SF
+#undef SF_ROOT
+#undef SF_MAXORD
+#undef SF_MULTGEN
+
 /* ------------------------------------------------------------------ exported C API (ctypes) */
 #define EXPORT __attribute__((visibility("default")))
 
@@ -214,6 +243,15 @@ EXPORT void oracle_set_batch_affine(int on) { oracle_batch_affine_on = on; }
         F##_t acc, t; F##_set_zero(&acc);                                                                                   \
         for (size_t i = 0; i < n; ++i) { F##_mul(&t, (const F##_t *)a + i, (const F##_t *)b + i); F##_add(&acc, &acc, &t); } \
         *(F##_t *)z = acc; }
+
+#define FFT_API(F)                                                                                                          \
+    EXPORT int oracle_##F##_fft_generator(uint64_t m, uint64_t *gen) { return F##_fft_generator(m, (F##_t *)gen); }           \
+    EXPORT int oracle_##F##_fft(uint64_t *a, size_t n, int inverse, int decimation, int coset) {                             \
+        return F##_fft_transform((F##_t *)a, n, inverse, decimation, coset); }                                               \
+    EXPORT void oracle_##F##_fft_bit_reverse(uint64_t *a, size_t n) { F##_fft_bit_reverse((F##_t *)a, n); }
+FFT_API(bn254_fr)
+FFT_API(bls12_381_fr)
+FFT_API(bw6_761_fr)
 
 PRIME_FIELD_API(bn254_fp)
 PRIME_FIELD_API(bn254_fr)

@@ -24,7 +24,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("msm_oracle.c", "fp_tmpl.h", "e2_tmpl.h", "curve_tmpl.h", "oracle_params.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("msm_oracle.c", "fp_tmpl.h", "e2_tmpl.h", "curve_tmpl.h", "fft_tmpl.h", "oracle_params.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -94,6 +94,44 @@ class Field:
 
     def from_mont(self, a): return self._un("from_mont", a)
     def to_mont(self, a): return self._un("to_mont", a)
+
+
+DIT, DIF = 0, 1  # fft.Decimation (fr/fft/fft.go:17-22)
+
+
+class FFT:
+    """fr/fft of one curve's scalar field: FFT('bn254'). Arrays are (n, fr_limbs) uint64 Montgomery limbs."""
+
+    def __init__(self, curve):
+        self.curve = curves.CURVES[curve] if isinstance(curve, str) else curve
+        self.name = f"{self.curve.name}_fr"
+        self.limbs = self.curve.fr_limbs
+        self.L = lib()
+
+    def generator(self, m):
+        """fr.Generator(m) (fr/generator.go:18): Montgomery limbs, or None when the root does not exist."""
+        z = np.zeros(self.limbs, dtype=np.uint64)
+        f = getattr(self.L, f"oracle_{self.name}_fft_generator")
+        f.argtypes = [ctypes.c_uint64, ctypes.c_void_p]
+        f.restype = ctypes.c_int
+        return z if f(m, _p(z)) == 0 else None
+
+    def transform(self, a, inverse=False, decimation=DIF, coset=False):
+        """(*Domain).FFT / FFTInverse on a copy of a (len = cardinality)."""
+        a = np.array(a, dtype=np.uint64).reshape(-1, self.limbs)
+        f = getattr(self.L, f"oracle_{self.name}_fft")
+        f.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        f.restype = ctypes.c_int
+        if f(_p(a), a.shape[0], int(inverse), int(decimation), int(coset)) != 0:
+            raise ValueError("len(a) must be a power of two within the field's 2-adicity")
+        return a
+
+    def bit_reverse(self, a):
+        a = np.array(a, dtype=np.uint64).reshape(-1, self.limbs)
+        f = getattr(self.L, f"oracle_{self.name}_fft_bit_reverse")
+        f.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        f(_p(a), a.shape[0])
+        return a
 
 
 class Oracle:

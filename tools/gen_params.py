@@ -50,6 +50,10 @@ def curve_block(c):
     out += field_block(f"{c.name}_fp", c.p, nfp)
     out += field_block(f"{c.name}_fr", c.r, nfr)
     mont = lambda v: limbs64(v * R % c.p, nfp)
+    Rr = c.fr_R
+    out += carr(f"{c.name}_fr_root_of_unity", limbs64(c.fr_root_of_unity * Rr % c.r, nfr))
+    out += f"#define {c.name.upper()}_FR_MAX_ORDER {c.fr_max_order}\n"
+    out += carr(f"{c.name}_fr_mult_gen", limbs64(c.fr_mult_gen * Rr % c.r, nfr))
     out += carr(f"{c.name}_g1_gen", mont(c.g1[0]) + mont(c.g1[1]))
     if c.g2_ext == 2:
         (x0, x1), (y0, y1) = c.g2
@@ -64,8 +68,9 @@ def limbs32(v, n64):
     return [(v >> (32 * i)) & 0xFFFFFFFF for i in range(2 * n64)]
 
 
-def cxx_field(prefix, q, n64):
-    """constexpr 32-bit-limb parameter struct for the HIP kernels (folded into instruction literals)."""
+def cxx_field(prefix, q, n64, fft=None):
+    """constexpr 32-bit-limb parameter struct for the HIP kernels (folded into instruction literals).
+    fft = (root_of_unity, max_order, mult_gen): the scalar field's FFT constants (fr/generator.go, fr/fft/domain.go)."""
     R = 1 << (64 * n64)
     n = 2 * n64
     arr = lambda name, v: f"    static constexpr uint32_t {name}[{n}] = {{" + ", ".join(f"0x{x:08x}u" for x in limbs32(v, n64)) + "};\n"
@@ -77,6 +82,13 @@ def cxx_field(prefix, q, n64):
     out += arr("ONE", R % q)
     out += arr("RSQ", R * R % q)
     out += unsat_block(q, n64)
+    if fft:
+        root, max_order, gen = fft
+        assert pow(root, 1 << max_order, q) == 1 and pow(root, 1 << (max_order - 1), q) == q - 1
+        out += "    /* FFT domain constants, Montgomery form: primitive 2^MAX_ORDER-th root of unity, generator of Fr^* (coset shift) */\n"
+        out += arr("ROOT_OF_UNITY", root * R % q)
+        out += f"    static constexpr unsigned MAX_ORDER = {max_order};\n"
+        out += arr("MULT_GEN", gen * R % q)
     out += "};\n"
     return out
 
@@ -163,7 +175,7 @@ def render_cxx():
     s += "#pragma once\n#include <stdint.h>\n\nnamespace gmsm {\n\n"
     for c in curves.CURVES.values():
         s += cxx_field(f"{c.name}_fp", c.p, c.fp_limbs)
-        s += cxx_field(f"{c.name}_fr", c.r, c.fr_limbs)
+        s += cxx_field(f"{c.name}_fr", c.r, c.fr_limbs, (c.fr_root_of_unity, c.fr_max_order, c.fr_mult_gen))
         s += group_consts(c)
         s += "\n"
     s += "}  // namespace gmsm\n"
