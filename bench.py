@@ -193,6 +193,36 @@ def also_config(gm, lib, torch, curve, group, logn, steps, host_legs):
     return out
 
 
+def fft_config(gm, torch, curve="bn254", logn=24, reps=5):
+    """fr/fft next to the MSM: (*Domain).FFT DIF on 2^logn resident coefficients, and the round trip
+    FFTInverse(DIT) o FFT(DIF) == identity as the size-independent check (fft_test.go:160-180)."""
+    c = gm.CURVES[curve]
+    n = 1 << logn
+    rng = np.random.default_rng([0x666674, logn])
+    a = rng.integers(0, 2**62, size=(n, c.fr_limbs), dtype=np.uint64)  # any limbs below r are field elements
+    t = torch.from_numpy(a.view(np.int64)).cuda()
+    d = gm.fft.NewDomain(curve, n)
+    stream = torch.cuda.current_stream().cuda_stream
+    d.fft_device(t.data_ptr(), gm.fft.DIF, stream=stream)
+    d.fft_device(t.data_ptr(), gm.fft.DIT, inverse=True, stream=stream)
+    ok = bool((t.cpu().numpy().view(np.uint64) == a).all())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        d.fft_device(t.data_ptr(), gm.fft.DIF, stream=stream)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    d.release()
+    passes = 1 + (max(0, logn - 11) + 7) // 8  # gmsm_fft.h: the low 11 bits in one pass, the rest in passes of <= 8
+    traffic = passes * 2 * n * 8 * c.fr_limbs
+    return {"workload": f"{curve.upper()} fr FFT (DIF) 2^{logn} elements resident in HBM", "ms": ms, "ffts_per_s": 1e3 / ms,
+            "butterflies_per_s": n * logn / 2 / (ms * 1e-3), "hbm_passes": passes,
+            "roofline": {"bound": "hbm", "achieved": traffic / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "note": "compulsory bytes of the passes / wall time; the butterflies (one saturated Montgomery product each) bind first"},
+            "round_trip_exact": ok}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -451,6 +481,7 @@ def main():
             torch.cuda.empty_cache()
             out["also"] = [also_config(gm, lib, torch, *cfg_) for cfg_ in ALSO
                            if (cfg_[0], cfg_[1], cfg_[2]) != (args.curve, args.group, args.logn)]
+            out["fft"] = [fft_config(gm, torch, "bn254", 20), fft_config(gm, torch, "bn254", 24)]
         print(json.dumps(out), file=json_out, flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -9,10 +9,11 @@
 //   BitReverse                    ecc/bn254/fr/fft/bitreverse.go:20-45
 // and the twins of BLS12-381 and BW6-761 (same templates, other scalar fields).
 //
-// Shape on the GPU: the reference recurses over halves with one goroutine per half; here every radix-2 stage is one
-// launch over all n/2 butterflies (coalesced 32-byte elements, twiddles w^t for t < n/2 resident per domain like the
-// reference's precomputed tables). The arithmetic is the canonical saturated Montgomery field (gmsm_field.h), so every
-// intermediate equals the reference's and the result needs no normalisation.
+// Shape on the GPU: the reference recurses over halves with one goroutine per half; here the log2 n radix-2 stages run
+// as a few passes over HBM, each pass doing up to 8-11 stages on LDS-resident tiles (k_fft_pass; 2^24: three passes
+// instead of 24), with the twiddles w^t for t < n/2 resident per domain like the reference's precomputed tables. The
+// arithmetic is the canonical saturated Montgomery field (gmsm_field.h), so every intermediate equals the reference's
+// and the result needs no normalisation. The one-launch-per-stage kernels stay as the A/B baseline (GMSM_FFT_STAGEWISE=1).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gmsm_context.h"
@@ -110,6 +111,58 @@ __global__ void __launch_bounds__(256) k_fft_dit_stage(Fp<FrP> *__restrict__ a, 
     fft_store(a, i + half, fp_sub(x, t));
 }
 
+// Several consecutive radix-2 stages in one pass over HBM. A stage pairs elements whose indices differ in one bit b
+// (DIF walks b downwards from log2n-1, DIT upwards from 0); a pass takes the B stages of bits [bl, bl+B) and a workgroup
+// owns a tile of 2^B x C elements - every value of those B bits x C consecutive values of the low bits (C x 32 bytes
+// contiguous per row, so the strided passes still move whole 128-256-byte runs) - stages it in LDS, runs the B stages
+// with a barrier in between and writes it back: one read and one write of the vector per pass instead of per stage
+// (2^24: 3 passes instead of 24 trips through HBM). Same butterflies, same twiddles w^(j << (log2n-1-b)), j = i mod 2^b,
+// as the per-stage kernels above.
+template <class FrP, bool DIF>
+__global__ void __launch_bounds__(256) k_fft_pass(Fp<FrP> *__restrict__ a, unsigned log2n, unsigned bl, unsigned B, unsigned log2C,
+                                                  const Fp<FrP> *__restrict__ tw) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    using Fr = Fp<FrP>;
+    Fr *tile = reinterpret_cast<Fr *>(lds_raw);  // [2^B][C]
+    const unsigned C = 1u << log2C, T = blockDim.x, t = threadIdx.x;
+    const size_t ntile_lo = ((size_t)1 << bl) >> log2C;  // tiles along the low bits
+    const size_t lo0 = ((size_t)blockIdx.x % ntile_lo) << log2C, hi = (size_t)blockIdx.x / ntile_lo;
+    const size_t base = (hi << (bl + B)) | lo0;
+    const unsigned elems = (1u << B) << log2C;
+    for (unsigned e = t; e < elems; e += T) {
+        const unsigned mid = e >> log2C, c = e & (C - 1);
+        tile[e] = fft_load(a, base + ((size_t)mid << bl) + c);
+    }
+    __syncthreads();
+    const unsigned nbf = elems >> 1;  // butterflies per stage
+    for (unsigned st = 0; st < B; ++st) {
+        const unsigned bb = DIF ? B - 1 - st : st;  // bit inside the tile; global bit b = bl + bb
+        const unsigned b = bl + bb;
+        for (unsigned q = t; q < nbf; q += T) {
+            const unsigned c = q & (C - 1), p = q >> log2C;
+            const unsigned mid0 = ((p >> bb) << (bb + 1)) | (p & ((1u << bb) - 1)), mid1 = mid0 | (1u << bb);
+            const size_t i = base + ((size_t)mid0 << bl) + c;
+            const size_t j = i & (((size_t)1 << b) - 1);
+            Fr x = tile[(mid0 << log2C) + c], y = tile[(mid1 << log2C) + c];
+            if (DIF) {
+                Fr d = fp_sub(x, y);
+                if (j) d = fp_mul(d, fft_load(tw, j << (log2n - 1 - b)));
+                tile[(mid0 << log2C) + c] = fp_add(x, y);
+                tile[(mid1 << log2C) + c] = d;
+            } else {
+                if (j) y = fp_mul(y, fft_load(tw, j << (log2n - 1 - b)));
+                tile[(mid0 << log2C) + c] = fp_add(x, y);
+                tile[(mid1 << log2C) + c] = fp_sub(x, y);
+            }
+        }
+        __syncthreads();
+    }
+    for (unsigned e = t; e < elems; e += T) {
+        const unsigned mid = e >> log2C, c = e & (C - 1);
+        fft_store(a, base + ((size_t)mid << bl) + c, tile[e]);
+    }
+}
+
 // BitReverse (bitreverse.go:33-45): swap a[i] and a[rev(i)] once per pair
 template <class FrP>
 __global__ void __launch_bounds__(256) k_fft_bit_reverse(Fp<FrP> *__restrict__ a, size_t n, unsigned log2n) {
@@ -124,6 +177,20 @@ __global__ void __launch_bounds__(256) k_fft_bit_reverse(Fp<FrP> *__restrict__ a
 }
 
 // ------------------------------------------------------------------ host side of one scalar field
+// dynamic LDS above 64 KiB needs the attribute once per kernel (per device; set on whichever device is current)
+static inline int ctx_allow_lds(const void *kernel, int bytes) {
+    static std::mutex mu;
+    static std::vector<std::pair<const void *, int>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &e : done)
+        if (e.first == kernel && e.second == dev) return GMSM_OK;
+    HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.emplace_back(kernel, dev);
+    return GMSM_OK;
+}
+
 template <class FrP>
 struct FftField {
     using Fr = Fp<FrP>;
@@ -154,8 +221,7 @@ struct FftField {
         const Fr gen = pow2k(from_words(FrP::ROOT_OF_UNITY), FrP::MAX_ORDER - log2n);
         const Fr gen_inv = fp_inv(gen);
         const Fr shift = from_words(FrP::MULT_GEN), shift_inv = fp_inv(shift);
-        Fr card = Fr::zero();  // n as a field element: Montgomery form of 2^log2n = ONE doubled log2n times
-        card = Fr::one();
+        Fr card = Fr::one();  // n as a field element: Montgomery form of 2^log2n = ONE doubled log2n times
         for (unsigned i = 0; i < log2n; ++i) card = fp_dbl(card);
         const Fr card_inv = fp_inv(card);
         auto put = [&](std::vector<uint64_t> &dst, const Fr &v) {
@@ -217,12 +283,43 @@ struct FftField {
                                dif ? 0 : 1);
         const Fr *tw = (const Fr *)(inverse ? d->twiddles_inv.ptr : d->twiddles.ptr);
         if (n > 1) {
-            if (dif)
-                for (unsigned s = 0; s < log2n; ++s)
-                    hipLaunchKernelGGL((k_fft_dif_stage<FrP>), dim3(blocks_h), dim3(256), 0, stream, a, n, log2n, s, tw);
-            else
-                for (unsigned s = 0; s < log2n; ++s)
-                    hipLaunchKernelGGL((k_fft_dit_stage<FrP>), dim3(blocks_h), dim3(256), 0, stream, a, n, log2n, s, tw);
+            if (env_uint("GMSM_FFT_STAGEWISE", 0)) {  // one launch per stage (the first version; kept for A/B)
+                for (unsigned s = 0; s < log2n; ++s) {
+                    if (dif) hipLaunchKernelGGL((k_fft_dif_stage<FrP>), dim3(blocks_h), dim3(256), 0, stream, a, n, log2n, s, tw);
+                    else hipLaunchKernelGGL((k_fft_dit_stage<FrP>), dim3(blocks_h), dim3(256), 0, stream, a, n, log2n, s, tw);
+                }
+            } else {
+                // passes over the bit positions: the lowest LOWB bits as one contiguous pass (tiles of 2^LOWB elements,
+                // C = 1), the rest in passes of <= 8 bits with C = 8 consecutive elements per row. DIF runs the passes
+                // from the top bits down, DIT from the bottom up.
+                constexpr unsigned LOWB = sizeof(Fr) <= 32 ? 11 : 10;  // 2^11 x 32 B = 64 KiB of LDS
+                struct Pass { unsigned bl, B, log2C; } passes[16];
+                int np = 0;
+                const unsigned low = std::min(log2n, LOWB);
+                passes[np++] = Pass{0, low, 0};
+                unsigned rest = log2n - low, bl = low;
+                const unsigned nhi = (rest + 7) / 8;
+                for (unsigned k = 0; k < nhi; ++k) {
+                    const unsigned Bk = rest / (nhi - k) + ((rest % (nhi - k)) ? 1 : 0);
+                    passes[np++] = Pass{bl, Bk, 3};
+                    bl += Bk;
+                    rest -= Bk;
+                }
+                for (int k = 0; k < np; ++k) {
+                    const Pass &ps = passes[dif ? np - 1 - k : k];
+                    const size_t lds = ((size_t)sizeof(Fr) << ps.B) << ps.log2C;
+                    const size_t tiles = n >> (ps.B + ps.log2C);
+                    if (dif) {
+                        if ((rc = ctx_allow_lds((const void *)k_fft_pass<FrP, true>, 128 * 1024))) return rc;
+                        hipLaunchKernelGGL((k_fft_pass<FrP, true>), dim3((unsigned)tiles), dim3(256), lds, stream, a, log2n, ps.bl, ps.B,
+                                           ps.log2C, tw);
+                    } else {
+                        if ((rc = ctx_allow_lds((const void *)k_fft_pass<FrP, false>, 128 * 1024))) return rc;
+                        hipLaunchKernelGGL((k_fft_pass<FrP, false>), dim3((unsigned)tiles), dim3(256), lds, stream, a, log2n, ps.bl, ps.B,
+                                           ps.log2C, tw);
+                    }
+                }
+            }
         }
         if (inverse) {
             if (!coset) {
