@@ -15,6 +15,12 @@
 
 namespace gmsm {
 
+// Y3 of the additions as one double product with a single Montgomery reduction (fpu_mul_add): measured on BN254 G1,
+// k_accumulate_seg 1.385 -> 1.286 ms at 2^20 (-7 %), 20.96 -> 20.10 ms at 2^24. GMSM_Y3_MERGE=0 builds the two-product form.
+#ifndef GMSM_Y3_MERGE
+#define GMSM_Y3_MERGE 1
+#endif
+
 template <class U>
 struct XYZZL {  // extended-Jacobian point over a lazy element type (FpU<P> or Fp2U<P>)
     U x, y, zz, zzz;
@@ -79,7 +85,13 @@ GMSM_HD void madd_u(XYZZU<P> &acc, bool &inf, const FpU<P> &px, const FpU<P> &py
     const FpU<P> Q = fmul<INL>(acc.x, PP);                             // < 2
     const FpU<P> RR = fsqr<INL>(Rv);                                   // < 3
     const FpU<P> X3 = fpu_sub_sub2<P>(RR, PPP, Q);                                              // < 3 + 8 = 11
-    const FpU<P> Y3 = fpu_sub<P, 4>(fmul<INL>(fpu_sub<P, 16>(Q, X3), Rv), fmul<INL>(acc.y, PPP));  // < 7
+    FpU<P> Y3;
+    if constexpr (GMSM_Y3_MERGE) {
+        // Y3 = (Q - X3) R - y PPP as ONE reduced product: (Q - X3) R + (8q - y) PPP  (18*18 + 8*2 = 340 < 3*169 -> < 4)
+        Y3 = fmuladd<INL>(fpu_sub<P, 16>(Q, X3), Rv, fpu_neg8c<P>(acc.y), PPP);
+    } else {
+        Y3 = fpu_sub<P, 4>(fmul<INL>(fpu_sub<P, 16>(Q, X3), Rv), fmul<INL>(acc.y, PPP));  // < 7
+    }
     acc.x = X3;
     acc.y = Y3;
     acc.zz = fmul<INL>(acc.zz, PP);
@@ -126,9 +138,14 @@ GMSM_HD void add_u(XYZZU<P> &p, bool &pinf, const XYZZU<P> &q, bool qinf) {
     }
     const FpU<P> PPP = fmul<INL>(A, PP);                                  // < 2
     const FpU<P> Q = fmul<INL>(U1, PP);                                   // < 2
-    const FpU<P> V = fmul<INL>(S1, PPP);                                  // < 2
     const FpU<P> X3 = fpu_sub<P, 4>(fpu_sub<P, 4>(fsqr<INL>(B), PPP), fpu_dbl(Q));  // < 2 + 4 + 4
-    p.y = fpu_sub<P, 4>(fmul<INL>(fpu_sub<P, 16>(Q, X3), B), V);          // < 6
+    if constexpr (GMSM_Y3_MERGE) {
+        // Y3 = (Q - X3) B - S1 PPP with one reduction: (Q - X3) B + (8q - S1) PPP  (18*6 + 8*2 = 124 -> < 2)
+        p.y = fmuladd<INL>(fpu_sub<P, 16>(Q, X3), B, fpu_neg8c<P>(S1), PPP);
+    } else {
+        const FpU<P> V = fmul<INL>(S1, PPP);                              // < 2
+        p.y = fpu_sub<P, 4>(fmul<INL>(fpu_sub<P, 16>(Q, X3), B), V);      // < 6
+    }
     p.x = X3;
     p.zz = fmul<INL>(fmul<INL>(p.zz, q.zz), PP);
     p.zzz = fmul<INL>(fmul<INL>(p.zzz, q.zzz), PPP);

@@ -124,14 +124,28 @@ template <class P> GMSM_HD FpU<P> lz_one(const FpU<P> *) {
     return r;
 }
 
+// (a0 + a1 u)(b0 + b1 u), u^2 = -1 (e2_bn254.go:28-37), as two double products with ONE Montgomery reduction each:
+//   c0 = a0 b0 + (8q - a1) b1,   c1 = a0 b1 + a1 b0        (operands in R = [0,4q): 48 q^2 / 2^(L W) + q < 2q, in R;
+//   8q and not 4q: a1 may be as large as 4q - 1, one unit above the top limb of the borrow form of 4q)
+// Same number of multiplies as Karatsuba's three reduced products (6 L^2 + 2 L against 6 L^2 + 3 L) but none of its
+// three exact subtractions, each a sequential borrow chain with a conditional +4q (GMSM_FP2_KARATSUBA=1 builds the
+// Karatsuba form for A/B measurements: BLS12-381 G2 accumulates ~20 % slower with it).
+#ifndef GMSM_FP2_KARATSUBA
+#define GMSM_FP2_KARATSUBA 0
+#endif
 template <bool INL, class P>
-GMSM_HD Fp2U<P> lz_mul(const Fp2U<P> &x, const Fp2U<P> &y) {  // Karatsuba, u^2 = -1 (e2_bn254.go:28-37)
+GMSM_HD Fp2U<P> lz_mul(const Fp2U<P> &x, const Fp2U<P> &y) {
+    Fp2U<P> z;
+#if GMSM_FP2_KARATSUBA
     const FpU<P> t0 = fmul<INL>(x.a0, y.a0);                                          // < 2q
     const FpU<P> t1 = fmul<INL>(x.a1, y.a1);                                          // < 2q
     const FpU<P> t2 = fmul<INL>(fpu_add_raw(x.a0, x.a1), fpu_add_raw(y.a0, y.a1));    // operands < 8q -> < 2q
-    Fp2U<P> z;
     z.a0 = fpu_subr(t0, t1);
     z.a1 = fpu_subr(fpu_subr(t2, t0), t1);
+#else
+    z.a0 = fmuladd<INL>(x.a0, y.a0, fpu_neg8n<P>(x.a1), y.a1);
+    z.a1 = fmuladd<INL>(x.a0, y.a1, x.a1, y.a0);
+#endif
     return z;
 }
 

@@ -86,6 +86,16 @@ GMSM_HD FpU<P> fpu_neg4(const FpU<P> &b) {
     return r;
 }
 
+// 8q - b for a normalised b < 4q (any member of the reduced class R of gmsm_field2u.h): like fpu_neg4 but safe up to
+// 4q - 1, where 4q's own top limb would underflow. Result limbs in (0, 2^(W+1)), no carry pass.
+template <class P>
+GMSM_HD FpU<P> fpu_neg8n(const FpU<P> &b) {
+    FpU<P> r;
+#pragma unroll
+    for (int i = 0; i < P::UL; ++i) r.l[i] = P::UK8N[i] - b.l[i];
+    return r;
+}
+
 // a - b - 2c + 8q in one pass (X3 = R^2 - PPP - 2Q): requires b + 2c < 8q limb-wise (b, c nearly normalised).
 // Value bound: bound(a) + 8.
 template <class P>
@@ -159,6 +169,52 @@ GMSM_HD FpU<P> fpu_mul(const FpU<P> &a, const FpU<P> &b) {
     return r;
 }
 
+// (a*b + c*d) * 2^-(L*W) mod q with ONE Montgomery reduction: both product rows go into the same column accumulators
+// (3L products of < 2^(2W+0.1) per column: 27 * 2^58.1 < 2^63 for L = 9, W = 29 - the operands must be nearly normalised,
+// limbs <= 2^W + 2^(32-W), which every carry-passed value is). Saves the L^2 + L multiplies of a second reduction.
+// Bound: (bound(a) bound(b) + bound(c) bound(d)) / (2^(L*W)/q) + 1.
+template <class P>
+GMSM_HD FpU<P> fpu_mul_add(const FpU<P> &a, const FpU<P> &b, const FpU<P> &c, const FpU<P> &d) {
+    constexpr int L = P::UL, W = P::UW;
+    constexpr uint32_t MASK = FpU<P>::MASK;
+    // worst admitted mix: one operand of one product un-carried (fpu_neg4: limbs < 2^(W+1)), everything else nearly
+    // normalised: L * (2^(2W+1) + 2 * 2^(2W)) per column
+    static_assert((unsigned long long)L * 4 * (1ull << (2 * W)) < (1ull << 63) + ((1ull << 63) - 1), "column accumulator overflow");
+    uint32_t m[L];
+    FpU<P> r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * L - 1; ++k) {
+        const int lo = k < L ? 0 : k - L + 1, hi = k < L ? k : L - 1;
+#pragma unroll
+        for (int i = lo; i <= hi; ++i) {
+            acc += (uint64_t)a.l[i] * b.l[k - i];
+            acc += (uint64_t)c.l[i] * d.l[k - i];
+        }
+#pragma unroll
+        for (int i = (k < L ? 0 : k - L + 1); i < (k < L ? k : L); ++i) acc += (uint64_t)m[i] * P::UQ[k - i];
+        if (k < L) {
+            m[k] = ((uint32_t)acc * P::UQINV) & MASK;
+            acc += (uint64_t)m[k] * P::UQ[0];
+        } else {
+            r.l[k - L] = (uint32_t)acc & MASK;
+        }
+        acc >>= W;
+    }
+    r.l[L - 1] = (uint32_t)acc;
+    return r;
+}
+
+// K*q - b, carry-passed (nearly normalised limbs): the subtrahend of a merged product, K = 8 (b < 8q)
+template <class P>
+GMSM_HD FpU<P> fpu_neg8c(const FpU<P> &b) {
+    FpU<P> r;
+#pragma unroll
+    for (int i = 0; i < P::UL; ++i) r.l[i] = P::UK8[i] - b.l[i];
+    fpu_carry(r);
+    return r;
+}
+
 // Montgomery square: cross products once with a doubled operand (L(L+1)/2 instead of L^2 products for a*a).
 template <class P>
 GMSM_HD FpU<P> fpu_sqr(const FpU<P> &a) {
@@ -229,6 +285,15 @@ template <bool INL, class P>
 GMSM_HD FpU<P> fmul(const FpU<P> &a, const FpU<P> &b) {
     if constexpr (INL) return fpu_mul(a, b);
     else return fpu_mul_ni<P>(a, b);
+}
+template <class P>
+__host__ __device__ __noinline__ FpU<P> fpu_mul_add_ni(FpU<P> a, FpU<P> b, FpU<P> c, FpU<P> d) {
+    return fpu_mul_add(a, b, c, d);
+}
+template <bool INL, class P>
+GMSM_HD FpU<P> fmuladd(const FpU<P> &a, const FpU<P> &b, const FpU<P> &c, const FpU<P> &d) {
+    if constexpr (INL) return fpu_mul_add(a, b, c, d);
+    else return fpu_mul_add_ni<P>(a, b, c, d);
 }
 template <bool INL, class P>
 GMSM_HD FpU<P> fsqr(const FpU<P> &a) {

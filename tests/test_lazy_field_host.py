@@ -1,0 +1,17 @@
+"""The lazy-limb field code of the kernels (gmsm_fieldu.h, gmsm_field2u.h) compiled for the HOST with g++ and checked
+against itself in two formulations (tests/c/lazy_field_check.cpp): double product with one Montgomery reduction vs two
+reduced products, lazy-reduction Fp2 product vs Karatsuba, on random values and on every edge of the reduced class
+[0, 4q) - the class boundary 4q - 1 is exactly where a 4q-based negation underflows. No GPU needed."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_lazy_field_formulations_agree(tmp_path):
+    exe = tmp_path / "lazy_field_check"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__host__=", "-D__device__=", "-D__noinline__=", "-o", str(exe),
+                           os.path.join(ROOT, "tests", "c", "lazy_field_check.cpp")])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout
+    assert r.stdout.count("0 mismatches") == 3, r.stdout

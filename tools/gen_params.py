@@ -128,6 +128,7 @@ def unsat_block(q, n64):
     out += uarr("UK4", redundant_multiple(q, 4, UL, UW))
     out += uarr("UK4N", redundant_multiple(q, 4, UL, UW, borrow_units=1))  # 4q with limbs < 2^(UW+1): negation without a carry pass
     out += uarr("UK8", redundant_multiple(q, 8, UL, UW))
+    out += uarr("UK8N", redundant_multiple(q, 8, UL, UW, borrow_units=1))  # 8q with limbs < 2^(UW+1): 8q - b for any normalised b < 4q, no carry pass
     out += uarr("UK16", redundant_multiple(q, 16, UL, UW))
     out += uarr("UQ1", ulimbs(q)) + uarr("UQ2", ulimbs(2 * q))     # candidates for the exact zero test of a value < 3q
     out += uarr("UQ3", ulimbs(3 * q)) + uarr("UQ4", ulimbs(4 * q))  # reduced-class ([0,4q)) arithmetic of the Fp2 path
