@@ -199,7 +199,8 @@ def fft_config(gm, torch, curve="bn254", logn=24, reps=5):
     c = gm.CURVES[curve]
     n = 1 << logn
     rng = np.random.default_rng([0x666674, logn])
-    a = rng.integers(0, 2**62, size=(n, c.fr_limbs), dtype=np.uint64)  # any limbs below r are field elements
+    a = rng.integers(0, 2**64, size=(n, c.fr_limbs), dtype=np.uint64)
+    a[:, -1] &= np.uint64((1 << (c.fr_bits - 64 * (c.fr_limbs - 1) - 1)) - 1)  # below 2^(fr_bits-1) < r: canonical elements
     t = torch.from_numpy(a.view(np.int64)).cuda()
     d = gm.fft.NewDomain(curve, n)
     stream = torch.cuda.current_stream().cuda_stream

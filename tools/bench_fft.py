@@ -17,7 +17,8 @@ def main():
     for logn in logns:
         n = 1 << logn
         rng = np.random.default_rng(logn)
-        a = rng.integers(0, 2**62, size=(n, c.fr_limbs), dtype=np.uint64)
+        a = rng.integers(0, 2**64, size=(n, c.fr_limbs), dtype=np.uint64)
+        a[:, -1] &= np.uint64((1 << (c.fr_bits - 64 * (c.fr_limbs - 1) - 1)) - 1)  # canonical field elements
         t = torch.from_numpy(a.view(np.int64)).cuda()
         d = gm.fft.NewDomain(curve, n)
         stream = torch.cuda.current_stream().cuda_stream

@@ -18,3 +18,10 @@ run bls12_381_g1_22 --curve bls12_381 --group g1 --logn 22 --steps 5
 run bls12_381_g2_22 --curve bls12_381 --group g2 --logn 22 --steps 3
 run bw6_761_g1_20 --curve bw6_761 --group g1 --logn 20 --steps 3
 du -sh $out
+cd /root/repo
+tools/ubench_fpmul > $out/ubench_fpmul.log 2>&1
+tools/ubench_madd > $out/ubench_madd.log 2>&1
+tools/ubench_madd_bw6 > $out/ubench_madd_bw6.log 2>&1
+python tools/bench_fft.py bn254 16 20 22 24 > $out/fft_bn254.log 2>&1
+python tools/bench_fft.py bls12_381 20 24 >> $out/fft_bn254.log 2>&1
+python tools/bench_fft.py bw6_761 20 >> $out/fft_bn254.log 2>&1
