@@ -193,6 +193,57 @@ def also_config(gm, lib, torch, curve, group, logn, steps, host_legs):
     return out
 
 
+def sharded_also(gm, torch, dist, sharding, rank, world, local_rank, mode, logn=24, steps=5):
+    """BASELINE.json configs[2]: BN254 G1 2^logn as ONE MultiExp over all ranks, timed like the headline loop (barrier +
+    synchronize on both sides, max over ranks). Every rank builds the same bases [a_i]G on its device from the same
+    seed; the result is checked against the closed form [sum a_i b_i]G on rank 0."""
+    g = gm.G1Jac("bn254")
+    n = 1 << logn
+    rng = np.random.default_rng([0x6D736D, logn, 5, 0])
+    a = uniform_scalars(rng, g, n)
+    b = uniform_scalars(rng, g, n)
+    stream = torch.cuda.current_stream().cuda_stream
+    plan = sharding.shard_plan(g, n, rank, world, mode)
+    lo, hi = plan["lo"], plan["hi"]
+    d_a = torch.from_numpy(a[lo:hi].view(np.int64)).cuda()
+    d_b = torch.from_numpy(b[lo:hi].view(np.int64)).cuda()
+    d_pts = torch.empty((hi - lo, g.aff_limbs), dtype=torch.int64, device="cuda")
+    g.batch_scalar_mul_device(g.generator, d_a.data_ptr(), hi - lo, d_pts.data_ptr(), stream)
+    del d_a
+    exchange = sharding.Exchange(dist, torch.device("cuda", local_rank), plan["rows"], g.xyzz_limbs)
+
+    def enqueue(plan_, local):
+        g.window_sums_enqueue(d_pts.data_ptr(), d_b.data_ptr(), hi - lo, plan_["c"], plan_["win_first"], plan_["win_stride"],
+                              stream, local.data_ptr())
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    jac = sharding.sharded_multiexp_exchange(g, plan, enqueue, exchange)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        jac = sharding.sharded_multiexp_exchange(g, plan, enqueue, exchange)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    out = {"workload": f"BN254 G1 MultiExp 2^{logn} points, {plan['mode']}-sharded x{world} + one RCCL all-gather",
+           "value": steps / dt, "unit": "MSM/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "n_gpus": world,
+           "scaling": "strong"}
+    if rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle  # test infrastructure: the checker
+        expected = oracle.Oracle("bn254", "g1").fixed_base_msm_affine(a, b)
+        out["bit_exact"] = bool((g.jac_to_affine(jac) == expected).all())
+    return out
+
+
 def fft_config(gm, torch, curve="bn254", logn=24, reps=5):
     """fr/fft next to the MSM: (*Domain).FFT DIF on 2^logn resident coefficients, and the round trip
     FFTInverse(DIT) o FFT(DIF) == identity as the size-independent check (fft_test.go:160-180)."""
@@ -446,6 +497,12 @@ def main():
                       "note": "cold: bases+scalars copied from pageable host memory every call (gmsm_<curve>_g1_multiexp); "
                               "warm-bases: registered bases, scalars copied every call (gmsm_multiexp_bases); median of 5"}
 
+    # N > 1: the 2^24 half of BASELINE.json's metric, sharded the same way (every rank takes part; rank 0 reports)
+    also_sharded = None
+    if sharded and not args.no_also and (args.curve, args.group) == ("bn254", "g1"):
+        del d_pts_loc, d_sc_loc
+        also_sharded = sharded_also(gm, torch, dist, sharding, rank, world, local_rank, args.shard)
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = args.steps / dt
@@ -475,6 +532,8 @@ def main():
             # the sharded result against the same MultiExp computed by this rank alone (after the timed region)
             single = g.multiexp_device(d_pts.data_ptr(), d_sc.data_ptr(), n, stream)
             out["equal_to_single_gpu_result"] = bool((g.jac_to_affine(single) == g.jac_to_affine(jac)).all())
+            if also_sharded is not None:
+                out["also"] = [also_sharded]
         if world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline(g, pts, sc, jac, args.curve, args.group))
         if world == 1 and not sharded and not args.no_also:
