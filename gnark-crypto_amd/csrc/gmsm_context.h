@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <condition_variable>
 #include <memory>
@@ -333,6 +335,23 @@ static inline unsigned num_windows(unsigned fr_bits, unsigned c) { return (fr_bi
 static inline unsigned last_c(unsigned fr_bits, unsigned c) {                                         // multiexp.go:690
     unsigned avail = num_windows(fr_bits, c) * c - fr_bits;
     return c + 1 - avail;
+}
+
+// Host threads this process may keep busy: the hardware thread count capped by the cgroup v2 CPU quota (the GPU boxes
+// expose 256 hardware threads to a container that may use 16 CPUs).
+static inline unsigned usable_cpus() {
+    unsigned n = std::thread::hardware_concurrency();
+    if (n == 0) n = 1;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        unsigned long period = 0;
+        if (fscanf(f, "%31s %lu", quota, &period) == 2 && period > 0 && quota[0] != 'm') {
+            const unsigned long q = strtoul(quota, nullptr, 10);
+            if (q > 0) n = std::min<unsigned>(n, (unsigned)std::max<unsigned long>(1, q / period));
+        }
+        fclose(f);
+    }
+    return n;
 }
 
 static inline unsigned env_uint(const char *name, unsigned dflt) {

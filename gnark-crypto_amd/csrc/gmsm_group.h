@@ -229,8 +229,13 @@ struct Group {
                         }
                         if (log2L == 0) log2L = 8;
                     } else {
+                        // one workgroup per CU - plus up to an eighth more: two of these workgroups fit a CU (75 KB of LDS,
+                        // 256 registers each), and a few doubly occupied CUs cost less than doubling L for everybody
+                        // (17 windows at c = 15: 272 workgroups at L = 4, 27 dependent steps instead of 36)
                         log2L = 1;
-                        while ((size_t)q.nw * blocks1(log2L) > (size_t)ctx.num_cus && blocks1(log2L) > 1) ++log2L;
+                        const size_t wg_cap = 2 * RED_TPB * sizeof(OpsElem) * 2 <= 160 * 1024 ? (size_t)ctx.num_cus + ctx.num_cus / 8
+                                                                                                : (size_t)ctx.num_cus;
+                        while ((size_t)q.nw * blocks1(log2L) > wg_cap && blocks1(log2L) > 1) ++log2L;
                     }
                 }
                 while (blocks1(log2L) > (size_t)RED2_TPB) ++log2L;
@@ -636,7 +641,7 @@ struct Group {
         if (c < 2 || c > 14) return fail(GMSM_ERR_ARG, "GMSM_FB_C out of range (2..14)");
         const WindowPlan plan = make_plan(c, 0, 1);
         std::vector<Aff> table;
-        build_fixed_base_table(base, plan, (int)std::min<unsigned>(16, std::thread::hardware_concurrency()), table);
+        build_fixed_base_table(base, plan, (int)std::min<unsigned>(16, usable_cpus()), table);
         int rc;
         const size_t tn = table.size();
         if ((rc = ws.h2d_points.ensure(tn * AFF_BYTES))) return rc;
