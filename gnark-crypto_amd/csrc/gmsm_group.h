@@ -229,13 +229,11 @@ struct Group {
                         }
                         if (log2L == 0) log2L = 8;
                     } else {
-                        // one workgroup per CU - plus up to an eighth more: two of these workgroups fit a CU (75 KB of LDS,
-                        // 256 registers each), and a few doubly occupied CUs cost less than doubling L for everybody
-                        // (17 windows at c = 15: 272 workgroups at L = 4, 27 dependent steps instead of 36)
+                        // (Letting an eighth of the CUs take a second workgroup to halve L - 17 windows at c = 15 are 272
+                        // workgroups at L = 4 - was measured: the doubly occupied CUs run both chains at half speed and
+                        // the kernel gets slower, 0.45 against 0.37 ms at 2^16.)
                         log2L = 1;
-                        const size_t wg_cap = 2 * RED_TPB * sizeof(OpsElem) * 2 <= 160 * 1024 ? (size_t)ctx.num_cus + ctx.num_cus / 8
-                                                                                                : (size_t)ctx.num_cus;
-                        while ((size_t)q.nw * blocks1(log2L) > wg_cap && blocks1(log2L) > 1) ++log2L;
+                        while ((size_t)q.nw * blocks1(log2L) > (size_t)ctx.num_cus && blocks1(log2L) > 1) ++log2L;
                     }
                 }
                 while (blocks1(log2L) > (size_t)RED2_TPB) ++log2L;
