@@ -368,7 +368,7 @@ static inline unsigned env_uint(const char *name, unsigned dflt) {
 // GMSM_C overrides for experiments.
 static inline unsigned choose_c(unsigned fr_bits, size_t n) {
     unsigned forced = env_uint("GMSM_C", 0);
-    if (forced >= 2 && forced <= 16) return forced;
+    if (forced >= 2 && forced <= 24) return forced;
     const unsigned cmax = n < ((size_t)1 << 13) ? 8u : n < ((size_t)1 << 15) ? 13u : n < ((size_t)1 << 17) ? 15u : 16u;
     for (unsigned c = cmax; c + 4 >= cmax && c >= 4; --c) {
         const unsigned nwin = num_windows(fr_bits, c);
