@@ -12,12 +12,16 @@
 // Shape on the GPU: the reference recurses over halves with one goroutine per half; here the log2 n radix-2 stages run
 // as a few passes over HBM, each pass doing up to 8-11 stages on LDS-resident tiles (k_fft_pass; 2^24: three passes
 // instead of 24), with the twiddles w^t for t < n/2 resident per domain like the reference's precomputed tables. The
-// arithmetic is the canonical saturated Montgomery field (gmsm_field.h), so every intermediate equals the reference's
-// and the result needs no normalisation. The one-launch-per-stage kernels stay as the A/B baseline (GMSM_FFT_STAGEWISE=1).
+// butterflies run on lazy 29-bit limbs (gmsm_fft_lazy.h: one v_mad_u64_u32 per partial product, values reduced by a
+// top-limb test between products, canonical again on every store), and the coset / 1/n scalings ride on the first
+// load and the last store of the transform instead of being passes of their own. The first version - canonical
+// saturated arithmetic (gmsm_field.h), one launch per stage or per pass - stays as the A/B baseline
+// (GMSM_FFT_LAZY=0, GMSM_FFT_STAGEWISE=1).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gmsm_context.h"
 #include "gmsm_field.h"
+#include "gmsm_fft_lazy.h"
 
 namespace gmsm {
 
@@ -60,22 +64,24 @@ __device__ __forceinline__ size_t fft_bitrev(size_t i, unsigned log2n) {
     return log2n ? (size_t)(__brevll((unsigned long long)i) >> (64 - log2n)) : 0;
 }
 
-// a[i] *= table[rev ? bitrev(i) : i]   (coset scaling; table may carry 1/n folded in)
+// a[i] *= table[rev ? bitrev(i) : i] (coset scaling; the table may carry 1/n folded in) and a[i] *= c (CardinalityInv,
+// fft.go:144-150), tables / constants in the lazy domain (2^DOMAIN_SHIFT * factor, gmsm_fft_lazy.h). Launched on their
+// own only by the A/B paths and for n = 1: k_fft_pass_lz fuses them into its loads and stores.
 template <class FrP>
-__global__ void __launch_bounds__(256) k_fft_scale_table(Fp<FrP> *__restrict__ a, size_t n, unsigned log2n,
-                                                         const Fp<FrP> *__restrict__ table, int rev) {
+__global__ void __launch_bounds__(256) k_fft_scale_table_lz(Fp<FrP> *__restrict__ a, size_t n, unsigned log2n,
+                                                            const Fp<FrP> *__restrict__ table, int rev) {
+    using Z = FftLz<FrP>;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const size_t t = rev ? fft_bitrev(i, log2n) : i;
-    fft_store(a, i, fp_mul(fft_load(a, i), fft_load(table, t)));
+    fft_store(a, i, Z::store(Z::mul(Z::load(fft_load(a, i)), fft_load(table, t))));
 }
-
-// a[i] *= c   (CardinalityInv, fft.go:144-150)
 template <class FrP>
-__global__ void __launch_bounds__(256) k_fft_scale_const(Fp<FrP> *__restrict__ a, size_t n, Fp<FrP> c) {
+__global__ void __launch_bounds__(256) k_fft_scale_const_lz(Fp<FrP> *__restrict__ a, size_t n, Fp<FrP> c) {
+    using Z = FftLz<FrP>;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    fft_store(a, i, fp_mul(fft_load(a, i), c));
+    fft_store(a, i, Z::store(Z::mul(Z::load(fft_load(a, i)), c)));
 }
 
 // One decimation-in-frequency stage (difFFT, fft.go:198-262): stage s works on blocks of 2*half, half = n >> (s+1):
@@ -163,6 +169,61 @@ __global__ void __launch_bounds__(256) k_fft_pass(Fp<FrP> *__restrict__ a, unsig
     }
 }
 
+// k_fft_pass on lazy limbs. The tile holds FpU values of the class A2 (36 bytes per BN254 element: an odd number of
+// words, so consecutive elements fall into different LDS banks); `twz` and the scaling tables are in the lazy domain.
+// Scalings of the transform fused into the pass that touches the vector first / last:
+//   pre  != null : every element is multiplied by pre[pre_rev ? bitrev(i) : i] as it is loaded (coset FFT, fft.go:43-82)
+//   post_mode 1/2: ... by post[i] / post[bitrev(i)] as it is stored (inverse coset FFT, fft.go:153-195)
+//   post_mode 3  : ... by the constant post_c (CardinalityInv, fft.go:144-150)
+template <class FrP, bool DIF>
+__global__ void __launch_bounds__(256) k_fft_pass_lz(Fp<FrP> *__restrict__ a, unsigned log2n, unsigned bl, unsigned B, unsigned log2C,
+                                                     const Fp<FrP> *__restrict__ twz, const Fp<FrP> *__restrict__ pre, int pre_rev,
+                                                     const Fp<FrP> *__restrict__ post, int post_mode, Fp<FrP> post_c) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    using Z = FftLz<FrP>;
+    using U = FpU<FrP>;
+    U *tile = reinterpret_cast<U *>(lds_raw);  // [2^B][C]
+    const unsigned C = 1u << log2C, T = blockDim.x, t = threadIdx.x;
+    const size_t ntile_lo = ((size_t)1 << bl) >> log2C;
+    const size_t lo0 = ((size_t)blockIdx.x % ntile_lo) << log2C, hi = (size_t)blockIdx.x / ntile_lo;
+    const size_t base = (hi << (bl + B)) | lo0;
+    const unsigned elems = (1u << B) << log2C;
+    for (unsigned e = t; e < elems; e += T) {
+        const unsigned mid = e >> log2C, c = e & (C - 1);
+        const size_t g = base + ((size_t)mid << bl) + c;
+        U x = Z::load(fft_load(a, g));
+        if (pre != nullptr) x = Z::mul(x, fft_load(pre, pre_rev ? fft_bitrev(g, log2n) : g));
+        tile[e] = x;
+    }
+    __syncthreads();
+    const unsigned nbf = elems >> 1;
+    for (unsigned st = 0; st < B; ++st) {
+        const unsigned bb = DIF ? B - 1 - st : st;
+        const unsigned b = bl + bb;
+        for (unsigned q = t; q < nbf; q += T) {
+            const unsigned c = q & (C - 1), p = q >> log2C;
+            const unsigned mid0 = ((p >> bb) << (bb + 1)) | (p & ((1u << bb) - 1)), mid1 = mid0 | (1u << bb);
+            const size_t i = base + ((size_t)mid0 << bl) + c;
+            const size_t j = i & (((size_t)1 << b) - 1);
+            U x = tile[(mid0 << log2C) + c], y = tile[(mid1 << log2C) + c];
+            const Fp<FrP> w = fft_load(twz, j << (log2n - 1 - b));  // entry 0 is the domain's one: no special case
+            if (DIF) Z::dif(x, y, w);
+            else Z::dit(x, y, w);
+            tile[(mid0 << log2C) + c] = x;
+            tile[(mid1 << log2C) + c] = y;
+        }
+        __syncthreads();
+    }
+    for (unsigned e = t; e < elems; e += T) {
+        const unsigned mid = e >> log2C, c = e & (C - 1);
+        const size_t g = base + ((size_t)mid << bl) + c;
+        U x = tile[e];
+        if (post_mode == 3) x = Z::mul(x, post_c);
+        else if (post_mode != 0) x = Z::mul(x, fft_load(post, post_mode == 2 ? fft_bitrev(g, log2n) : g));
+        fft_store(a, g, Z::store(x));
+    }
+}
+
 // BitReverse (bitreverse.go:33-45): swap a[i] and a[rev(i)] once per pair
 template <class FrP>
 __global__ void __launch_bounds__(256) k_fft_bit_reverse(Fp<FrP> *__restrict__ a, size_t n, unsigned log2n) {
@@ -231,39 +292,71 @@ struct FftField {
         put(d->generator, gen);
         put(d->generator_inv, gen_inv);
         put(d->cardinality_inv, card_inv);
+        put(d->cardinality_inv_lz, fp_mul(card_inv, lazy_shift()));
         put(d->shift, shift);
         put(d->shift_inv, shift_inv);
-        // twiddles w^t and w^-t, t < n/2 (preComputeTwiddles, domain.go:128-160, flattened to one table per direction)
+        // twiddles w^t and w^-t, t < n/2 (preComputeTwiddles, domain.go:128-160, flattened to one table per direction),
+        // in the lazy domain
         const size_t half = n / 2;
         int rc;
         if (half) {
-            if ((rc = d->twiddles.ensure(half * sizeof(Fr)))) return rc;
-            if ((rc = d->twiddles_inv.ensure(half * sizeof(Fr)))) return rc;
+            if ((rc = d->twiddles_lz.ensure(half * sizeof(Fr)))) return rc;
+            if ((rc = d->twiddles_inv_lz.ensure(half * sizeof(Fr)))) return rc;
             const unsigned blocks = (unsigned)((half + 255) / 256);
-            hipLaunchKernelGGL((k_fft_pow_table<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(gen), Fr::one(), half,
-                               (Fr *)d->twiddles.ptr);
-            hipLaunchKernelGGL((k_fft_pow_table<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(gen_inv), Fr::one(), half,
-                               (Fr *)d->twiddles_inv.ptr);
+            hipLaunchKernelGGL((k_fft_pow_table<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(gen), lazy_shift(), half,
+                               (Fr *)d->twiddles_lz.ptr);
+            hipLaunchKernelGGL((k_fft_pow_table<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(gen_inv), lazy_shift(), half,
+                               (Fr *)d->twiddles_inv_lz.ptr);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
         return GMSM_OK;
     }
 
-    // cosetTable = u^i and cosetTableInv (with 1/n folded in) = u^-i / n, built on first use (domain.go:150-160)
+    // 2^(L*W - 32N) as a field element: the factor every lazy-domain table entry carries (gmsm_fft_lazy.h)
+    static Fr lazy_shift() {
+        Fr s = Fr::one();
+        for (unsigned i = 0; i < FftLz<FrP>::DOMAIN_SHIFT; ++i) s = fp_dbl(s);
+        return s;
+    }
+
+    // the plain-Montgomery twiddle tables of the first version (A/B paths only)
+    static int ensure_sat_twiddles(hipStream_t stream, FftDomain *d) {
+        if (d->sat_ready) return GMSM_OK;
+        const size_t half = ((size_t)1 << d->log2n) / 2;
+        if (half) {
+            int rc;
+            if ((rc = d->twiddles.ensure(half * sizeof(Fr)))) return rc;
+            if ((rc = d->twiddles_inv.ensure(half * sizeof(Fr)))) return rc;
+            Fr gen, gen_inv;
+            memcpy(&gen, d->generator.data(), sizeof(Fr));
+            memcpy(&gen_inv, d->generator_inv.data(), sizeof(Fr));
+            const unsigned blocks = (unsigned)((half + 255) / 256);
+            hipLaunchKernelGGL((k_fft_pow_table<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(gen), Fr::one(), half,
+                               (Fr *)d->twiddles.ptr);
+            hipLaunchKernelGGL((k_fft_pow_table<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(gen_inv), Fr::one(), half,
+                               (Fr *)d->twiddles_inv.ptr);
+            HIP_TRY(hipGetLastError());
+        }
+        d->sat_ready = true;
+        return GMSM_OK;
+    }
+
+    // cosetTable = u^i and cosetTableInv (with 1/n folded in) = u^-i / n, built on first use (domain.go:150-160); both in
+    // the lazy domain
     static int ensure_coset_tables(hipStream_t stream, FftDomain *d) {
         if (d->coset_ready) return GMSM_OK;
         const size_t n = (size_t)1 << d->log2n;
         int rc;
         if ((rc = d->coset.ensure(n * sizeof(Fr)))) return rc;
         if ((rc = d->coset_inv_scaled.ensure(n * sizeof(Fr)))) return rc;
-        Fr shift, shift_inv, card_inv;
+        Fr shift, shift_inv, card_inv_lz;
         memcpy(&shift, d->shift.data(), sizeof(Fr));
         memcpy(&shift_inv, d->shift_inv.data(), sizeof(Fr));
-        memcpy(&card_inv, d->cardinality_inv.data(), sizeof(Fr));
+        memcpy(&card_inv_lz, d->cardinality_inv_lz.data(), sizeof(Fr));
         const unsigned blocks = (unsigned)((n + 255) / 256);
-        hipLaunchKernelGGL((k_fft_pow_table<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(shift), Fr::one(), n, (Fr *)d->coset.ptr);
-        hipLaunchKernelGGL((k_fft_pow_table<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(shift_inv), card_inv, n,
+        hipLaunchKernelGGL((k_fft_pow_table<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(shift), lazy_shift(), n, (Fr *)d->coset.ptr);
+        hipLaunchKernelGGL((k_fft_pow_table<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(shift_inv), card_inv_lz, n,
                            (Fr *)d->coset_inv_scaled.ptr);
         HIP_TRY(hipGetLastError());
         d->coset_ready = true;
@@ -278,33 +371,46 @@ struct FftField {
         const unsigned blocks_n = (unsigned)((n + 255) / 256), blocks_h = (unsigned)((n / 2 + 255) / 256);
         int rc;
         if (coset && (rc = ensure_coset_tables(stream, d))) return rc;
-        if (coset && !inverse)  // fft.go:43-82: DIT input is bit-reversed, so the table is read in bit-reversed order
-            hipLaunchKernelGGL((k_fft_scale_table<FrP>), dim3(blocks_n), dim3(256), 0, stream, a, n, log2n, (const Fr *)d->coset.ptr,
-                               dif ? 0 : 1);
-        const Fr *tw = (const Fr *)(inverse ? d->twiddles_inv.ptr : d->twiddles.ptr);
+        const bool stagewise = env_uint("GMSM_FFT_STAGEWISE", 0) != 0, lazy = env_uint("GMSM_FFT_LAZY", 1) != 0 && !stagewise;
+        const bool fused = lazy && n > 1;  // the scalings ride on the first / last pass
+        Fr card_inv_lz;
+        memcpy(&card_inv_lz, d->cardinality_inv_lz.data(), sizeof(Fr));
+        // the two scalings of the transform (fft.go:43-82, :144-195): DIT input and DIF output are bit-reversed, so the
+        // tables are read in bit-reversed order there
+        const Fr *pre = (coset && !inverse) ? (const Fr *)d->coset.ptr : nullptr;
+        const int pre_rev = dif ? 0 : 1;
+        const Fr *post = (inverse && coset) ? (const Fr *)d->coset_inv_scaled.ptr : nullptr;
+        const int post_mode = !inverse ? 0 : coset ? (dif ? 2 : 1) : 3;
+        if (pre && !fused)
+            hipLaunchKernelGGL((k_fft_scale_table_lz<FrP>), dim3(blocks_n), dim3(256), 0, stream, a, n, log2n, pre, pre_rev);
         if (n > 1) {
-            if (env_uint("GMSM_FFT_STAGEWISE", 0)) {  // one launch per stage (the first version; kept for A/B)
+            // passes over the bit positions: the lowest LOWB bits as one contiguous pass (tiles of 2^LOWB elements,
+            // C = 1), the rest in passes of <= 8 bits with C = 8 consecutive elements per row. DIF runs the passes
+            // from the top bits down, DIT from the bottom up.
+            constexpr unsigned LOWB = sizeof(Fr) <= 32 ? 11 : 10;  // 2^11 x 36 B = 72 KiB of LDS
+            static_assert(LOWB <= FFT_MAX_CHAIN, "additions between two reductions to canonical form");
+            struct Pass { unsigned bl, B, log2C; } passes[16];
+            int np = 0;
+            const unsigned low = std::min(log2n, LOWB);
+            passes[np++] = Pass{0, low, 0};
+            unsigned rest = log2n - low, bl = low;
+            const unsigned nhi = (rest + 7) / 8;
+            for (unsigned k = 0; k < nhi; ++k) {
+                const unsigned Bk = rest / (nhi - k) + ((rest % (nhi - k)) ? 1 : 0);
+                passes[np++] = Pass{bl, Bk, 3};
+                bl += Bk;
+                rest -= Bk;
+            }
+            if (stagewise) {  // one launch per stage (the first version; kept for A/B)
+                if ((rc = ensure_sat_twiddles(stream, d))) return rc;
+                const Fr *tw = (const Fr *)(inverse ? d->twiddles_inv.ptr : d->twiddles.ptr);
                 for (unsigned s = 0; s < log2n; ++s) {
                     if (dif) hipLaunchKernelGGL((k_fft_dif_stage<FrP>), dim3(blocks_h), dim3(256), 0, stream, a, n, log2n, s, tw);
                     else hipLaunchKernelGGL((k_fft_dit_stage<FrP>), dim3(blocks_h), dim3(256), 0, stream, a, n, log2n, s, tw);
                 }
-            } else {
-                // passes over the bit positions: the lowest LOWB bits as one contiguous pass (tiles of 2^LOWB elements,
-                // C = 1), the rest in passes of <= 8 bits with C = 8 consecutive elements per row. DIF runs the passes
-                // from the top bits down, DIT from the bottom up.
-                constexpr unsigned LOWB = sizeof(Fr) <= 32 ? 11 : 10;  // 2^11 x 32 B = 64 KiB of LDS
-                struct Pass { unsigned bl, B, log2C; } passes[16];
-                int np = 0;
-                const unsigned low = std::min(log2n, LOWB);
-                passes[np++] = Pass{0, low, 0};
-                unsigned rest = log2n - low, bl = low;
-                const unsigned nhi = (rest + 7) / 8;
-                for (unsigned k = 0; k < nhi; ++k) {
-                    const unsigned Bk = rest / (nhi - k) + ((rest % (nhi - k)) ? 1 : 0);
-                    passes[np++] = Pass{bl, Bk, 3};
-                    bl += Bk;
-                    rest -= Bk;
-                }
+            } else if (!lazy) {  // LDS-tiled passes on the saturated field (the second version; kept for A/B)
+                if ((rc = ensure_sat_twiddles(stream, d))) return rc;
+                const Fr *tw = (const Fr *)(inverse ? d->twiddles_inv.ptr : d->twiddles.ptr);
                 for (int k = 0; k < np; ++k) {
                     const Pass &ps = passes[dif ? np - 1 - k : k];
                     const size_t lds = ((size_t)sizeof(Fr) << ps.B) << ps.log2C;
@@ -319,17 +425,29 @@ struct FftField {
                                            ps.log2C, tw);
                     }
                 }
+            } else {
+                const Fr *twz = (const Fr *)(inverse ? d->twiddles_inv_lz.ptr : d->twiddles_lz.ptr);
+                for (int k = 0; k < np; ++k) {
+                    const Pass &ps = passes[dif ? np - 1 - k : k];
+                    const size_t lds = ((size_t)sizeof(FpU<FrP>) << ps.B) << ps.log2C;
+                    const size_t tiles = n >> (ps.B + ps.log2C);
+                    const Fr *pre_k = k == 0 ? pre : nullptr;
+                    const int post_k = k == np - 1 ? post_mode : 0;
+                    if (dif) {
+                        if ((rc = ctx_allow_lds((const void *)k_fft_pass_lz<FrP, true>, 128 * 1024))) return rc;
+                        hipLaunchKernelGGL((k_fft_pass_lz<FrP, true>), dim3((unsigned)tiles), dim3(256), lds, stream, a, log2n, ps.bl,
+                                           ps.B, ps.log2C, twz, pre_k, pre_rev, post, post_k, card_inv_lz);
+                    } else {
+                        if ((rc = ctx_allow_lds((const void *)k_fft_pass_lz<FrP, false>, 128 * 1024))) return rc;
+                        hipLaunchKernelGGL((k_fft_pass_lz<FrP, false>), dim3((unsigned)tiles), dim3(256), lds, stream, a, log2n, ps.bl,
+                                           ps.B, ps.log2C, twz, pre_k, pre_rev, post, post_k, card_inv_lz);
+                    }
+                }
             }
         }
-        if (inverse) {
-            if (!coset) {
-                Fr card_inv;
-                memcpy(&card_inv, d->cardinality_inv.data(), sizeof(Fr));
-                hipLaunchKernelGGL((k_fft_scale_const<FrP>), dim3(blocks_n), dim3(256), 0, stream, a, n, card_inv);
-            } else {  // fft.go:153-195: DIT output is natural, DIF output bit-reversed
-                hipLaunchKernelGGL((k_fft_scale_table<FrP>), dim3(blocks_n), dim3(256), 0, stream, a, n, log2n,
-                                   (const Fr *)d->coset_inv_scaled.ptr, dif ? 1 : 0);
-            }
+        if (inverse && !fused) {
+            if (!coset) hipLaunchKernelGGL((k_fft_scale_const_lz<FrP>), dim3(blocks_n), dim3(256), 0, stream, a, n, card_inv_lz);
+            else hipLaunchKernelGGL((k_fft_scale_table_lz<FrP>), dim3(blocks_n), dim3(256), 0, stream, a, n, log2n, post, post_mode == 2 ? 1 : 0);
         }
         HIP_TRY(hipGetLastError());
         return GMSM_OK;

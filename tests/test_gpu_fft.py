@@ -34,7 +34,7 @@ def test_domain_constants(gm, oracle_mod, curve):
 
 
 @pytest.mark.parametrize("curve", CURVE_NAMES)
-@pytest.mark.parametrize("logn", [0, 1, 2, 5, 10, 16])
+@pytest.mark.parametrize("logn", [0, 1, 2, 5, 10, 11, 12, 13, 16, 20])
 def test_fft_matches_oracle(gm, oracle_mod, curve, logn):
     F = oracle_mod.FFT(curve)
     c = F.curve
@@ -49,6 +49,57 @@ def test_fft_matches_oracle(gm, oracle_mod, curve, logn):
                 want = F.transform(a, inverse=inverse, decimation=dec, coset=coset)
                 assert (got == want).all(), (inverse, dec, coset)
     assert (gm.fft.BitReverse(curve, a) == F.bit_reverse(a)).all()
+    d.release()
+
+
+@pytest.mark.parametrize("curve", CURVE_NAMES)
+def test_fft_class_edges(gm, oracle_mod, curve):
+    """Inputs that push the lazy-limb butterflies to the edge of their value class: every element r - 1 (eleven
+    additions in a row double the largest representable residue each time), all zero, alternating, a single spike."""
+    F = oracle_mod.FFT(curve)
+    c = F.curve
+    for logn in (11, 14):
+        n = 1 << logn
+        rm1 = np.array([(c.r - 1 >> (64 * k)) & (2**64 - 1) for k in range(c.fr_limbs)], dtype=np.uint64)
+        fr = oracle_mod.Field(f"{c.name}_fr", c.fr_limbs)
+        top = np.tile(fr.to_mont(rm1), (n, 1))  # Montgomery form of r - 1
+        raw = np.tile(rm1, (n, 1))              # the limbs r - 1 themselves: the largest canonical limb pattern
+        alt = raw.copy()
+        alt[1::2] = 0
+        spike = np.zeros_like(raw)
+        spike[n // 3] = rm1
+        d = gm.fft.NewDomain(curve, n)
+        for a in (top, raw, alt, spike, np.zeros_like(raw)):
+            for inverse in (False, True):
+                for dec in (gm.fft.DIT, gm.fft.DIF):
+                    for coset in (False, True):
+                        opts = (gm.fft.OnCoset(),) if coset else ()
+                        got = (d.FFTInverse if inverse else d.FFT)(a, dec, *opts)
+                        want = F.transform(a, inverse=inverse, decimation=dec, coset=coset)
+                        assert (got == want).all(), (logn, inverse, dec, coset)
+        d.release()
+
+
+@pytest.mark.parametrize("curve", CURVE_NAMES)
+@pytest.mark.parametrize("env", [{"GMSM_FFT_LAZY": "0"}, {"GMSM_FFT_STAGEWISE": "1"}])
+def test_fft_baseline_paths_agree(gm, oracle_mod, monkeypatch, curve, env):
+    """The A/B baselines (saturated field: LDS passes, one launch per stage) give the same limbs as the default path."""
+    cc = oracle_mod.FFT(curve).curve
+    n = 1 << 13
+    a = random_field_limbs(rng_for(83, cc.fr_limbs), cc.r, cc.fr_limbs, n)
+    d = gm.fft.NewDomain(curve, n)
+    want = {}
+    for inverse in (False, True):
+        for dec in (gm.fft.DIT, gm.fft.DIF):
+            for coset in (False, True):
+                opts = (gm.fft.OnCoset(),) if coset else ()
+                want[(inverse, dec, coset)] = (d.FFTInverse if inverse else d.FFT)(a, dec, *opts)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for (inverse, dec, coset), w in want.items():
+        opts = (gm.fft.OnCoset(),) if coset else ()
+        got = (d.FFTInverse if inverse else d.FFT)(a, dec, *opts)
+        assert (got == w).all(), (env, inverse, dec, coset)
     d.release()
 
 

@@ -15,3 +15,20 @@ def test_lazy_field_formulations_agree(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout
     assert r.stdout.count("0 mismatches") == 3, r.stdout
+
+
+def test_lazy_fft_butterflies_match_saturated_field(tmp_path):
+    """tests/c/lazy_fft_check.cpp: 2^11-point DIF and DIT transforms on the lazy-limb butterflies (gmsm_fft_lazy.h, eleven
+    stages without a canonical reduction = the longest chain a device pass runs) against the saturated field, for the
+    three scalar fields, with the value class checked after every butterfly. The saturated field code uses clang's
+    carry builtins, so this one is compiled with the ROCm clang++."""
+    import pytest
+    cxx = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(cxx):
+        pytest.skip("ROCm clang++ not found")
+    exe = tmp_path / "lazy_fft_check"
+    subprocess.check_call([cxx, "-O2", "-std=c++17", "-D__host__=", "-D__device__=", "-D__noinline__=", "-o", str(exe),
+                           os.path.join(ROOT, "tests", "c", "lazy_fft_check.cpp")])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout
+    assert r.stdout.count("0 mismatches, 0 class violations") == 3, r.stdout
