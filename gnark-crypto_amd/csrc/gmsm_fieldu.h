@@ -65,13 +65,28 @@ GMSM_HD FpU<P> fpu_dbl(const FpU<P> &a) {
     return r;
 }
 
-// a - b + K*q with K = 4 or 16: requires b < K*q (strictly: top limb of b <= top limb of the redundant K*q) and b's
-// limbs < 2^(W+2). Value bound: bound(a) + K.
+// the redundant form of K*q (gmsm_params32.h: every low limb carries 4*2^W borrowed from the limb above)
+template <class P, int K>
+GMSM_HD constexpr uint32_t fpu_kq(int i) {
+    static_assert(K == 4 || K == 8 || K == 16 || K == 32, "redundant multiples of q in the parameter tables");
+    return K == 4 ? P::UK4[i] : K == 8 ? P::UK8[i] : K == 16 ? P::UK16[i] : P::UK32[i];
+}
+// a - b + K*q with K = 4, 8, 16 or 32: requires b < K*q (strictly: top limb of b <= top limb of the redundant K*q) and
+// b's limbs < 2^(W+2). Value bound: bound(a) + K.
 template <class P, int K>
 GMSM_HD FpU<P> fpu_sub(const FpU<P> &a, const FpU<P> &b) {
     FpU<P> r;
 #pragma unroll
-    for (int i = 0; i < P::UL; ++i) r.l[i] = a.l[i] + (K == 4 ? P::UK4[i] : P::UK16[i]) - b.l[i];
+    for (int i = 0; i < P::UL; ++i) r.l[i] = a.l[i] + fpu_kq<P, K>(i) - b.l[i];
+    fpu_carry(r);
+    return r;
+}
+// K*q - b, carry-passed (nearly normalised limbs, fit to be any operand of fpu_mul_add); same requirement on b
+template <class P, int K>
+GMSM_HD FpU<P> fpu_negc(const FpU<P> &b) {
+    FpU<P> r;
+#pragma unroll
+    for (int i = 0; i < P::UL; ++i) r.l[i] = fpu_kq<P, K>(i) - b.l[i];
     fpu_carry(r);
     return r;
 }
@@ -190,6 +205,42 @@ GMSM_HD FpU<P> fpu_mul_add(const FpU<P> &a, const FpU<P> &b, const FpU<P> &c, co
         for (int i = lo; i <= hi; ++i) {
             acc += (uint64_t)a.l[i] * b.l[k - i];
             acc += (uint64_t)c.l[i] * d.l[k - i];
+        }
+#pragma unroll
+        for (int i = (k < L ? 0 : k - L + 1); i < (k < L ? k : L); ++i) acc += (uint64_t)m[i] * P::UQ[k - i];
+        if (k < L) {
+            m[k] = ((uint32_t)acc * P::UQINV) & MASK;
+            acc += (uint64_t)m[k] * P::UQ[0];
+        } else {
+            r.l[k - L] = (uint32_t)acc & MASK;
+        }
+        acc >>= W;
+    }
+    r.l[L - 1] = (uint32_t)acc;
+    return r;
+}
+
+// (a*b + c*d + e*f + g*h) * 2^-(L*W) mod q with ONE reduction: one component of the difference of two Fp2 products
+// (gmsm_curveu.h, madd_t). Every operand nearly normalised (limbs <= 2^W + 2^(32-W)): 5L products per column.
+// Bound: (sum of the four bound products) / (2^(L*W)/q) + 1.
+template <class P>
+GMSM_HD FpU<P> fpu_mul_add4(const FpU<P> &a, const FpU<P> &b, const FpU<P> &c, const FpU<P> &d, const FpU<P> &e,
+                            const FpU<P> &f, const FpU<P> &g, const FpU<P> &h) {
+    constexpr int L = P::UL, W = P::UW;
+    constexpr uint32_t MASK = FpU<P>::MASK;
+    static_assert((unsigned long long)L * 5 * ((1ull << (2 * W)) + (1ull << (W + 6))) < (1ull << 63), "column accumulator overflow");
+    uint32_t m[L];
+    FpU<P> r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * L - 1; ++k) {
+        const int lo = k < L ? 0 : k - L + 1, hi = k < L ? k : L - 1;
+#pragma unroll
+        for (int i = lo; i <= hi; ++i) {
+            acc += (uint64_t)a.l[i] * b.l[k - i];
+            acc += (uint64_t)c.l[i] * d.l[k - i];
+            acc += (uint64_t)e.l[i] * f.l[k - i];
+            acc += (uint64_t)g.l[i] * h.l[k - i];
         }
 #pragma unroll
         for (int i = (k < L ? 0 : k - L + 1); i < (k < L ? k : L); ++i) acc += (uint64_t)m[i] * P::UQ[k - i];

@@ -97,9 +97,10 @@ __global__ void __launch_bounds__(256) k_fixed_base(const uint32_t *__restrict__
         }
         if (code) {
             const UAffine<U> p = load_struct<UAffine<U>>(table, (size_t)w * plan.nbuckets + code_bucket(code));
-            lz_madd<INL>(acc, inf, T::unpack(p.x), T::unpack(p.y), (code & 1u) != 0);
+            lz_madd_acc<INL>(acc, inf, T::unpack(p.x), T::unpack(p.y), (code & 1u) != 0);
         }
     }
+    lz_acc_finish(acc, inf);
     lazy_store<U>(recs, i, acc, inf);
 }
 

@@ -986,8 +986,10 @@ __global__ void k_lazy_group_op(int op, const XYZZ<typename LzTraits<U>::Sat> *a
     UnsatElem<U> p = to_lazy(acc[i]);
     if (op == 0 || op == 1) {
         const Affine<S> a = reinterpret_cast<const Affine<S> *>(other)[i];
-        if (!a.is_infinity())  // the pipeline drops points at infinity before the accumulation (k_decompose skip flags)
-            lz_madd<true>(p.v, p.inf, T::template from_sat<true>(a.x), T::template from_sat<true>(a.y), op == 1);
+        if (!a.is_infinity()) {  // the pipeline drops points at infinity before the accumulation (k_decompose skip flags)
+            lz_madd_acc<true>(p.v, p.inf, T::template from_sat<true>(a.x), T::template from_sat<true>(a.y), op == 1);
+            lz_acc_finish(p.v, p.inf);
+        }
     } else if (op == 2) {
         const UnsatElem<U> q = to_lazy(reinterpret_cast<const XYZZ<S> *>(other)[i]);
         lz_padd<true>(p.v, p.inf, q.v, q.inf);

@@ -465,6 +465,7 @@ __global__ void __launch_bounds__(256, AccWaves<U>::value) k_accumulate_seg(cons
     UAffine<U> p = load_struct<UAffine<U>>(upoints, v >> 1);
     for (uint32_t e = e0; e < e1; ++e) {
         if (e == bend) {  // the current run is complete on the right
+            lz_acc_finish(acc, inf);
             if (open_left) {
                 lazy_store<U>(partials, tg * 2 + 0, acc, inf);
                 flags |= SegFlags::HAS_P0;
@@ -487,10 +488,11 @@ __global__ void __launch_bounds__(256, AccWaves<U>::value) k_accumulate_seg(cons
         if (e + 1 < e1) p = load_struct<UAffine<U>>(upoints, vn >> 1);
         v = vn;
         vn = vnn;
-        lz_madd<true>(acc, inf, T::unpack(pc.x), T::unpack(pc.y), (vc & 1u) != 0);
+        lz_madd_acc<true>(acc, inf, T::unpack(pc.x), T::unpack(pc.y), (vc & 1u) != 0);
     }
     {
         const bool open_right = bend > e1;
+        lz_acc_finish(acc, inf);
         if (open_left) {
             lazy_store<U>(partials, tg * 2 + 0, acc, inf);
             flags |= SegFlags::HAS_P0 | (open_right ? SegFlags::P0_OPEN_RIGHT : 0u);

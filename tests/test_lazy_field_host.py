@@ -32,3 +32,19 @@ def test_lazy_fft_butterflies_match_saturated_field(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout
     assert r.stdout.count("0 mismatches, 0 class violations") == 3, r.stdout
+
+
+def test_tracked_fp2_mixed_addition_matches_reduced_class(tmp_path):
+    """tests/c/lazy_g2_check.cpp: the bound-tracked Fp2 mixed addition of the BLS12-381 G2 accumulation loop (madd_t)
+    against the exact reduced-class form (madd_g) over chains of additions with edge-valued coordinates, doublings and
+    cancellations; after lz_acc_finish the limbs are exactly normalised and below 4q."""
+    import pytest
+    cxx = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(cxx):
+        pytest.skip("ROCm clang++ not found")
+    exe = tmp_path / "lazy_g2_check"
+    subprocess.check_call([cxx, "-O2", "-std=c++17", "-D__host__=", "-D__device__=", "-D__noinline__=", "-D__forceinline__=inline",
+                           "-o", str(exe), os.path.join(ROOT, "tests", "c", "lazy_g2_check.cpp")])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout
+    assert " 0 mismatches" in r.stdout, r.stdout

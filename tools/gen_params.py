@@ -130,6 +130,7 @@ def unsat_block(q, n64):
     out += uarr("UK8", redundant_multiple(q, 8, UL, UW))
     out += uarr("UK8N", redundant_multiple(q, 8, UL, UW, borrow_units=1))  # 8q with limbs < 2^(UW+1): 8q - b for any normalised b < 4q, no carry pass
     out += uarr("UK16", redundant_multiple(q, 16, UL, UW))
+    out += uarr("UK32", redundant_multiple(q, 32, UL, UW))         # bound-tracked Fp2 additions (operands up to 18q)
     out += uarr("UQ1", ulimbs(q)) + uarr("UQ2", ulimbs(2 * q))     # candidates for the exact zero test of a value < 3q
     out += uarr("UQ3", ulimbs(3 * q)) + uarr("UQ4", ulimbs(4 * q))  # reduced-class ([0,4q)) arithmetic of the Fp2 path
     return out
