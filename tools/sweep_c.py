@@ -1,5 +1,5 @@
 """Window-size sweep: ms per MultiExp for every c in a range, sizes 2^lo..2^hi (BN254 G1 unless told otherwise).
-usage: python tools/sweep_c.py [lo hi [curve group]]   (GMSM_C is read by the library on every call)"""
+usage: python tools/sweep_c.py [lo hi [curve group [cmin cmax]]]   (GMSM_C is read by the library on every call)"""
 import importlib
 import os
 import sys
@@ -15,6 +15,7 @@ gm = importlib.import_module("gnark-crypto_amd")
 def main():
     lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (12, 21)
     curve, group = (sys.argv[3], sys.argv[4]) if len(sys.argv) > 4 else ("bn254", "g1")
+    cmin, cmax = (int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (7, 16)
     g = (gm.G1Jac if group == "g1" else gm.G2Jac)(curve)
     nmax = 1 << hi
     rng = np.random.default_rng(7)
@@ -30,7 +31,7 @@ def main():
         os.environ.pop("GMSM_C", None)
         default_c = g.default_window_bits(n)
         row = {}
-        for c in range(7, 17):
+        for c in range(cmin, cmax + 1):
             os.environ["GMSM_C"] = str(c)
             g.multiexp_device(d_pts.data_ptr(), d_sc.data_ptr(), n, stream)
             torch.cuda.synchronize()
@@ -41,7 +42,7 @@ def main():
             torch.cuda.synchronize()
             row[c] = (time.perf_counter() - t0) / reps * 1e3
         best = min(row, key=row.get)
-        print(f"2^{logn}: default c={default_c} {row[default_c]:.3f} ms | best c={best} {row[best]:.3f} ms | " +
+        print(f"{curve} {group} 2^{logn}: default c={default_c} {row.get(default_c, float('nan')):.3f} ms | best c={best} {row[best]:.3f} ms | " +
               " ".join(f"{c}:{v:.3f}" for c, v in row.items()), flush=True)
     os.environ.pop("GMSM_C", None)
 
