@@ -365,23 +365,36 @@ static inline unsigned env_uint(const char *name, unsigned dflt) {
 }
 
 // Window width. The affine result does not depend on it (the reference asserts exactly that for c in 2..16,
-// multiexp_test.go:95-126), so it is purely a cost choice. Measured on MI355X (BN254 G1): below ~2^17 points the
-// pipeline is latency-bound (~0.8-1.1 ms whatever c), from 2^18 on c = 16 (the largest window whose 2^15-entry
-// histogram fits the 160 KiB LDS) minimises the n*nwin mixed additions. A candidate is skipped when its top window
-// holds so few bits that the buckets of that window would be split over very long chains of accumulation threads.
-// GMSM_C overrides for experiments.
-static inline unsigned choose_c(unsigned fr_bits, size_t n) {
+// multiexp_test.go:95-126), so it is purely a cost choice - and the cost depends on the element type: a bucket of a
+// wide type costs far more to reduce than to fill, so those groups want fewer buckets than BN254 G1 does.
+// Measured on MI355X for every group and size 2^10..2^21/2^26 (profiles/r02_window_sweeps.log), indexed by
+// floor(log2 n):
+//   BN254 G1       < 2^13: 8   < 2^15: 13   < 2^17: 15   < 2^21: 16   from 2^21: 17 (15 windows of 2^16 buckets: one
+//                  accumulation pass less for 0.15 ms more reduction: 2^21 3.68 -> 3.58 ms, 2^22 6.72 -> 6.52, 2^24
+//                  24.1 -> 22.9, 2^26 97.1 -> 91.2; c = 20 gains less - 23.7 at 2^24 - because 13 x 2^19 buckets cost
+//                  2.1 ms to reduce)
+//   BN254 G2       < 2^15: 8   2^15: 13   2^16: 15   < 2^22: 16   from 2^22: 17 (2^22: 20.2 -> 19.7 ms)
+//   BLS12-381 G1   < 2^15: 8   2^15: 13   < 2^24: 16   from 2^24: 17 (2^24: 45.2 -> 43.2 ms; at 2^22 17 is slower, 13.1
+//                  against 12.5; c = 15 gives 17 full windows and an 18th for the carry: always worse)
+//   BLS12-381 G2   < 2^15: 8   2^15: 10   2^16: 12   2^17, 2^18: 13   then 16   (2^16: 4.93 against 7.27 ms with c = 15)
+//   BW6-761 G1/G2  < 2^17: 9   2^17..2^20: 14   then 16   (2^13: 4.1 against 5.6 ms, 2^18: 9.7 against 13.0, 2^20:
+//                  23.3 against 25.3; c = 10, 15 and 17 leave a top window of a few bits and are far slower)
+// Below ~2^17 points the pipeline is latency-bound (~0.6-1 ms for BN254 G1 whatever c). The entries were measured with
+// the width forced, so they include what a narrow top window costs (long chains of partial sums for k_fixup_long, one
+// crowded sort partition): widths whose top window holds only a few bits simply never won. GMSM_C overrides.
+static inline unsigned preferred_c(unsigned fr_bits, size_t aff_bytes, size_t n) {
+    unsigned lg = 0;
+    while (lg < 63 && ((size_t)2 << lg) <= n) ++lg;  // floor(log2 n), n >= 1
+    if (fr_bits > 320) return lg < 17 ? 9u : lg <= 20 ? 14u : 16u;                                    // BW6-761
+    if (fr_bits == 255 && aff_bytes > 96) return lg < 15 ? 8u : lg == 15 ? 10u : lg == 16 ? 12u : lg <= 18 ? 13u : 16u;  // BLS12-381 G2
+    if (fr_bits == 255) return lg < 15 ? 8u : lg == 15 ? 13u : lg < 24 ? 16u : 17u;                 // BLS12-381 G1
+    if (aff_bytes > 64) return lg < 15 ? 8u : lg == 15 ? 13u : lg == 16 ? 15u : lg < 22 ? 16u : 17u; // BN254 G2
+    return lg < 13 ? 8u : lg < 15 ? 13u : lg < 17 ? 15u : lg < 21 ? 16u : 17u;                       // BN254 G1
+}
+static inline unsigned choose_c(unsigned fr_bits, size_t aff_bytes, size_t n) {
     unsigned forced = env_uint("GMSM_C", 0);
     if (forced >= 2 && forced <= 24) return forced;
-    const unsigned cmax = n < ((size_t)1 << 13) ? 8u : n < ((size_t)1 << 15) ? 13u : n < ((size_t)1 << 17) ? 15u : 16u;
-    for (unsigned c = cmax; c + 4 >= cmax && c >= 4; --c) {
-        const unsigned nwin = num_windows(fr_bits, c);
-        const unsigned top_bits = fr_bits - (nwin - 1) * c;
-        size_t seg = (size_t)nwin * n / 196608;
-        seg = seg < 32 ? 32 : seg > 256 ? 256 : seg;
-        if ((n >> top_bits) <= 40 * seg) return c;
-    }
-    return cmax;
+    return preferred_c(fr_bits, aff_bytes, n ? n : 1);
 }
 
 struct GroupVTable {

@@ -701,7 +701,7 @@ GMSM_EXPORT int gmsm_batch_jac_to_affine(int group, const uint64_t *jac, size_t 
 
 GMSM_EXPORT unsigned gmsm_default_window_bits(int group, size_t n) {
     const GroupVTable *vt = vtable(group);
-    return vt ? choose_c(vt->fr_bits, n) : 0;
+    return vt ? choose_c(vt->fr_bits, vt->aff_bytes, n) : 0;
 }
 
 GMSM_EXPORT unsigned gmsm_num_windows(int group, unsigned c) {
@@ -712,7 +712,7 @@ GMSM_EXPORT unsigned gmsm_num_windows(int group, unsigned c) {
 GMSM_EXPORT int gmsm_window_sums_device(int group, const void *d_points, const void *d_scalars, size_t n, unsigned c,
                                         unsigned win_first, unsigned win_stride, void *hip_stream, uint64_t *out_xyzz) {
     VT_OR_FAIL(group);
-    if (c < 2 || c > 16) return fail(GMSM_ERR_ARG, "c out of range (2..16)");
+    if (c < 2 || c > 20) return fail(GMSM_ERR_ARG, "c out of range (2..20)");
     Context *ctx;
     int rc = get_context_of_pointer(d_scalars, &ctx);
     if (rc) return rc;
@@ -724,7 +724,7 @@ GMSM_EXPORT int gmsm_window_sums_enqueue(int group, const void *d_points, uint64
                                          size_t n, unsigned c, unsigned win_first, unsigned win_stride, void *hip_stream,
                                          void *d_out_xyzz) {
     VT_OR_FAIL(group);
-    if (c < 2 || c > 16) return fail(GMSM_ERR_ARG, "c out of range (2..16)");
+    if (c < 2 || c > 20) return fail(GMSM_ERR_ARG, "c out of range (2..20)");
     if (!d_out_xyzz) return fail(GMSM_ERR_ARG, "d_out_xyzz is null");
     BasesRef rb;
     if (bases_handle) {

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "gmsm_context.h"
@@ -43,7 +44,14 @@ struct Group {
 #define GMSM_INLINE_ALL_OPS 0
 #endif
     static constexpr bool INLINE_OPS = GMSM_INLINE_ALL_OPS || sizeof(U) <= 14 * 4;
-    template <bool Fast, class Dummy = void> struct OpsSel { using type = UnsatOpsNI<U>; };
+#ifndef GMSM_WIDE_OPS_MID
+#define GMSM_WIDE_OPS_MID 0  // 1: UnsatOpsMid (additions out of line, products inlined inside them) - A/B builds only:
+                            // BN254 G2 runs correctly with it, BLS12-381 G2 did not come back from its first MultiExp on
+                            // the GPU box (profiles/r02_window_sweeps.log, gpu_r2o), so the shipped form stays UnsatOpsNI
+#endif
+    template <bool Fast, class Dummy = void> struct OpsSel {
+        using type = typename std::conditional<GMSM_WIDE_OPS_MID != 0, UnsatOpsMid<U>, UnsatOpsNI<U>>::type;
+    };
     template <class Dummy> struct OpsSel<true, Dummy> { using type = UnsatOps<U>; };
     using Ops = typename OpsSel<INLINE_OPS>::type;     // arithmetic of k_fixup_seg and the reduction kernels
     using OpsNI = UnsatOpsNI<U>;                       // small-code variant for k_fixup_level
@@ -294,6 +302,7 @@ struct Group {
         const uint32_t part_log2 = env_uint("GMSM_PART_LOG2", log2n <= 21 ? 13 : log2n >= 24 ? 15 : 14);
         int fb = (int)part_log2 + (int)log2NB - (int)log2n;
         if (fb > (int)log2NB) fb = (int)log2NB;
+        if (fb > 15) fb = 15;  // the fine pass keeps 2^fb counters in LDS (128 KiB): windows wider than 16 bits on few points
         if (fb < 0) fb = 0;
         if (fb + lidx > 32) fb = 32 - lidx;
         const uint32_t fbits = (uint32_t)fb;
@@ -309,6 +318,8 @@ struct Group {
         const uint32_t stage_cap = fine_cnt_bytes >= 156 * 1024 ? 0u
                                    : (uint32_t)std::min<size_t>(env_uint("GMSM_STAGE_CAP", part_log2 >= 15 ? 39000 : 24576),
                                                               (156 * 1024 - fine_cnt_bytes) / 4);
+        if (fine_cnt_bytes + (size_t)stage_cap * 4 > 160 * 1024)  // cannot happen with fb <= 15; a failed launch must not
+            return fail(GMSM_ERR_ARG, "window geometry: fine-sort counters exceed the LDS");  // leave garbage for the next kernels
         const bool d16 = max_digit_code(plan) < 65536 && env_uint("GMSM_DIGIT32", 0) == 0;
         const size_t dsz = d16 ? 2 : 4;
 
@@ -738,7 +749,7 @@ struct Group {
                                hipStream_t caller_stream, J *out, const ResidentBases *resident = nullptr) {
         const size_t run = max_run_points();
         if (n <= run) {
-            const unsigned c = choose_c(FR_BITS, n);
+            const unsigned c = choose_c(FR_BITS, AFF_BYTES, n);
             WindowPlan plan = make_plan(c, 0, 1);
             std::vector<Ext> totals(plan.nwin_total);
             int rc = window_sums(ctx, ws, d_points, d_scalars, n, plan, caller_stream, totals.data(), resident);
@@ -748,7 +759,7 @@ struct Group {
         }
         const unsigned nruns = (unsigned)((n + run - 1) / run);
         const size_t per = (n + nruns - 1) / nruns;
-        const unsigned c = choose_c(FR_BITS, per);  // one c for every range: the totals must line up
+        const unsigned c = choose_c(FR_BITS, AFF_BYTES, per);  // one c for every range: the totals must line up
         WindowPlan plan = make_plan(c, 0, 1);
         std::vector<Ext> sets((size_t)nruns * plan.nwin_total);
         for (unsigned r = 0; r < nruns; ++r) {
@@ -767,7 +778,7 @@ struct Group {
     static int multiexp_submit(Context &ctx, Workspace &ws, const void *d_scalars, size_t n, const ResidentBases *resident) {
         if (n > max_run_points())
             return fail(GMSM_ERR_ARG, "submit/collect takes at most 2^27 points per ticket: use the blocking entry, which splits larger inputs");
-        const unsigned c = choose_c(FR_BITS, n);
+        const unsigned c = choose_c(FR_BITS, AFF_BYTES, n);
         WindowPlan plan = make_plan(c, 0, 1);
         int rc = enqueue_window_sums(ctx, ws, nullptr, d_scalars, n, plan, ws.stream, resident);
         if (rc) return rc;
@@ -826,7 +837,7 @@ struct Group {
         if ((n + nr - 1) / nr > run) nr = (unsigned)((n + run - 1) / run);
         const size_t per = (n + nr - 1) / nr;
         nr = (unsigned)((n + per - 1) / per);
-        const unsigned c = choose_c(FR_BITS, per);  // one c for every range: the totals must line up
+        const unsigned c = choose_c(FR_BITS, AFF_BYTES, per);  // one c for every range: the totals must line up
         WindowPlan plan = make_plan(c, 0, 1);
         const uint32_t nw = plan.nwin_total;
         Workspace *w[2] = {&first, nr > 1 ? ctx.acquire(false) : nullptr};

@@ -185,8 +185,11 @@ int gmsm_fft_bit_reverse(int group, uint64_t *a, void *d_a, size_t n, void *hip_
  *      handled by this device; the tiny per-window totals are exchanged by the caller, e.g. one RCCL all-gather).
  *      out_xyzz (host) receives nwin_local x {X,Y,ZZ,ZZZ} extended-Jacobian window totals
  *      (= what processChunkG1Jacobian sends on chRes, multiexp_jacobian.go:60). ---- */
-unsigned gmsm_default_window_bits(int group, size_t n);            /* the engine's choice of c for n points */
+unsigned gmsm_default_window_bits(int group, size_t n);            /* the engine's choice of c for n points: a measured
+                                                                      table per group, 8..17; c = 17 (BN254 G1 from 2^22
+                                                                      points) is beyond the reference's uint16 digits */
 unsigned gmsm_num_windows(int group, unsigned c);                  /* computeNbChunks, multiexp.go:681 */
+/* c: 2..20 (the affine result does not depend on it, multiexp_test.go:95-126; the reference stops at 16) */
 int gmsm_window_sums_device(int group, const void *d_points, const void *d_scalars, size_t n, unsigned c,
                             unsigned win_first, unsigned win_stride, void *hip_stream, uint64_t *out_xyzz);
 /* The same pipeline without the copy-back: the nwin_local totals are written to the DEVICE buffer d_out_xyzz in stream

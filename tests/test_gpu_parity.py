@@ -192,7 +192,7 @@ def test_msm_sum_of_squares_identity_all_c(gm, oracle_mod, pyref_mod, curve, whi
     assert (o.msm_affine(pts, sc, c=7) == exp_limbs).all()
     d_pts = torch.from_numpy(pts.view(np.int64)).cuda()
     d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
-    for c in range(2, 17):
+    for c in range(2, 21):  # 2..16 as the reference does; 17..20 are widths only this engine uses (large n)
         w = g.window_sums_device(d_pts.data_ptr(), d_sc.data_ptr(), n, c)
         aff = g.jac_to_affine(g.fold_windows(w, c))
         assert (aff == exp_limbs).all(), (curve, which, c)
@@ -296,9 +296,9 @@ def test_msm_skewed_bucket_distributions(gm, oracle_mod, curve, which):
     assert (_msm_gpu_affine(g, same_base, sc) == o.msm_affine(same_base, sc, nthreads=8)).all()
     d_pts = torch.from_numpy(pts.view(np.int64)).cuda()
     d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
-    for c in (9, 12, 13, 14):
+    for c in (9, 12, 13, 14, 17, 20):  # the oracle, like the reference, stops at 16: the affine result does not depend on c
         w = g.window_sums_device(d_pts.data_ptr(), d_sc.data_ptr(), n, c)
-        assert (g.jac_to_affine(g.fold_windows(w, c)) == o.msm_affine(pts, sc, c=c, nthreads=8)).all(), c
+        assert (g.jac_to_affine(g.fold_windows(w, c)) == o.msm_affine(pts, sc, c=min(c, 16), nthreads=8)).all(), c
 
 
 # ------------------------------------------------------------------ BASELINE.json configurations at their full sizes
