@@ -44,6 +44,9 @@ struct Group {
 #define GMSM_INLINE_ALL_OPS 0
 #endif
     static constexpr bool INLINE_OPS = GMSM_INLINE_ALL_OPS || sizeof(U) <= 14 * 4;
+#ifndef GMSM_COMBINE_INLINE
+#define GMSM_COMBINE_INLINE -1  // -1: per element type (below); 0 / 1 force it off / on for A/B builds
+#endif
 #ifndef GMSM_WIDE_OPS_MID
 #define GMSM_WIDE_OPS_MID 0  // 1: UnsatOpsMid (additions out of line, products inlined inside them) - A/B builds only:
                             // BN254 G2 runs correctly with it, BLS12-381 G2 did not come back from its first MultiExp on
@@ -65,6 +68,14 @@ struct Group {
     // GMSM_SPLIT_REDUCE=0/1 overrides for A/B measurements.
     static constexpr bool SPLIT_REDUCE_DEFAULT = sizeof(U) > 9 * 4;
     using OpsSerial = UnsatOps<U>;
+    // The element types whose `Ops` are out of line (Fp2, 28 limbs) still inline the group law where a kernel has a
+    // SINGLE call site of the addition: k_fixup_seg, and the combine step of the split reduction as its own kernel
+    // (k_reduce_combine) instead of the two-program k_reduce1. Measured with an A/B library (profiles/
+    // r02_window_sweeps.log, gpu_r2q): BN254 G2 2^20 6.97 -> 6.52 ms (reduce 1.8 -> 1.38), BW6-761 fix-up 1.45 -> 0.77 ms,
+    // BLS12-381 G2 fix-up 0.34 -> 0.1 ms; the combine of the 28-word types itself does not get faster (its five live
+    // XYZZ values spill either way).
+    static constexpr bool COMBINE_INLINE = GMSM_COMBINE_INLINE < 0 ? !INLINE_OPS : (GMSM_COMBINE_INLINE != 0);
+    using FixOps = typename std::conditional<COMBINE_INLINE, OpsSerial, Ops>::type;
     static constexpr bool QUAD_REDUCE = true;  // level 2 of the reduction on lane quads (GMSM_QUAD=0 switches it off)
 
     static WindowPlan make_plan(unsigned c, unsigned win_first, unsigned win_stride) {
@@ -357,6 +368,8 @@ struct Group {
         if ((rc = ctx.allow_lds((const void *)k_fine_sort, 160 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_fixup_long<Ops>, (int)(256 * sizeof(OpsElem))))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_reduce1<Ops, RED_TPB>, (int)(2 * RED_TPB * sizeof(OpsElem))))) return rc;
+        if constexpr (COMBINE_INLINE)
+            if ((rc = ctx.allow_lds((const void *)k_reduce_combine<OpsSerial, RED_TPB>, (int)(2 * RED_TPB * sizeof(OpsElem))))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_reduce2<Ops, RED2_TPB>, (int)(2 * RED2_TPB * sizeof(OpsElem))))) return rc;
 
         StageTimer timer(ws);
@@ -440,7 +453,7 @@ struct Group {
                                starts, sorted, buckets, seg_partials, seg_flags, seg_bucket, q.tpw);
             if (p + 1 < npieces) HIP_TRY(hipEventRecord(ws.ev_acc[p], st));
             timer.mark(p, T_FIXUP, st);
-            hipLaunchKernelGGL((k_fixup_seg<Ops>), dim3((q.tpw + 255) / 256, nwp), dim3(256), 0, st, NB, seg_partials,
+            hipLaunchKernelGGL((k_fixup_seg<FixOps>), dim3((q.tpw + 255) / 256, nwp), dim3(256), 0, st, NB, seg_partials,
                                (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets, long_flag, long_list);
             hipLaunchKernelGGL((k_fixup_long<Ops>), dim3(2 * ctx.num_cus), dim3(256), 256 * sizeof(OpsElem), st, NB, seg_partials,
                                (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets,
@@ -461,8 +474,17 @@ struct Group {
                                        q.log2L, T, starts, pre_w);
                     pre = pre_w;
                 }
-                hipLaunchKernelGGL((k_reduce1<Ops, RED_TPB>), dim3(q.nblocks1, nwp), dim3(RED_TPB), 2 * RED_TPB * sizeof(OpsElem), st,
-                                   buckets, NB, q.log2L, partials, starts, prescale, pre, T);
+                bool combined = false;
+                if constexpr (COMBINE_INLINE) {
+                    if (split_reduce) {
+                        hipLaunchKernelGGL((k_reduce_combine<OpsSerial, RED_TPB>), dim3(q.nblocks1, nwp), dim3(RED_TPB),
+                                           2 * RED_TPB * sizeof(OpsElem), st, q.log2L, partials, prescale, pre, T);
+                        combined = true;
+                    }
+                }
+                if (!combined)
+                    hipLaunchKernelGGL((k_reduce1<Ops, RED_TPB>), dim3(q.nblocks1, nwp), dim3(RED_TPB), 2 * RED_TPB * sizeof(OpsElem), st,
+                                       buckets, NB, q.log2L, partials, starts, prescale, pre, T);
                 bool l2 = false;
                 if constexpr (QUAD_REDUCE) {
                     // level 2 on quads of lanes (4 lanes share the products of one addition). Level 1 stays

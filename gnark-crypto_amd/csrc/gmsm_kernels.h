@@ -811,6 +811,32 @@ __global__ void __launch_bounds__(TPB) k_reduce1(const void *__restrict__ bucket
     if (t == 0) A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 1, W_out);
 }
 
+// The combine step of level 1 alone, for the split reduction (k_reduce_serial has produced the threads' (S_t, W_t)): the
+// same program as k_reduce1 without its serial phase, so that the kernel holds exactly ONE call site of the addition and
+// one of the doubling and can afford to INLINE them even for the widest element types (the fused k_reduce1 holds two
+// copies of the program - with and without `pre` - and uses the out-of-line policy for those types: 180 us per step for
+// BW6-761 against 43 us for an inlined addition at the multiplier rate). Used for the element types whose policy is
+// out of line (Group::COMBINE_INLINE).
+template <class A, int TPB>
+__global__ void __launch_bounds__(TPB) k_reduce_combine(uint32_t log2L, void *__restrict__ out1, uint32_t prescale,
+                                                        const void *__restrict__ pre, uint32_t T) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    using E = typename A::Elem;
+    E *lds = reinterpret_cast<E *>(lds_raw);
+    const uint32_t k = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
+    const uint32_t g = blk * TPB + t;
+    E S = A::infinity(), W = A::infinity();
+    if (g < T) {
+        S = A::load(pre, ((size_t)k * T + g) * 2 + 0);
+        W = A::load(pre, ((size_t)k * T + g) * 2 + 1);
+    }
+    E S_out = A::infinity(), W_out = A::infinity();
+    auto no_buckets = [&](uint32_t) -> E { return A::infinity(); };
+    reduce_program<A, TPB>(no_buckets, 0u, S, W, log2L, (uint32_t)TPB, prescale, lds, S_out, W_out);
+    if (t == (prescale != 0 && TPB >= 256 ? 64u : 0u)) A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 0, S_out);
+    if (t == 0) A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 1, W_out);
+}
+
 // grid = nwin_local, block = TPB >= nblocks1 threads. Thread j holds level-1 block j: (S_j, W_j) covering
 // TPB1*L buckets = 2^log2span. window_total[k] = sum_j W_j + span * sum_j j*S_j.
 template <class A, int TPB>

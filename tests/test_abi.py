@@ -39,6 +39,37 @@ def test_layout_sizes(gm, curve, which):
         assert lib.gmsm_num_windows(g.gid, c) == (g.curve.fr_bits + c - 1) // c
 
 
+@pytest.mark.parametrize("curve,which", ALL_GROUPS)
+def test_default_window_table(gm, curve, which, monkeypatch):
+    """gmsm_default_window_bits: the measured per-group table (gmsm_context.h, profiles/r02_window_sweeps.log). It is a
+    pure cost choice, but the sharded paths rely on every rank getting the same answer for the same n, on the width
+    staying inside what gmsm_window_sums_* accept, and on the top window never being the few-bit kind that serialises
+    the sort."""
+    monkeypatch.delenv("GMSM_C", raising=False)
+    g = (gm.G1Jac if which == "g1" else gm.G2Jac)(curve)
+    fr_bits = g.curve.fr_bits
+    prev = None
+    for lg in range(0, 31):
+        for n in {1 << lg, (1 << lg) + 1, (1 << (lg + 1)) - 1}:
+            c = g.default_window_bits(n)
+            assert 2 <= c <= 17, (n, c)
+            nwin = g.num_windows(c)
+            assert nwin == (fr_bits + c - 1) // c
+            top_bits = fr_bits - (nwin - 1) * c
+            assert top_bits >= 6 or n < (1 << 17), (n, c, top_bits)  # narrow top windows only where they were measured to win
+            assert c == g.default_window_bits(1 << lg), "one width per power-of-two band"
+        if prev is not None and lg >= 17:
+            assert c >= prev or (curve == "bw6_761"), "the width does not shrink as n grows (large n)"
+        prev = c
+    table = {("bn254", "g1"): {20: 16, 21: 17, 24: 17, 26: 17}, ("bn254", "g2"): {20: 16, 22: 17},
+             ("bls12_381", "g1"): {22: 16, 24: 17}, ("bls12_381", "g2"): {16: 12, 22: 16},
+             ("bw6_761", "g1"): {13: 9, 20: 14, 22: 16}, ("bw6_761", "g2"): {13: 9, 20: 14, 22: 16}}[(curve, which)]
+    for lg, c in table.items():
+        assert g.default_window_bits(1 << lg) == c, (lg, c)
+    monkeypatch.setenv("GMSM_C", "11")
+    assert g.default_window_bits(1 << 20) == 11
+
+
 def test_reference_argument_errors(gm):
     g = gm.G1Jac("bn254")
     pts = np.zeros((3, 8), dtype=np.uint64)
