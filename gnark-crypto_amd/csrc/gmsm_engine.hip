@@ -3,6 +3,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <sys/stat.h>
 
 #include "gmsm_context.h"
 
@@ -336,6 +337,15 @@ GMSM_EXPORT int gmsm_bases_register_dump(int group, const char *path, uint64_t o
     size_t n = (size_t)word;
     if (max_points && n > max_points) n = max_points;  // ReadSlice's maxElements
     if (n >= ((size_t)1 << 31)) return fail(GMSM_ERR_ARG, "gmsm_bases_register_dump: more than 2^31 points");
+    {   // the length word comes from the file: believe it only as far as the file goes (before any device memory is asked for)
+        const off_t here = ftello(f);
+        struct stat st;
+        if (here >= 0 && fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode)) {
+            const uint64_t left = st.st_size > here ? (uint64_t)(st.st_size - here) : 0;
+            if ((uint64_t)n * vt->aff_bytes > left)
+                return fail(GMSM_ERR_ARG, "gmsm_bases_register_dump: short read (points): the file holds fewer points than its length word says");
+        }
+    }
     Context *ctx;
     int rc = get_context(&ctx);
     if (rc) return rc;

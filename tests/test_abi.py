@@ -70,6 +70,30 @@ def test_default_window_table(gm, curve, which, monkeypatch):
     assert g.default_window_bits(1 << 20) == 11
 
 
+def test_dump_header_errors_need_no_device(gm, tmp_path):
+    """gmsm_bases_register_dump checks the file before it touches the device: missing file, wrong marker
+    (utils/unsafe/dump_slice.go:91-103), truncated header, and a length word that promises more points than the file
+    holds (ReadSlice would hit io.ErrUnexpectedEOF, dump_slice.go:35-76) all fail with the argument error."""
+    g = gm.G1Affine("bn254")
+    rb, err = g.register_bases_dump(tmp_path / "missing.dump")
+    assert rb is None and "cannot open" in err
+    path = tmp_path / "srs.dump"
+    path.write_bytes((0xdeadbeef).to_bytes(8, "little")[:5])
+    rb, err = g.register_bases_dump(path)
+    assert rb is None and "short read (marker)" in err
+    path.write_bytes((0xfeedface).to_bytes(8, "little") + (4).to_bytes(8, "little") + bytes(4 * 64))
+    rb, err = g.register_bases_dump(path)
+    assert rb is None and "marker mismatch" in err
+    path.write_bytes((0xdeadbeef).to_bytes(8, "little") + (4).to_bytes(8, "little")[:3])
+    rb, err = g.register_bases_dump(path)
+    assert rb is None and "short read (length)" in err
+    path.write_bytes((0xdeadbeef).to_bytes(8, "little") + (1 << 20).to_bytes(8, "little") + bytes(3 * 64))
+    rb, err = g.register_bases_dump(path)
+    assert rb is None and "fewer points than its length word says" in err
+    rb, err = g.register_bases_dump(path, max_points=4)  # maxElements caps the read, but 4 points are not there either
+    assert rb is None and "fewer points than its length word says" in err
+
+
 def test_reference_argument_errors(gm):
     g = gm.G1Jac("bn254")
     pts = np.zeros((3, 8), dtype=np.uint64)
