@@ -114,7 +114,7 @@ def int_roofline_record(madds, acc_ms_total):
             "frac": mulmods_per_s / int_peak, "frac_of_measured": (mulmods_per_s / measured) if measured else None}
 
 
-def measured_traffic(curve, group, logn, world):
+def measured_traffic(curve, group, logn, world, nwin=None):
     """HBM/fabric bytes per k_accumulate_seg launch from the committed rocprofv3 PMC passes of THIS round's build
     (FETCH_SIZE + WRITE_SIZE, separate passes; profiles/traffic_r02.json, keyed curve_group_logn).  Counters cannot be
     read from inside the timed run, so this is the profiled value for the same workload - or None when that workload was
@@ -123,7 +123,11 @@ def measured_traffic(curve, group, logn, world):
         return None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic_r02.json")) as f:
-            return json.load(f)["k_accumulate_seg"].get(f"{curve}_{group}_{logn}")
+            rec = json.load(f)
+        key = f"{curve}_{group}_{logn}"
+        if nwin is not None and rec.get("windows", {}).get(key, nwin) != nwin:
+            return None  # profiled with another window width: not this workload's traffic
+        return rec["k_accumulate_seg"].get(key)
     except (OSError, KeyError, ValueError):
         return None
 
@@ -170,7 +174,7 @@ def also_config(gm, lib, torch, curve, group, logn, steps, host_legs):
     out = {"workload": f"{curve.upper()} {group.upper()} MultiExp 2^{logn} points, bases+scalars resident in HBM",
            "value": steps / dt, "unit": "MSM/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "window_bits": c,
            "windows": nwin, "stage_ms": stages,
-           "roofline": roofline_record(g, n, 1.0, stages, acc_launches, measured_traffic(curve, group, logn, 1))}
+           "roofline": roofline_record(g, n, 1.0, stages, acc_launches, measured_traffic(curve, group, logn, 1, nwin))}
     if host_legs:
         pts_host = d_pts.cpu().numpy().view(np.uint64)
         cfg = gm.MultiExpConfig()
@@ -525,7 +529,7 @@ def main():
             "host_entry": host_entry,
             "replica_batch": replica,
             "roofline": roofline_record(g, n, my_pairs / (n * nwin), stages, acc_launches,
-                                        measured_traffic(args.curve, args.group, args.logn, world)),
+                                        measured_traffic(args.curve, args.group, args.logn, world, nwin)),
             "int_roofline": int_roofline_record(my_pairs, stages["accumulate"]),
         }
         if sharded:
