@@ -47,6 +47,12 @@ struct Group {
 #ifndef GMSM_COMBINE_INLINE
 #define GMSM_COMBINE_INLINE -1  // -1: per element type (below); 0 / 1 force it off / on for A/B builds
 #endif
+#ifndef GMSM_FIXLONG_INLINE
+#define GMSM_FIXLONG_INLINE 0  // 1: k_fixup_long<UnsatOps, ONE_SITE> for the wide element types (A/B builds)
+#endif
+#ifndef GMSM_QUAD_INLINE
+#define GMSM_QUAD_INLINE 0     // 1: the lane-quad level 2 inlines its field products for the wide element types too (A/B builds)
+#endif
 #ifndef GMSM_WIDE_OPS_MID
 #define GMSM_WIDE_OPS_MID 0  // 1: UnsatOpsMid (additions out of line, products inlined inside them) - A/B builds only:
                             // BN254 G2 runs correctly with it, BLS12-381 G2 did not come back from its first MultiExp on
@@ -76,6 +82,9 @@ struct Group {
     // XYZZ values spill either way).
     static constexpr bool COMBINE_INLINE = GMSM_COMBINE_INLINE < 0 ? !INLINE_OPS : (GMSM_COMBINE_INLINE != 0);
     using FixOps = typename std::conditional<COMBINE_INLINE, OpsSerial, Ops>::type;
+    static constexpr bool FIXLONG_ONE_SITE = GMSM_FIXLONG_INLINE != 0 && !INLINE_OPS;
+    using FixLongOps = typename std::conditional<FIXLONG_ONE_SITE, OpsSerial, Ops>::type;
+    static constexpr bool QUAD_INL = INLINE_OPS || GMSM_QUAD_INLINE != 0;
     static constexpr bool QUAD_REDUCE = true;  // level 2 of the reduction on lane quads (GMSM_QUAD=0 switches it off)
 
     static WindowPlan make_plan(unsigned c, unsigned win_first, unsigned win_stride) {
@@ -366,7 +375,7 @@ struct Group {
         if ((rc = ctx.allow_lds((const void *)k_part_scatter<uint16_t>, 152 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_part_scatter<uint32_t>, 152 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_fine_sort, 160 * 1024))) return rc;
-        if ((rc = ctx.allow_lds((const void *)k_fixup_long<Ops>, (int)(256 * sizeof(OpsElem))))) return rc;
+        if ((rc = ctx.allow_lds((const void *)k_fixup_long<FixLongOps, FIXLONG_ONE_SITE>, (int)(256 * sizeof(OpsElem))))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_reduce1<Ops, RED_TPB>, (int)(2 * RED_TPB * sizeof(OpsElem))))) return rc;
         if constexpr (COMBINE_INLINE)
             if ((rc = ctx.allow_lds((const void *)k_reduce_combine<OpsSerial, RED_TPB>, (int)(2 * RED_TPB * sizeof(OpsElem))))) return rc;
@@ -455,7 +464,7 @@ struct Group {
             timer.mark(p, T_FIXUP, st);
             hipLaunchKernelGGL((k_fixup_seg<FixOps>), dim3((q.tpw + 255) / 256, nwp), dim3(256), 0, st, NB, seg_partials,
                                (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets, long_flag, long_list);
-            hipLaunchKernelGGL((k_fixup_long<Ops>), dim3(2 * ctx.num_cus), dim3(256), 256 * sizeof(OpsElem), st, NB, seg_partials,
+            hipLaunchKernelGGL((k_fixup_long<FixLongOps, FIXLONG_ONE_SITE>), dim3(2 * ctx.num_cus), dim3(256), 256 * sizeof(OpsElem), st, NB, seg_partials,
                                (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets,
                                (const uint32_t *)long_flag, (const LongChain *)long_list);
             // ---- 3. bucket reduction -> window totals (empty buckets are never written: the reduction consults starts[])
@@ -493,7 +502,7 @@ struct Group {
                     if (env_uint("GMSM_QUAD", 1) >= 1) {
                         uint32_t active = 2;
                         while (active < q.nblocks1) active <<= 1;
-                        hipLaunchKernelGGL((k_reduce2_quad<U, INLINE_OPS>), dim3(nwp), dim3(4 * active), active * sizeof(OpsElem),
+                        hipLaunchKernelGGL((k_reduce2_quad<U, QUAD_INL>), dim3(nwp), dim3(4 * active), active * sizeof(OpsElem),
                                            st, partials, q.nblocks1, q.log2span - prescale, active, totals);
                         l2 = true;
                     }

@@ -567,7 +567,10 @@ __global__ void __launch_bounds__(256) k_fixup_seg(uint32_t nbuckets, const void
 }
 
 // grid = any (grid-stride over the list), block = 256, dynamic LDS = 256 * sizeof(A::Elem).
-template <class A>
+// ONE_SITE: the strided sums and the tree run as ONE loop with a single call site of the addition (the operand is a loaded
+// partial sum in the first ceil(m/256) steps and a neighbour's value out of LDS afterwards), so that the wide element types
+// can inline the group law here as well (A = UnsatOps). A/B form (-DGMSM_FIXLONG_INLINE=1), not yet through the GPU suite.
+template <class A, bool ONE_SITE = false>
 __global__ void __launch_bounds__(256) k_fixup_long(uint32_t nbuckets, const void *__restrict__ partials,
                                                     const uint32_t *__restrict__ pflags, const uint32_t *__restrict__ pbucket,
                                                     uint32_t threads_per_win, void *__restrict__ buckets,
@@ -598,19 +601,42 @@ __global__ void __launch_bounds__(256) k_fixup_long(uint32_t nbuckets, const voi
         __syncthreads();
         const uint32_t m = s_len != 0xffffffffu ? s_len : threads_per_win - lc.head;
         E mine = A::infinity();
-        for (uint32_t j = tid; j < m; j += 256) {
-            const E piece = j == 0 ? A::load(partials, (base + lc.head) * 2 + 1) : A::load(partials, (base + lc.head + j) * 2 + 0);
-            A::add(mine, piece);
-        }
-        uint32_t active = 256;
-        while (active / 2 >= m && active > 1) active >>= 1;  // smallest power of two >= min(m, 256)
-        for (uint32_t d = active >> 1; d >= 1; d >>= 1) {
-            if (tid < 2 * d) lds[tid] = mine;
-            __syncthreads();
-            E other = A::infinity();
-            if (tid < d) other = lds[tid + d];
-            __syncthreads();
-            A::add(mine, other);
+        if constexpr (ONE_SITE) {
+            uint32_t active = 256;
+            while (active / 2 >= m && active > 1) active >>= 1;  // smallest power of two >= min(m, 256)
+            const uint32_t nstr = (m + 255u) / 256u;
+            uint32_t ntree = 0;
+            while ((1u << ntree) < active) ++ntree;
+#pragma nounroll
+            for (uint32_t s = 0; s < nstr + ntree; ++s) {
+                E Y = A::infinity();
+                if (s < nstr) {
+                    const uint32_t j = tid + s * 256u;
+                    if (j < m) Y = j == 0 ? A::load(partials, (base + lc.head) * 2 + 1) : A::load(partials, (base + lc.head + j) * 2 + 0);
+                } else {
+                    const uint32_t d = active >> (s - nstr + 1);
+                    if (tid < 2 * d) lds[tid] = mine;
+                    __syncthreads();
+                    if (tid < d) Y = lds[tid + d];
+                    __syncthreads();
+                }
+                A::add(mine, Y);
+            }
+        } else {
+            for (uint32_t j = tid; j < m; j += 256) {
+                const E piece = j == 0 ? A::load(partials, (base + lc.head) * 2 + 1) : A::load(partials, (base + lc.head + j) * 2 + 0);
+                A::add(mine, piece);
+            }
+            uint32_t active = 256;
+            while (active / 2 >= m && active > 1) active >>= 1;  // smallest power of two >= min(m, 256)
+            for (uint32_t d = active >> 1; d >= 1; d >>= 1) {
+                if (tid < 2 * d) lds[tid] = mine;
+                __syncthreads();
+                E other = A::infinity();
+                if (tid < d) other = lds[tid + d];
+                __syncthreads();
+                A::add(mine, other);
+            }
         }
         if (tid == 0) A::store(buckets, (size_t)lc.window * nbuckets + pbucket[base + lc.head], mine);
         __syncthreads();
