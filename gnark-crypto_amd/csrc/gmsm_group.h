@@ -330,9 +330,11 @@ struct Group {
         const uint32_t pchunks = (uint32_t)((n + PART_CHUNK - 1) / PART_CHUNK);  // chunk = one LDS staging buffer
         const size_t pchunk_len = PART_CHUNK;
         const size_t scatter_lds = (size_t)nparts * 8 + (size_t)PART_CHUNK * 6;
-        if (scatter_lds > 152 * 1024)
-            return fail(GMSM_ERR_ARG, "more than 2^27 points in one pipeline run: split the window sums by point range and add "
-                                      "the sets (gmsm_fold_window_sets); the MultiExp entries do this themselves");
+        if (scatter_lds > 152 * 1024)  // 32-bit sort entries: bucket bits + index bits; reached beyond 2^27 points at c <= 17
+            return fail(GMSM_ERR_ARG, plan.c > 17 ? "window width too large for this many points in one pipeline run (a run takes up to "
+                                                    "2^(44-c) points for c > 17): use a smaller c or split by point range"
+                                                  : "more than 2^27 points in one pipeline run: split the window sums by point range "
+                                                    "and add the sets (gmsm_fold_window_sets); the MultiExp entries do this themselves");
         // staging slots of the fine pass: up to 96 KiB next to the 2^fbits counters; larger partitions go direct
         const size_t fine_cnt_bytes = (size_t)4 << fbits;
         const uint32_t stage_cap = fine_cnt_bytes >= 156 * 1024 ? 0u

@@ -189,7 +189,9 @@ unsigned gmsm_default_window_bits(int group, size_t n);            /* the engine
                                                                       table per group, 8..17; c = 17 (BN254 G1 from 2^22
                                                                       points) is beyond the reference's uint16 digits */
 unsigned gmsm_num_windows(int group, unsigned c);                  /* computeNbChunks, multiexp.go:681 */
-/* c: 2..20 (the affine result does not depend on it, multiexp_test.go:95-126; the reference stops at 16) */
+/* c: 2..20 (the affine result does not depend on it, multiexp_test.go:95-126; the reference stops at 16); one call takes
+ * up to 2^27 points for c <= 17 and 2^(44-c) beyond (32-bit sort entries) - larger inputs: split by point range and add
+ * the sets with gmsm_fold_window_sets */
 int gmsm_window_sums_device(int group, const void *d_points, const void *d_scalars, size_t n, unsigned c,
                             unsigned win_first, unsigned win_stride, void *hip_stream, uint64_t *out_xyzz);
 /* The same pipeline without the copy-back: the nwin_local totals are written to the DEVICE buffer d_out_xyzz in stream
