@@ -47,6 +47,9 @@ struct Group {
 #ifndef GMSM_COMBINE_INLINE
 #define GMSM_COMBINE_INLINE -1  // -1: per element type (below); 0 / 1 force it off / on for A/B builds
 #endif
+#ifndef GMSM_COMBINE_LDS
+#define GMSM_COMBINE_LDS 0     // 1: the inlined combine keeps its per-thread state in LDS (k_reduce_combine_lds; A/B builds)
+#endif
 #ifndef GMSM_FIXLONG_INLINE
 #define GMSM_FIXLONG_INLINE 0  // 1: k_fixup_long<UnsatOps, ONE_SITE> for the wide element types (A/B builds)
 #endif
@@ -65,7 +68,7 @@ struct Group {
     using Ops = typename OpsSel<INLINE_OPS>::type;     // arithmetic of k_fixup_seg and the reduction kernels
     using OpsNI = UnsatOpsNI<U>;                       // small-code variant for k_fixup_level
     using OpsElem = typename Ops::Elem;
-    static_assert(2 * (sizeof(XYZZ<F>) > 256 ? 128 : 256) * sizeof(OpsElem) <= 160 * 1024, "reduction LDS budget");
+    static_assert((2 * (sizeof(XYZZ<F>) > 256 ? 128 : 256) + 1) * sizeof(OpsElem) <= 160 * 1024, "reduction LDS budget");
     static constexpr int RED_TPB = sizeof(XYZZ<F>) > 256 ? 128 : 256;  // 2*TPB*sizeof(Elem) of LDS must fit 160 KiB
     static constexpr int RED2_TPB = 64;
     // Every element type except the 9-limb prime field runs the serial part of reduction level 1 as its own kernel
@@ -379,8 +382,11 @@ struct Group {
         if ((rc = ctx.allow_lds((const void *)k_fine_sort, 160 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_fixup_long<FixLongOps, FIXLONG_ONE_SITE>, (int)(256 * sizeof(OpsElem))))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_reduce1<Ops, RED_TPB>, (int)(2 * RED_TPB * sizeof(OpsElem))))) return rc;
-        if constexpr (COMBINE_INLINE)
+        if constexpr (COMBINE_INLINE) {
             if ((rc = ctx.allow_lds((const void *)k_reduce_combine<OpsSerial, RED_TPB>, (int)(2 * RED_TPB * sizeof(OpsElem))))) return rc;
+            if constexpr (GMSM_COMBINE_LDS != 0)
+                if ((rc = ctx.allow_lds((const void *)k_reduce_combine_lds<OpsSerial, RED_TPB>, (int)((2 * RED_TPB + 1) * sizeof(OpsElem))))) return rc;
+        }
         if ((rc = ctx.allow_lds((const void *)k_reduce2<Ops, RED2_TPB>, (int)(2 * RED2_TPB * sizeof(OpsElem))))) return rc;
 
         StageTimer timer(ws);
@@ -488,8 +494,12 @@ struct Group {
                 bool combined = false;
                 if constexpr (COMBINE_INLINE) {
                     if (split_reduce) {
-                        hipLaunchKernelGGL((k_reduce_combine<OpsSerial, RED_TPB>), dim3(q.nblocks1, nwp), dim3(RED_TPB),
-                                           2 * RED_TPB * sizeof(OpsElem), st, q.log2L, partials, prescale, pre, T);
+                        if constexpr (GMSM_COMBINE_LDS != 0)
+                            hipLaunchKernelGGL((k_reduce_combine_lds<OpsSerial, RED_TPB>), dim3(q.nblocks1, nwp), dim3(RED_TPB),
+                                               (2 * RED_TPB + 1) * sizeof(OpsElem), st, q.log2L, partials, prescale, pre, T);
+                        else
+                            hipLaunchKernelGGL((k_reduce_combine<OpsSerial, RED_TPB>), dim3(q.nblocks1, nwp), dim3(RED_TPB),
+                                               2 * RED_TPB * sizeof(OpsElem), st, q.log2L, partials, prescale, pre, T);
                         combined = true;
                     }
                 }

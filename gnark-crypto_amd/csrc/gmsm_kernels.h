@@ -863,6 +863,108 @@ __global__ void __launch_bounds__(TPB) k_reduce_combine(uint32_t log2L, void *__
     if (t == 0) A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 1, W_out);
 }
 
+// The same combine with the per-thread state in LDS instead of registers (A/B form, -DGMSM_COMBINE_LDS=1, not yet through
+// the GPU suite). reduce_program keeps run / tot / suf / mine and the two operands alive across its one call site of the
+// addition: five or six extended-Jacobian values, 3 KB of scratch per lane for the 28-word element types. Here a step
+// reads its two operands from LDS, adds, and writes the result back, so only X and Y (and the addition's temporaries)
+// are live at the call - the register picture of k_reduce_serial, which runs at the multiplier rate.
+//   SUF[t]  S_t, then its inclusive suffix sums (Hillis-Steele in place: all reads of a step, barrier, all writes)
+//   TOT[t]  W_t
+//   trees   lower half of the threads over SUF[1..] (U = sum_{t>=1} Suf_t; slot 0 is read as infinity in the first
+//           step), upper half over TOT, both in place;  PARK = S_blk, saved by thread 0 when the scan ends
+//   finish  thread 0: U <- 2^log2L U, W <- W + U
+// prescale > 0 (TPB >= 256): thread 64, idle from the second tree step on, doubles PARK once per step.
+// dynamic LDS = (2 * TPB + 1) * sizeof(A::Elem).
+template <class A, int TPB>
+__global__ void __launch_bounds__(TPB) k_reduce_combine_lds(uint32_t log2L, void *__restrict__ out1, uint32_t prescale,
+                                                            const void *__restrict__ pre, uint32_t T) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    using E = typename A::Elem;
+    E *SUF = reinterpret_cast<E *>(lds_raw), *TOT = SUF + TPB, *PARK = SUF + 2 * TPB;
+    const uint32_t k = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
+    const uint32_t g = blk * TPB + t;
+    {
+        E S = A::infinity(), W = A::infinity();
+        if (g < T) {
+            S = A::load(pre, ((size_t)k * T + g) * 2 + 0);
+            W = A::load(pre, ((size_t)k * T + g) * 2 + 1);
+        }
+        SUF[t] = S;
+        TOT[t] = W;
+    }
+    __syncthreads();
+    uint32_t lg = 0;
+    while ((1u << lg) < (uint32_t)TPB) ++lg;
+    const uint32_t n_scan = lg, n_tree = lg, n_fin = log2L + 1, total = n_scan + n_tree + n_fin;
+    const bool upper = t >= TPB / 2;
+    const uint32_t tt = upper ? t - TPB / 2 : t;
+    const bool doubler = TPB >= 256 && prescale != 0 && t == 64;
+    uint32_t dbl_left = prescale;
+#pragma nounroll
+    for (uint32_t s = 0; s < total; ++s) {
+        E X = A::infinity(), Y = A::infinity();
+        int dest = -1;  // 0: SUF[t]  1: tree slot arr[tt]  2: SUF[0] (finish doubling)  3: TOT[0] (finish add)  4: PARK
+        bool do_dbl = false;
+        if (s < n_scan) {
+            const uint32_t d = 1u << s;
+            X = SUF[t];
+            if (t + d < (uint32_t)TPB) Y = SUF[t + d];
+            dest = 0;
+        } else if (s < n_scan + n_tree) {
+            const uint32_t step = s - n_scan, d = (uint32_t)TPB >> (step + 1);
+            E *arr = upper ? TOT : SUF;
+            if (tt < d) {
+                if (!(step == 0 && !upper && tt == 0)) X = arr[tt];  // U excludes Suf_0 (= S_blk, parked)
+                Y = arr[tt + d];
+                dest = 1;
+            } else if (doubler && step >= 1 && dbl_left > 0) {
+                X = PARK[0];
+                do_dbl = true;
+                dest = 4;
+                --dbl_left;
+            }
+        } else {
+            const uint32_t step = s - n_scan - n_tree;
+            if (t == 0) {
+                if (step < log2L) {
+                    X = SUF[0];
+                    do_dbl = true;
+                    dest = 2;
+                } else {
+                    X = TOT[0];
+                    Y = SUF[0];
+                    dest = 3;
+                }
+            } else if (doubler && dbl_left > 0) {
+                X = PARK[0];
+                do_dbl = true;
+                dest = 4;
+                --dbl_left;
+            }
+        }
+        __syncthreads();  // every read of this step is done
+        if (do_dbl) A::dbl(X);
+        else if (dest >= 0) A::add(X, Y);
+        if (dest == 0) {
+            SUF[t] = X;
+            if (s + 1 == n_scan && t == 0) PARK[0] = X;  // S_blk
+        } else if (dest == 1) {
+            (upper ? TOT : SUF)[tt] = X;
+        } else if (dest == 2) {
+            SUF[0] = X;
+        } else if (dest == 3) {
+            TOT[0] = X;
+        } else if (dest == 4) {
+            PARK[0] = X;
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 0, PARK[0]);
+        A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 1, TOT[0]);
+    }
+}
+
 // grid = nwin_local, block = TPB >= nblocks1 threads. Thread j holds level-1 block j: (S_j, W_j) covering
 // TPB1*L buckets = 2^log2span. window_total[k] = sum_j W_j + span * sum_j j*S_j.
 template <class A, int TPB>
