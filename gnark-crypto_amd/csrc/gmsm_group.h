@@ -57,9 +57,10 @@ struct Group {
 #define GMSM_QUAD_INLINE 0     // 1: the lane-quad level 2 inlines its field products for the wide element types too (A/B builds)
 #endif
 #ifndef GMSM_WIDE_OPS_MID
-#define GMSM_WIDE_OPS_MID 0  // 1: UnsatOpsMid (additions out of line, products inlined inside them) - A/B builds only:
-                            // BN254 G2 runs correctly with it, BLS12-381 G2 did not come back from its first MultiExp on
-                            // the GPU box (profiles/r02_window_sweeps.log, gpu_r2o), so the shipped form stays UnsatOpsNI
+#define GMSM_WIDE_OPS_MID 0  // 1: UnsatOpsMid (additions out of line, products inlined inside them) - A/B builds only.
+                            // BN254 G2 runs correctly with it; for the 28-word element types the function body exceeds
+                            // the reach of s_cbranch and LLVM's long-branch expansion goes through s[30:31], the return
+                            // address: the call never returns (tools/check_long_branch.py)
 #endif
     template <bool Fast, class Dummy = void> struct OpsSel {
         using type = typename std::conditional<GMSM_WIDE_OPS_MID != 0, UnsatOpsMid<U>, UnsatOpsNI<U>>::type;
