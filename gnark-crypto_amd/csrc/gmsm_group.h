@@ -481,7 +481,9 @@ struct Group {
             {
                 // level 1 doubles its S_blk log2span times in an otherwise idle wave (256-thread blocks only): level 2 then
                 // has no serial doubling tail (11 of its 20 steps at c = 16)
-                const uint32_t prescale = (RED_TPB >= 256 && env_uint("GMSM_PRESCALE", 1)) ? q.log2span : 0u;
+                // (k_reduce_combine_lds prescales for every workgroup size)
+                const bool lds_combine = GMSM_COMBINE_LDS != 0 && COMBINE_INLINE && split_reduce;
+                const uint32_t prescale = ((RED_TPB >= 256 || lds_combine) && env_uint("GMSM_PRESCALE", 1)) ? q.log2span : 0u;
                 const void *pre = nullptr;
                 uint32_t T = 0;
                 if (split_reduce) {

@@ -873,7 +873,9 @@ __global__ void __launch_bounds__(TPB) k_reduce_combine(uint32_t log2L, void *__
 //   trees   lower half of the threads over SUF[1..] (U = sum_{t>=1} Suf_t; slot 0 is read as infinity in the first
 //           step), upper half over TOT, both in place;  PARK = S_blk, saved by thread 0 when the scan ends
 //   finish  thread 0: U <- 2^log2L U, W <- W + U
-// prescale > 0 (TPB >= 256): thread 64, idle from the second tree step on, doubles PARK once per step.
+// prescale > 0: thread TPB/4, idle from the second tree step on, doubles PARK once per step (log2 TPB - 1 tree steps and
+// log2L + 1 finishing steps are left: exactly log2span = log2L + log2 TPB doublings fit, for every TPB - the fused
+// k_reduce1 only does this for 256-thread workgroups).
 // dynamic LDS = (2 * TPB + 1) * sizeof(A::Elem).
 template <class A, int TPB>
 __global__ void __launch_bounds__(TPB) k_reduce_combine_lds(uint32_t log2L, void *__restrict__ out1, uint32_t prescale,
@@ -898,7 +900,7 @@ __global__ void __launch_bounds__(TPB) k_reduce_combine_lds(uint32_t log2L, void
     const uint32_t n_scan = lg, n_tree = lg, n_fin = log2L + 1, total = n_scan + n_tree + n_fin;
     const bool upper = t >= TPB / 2;
     const uint32_t tt = upper ? t - TPB / 2 : t;
-    const bool doubler = TPB >= 256 && prescale != 0 && t == 64;
+    const bool doubler = prescale != 0 && t == TPB / 4;
     uint32_t dbl_left = prescale;
 #pragma nounroll
     for (uint32_t s = 0; s < total; ++s) {

@@ -17,7 +17,7 @@ def combine_lds(TPB, log2L, prescale, S, W):
         for t in range(TPB):
             upper = t >= TPB // 2
             tt = t - TPB // 2 if upper else t
-            doubler = TPB >= 256 and prescale != 0 and t == 64
+            doubler = prescale != 0 and t == TPB // 4
             X = Y = 0
             dest, do_dbl = -1, False
             if s < n_scan:
@@ -63,7 +63,7 @@ def combine_lds(TPB, log2L, prescale, S, W):
                 TOT[0] = X
             elif dest == 4:
                 PARK[0] = X
-    assert dbl_left == 0 or not (TPB >= 256 and prescale)
+    assert dbl_left == 0
     return PARK[0], TOT[0]
 
 
@@ -71,7 +71,7 @@ def test_combine_program_identity():
     rng = random.Random(20260925)
     for TPB in (128, 256):
         for log2L in (1, 3, 4, 5, 8):
-            for prescale in ([0] if TPB < 256 else [0, log2L + 8]):  # log2span = log2L + log2 TPB, as the host passes it
+            for prescale in (0, log2L + TPB.bit_length() - 1):  # log2span = log2L + log2 TPB, as the host passes it
                 for _ in range(10):
                     S = [rng.randrange(1 << 40) if rng.random() < 0.8 else 0 for _ in range(TPB)]
                     W = [rng.randrange(1 << 40) for _ in range(TPB)]
