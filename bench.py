@@ -4,10 +4,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--logn 20]
 
 One "step" = one complete MultiExp (device-resident bases and scalars -> Jacobian result on the host) of
-n = 2^logn points.  N = 1: the whole MSM on one GPU (BASELINE config C2 at the default logn = 20).  N > 1 (launched by
-torch.distributed.run, one rank per GPU): the SAME MSM is sharded over the ranks (points or windows, sharding.py), the
-per-window totals are exchanged with one RCCL all-gather and folded (strong scaling of one MSM, as BASELINE.json's
-north_star describes).
+n = 2^logn points.  N = 1: the whole MSM on one GPU (BASELINE config C2 at the default logn = 20).  N > 1 (one rank per GPU under
+torch.distributed.run; started as a plain `python bench.py --gpus N` the script re-executes itself under that launcher):
+the SAME MSM is sharded over the ranks (points or windows, sharding.py), the per-window totals are exchanged with one
+RCCL all-gather and folded (strong scaling of one MSM, as BASELINE.json's north_star describes).
 
 Rank 0 prints one JSON line.  Besides the contract fields it carries
   value_cold / value_warm_bases   SURVEY.md §8(d): the same MSM through the drop-in C entries with host buffers
@@ -17,10 +17,13 @@ Rank 0 prints one JSON line.  Besides the contract fields it carries
   int_roofline  the bound that actually binds: field multiplications per second against the v_mad_u64_u32 issue peak
   cpu_baseline  the oracle (C restatement of gnark-crypto's algorithm, kind "port") timed on this box's host cores
   bit_exact     GPU affine result == oracle affine result on the timed input
-  also          the other BASELINE.json configurations, timed in the same run: BN254 G1 2^24 (resident, warm-bases,
-                cold), BLS12-381 G1 and G2 2^22, BW6-761 G1 2^20; each with ms_per_step, stage_ms, roofline and a
-                closed-form bit_exact check (bases [a_i]G built on the device, expected result [sum a_i b_i]G from the
-                oracle: the shape of the reference's own MSM identity, multiexp_test.go:54-60)
+  also          the other BASELINE.json configurations, timed in the same run: BN254 G1 2^22, 2^24 (resident,
+                warm-bases, cold) and 2^26, BLS12-381 G1 and G2 2^22, BW6-761 G1 2^20; each with ms_per_step, stage_ms,
+                roofline (traffic from the committed PMC passes), its own cpu_baseline (the oracle on the same input,
+                one repetition) and a closed-form bit_exact check (bases [a_i]G built on the device, expected result
+                [sum a_i b_i]G from the oracle: the shape of the reference's own MSM identity, multiexp_test.go:54-60)
+  c_abi_sharded the same MultiExp through the drop-in C entry with the library itself spreading it over the devices
+                (gmsm_multiexp_sharded / gmsm_bases_register_sharded: one process, one host thread per device)
   replica_batch (--batch K) K MultiExp over the same registered bases spread over the ranks, one all-gather of results
 """
 import argparse
@@ -35,12 +38,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-STAGES = ["decompose", "histogram", "scans", "scatter", "accumulate", "fixup", "reduce", "wait_prev_group"]
+STAGES = ["decompose", "histogram", "scans", "scatter", "accumulate", "fixup", "reduce", "reserved"]
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md
 
 # BASELINE.json configs beyond the headline one: (curve, group, logn, steps, host-entry legs too)
-ALSO = [("bn254", "g1", 24, 5, True), ("bls12_381", "g1", 22, 5, False), ("bls12_381", "g2", 22, 3, False),
-        ("bw6_761", "g1", 20, 3, False)]
+ALSO = [("bn254", "g1", 24, 5, True), ("bn254", "g1", 22, 5, True), ("bn254", "g1", 26, 3, False),
+        ("bls12_381", "g1", 22, 5, False), ("bls12_381", "g2", 22, 3, False), ("bw6_761", "g1", 20, 3, False)]
 
 
 def uniform_scalars(rng, g, n):
@@ -116,13 +119,13 @@ def int_roofline_record(madds, acc_ms_total):
 
 def measured_traffic(curve, group, logn, world, nwin=None):
     """HBM/fabric bytes per k_accumulate_seg launch from the committed rocprofv3 PMC passes of THIS round's build
-    (FETCH_SIZE + WRITE_SIZE, separate passes; profiles/traffic_r02.json, keyed curve_group_logn).  Counters cannot be
+    (FETCH_SIZE + WRITE_SIZE, separate passes; profiles/traffic_r03.json, keyed curve_group_logn).  Counters cannot be
     read from inside the timed run, so this is the profiled value for the same workload - or None when that workload was
     not profiled."""
     if world != 1:
         return None
     try:
-        with open(os.path.join(ROOT, "profiles", "traffic_r02.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "traffic_r03.json")) as f:
             rec = json.load(f)
         key = f"{curve}_{group}_{logn}"
         if nwin is not None and rec.get("windows", {}).get(key, nwin) != nwin:
@@ -142,7 +145,7 @@ def median_ms(fn, reps=5):
     return sorted(ts)[len(ts) // 2]
 
 
-def also_config(gm, lib, torch, curve, group, logn, steps, host_legs):
+def also_config(gm, lib, torch, curve, group, logn, steps, host_legs, with_cpu=True):
     """One of the other BASELINE.json configurations on this GPU: bases [a_i]G built ON the device (fixed-base batch,
     gmsm_batch_scalar_mul_device), uniform scalars b_i, K timed MultiExp calls over resident inputs, and the closed form
     [sum a_i b_i]G from the oracle as the bit-exactness check."""
@@ -175,8 +178,8 @@ def also_config(gm, lib, torch, curve, group, logn, steps, host_legs):
            "value": steps / dt, "unit": "MSM/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "window_bits": c,
            "windows": nwin, "stage_ms": stages,
            "roofline": roofline_record(g, n, 1.0, stages, acc_launches, measured_traffic(curve, group, logn, 1, nwin))}
+    pts_host = d_pts.cpu().numpy().view(np.uint64) if (host_legs or with_cpu) else None
     if host_legs:
-        pts_host = d_pts.cpu().numpy().view(np.uint64)
         cfg = gm.MultiExpConfig()
         rb = g.register_bases(d_points=d_pts.data_ptr(), n=n)
         warm = median_ms(lambda: rb.MultiExp(b, cfg), reps=3)
@@ -187,7 +190,11 @@ def also_config(gm, lib, torch, curve, group, logn, steps, host_legs):
         out.update({"value_warm_bases": 1e3 / warm, "warm_bases_ms": warm, "value_cold": 1e3 / cold, "cold_ms": cold,
                     "host_entries_equal_resident": bool((g.jac_to_affine(jw) == g.jac_to_affine(jac)).all()
                                                         and (g.jac_to_affine(jc) == g.jac_to_affine(jac)).all())})
-        del pts_host
+    if with_cpu:  # the CPU port on the same input, one repetition (the baseline beside every timed size)
+        rec = cpu_baseline(g, pts_host, b, jac, curve, group, min_seconds=0.0)
+        out["cpu_baseline"] = rec["cpu_baseline"]
+        out["bit_exact_vs_cpu_port"] = rec["bit_exact"]
+    del pts_host
     t0 = time.perf_counter()
     expected = oracle.Oracle(curve, group).fixed_base_msm_affine(a, b)
     out["bit_exact"] = bool((g.jac_to_affine(jac) == expected).all())
@@ -195,6 +202,44 @@ def also_config(gm, lib, torch, curve, group, logn, steps, host_legs):
     del d_pts, d_b
     torch.cuda.empty_cache()
     return out
+
+
+def host_side_wait(dist, rank, key, work):
+    """Rank 0 runs work() while the other ranks wait on the HOST (a key in the rendezvous store): an RCCL barrier would
+    keep their GPUs spinning in a collective kernel, and rank 0 is about to use those GPUs from its own process."""
+    store = dist.distributed_c10d._get_default_store()
+    out = None
+    if rank == 0:
+        try:
+            out = work()
+        finally:
+            store.set(key, "1")
+    else:
+        store.wait([key])
+    return out
+
+
+def c_abi_sharded(gm, g, pts, sc, devices, reference_affine, reps=5):
+    """The drop-in C entry with the LIBRARY spreading the MultiExp over `devices` (one process, one host thread per
+    logical rank, window totals back through each device's pinned buffer, one fold): cold = bases + scalars from host
+    memory every call (every device pulls its slice over its own PCIe link), warm-bases = gmsm_bases_register_sharded
+    once, scalars from host memory every call."""
+    cfg = gm.MultiExpConfig()
+    cold = median_ms(lambda: g.MultiExpSharded(pts, sc, cfg, devices=devices), reps=reps)
+    jc, err = g.MultiExpSharded(pts, sc, cfg, devices=devices)
+    assert err is None, err
+    t0 = time.perf_counter()
+    rbs = g.register_bases_sharded(pts, devices=devices)
+    t_reg = (time.perf_counter() - t0) * 1e3
+    warm = median_ms(lambda: rbs.MultiExp(sc, cfg), reps=reps)
+    jw, err = rbs.MultiExp(sc, cfg)
+    assert err is None, err
+    rbs.release()
+    return {"entry": "gmsm_multiexp_sharded / gmsm_bases_register_sharded + gmsm_multiexp_bases (host buffers, one process)",
+            "devices": list(devices), "points": int(pts.shape[0]), "cold_ms": round(cold, 3), "value_cold": round(1e3 / cold, 2),
+            "warm_bases_ms": round(warm, 3), "value_warm_bases": round(1e3 / warm, 2), "register_ms": round(t_reg, 1),
+            "unit": "MSM/s", "equal_to_reference_result": bool((g.jac_to_affine(jc) == reference_affine).all()
+                                                               and (g.jac_to_affine(jw) == reference_affine).all())}
 
 
 def sharded_also(gm, torch, dist, sharding, rank, world, local_rank, mode, logn=24, steps=5):
@@ -240,11 +285,27 @@ def sharded_also(gm, torch, dist, sharding, rank, world, local_rank, mode, logn=
     out = {"workload": f"BN254 G1 MultiExp 2^{logn} points, {plan['mode']}-sharded x{world} + one RCCL all-gather",
            "value": steps / dt, "unit": "MSM/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "n_gpus": world,
            "scaling": "strong"}
+    expected = None
     if rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle  # test infrastructure: the checker
         expected = oracle.Oracle("bn254", "g1").fixed_base_msm_affine(a, b)
         out["bit_exact"] = bool((g.jac_to_affine(jac) == expected).all())
+    del d_pts, d_b
+    torch.cuda.empty_cache()
+
+    def through_the_c_abi():  # rank 0 alone drives all `world` devices from its one process
+        d_a0 = torch.from_numpy(a.view(np.int64)).cuda()
+        d_p0 = torch.empty((n, g.aff_limbs), dtype=torch.int64, device="cuda")
+        g.batch_scalar_mul_device(g.generator, d_a0.data_ptr(), n, d_p0.data_ptr(), stream)
+        pts_host = d_p0.cpu().numpy().view(np.uint64)
+        del d_a0, d_p0
+        torch.cuda.empty_cache()
+        return c_abi_sharded(gm, g, pts_host, b, list(range(world)), expected, reps=3)
+    if world > 1:
+        rec = host_side_wait(dist, rank, f"c_abi_{logn}", through_the_c_abi)
+        if rank == 0:
+            out["c_abi_sharded"] = rec
     return out
 
 
@@ -312,11 +373,26 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (one rank per GPU, RCCL over xGMI); rank 0 of the
+        # relaunched job prints the JSON line on this process's stdout
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: needs {args.gpus} devices, this machine exposes {have}")
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.dup2(json_out.fileno(), 1)  # give the real stdout back to the ranks
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    if args.gpus != world:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: the two must agree")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} needs device {local_rank}, this machine exposes {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -501,6 +577,19 @@ def main():
                       "note": "cold: bases+scalars copied from pageable host memory every call (gmsm_<curve>_g1_multiexp); "
                               "warm-bases: registered bases, scalars copied every call (gmsm_multiexp_bases); median of 5"}
 
+    # The same MultiExp through the drop-in C entry with the library spreading it over the devices (one process): all
+    # `world` devices driven by rank 0 while the other ranks wait on the host; on one GPU two logical ranks on device 0
+    # (a functional check of the path, not a speed-up: both ranks share one device and one PCIe link).
+    c_abi = None
+    if not args.no_host_entry:
+        def through_the_c_abi():
+            return c_abi_sharded(gm, g, pts, sc, list(range(world)) if world > 1 else [0, 0], g.jac_to_affine(jac))
+        if world > 1:
+            barrier()
+            c_abi = host_side_wait(dist, rank, "c_abi_headline", through_the_c_abi)
+        elif not sharded:
+            c_abi = through_the_c_abi()
+
     # N > 1: the 2^24 half of BASELINE.json's metric, sharded the same way (every rank takes part; rank 0 reports)
     also_sharded = None
     if sharded and not args.no_also and (args.curve, args.group) == ("bn254", "g1"):
@@ -527,6 +616,7 @@ def main():
             "stage_ms": stages,
             "pipelined": pipelined,
             "host_entry": host_entry,
+            "c_abi_sharded": c_abi,
             "replica_batch": replica,
             "roofline": roofline_record(g, n, my_pairs / (n * nwin), stages, acc_launches,
                                         measured_traffic(args.curve, args.group, args.logn, world, nwin)),
@@ -565,16 +655,17 @@ def effective_cpus():
     return n
 
 
-def cpu_baseline(g, pts, sc, gpu_jac, curve="bn254", group="g1"):
+def cpu_baseline(g, pts, sc, gpu_jac, curve="bn254", group="g1", min_seconds=10.0):
     """The oracle = C restatement of gnark-crypto's MultiExp (bestC, split recursion, one task per (leaf, window),
-    extended-Jacobian buckets), on all host cores.  Bounded: repeats whole MSMs until ~10 s have elapsed (at least 1)."""
+    extended-Jacobian / batch-affine buckets), on all host cores.  Bounded: repeats whole MSMs until ~min_seconds have
+    elapsed (at least 1)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle  # test infrastructure, used here only as the reported baseline and the checker
     o = oracle.Oracle(curve, group)
     cores = effective_cpus()
     threads = min(2 * cores, len(os.sched_getaffinity(0)))  # 2 software threads per allowed core measured best
     reps, t_total, jac = 0, 0.0, None
-    while reps < 1 or (t_total < 10.0 and reps < 50):
+    while reps < 1 or (t_total < min_seconds and reps < 50):
         t0 = time.perf_counter()
         err, jac = o.multiexp(pts, sc, nb_tasks=0, num_cpu=cores, nthreads=threads)
         t_total += time.perf_counter() - t0

@@ -4,5 +4,5 @@ Import with importlib (the directory name carries a hyphen):
     gm = importlib.import_module("gnark-crypto_amd")
 """
 from .curves import BLS12_381, BN254, BW6_761, CURVES  # noqa: F401
-from .multiexp import G1Affine, G1Jac, G2Affine, G2Jac, MultiExpConfig  # noqa: F401
+from .multiexp import G1Affine, G1Jac, G2Affine, G2Jac, MultiExpConfig, get_devices, set_devices  # noqa: F401
 from . import fft  # noqa: F401  (fr/fft mirror: fft.NewDomain, fft.DIT / fft.DIF, fft.OnCoset, fft.BitReverse)

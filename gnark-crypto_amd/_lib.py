@@ -31,6 +31,8 @@ ABI_SYMBOLS = [
     "gmsm_get_stage_launches", "gmsm_points_from_raw", "gmsm_points_validate", "gmsm_bases_register_raw",
     "gmsm_bases_register_dump", "gmsm_fft_domain_new", "gmsm_fft_domain_release", "gmsm_fft_domain_info", "gmsm_fft",
     "gmsm_fft_bit_reverse",
+    "gmsm_multiexp_sharded", "gmsm_bases_register_sharded", "gmsm_multiexp_bases_sharded", "gmsm_set_devices",
+    "gmsm_get_devices",
     "gmsm_device_count", "gmsm_set_device", "gmsm_last_error",
     "gmsm_version",
 ]
@@ -147,6 +149,17 @@ def load():
     L.gmsm_fft_bit_reverse.argtypes = [ctypes.c_int, u64p, vp, sz, vp]
     L.gmsm_get_stage_launches.restype = ctypes.c_int
     L.gmsm_get_stage_launches.argtypes = [vp, ctypes.c_int]
+    ip = ctypes.POINTER(ctypes.c_int)
+    L.gmsm_multiexp_sharded.restype = ctypes.c_int
+    L.gmsm_multiexp_sharded.argtypes = [ctypes.c_int, u64p, sz, u64p, sz, ctypes.c_int, ip, ctypes.c_int, ctypes.c_int, u64p]
+    L.gmsm_bases_register_sharded.restype = ctypes.c_int
+    L.gmsm_bases_register_sharded.argtypes = [ctypes.c_int, u64p, sz, ip, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+    L.gmsm_multiexp_bases_sharded.restype = ctypes.c_int
+    L.gmsm_multiexp_bases_sharded.argtypes = [ctypes.c_uint64, u64p, sz, ctypes.c_int, ctypes.c_int, u64p]
+    L.gmsm_set_devices.restype = ctypes.c_int
+    L.gmsm_set_devices.argtypes = [ip, ctypes.c_int]
+    L.gmsm_get_devices.restype = ctypes.c_int
+    L.gmsm_get_devices.argtypes = [ip, ctypes.c_int]
     L.gmsm_device_count.restype = ctypes.c_int
     L.gmsm_set_device.restype = ctypes.c_int
     L.gmsm_set_device.argtypes = [ctypes.c_int]

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -113,12 +114,8 @@ struct Workspace {
     DeviceBuffer parted;         // coarse-partitioned references (two-level grouping)
     DeviceBuffer digits, sorted, blockhist, counts, starts, buckets, partials, totals;
     DeviceBuffer red_pre;        // per-thread (S, W) of the split bucket reduction (k_reduce_serial -> k_reduce1)
-    static constexpr int MAX_PIECES = 4;   // window groups of one call (enqueue_window_sums): alternate between the streams
-    hipStream_t stream2 = nullptr;         // second stream of a call: the pieces' pipelines overlap each other
-    hipEvent_t events[MAX_PIECES][12] = {{nullptr}};  // stage boundaries per piece when profiling is on
-    int timed_pieces = 0;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // inputs ready -> stream2; stream2 done -> main stream
-    hipEvent_t ev_acc[MAX_PIECES] = {nullptr};        // accumulation kernel of piece p finished (piece p+1 waits for it)
+    hipEvent_t events[12] = {nullptr};  // stage boundaries of the call in flight when profiling is on
+    bool timed = false;                 // events[] were recorded by the last enqueue
     void *pinned = nullptr;             // pinned host buffer for the window totals
     size_t pinned_cap = 0;
     DeviceBuffer h2d_points, h2d_scalars;  // staging of the host-pointer entries
@@ -131,7 +128,6 @@ struct Workspace {
     uint32_t pending_nw = 0;
     uint32_t pending_gen = 0;   // ticket generation: a stale or repeated ticket is refused
     std::shared_ptr<ResidentBases> bases_ref;  // keeps the registered bases of the call in flight on this workspace alive
-    std::thread::id pending_owner;  // thread that submitted the ticket (it cannot collect while it waits for a lease)
     hipEvent_t dep = nullptr;   // orders the workspace stream after the caller's stream (scalars produced there)
     bool uncollected = false;          // stage events of an enqueue-only call not yet added to the profile
     hipEvent_t last_use = nullptr;     // recorded after the last call enqueued on this workspace ...
@@ -162,13 +158,7 @@ struct Context {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
         num_cus = prop.multiProcessorCount;
-        for (auto &w : ws) {
-            HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
-            HIP_TRY(hipStreamCreateWithFlags(&w.stream2, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming));
-            for (auto &e : w.ev_acc) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        }
+        for (auto &w : ws) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
         return GMSM_OK;
     }
     // Kernels that need more than the default 64 KiB of dynamic LDS: raise the limit once per kernel on this device.
@@ -184,11 +174,14 @@ struct Context {
     }
     // wait = false: nullptr when both workspaces are leased.
     // wait = true: blocks until a workspace is free. The one case that cannot be waited out: both leases are submitted
-    // tickets (only gmsm_multiexp_collect ends those) and the calling thread itself holds one of them - it would be
-    // waiting for its own collect. Tickets of other threads are waited for like any other lease.
+    // tickets (only gmsm_multiexp_collect ends those) and their holder is the caller itself - it would wait for its own
+    // collect. Callers are goroutines that migrate between OS threads, so the holder cannot be told from a thread id:
+    // instead the wait gives up (nullptr -> GMSM_ERR_ARG) once both workspaces have been uncollected tickets for
+    // TICKET_WAIT_MS without interruption; tickets of a caller that is about to collect them are waited for as usual.
+    static constexpr int TICKET_WAIT_MS = 2000;
     Workspace *acquire(bool wait) {
         std::unique_lock<std::mutex> lk(mu);
-        const std::thread::id self = std::this_thread::get_id();
+        int stuck_ms = 0;
         for (;;) {
             for (auto &w : ws)
                 if (!w.busy) {
@@ -196,8 +189,14 @@ struct Context {
                     return &w;
                 }
             if (!wait) return nullptr;
-            if (ws[0].pending && ws[1].pending && (ws[0].pending_owner == self || ws[1].pending_owner == self)) return nullptr;
-            cv.wait(lk);
+            if (ws[0].pending && ws[1].pending) {
+                if (stuck_ms >= TICKET_WAIT_MS) return nullptr;
+                cv.wait_for(lk, std::chrono::milliseconds(50));
+                stuck_ms += 50;
+            } else {
+                stuck_ms = 0;
+                cv.wait(lk);
+            }
         }
     }
     void release(Workspace *w) {
@@ -216,8 +215,13 @@ struct Lease {
     // A workspace can still be busy with work that an enqueue-only call (gmsm_window_sums_enqueue) left in flight on the
     // caller's stream after giving its lease back: whoever leases it next orders the workspace's own stream behind that
     // work before touching any scratch buffer (entries that run on another stream do the same through begin_use).
+    // A reference to registered bases that an enqueue-only call parked on the workspace is dropped here, outside the
+    // context lock (the last owner's destructor synchronises the device before it frees the SRS).
     Lease(Context &c, bool wait = true) : ctx(c), w(c.acquire(wait)) {
-        if (w && w->last_use && w->last_stream != w->stream) (void)hipStreamWaitEvent(w->stream, w->last_use, 0);
+        if (!w) return;
+        if (w->last_use && w->last_stream != w->stream) (void)hipStreamWaitEvent(w->stream, w->last_use, 0);
+        std::shared_ptr<ResidentBases> parked;
+        parked.swap(w->bases_ref);
     }
     ~Lease() {
         if (w) ctx.release(w);
@@ -258,11 +262,9 @@ static inline int end_use(Workspace &ws, hipStream_t stream) {
     return GMSM_OK;
 }
 
-// Per-stage device timing (HIP events on the streams the kernels are launched on). Off by default; bench.py switches
-// it on to obtain the dominant kernel's duration for the roofline record. One call runs as up to MAX_PIECES window
-// groups ("pieces") whose pipelines overlap on two streams, so the stage sums exceed the wall time of the call.
-// Order of the events inside one piece (T_ prefix); the ABI (gmsm_get_stage_times) keeps its historical indices:
-enum Stage {  // ABI index
+// Per-stage device timing (HIP events on the stream the kernels are launched on). Off by default; bench.py switches
+// it on to obtain the dominant kernel's duration for the roofline record.
+enum Stage {  // ABI index (gmsm_get_stage_times)
     STAGE_DECOMPOSE = 0,
     STAGE_HIST,
     STAGE_SCAN,
@@ -270,12 +272,12 @@ enum Stage {  // ABI index
     STAGE_ACCUMULATE,  // k_accumulate_seg alone: the dominant kernel of the roofline record
     STAGE_FIXUP,
     STAGE_REDUCE,
-    STAGE_WAIT,        // a piece's stream idle until the previous piece's accumulation kernel has finished
+    STAGE_RESERVED,    // (round 2: wait of a window group for the previous one; always 0 now)
     STAGE_COUNT
 };
-enum TimedEvent { T_DECOMPOSE = 0, T_HIST, T_SCAN, T_SCATTER, T_WAIT, T_ACCUMULATE, T_FIXUP, T_REDUCE, T_END };
+enum TimedEvent { T_DECOMPOSE = 0, T_HIST, T_SCAN, T_SCATTER, T_ACCUMULATE, T_FIXUP, T_REDUCE, T_END };
 static constexpr int T_TO_STAGE[T_END] = {STAGE_DECOMPOSE, STAGE_HIST, STAGE_SCAN, STAGE_SCATTER,
-                                          STAGE_WAIT,      STAGE_ACCUMULATE, STAGE_FIXUP, STAGE_REDUCE};
+                                          STAGE_ACCUMULATE, STAGE_FIXUP, STAGE_REDUCE};
 
 bool profiling_enabled();
 // adds one call's stage durations (and the number of kernel instances behind each) to the process-wide accumulators
@@ -285,23 +287,21 @@ struct StageTimer {
     Workspace &ws;
     bool on;
     explicit StageTimer(Workspace &w) : ws(w), on(profiling_enabled()) {
-        if (on && !ws.events[0][0])
-            for (auto &row : ws.events)
-                for (int i = 0; i <= T_END; ++i) (void)hipEventCreate(&row[i]);
+        if (on && !ws.events[0])
+            for (int i = 0; i <= T_END; ++i) (void)hipEventCreate(&ws.events[i]);
     }
-    void mark(int piece, int ev, hipStream_t stream) {
-        if (on) (void)hipEventRecord(ws.events[piece][ev], stream);
+    void mark(int ev, hipStream_t stream) {
+        if (on) (void)hipEventRecord(ws.events[ev], stream);
     }
-    static void collect(Workspace &ws) {  // call after the streams have been synchronised
+    static void collect(Workspace &ws) {  // call after the stream has been synchronised
         float ms[STAGE_COUNT] = {0};
         unsigned launches[STAGE_COUNT] = {0};
-        for (int p = 0; p < ws.timed_pieces; ++p)
-            for (int i = (p == 0 ? T_DECOMPOSE : T_HIST); i < T_END; ++i) {
-                float t = 0.f;
-                if (hipEventElapsedTime(&t, ws.events[p][i], ws.events[p][i + 1]) != hipSuccess) continue;
-                ms[T_TO_STAGE[i]] += t;
-                ++launches[T_TO_STAGE[i]];
-            }
+        for (int i = T_DECOMPOSE; i < T_END; ++i) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, ws.events[i], ws.events[i + 1]) != hipSuccess) continue;
+            ms[T_TO_STAGE[i]] += t;
+            ++launches[T_TO_STAGE[i]];
+        }
         record_stage_times(ms, launches);
     }
 };
@@ -358,11 +358,23 @@ static inline unsigned usable_cpus() {
     return n;
 }
 
+// Run-time switches of the shipped library, read from the environment at call time:
+//   GMSM_C            force the window width (2..20; cost only, the result does not depend on it)
+//   GMSM_MAX_RUN      lower the 2^27-point cap of one pipeline run  (tests of the point-range split)
+//   GMSM_HOST_RANGES  force the number of point ranges of a host-buffer call (tests)
+//   GMSM_DEVICES      devices the drop-in entries shard over, e.g. "0,1,2,3" (gmsm_set_devices overrides)
+// Everything else that was a knob while the engine was being tuned is a compile-time constant now: tune_uint() returns
+// its default unless the library is built with -DGMSM_EXPERIMENTS (A/B builds, tools/build_ab.sh).
 static inline unsigned env_uint(const char *name, unsigned dflt) {
     const char *v = getenv(name);
     if (!v || !*v) return dflt;
     return (unsigned)strtoul(v, nullptr, 10);
 }
+#ifdef GMSM_EXPERIMENTS
+static inline unsigned tune_uint(const char *name, unsigned dflt) { return env_uint(name, dflt); }
+#else
+static inline constexpr unsigned tune_uint(const char *, unsigned dflt) { return dflt; }
+#endif
 
 // Window width. The affine result does not depend on it (the reference asserts exactly that for c in 2..16,
 // multiexp_test.go:95-126), so it is purely a cost choice - and the cost depends on the element type: a bucket of a
@@ -393,7 +405,7 @@ static inline unsigned preferred_c(unsigned fr_bits, size_t aff_bytes, size_t n)
 }
 static inline unsigned choose_c(unsigned fr_bits, size_t aff_bytes, size_t n) {
     unsigned forced = env_uint("GMSM_C", 0);
-    if (forced >= 2 && forced <= 24) return forced;
+    if (forced >= 2 && forced <= 20) return forced;  // the range gmsm.h documents (gmsm_window_sums_*)
     return preferred_c(fr_bits, aff_bytes, n ? n : 1);
 }
 
@@ -420,7 +432,7 @@ struct GroupVTable {
                                unsigned win_first, unsigned win_stride, hipStream_t stream, void *d_out_xyzz,
                                const std::shared_ptr<ResidentBases> &resident);
     void (*fold_sets)(const uint64_t *xyzz_sets, unsigned nsets, unsigned c, uint64_t *out_jac);
-    int (*fold_points)(const uint64_t *points, size_t n, const uint64_t *coeff, int nb_tasks, uint64_t *out_jac);
+    void (*fold_powers)(const uint64_t *coeff, size_t n, uint64_t *out_scalars);  // 1, g, g^2, ... (Fold, multiexp.go:331)
     int (*multiexp_bases_host)(Context &ctx, const uint64_t *scalars, size_t n, uint64_t *out_jac,
                                const ResidentBases *resident);
     int (*batch_scalar_mul)(Context &ctx, const uint64_t *base, const uint64_t *scalars, const void *d_scalars, size_t n,
@@ -433,6 +445,11 @@ struct GroupVTable {
     int (*fft_domain_new)(Context &ctx, hipStream_t stream, unsigned log2n, FftDomain *out);
     int (*fft_run)(hipStream_t stream, FftDomain *d, void *d_a, bool inverse, bool dif, bool coset);
     int (*fft_bit_reverse)(hipStream_t stream, void *d_a, size_t n);
+    // one rank's piece of a MultiExp that the library shards over several devices (Group::shard_piece)
+    int (*shard_piece)(Context &ctx, const uint64_t *points, const ResidentBases *resident, size_t resident_base,
+                       const uint64_t *scalars, size_t n, unsigned c, unsigned win_first, unsigned win_stride,
+                       uint64_t *out_xyzz);
+    unsigned (*host_piece_ranges)(size_t n, bool with_points);  // point ranges a host-buffer piece of n points runs as
 };
 
 }  // namespace gmsm

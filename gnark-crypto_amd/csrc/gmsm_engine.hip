@@ -3,6 +3,9 @@
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <functional>
+#include <map>
 #include <sys/stat.h>
 
 #include "gmsm_context.h"
@@ -110,11 +113,229 @@ using namespace gmsm;
     const GroupVTable *vt = vtable(group);         \
     if (!vt) return fail(GMSM_ERR_ARG, "unknown group id")
 
+// ------------------------------------------------------------------ one MultiExp over several devices
+// The reference spreads one MultiExp over the cores of a machine: _innerMsmG1 starts a worker per c-bit window and
+// collects one g1JacExtended per window on a channel (ecc/bn254/multiexp.go:148-209), and above a size threshold the call
+// is first split in two halves of the points whose results are added (multiexp.go:98-140, AddAssign). Here the workers are
+// the GPUs of the node and the split happens inside the library, below the C ABI, so that a Go caller of
+// gmsm_<curve>_g1_multiexp gets all of them without knowing: one host thread per logical rank (a persistent pool, two
+// workers per device like the two workspaces), each running its piece on its device through Group::shard_piece;
+//   points   rank r owns points [r n/G, (r+1) n/G) and computes every window of its slice; window w of the whole MultiExp is
+//            the sum of the ranks' totals for w. Each device pulls only its slice over its own PCIe link; default.
+//   windows  rank r owns windows r, r+G, ... over all points (the reference's per-window workers); every device needs
+//            all bases, so this only pays with bases registered on every device and few points.
+// The exchange is the ranks' window totals - at most 64 extended-Jacobian points per rank, a few KB - copied from each
+// device's pinned result buffer by its own host thread; an RCCL all-gather would move the same bytes device-to-device
+// first and then still have to cross to the host for the fold, so the single-process form has no collective. (The
+// one-process-per-GPU form of the same decomposition, with one RCCL all-gather over xGMI, is gnark-crypto_amd/sharding.py.)
+// Then ONE fold (msmReduceChunk, multiexp.go:302-315) on the calling thread.
+namespace gmsm {
+
+struct ShardPool {
+    struct Dev {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<std::function<void()>> q;
+        bool started = false;
+    };
+    std::mutex mu;
+    std::map<int, Dev *> devs;  // never freed: the workers outlive every static destructor
+    void post(int device, std::function<void()> fn) {
+        Dev *d;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            Dev *&slot = devs[device];
+            if (!slot) slot = new Dev();
+            d = slot;
+        }
+        {
+            std::lock_guard<std::mutex> lk(d->mu);
+            if (!d->started) {
+                d->started = true;
+                for (int i = 0; i < 2; ++i)
+                    std::thread([d] {
+                        for (;;) {
+                            std::function<void()> job;
+                            {
+                                std::unique_lock<std::mutex> lk2(d->mu);
+                                d->cv.wait(lk2, [d] { return !d->q.empty(); });
+                                job = std::move(d->q.front());
+                                d->q.pop_front();
+                            }
+                            job();
+                        }
+                    }).detach();
+            }
+            d->q.push_back(std::move(fn));
+        }
+        d->cv.notify_one();
+    }
+};
+static ShardPool &shard_pool() {
+    static ShardPool *p = new ShardPool();
+    return *p;
+}
+
+// Devices the drop-in entries spread a MultiExp over, one entry per logical rank (a device may appear more than once).
+// Resolution: gmsm_set_devices; else a gmsm_set_device call pins the process to that one device; else GMSM_DEVICES
+// ("0,1,2,3"); else every visible device.
+static std::mutex g_devices_mu;
+static std::vector<int> g_devices;
+static bool g_devices_explicit = false;
+static std::atomic<bool> g_pinned{false};  // gmsm_set_device was called
+
+static std::vector<int> shard_devices() {
+    {
+        std::lock_guard<std::mutex> lk(g_devices_mu);
+        if (g_devices_explicit) return g_devices;
+    }
+    if (g_pinned.load()) return {};
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return {};
+    std::vector<int> out;
+    if (const char *v = getenv("GMSM_DEVICES")) {
+        for (const char *p = v; *p;) {
+            char *end = nullptr;
+            const long d = strtol(p, &end, 10);
+            if (end == p) break;
+            if (d >= 0 && d < ndev) out.push_back((int)d);
+            p = *end ? end + 1 : end;
+        }
+        return out;
+    }
+    for (int d = 0; d < ndev; ++d) out.push_back(d);
+    return out;
+}
+
+constexpr size_t SHARD_MIN_SLICE = (size_t)1 << 16;  // fewer points per rank than this are not worth a second device
+
+// mode: 0 auto, 1 points, 2 windows. `replicas[d]` = bases registered on device d (full copies), or empty with `points`.
+static int multiexp_sharded_run(int group, const uint64_t *points, const std::map<int, std::shared_ptr<ResidentBases>> *replicas,
+                                const uint64_t *scalars, size_t n, const std::vector<int> &devs, int mode, uint64_t *out_jac) {
+    const GroupVTable *vt = vtable(group);
+    size_t G = devs.size();
+    if (G == 0) return fail(GMSM_ERR_ARG, "sharded MultiExp: empty device list");
+    if (mode == 0) mode = 1;
+    if (mode != 1 && mode != 2) return fail(GMSM_ERR_ARG, "sharded MultiExp: mode must be 0 (auto), 1 (points) or 2 (windows)");
+    const bool with_points = points != nullptr;
+    unsigned c;
+    uint32_t nwin;
+    if (mode == 1) {
+        G = std::max<size_t>(1, std::min(G, n / SHARD_MIN_SLICE));
+        const size_t slice = (n + G - 1) / G;  // the largest slice decides c: the ranks' totals must line up
+        const unsigned nr = vt->host_piece_ranges(slice, with_points);
+        c = choose_c(vt->fr_bits, vt->aff_bytes, (slice + nr - 1) / nr);
+        nwin = num_windows(vt->fr_bits, c);
+    } else {
+        const unsigned nr = vt->host_piece_ranges(n, with_points);
+        c = choose_c(vt->fr_bits, vt->aff_bytes, (n + nr - 1) / nr);
+        nwin = num_windows(vt->fr_bits, c);
+        G = std::min<size_t>(G, nwin);
+    }
+    const size_t xl = vt->xyzz_bytes / 8;
+    const uint32_t rows = mode == 1 ? nwin : (uint32_t)((nwin + G - 1) / G);
+    std::vector<uint64_t> sets(G * rows * xl, 0);
+    struct Result {
+        int rc = GMSM_OK;
+        std::string err;
+    };
+    std::vector<Result> res(G);
+    std::mutex done_mu;
+    std::condition_variable done_cv;
+    size_t done = 0;
+    auto piece = [&](size_t r) {
+        Result &out = res[r];
+        const int dev = devs[r];
+        Context *ctx = nullptr;
+        out.rc = get_context_for(dev, &ctx);
+        if (out.rc == GMSM_OK && hipSetDevice(dev) != hipSuccess) out.rc = fail(GMSM_ERR_DEVICE, "hipSetDevice failed");
+        if (out.rc == GMSM_OK) {
+            const ResidentBases *rb = nullptr;
+            if (replicas) {
+                auto it = replicas->find(dev);
+                rb = it == replicas->end() ? nullptr : it->second.get();
+                if (!rb) out.rc = fail(GMSM_ERR_ARG, "sharded MultiExp: the bases are not registered on device " + std::to_string(dev));
+            }
+            if (out.rc == GMSM_OK) {
+                const size_t lo = mode == 1 ? r * n / G : 0, hi = mode == 1 ? (r + 1) * n / G : n;
+                out.rc = vt->shard_piece(*ctx, points ? points + lo * (vt->aff_bytes / 8) : nullptr, rb, lo,
+                                         scalars + lo * (vt->scalar_bytes / 8), hi - lo, c, mode == 1 ? 0u : (unsigned)r,
+                                         mode == 1 ? 1u : (unsigned)G, sets.data() + r * rows * xl);
+            }
+        }
+        if (out.rc != GMSM_OK) out.err = gmsm_last_error();
+    };
+    for (size_t r = 1; r < G; ++r)
+        shard_pool().post(devs[r], [&, r] {
+            piece(r);
+            std::lock_guard<std::mutex> lk(done_mu);  // the notify stays under the lock: the waiter owns these objects
+            ++done;
+            done_cv.notify_one();
+        });
+    int prev_dev = 0;
+    (void)hipGetDevice(&prev_dev);
+    piece(0);
+    (void)hipSetDevice(prev_dev);
+    {
+        std::unique_lock<std::mutex> lk(done_mu);
+        done_cv.wait(lk, [&] { return done == G - 1; });
+    }
+    for (size_t r = 0; r < G; ++r)
+        if (res[r].rc != GMSM_OK) return fail(res[r].rc, "rank " + std::to_string(r) + " (device " + std::to_string(devs[r]) + "): " + res[r].err);
+    if (mode == 1) {
+        vt->fold_sets(sets.data(), (unsigned)G, c, out_jac);
+    } else {
+        std::vector<uint64_t> totals((size_t)nwin * xl);
+        for (uint32_t w = 0; w < nwin; ++w)
+            memcpy(totals.data() + (size_t)w * xl, sets.data() + ((w % G) * rows + w / G) * xl, vt->xyzz_bytes);
+        vt->fold(totals.data(), c, out_jac);
+    }
+    return GMSM_OK;
+}
+
+// argument checks of (*G1Jac).MultiExp (multiexp.go:61-71) + the empty input, shared by the sharded entries
+static int multiexp_precheck(const GroupVTable *vt, size_t n_points, size_t n_scalars, int nb_tasks, uint64_t *out_jac, bool *done) {
+    *done = true;
+    if (n_points != n_scalars) return fail(GMSM_ERR_LEN, "len(points) != len(scalars)");
+    if (nb_tasks > 1024) return fail(GMSM_ERR_CONFIG, "invalid config: config.NbTasks > 1024");
+    if (n_points == 0) return vt->multiexp_host(nullptr, 0, nullptr, 0, nb_tasks, out_jac);  // infinity (Z = 0); still needs a device
+    *done = false;
+    return GMSM_OK;
+}
+
+}  // namespace gmsm
+
 extern "C" {
+
+GMSM_EXPORT int gmsm_multiexp_sharded(int group, const uint64_t *points, size_t n_points, const uint64_t *scalars,
+                                      size_t n_scalars, int nb_tasks, const int *devices, int n_devices, int mode,
+                                      uint64_t *out_jac) {
+    VT_OR_FAIL(group);
+    bool done;
+    int rc = multiexp_precheck(vt, n_points, n_scalars, nb_tasks, out_jac, &done);
+    if (rc || done) return rc;
+    std::vector<int> devs = (devices && n_devices > 0) ? std::vector<int>(devices, devices + n_devices) : shard_devices();
+    if (devs.empty()) {
+        int ndev = gmsm_device_count();
+        if (ndev <= 0) return fail(GMSM_ERR_DEVICE, "no usable HIP device; libgmsm has no CPU fallback");
+        for (int d = 0; d < ndev; ++d) devs.push_back(d);
+    }
+    const int ndev = gmsm_device_count();
+    for (int d : devs)
+        if (d < 0 || d >= ndev)
+            return fail(GMSM_ERR_DEVICE, "sharded MultiExp: device " + std::to_string(d) + " does not exist (" + std::to_string(ndev) + " visible)");
+    return multiexp_sharded_run(group, points, nullptr, scalars, n_points, devs, mode, out_jac);
+}
 
 GMSM_EXPORT int gmsm_multiexp(int group, const uint64_t *points, size_t n_points, const uint64_t *scalars,
                               size_t n_scalars, int nb_tasks, uint64_t *out_jac) {
     VT_OR_FAIL(group);
+    // more than one device configured (the default on a multi-GPU node unless gmsm_set_device pinned the process) and
+    // enough points for two slices: the call is spread over them
+    if (n_points == n_scalars && nb_tasks <= 1024 && n_points >= 2 * SHARD_MIN_SLICE) {
+        const std::vector<int> devs = shard_devices();
+        if (devs.size() > 1) return multiexp_sharded_run(group, points, nullptr, scalars, n_points, devs, 0, out_jac);
+    }
     return vt->multiexp_host(points, n_points, scalars, n_scalars, nb_tasks, out_jac);
 }
 
@@ -134,7 +355,7 @@ GMSM_EXPORT int gmsm_multiexp_affine(int group, const uint64_t *points, size_t n
                                      size_t n_scalars, int nb_tasks, uint64_t *out_affine) {
     VT_OR_FAIL(group);
     std::vector<uint64_t> jac(vt->jac_bytes / 8);
-    int rc = vt->multiexp_host(points, n_points, scalars, n_scalars, nb_tasks, jac.data());
+    int rc = gmsm_multiexp(group, points, n_points, scalars, n_scalars, nb_tasks, jac.data());
     if (rc) return rc;
     vt->jac_to_affine(jac.data(), out_affine);
     return GMSM_OK;
@@ -144,7 +365,9 @@ GMSM_EXPORT int gmsm_fold(int group, const uint64_t *points, size_t n_points, co
                           int nb_tasks, uint64_t *out_jac) {
     VT_OR_FAIL(group);
     if (!combination_coeff) return fail(GMSM_ERR_ARG, "combination_coeff is null");
-    return vt->fold_points(points, n_points, combination_coeff, nb_tasks, out_jac);
+    std::vector<uint64_t> powers(n_points * (vt->scalar_bytes / 8));  // 1, g, g^2, ... (multiexp.go:331-337)
+    vt->fold_powers(combination_coeff, n_points, powers.data());
+    return gmsm_multiexp(group, points, n_points, powers.data(), n_points, nb_tasks, out_jac);
 }
 
 GMSM_EXPORT int gmsm_multiexp_device(int group, const void *d_points, const void *d_scalars, size_t n, void *hip_stream,
@@ -408,14 +631,106 @@ GMSM_EXPORT int gmsm_bases_register_dump(int group, const char *path, uint64_t o
     return GMSM_OK;
 }
 
+// Bases registered on several devices (full copies: 1 GiB per device for 2^24 BN254 G1 points, of 288 GB): any prefix of
+// them can then be cut into equal point slices - or into window sets - over the ranks, whatever its length.
+struct ShardedBases {
+    int group = -1;
+    size_t n = 0;
+    std::vector<int> devices;                                  // logical ranks
+    std::map<int, std::shared_ptr<ResidentBases>> replicas;    // device -> its copy
+};
+constexpr uint64_t SHARDED_TAG = (uint64_t)1 << 62;
+static std::vector<std::shared_ptr<ShardedBases>> g_sharded;  // handle = SHARDED_TAG | (index + 1); under g_bases_mu
+
+static std::shared_ptr<ShardedBases> lookup_sharded(uint64_t handle) {
+    std::lock_guard<std::mutex> lk(g_bases_mu);
+    const uint64_t i = handle & ~SHARDED_TAG;
+    if (!(handle & SHARDED_TAG) || i == 0 || i > g_sharded.size()) return nullptr;
+    return g_sharded[i - 1];
+}
+
+GMSM_EXPORT int gmsm_bases_register_sharded(int group, const uint64_t *points, size_t n, const int *devices, int n_devices,
+                                            uint64_t *out_handle) {
+    VT_OR_FAIL(group);
+    if (!out_handle) return fail(GMSM_ERR_ARG, "gmsm_bases_register_sharded: out_handle is null");
+    if (n && !points) return fail(GMSM_ERR_ARG, "gmsm_bases_register_sharded: points is null");
+    auto sb = std::make_shared<ShardedBases>();
+    sb->group = group;
+    sb->n = n;
+    sb->devices = (devices && n_devices > 0) ? std::vector<int>(devices, devices + n_devices) : shard_devices();
+    const int ndev = gmsm_device_count();
+    if (ndev <= 0) return fail(GMSM_ERR_DEVICE, "no usable HIP device; libgmsm has no CPU fallback");
+    if (sb->devices.empty())
+        for (int d = 0; d < ndev; ++d) sb->devices.push_back(d);
+    for (int d : sb->devices)
+        if (d < 0 || d >= ndev)
+            return fail(GMSM_ERR_DEVICE, "gmsm_bases_register_sharded: device " + std::to_string(d) + " does not exist (" +
+                                             std::to_string(ndev) + " visible)");
+    // one upload per distinct device, all of them at once (every device has its own PCIe link)
+    std::vector<int> distinct;
+    for (int d : sb->devices)
+        if (std::find(distinct.begin(), distinct.end(), d) == distinct.end()) distinct.push_back(d);
+    std::vector<uint64_t> handles(distinct.size(), 0);
+    std::vector<int> rcs(distinct.size(), GMSM_OK);
+    std::vector<std::string> errs(distinct.size());
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < distinct.size(); ++i)
+        th.emplace_back([&, i] {
+            g_device = distinct[i];  // the worker's own device: gmsm_bases_register uploads to the calling thread's
+            rcs[i] = gmsm_bases_register(group, points, nullptr, n, &handles[i]);
+            if (rcs[i]) errs[i] = gmsm_last_error();
+        });
+    for (auto &t : th) t.join();
+    int rc = GMSM_OK;
+    for (size_t i = 0; i < distinct.size(); ++i) {
+        if (rcs[i] != GMSM_OK && rc == GMSM_OK) rc = fail(rcs[i], "device " + std::to_string(distinct[i]) + ": " + errs[i]);
+        if (handles[i]) {
+            sb->replicas[distinct[i]] = lookup_bases(handles[i]);
+            (void)gmsm_bases_release(handles[i]);  // the per-device table entry goes; `replicas` keeps the bases alive
+        }
+    }
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_bases_mu);
+    g_sharded.push_back(sb);
+    *out_handle = SHARDED_TAG | (uint64_t)g_sharded.size();
+    return GMSM_OK;
+}
+
 GMSM_EXPORT int gmsm_bases_release(uint64_t handle) {
     BasesRef rb;
+    std::shared_ptr<ShardedBases> sb;
     {
         std::lock_guard<std::mutex> lk(g_bases_mu);
-        if (handle == 0 || handle > g_bases.size() || !g_bases[handle - 1]) return fail(GMSM_ERR_ARG, "unknown bases handle");
-        rb.swap(g_bases[handle - 1]);
+        if (handle & SHARDED_TAG) {
+            const uint64_t i = handle & ~SHARDED_TAG;
+            if (i == 0 || i > g_sharded.size() || !g_sharded[i - 1]) return fail(GMSM_ERR_ARG, "unknown bases handle");
+            sb.swap(g_sharded[i - 1]);
+        } else {
+            if (handle == 0 || handle > g_bases.size() || !g_bases[handle - 1]) return fail(GMSM_ERR_ARG, "unknown bases handle");
+            rb.swap(g_bases[handle - 1]);
+        }
     }
-    // calls and tickets that are still using the bases hold their own references; the memory goes with the last one
+    // Calls and tickets that are still using the bases hold their own references; the memory goes with the last one. A
+    // reference that an enqueue-only call parked on an idle workspace would otherwise live until that workspace is leased
+    // again: drop it here once its work has finished (outside the context lock - the destructor synchronises the device).
+    std::vector<Context *> ctxs;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        ctxs = g_ctx;
+    }
+    for (Context *c : ctxs) {
+        if (!c) continue;
+        BasesRef parked[2];
+        {
+            std::lock_guard<std::mutex> lk(c->mu);
+            for (int i = 0; i < 2; ++i) {
+                Workspace &w = c->ws[i];
+                if (w.busy || !w.bases_ref) continue;
+                const bool mine = w.bases_ref == rb || (sb && sb->replicas.count(c->device) && sb->replicas[c->device] == w.bases_ref);
+                if (mine && (!w.last_use || hipEventQuery(w.last_use) == hipSuccess)) parked[i].swap(w.bases_ref);
+            }
+        }
+    }
     return GMSM_OK;
 }
 
@@ -434,9 +749,28 @@ static int multiexp_bases_impl(uint64_t handle, const uint64_t *scalars, const v
     return vt->multiexp_device(*ctx, nullptr, d_scalars, n, (hipStream_t)hip_stream, out_jac, rb.get());
 }
 
+static int multiexp_bases_sharded(uint64_t handle, const uint64_t *scalars, size_t n, int nb_tasks, int mode, uint64_t *out_jac) {
+    std::shared_ptr<ShardedBases> sb = lookup_sharded(handle);
+    if (!sb) return fail(GMSM_ERR_ARG, "unknown bases handle");
+    const GroupVTable *vt = vtable(sb->group);
+    if (n > sb->n) return fail(GMSM_ERR_LEN, "len(points) != len(scalars)");  // more scalars than registered bases
+    bool done;
+    int rc = multiexp_precheck(vt, n, n, nb_tasks, out_jac, &done);
+    if (rc || done) return rc;
+    if (!scalars) return fail(GMSM_ERR_ARG, "scalars is null");
+    return multiexp_sharded_run(sb->group, nullptr, &sb->replicas, scalars, n, sb->devices, mode, out_jac);
+}
+
 GMSM_EXPORT int gmsm_multiexp_bases(uint64_t handle, const uint64_t *scalars, size_t n_scalars, int nb_tasks,
                                     uint64_t *out_jac) {
+    if (handle & SHARDED_TAG) return multiexp_bases_sharded(handle, scalars, n_scalars, nb_tasks, 0, out_jac);
     return multiexp_bases_impl(handle, scalars, nullptr, n_scalars, nb_tasks, nullptr, out_jac);
+}
+
+GMSM_EXPORT int gmsm_multiexp_bases_sharded(uint64_t handle, const uint64_t *scalars, size_t n_scalars, int nb_tasks, int mode,
+                                            uint64_t *out_jac) {
+    if (!(handle & SHARDED_TAG)) return fail(GMSM_ERR_ARG, "gmsm_multiexp_bases_sharded: not a handle of gmsm_bases_register_sharded");
+    return multiexp_bases_sharded(handle, scalars, n_scalars, nb_tasks, mode, out_jac);
 }
 
 GMSM_EXPORT int gmsm_multiexp_bases_device(uint64_t handle, const void *d_scalars, size_t n_scalars, void *hip_stream,
@@ -467,7 +801,6 @@ GMSM_EXPORT int gmsm_multiexp_bases_submit(uint64_t handle, const void *d_scalar
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         ws->bases_ref = rb;  // the ticket owns a reference until it is collected
-        ws->pending_owner = std::this_thread::get_id();
         ws->pending = true;
         ws->pending_group = rb->group;
         ++ws->pending_gen;
@@ -637,8 +970,13 @@ GMSM_EXPORT int gmsm_fft(uint64_t handle, uint64_t *a, void *d_a, size_t n, int 
         if ((rc = ws.h2d_scalars.ensure(bytes))) return rc;
         HIP_TRY(hipMemcpyAsync(ws.h2d_scalars.ptr, a, bytes, hipMemcpyHostToDevice, ws.stream));
         dev = ws.h2d_scalars.ptr;
-    } else if ((rc = order_after(ws, (hipStream_t)hip_stream))) {
-        return rc;
+    } else {
+        hipPointerAttribute_t attr;  // a vector on another GPU would fault (or read garbage) under this domain's tables
+        if (hipPointerGetAttributes(&attr, d_a) != hipSuccess || attr.type != hipMemoryTypeDevice || attr.device != d->device) {
+            (void)hipGetLastError();
+            return fail(GMSM_ERR_ARG, "gmsm_fft: d_a is not device memory of the domain's device");
+        }
+        if ((rc = order_after(ws, (hipStream_t)hip_stream))) return rc;
     }
     {
         std::lock_guard<std::mutex> lk(d->mu);
@@ -846,7 +1184,38 @@ GMSM_EXPORT int gmsm_set_device(int device) {
     if (device < 0 || device >= n) return fail(GMSM_ERR_DEVICE, "gmsm_set_device: no such device");
     g_device = device;
     g_default_device.store(device);
+    g_pinned.store(true);
     return GMSM_OK;
+}
+
+GMSM_EXPORT int gmsm_set_devices(const int *devices, int count) {
+    std::vector<int> list;
+    if (count > 0) {
+        if (!devices) return fail(GMSM_ERR_ARG, "gmsm_set_devices: devices is null");
+        const int n = gmsm_device_count();
+        for (int i = 0; i < count; ++i) {
+            if (devices[i] < 0 || devices[i] >= n)
+                return fail(GMSM_ERR_DEVICE, "gmsm_set_devices: device " + std::to_string(devices[i]) + " does not exist (" +
+                                                 std::to_string(n) + " visible)");
+            list.push_back(devices[i]);
+        }
+    }
+    std::lock_guard<std::mutex> lk(g_devices_mu);
+    g_devices = list;
+    g_devices_explicit = count > 0;
+    if (count > 0) g_default_device.store(list[0]);  // the single-device entries follow the first of them
+    else g_pinned.store(false);                      // count = 0: back to "every visible device"
+    return GMSM_OK;
+}
+
+GMSM_EXPORT int gmsm_get_devices(int *out_devices, int max_devices) {
+    const std::vector<int> list = shard_devices();
+    if (list.empty()) {  // pinned: the calling thread's device
+        if (out_devices && max_devices > 0) out_devices[0] = g_device >= 0 ? g_device : g_default_device.load();
+        return 1;
+    }
+    for (int i = 0; i < (int)list.size() && i < max_devices; ++i) out_devices[i] = list[i];
+    return (int)list.size();
 }
 
 GMSM_EXPORT const char *gmsm_last_error(void) {
@@ -856,6 +1225,6 @@ GMSM_EXPORT const char *gmsm_last_error(void) {
     }
     return g_last_error.c_str();
 }
-GMSM_EXPORT const char *gmsm_version(void) { return "gmsm 0.1 (gfx950)"; }
+GMSM_EXPORT const char *gmsm_version(void) { return "gmsm 0.3 (gfx950)"; }
 
 }  // extern "C"

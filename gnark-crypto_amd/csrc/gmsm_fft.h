@@ -337,6 +337,7 @@ struct FftField {
             hipLaunchKernelGGL((k_fft_pow_table<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(gen_inv), Fr::one(), half,
                                (Fr *)d->twiddles_inv.ptr);
             HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(stream));  // shared by later transforms on other streams (see ensure_coset_tables)
         }
         d->sat_ready = true;
         return GMSM_OK;
@@ -359,6 +360,9 @@ struct FftField {
         hipLaunchKernelGGL((k_fft_pow_table<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(shift_inv), card_inv_lz, n,
                            (Fr *)d->coset_inv_scaled.ptr);
         HIP_TRY(hipGetLastError());
+        // The tables are shared by every later transform on ANY stream (the caller holds d->mu only while it enqueues):
+        // they must be complete before the flag says so, not merely queued on the builder's stream.
+        HIP_TRY(hipStreamSynchronize(stream));
         d->coset_ready = true;
         return GMSM_OK;
     }
@@ -371,7 +375,7 @@ struct FftField {
         const unsigned blocks_n = (unsigned)((n + 255) / 256), blocks_h = (unsigned)((n / 2 + 255) / 256);
         int rc;
         if (coset && (rc = ensure_coset_tables(stream, d))) return rc;
-        const bool stagewise = env_uint("GMSM_FFT_STAGEWISE", 0) != 0, lazy = env_uint("GMSM_FFT_LAZY", 1) != 0 && !stagewise;
+        const bool stagewise = tune_uint("GMSM_FFT_STAGEWISE", 0) != 0, lazy = tune_uint("GMSM_FFT_LAZY", 1) != 0 && !stagewise;
         const bool fused = lazy && n > 1;  // the scalings ride on the first / last pass
         Fr card_inv_lz;
         memcpy(&card_inv_lz, d->cardinality_inv_lz.data(), sizeof(Fr));

@@ -71,7 +71,7 @@ struct Group {
     using OpsElem = typename Ops::Elem;
     static_assert((2 * (sizeof(XYZZ<F>) > 256 ? 128 : 256) + 1) * sizeof(OpsElem) <= 160 * 1024, "reduction LDS budget");
     static constexpr int RED_TPB = sizeof(XYZZ<F>) > 256 ? 128 : 256;  // 2*TPB*sizeof(Elem) of LDS must fit 160 KiB
-    static constexpr int RED2_TPB = 64;
+    static constexpr int RED2_TPB = 64;  // level-1 workgroups per window that level 2 (k_reduce2_quad) takes
     // Every element type except the 9-limb prime field runs the serial part of reduction level 1 as its own kernel
     // (k_reduce_serial, group law inlined, no LDS): measured reduce times fused / split - BW6-761 G1 8.87 / 6.14 ms,
     // BLS12-381 G2 5.60 / 4.42, BN254 G2 2.60 / 1.99, BLS12-381 G1 0.98 / 0.84, BN254 G1 0.365 / 0.511 (stays fused).
@@ -89,7 +89,6 @@ struct Group {
     static constexpr bool FIXLONG_ONE_SITE = GMSM_FIXLONG_INLINE != 0 && !INLINE_OPS;
     using FixLongOps = typename std::conditional<FIXLONG_ONE_SITE, OpsSerial, Ops>::type;
     static constexpr bool QUAD_INL = INLINE_OPS || GMSM_QUAD_INLINE != 0;
-    static constexpr bool QUAD_REDUCE = true;  // level 2 of the reduction on lane quads (GMSM_QUAD=0 switches it off)
 
     static WindowPlan make_plan(unsigned c, unsigned win_first, unsigned win_stride) {
         WindowPlan p;
@@ -144,53 +143,93 @@ struct Group {
         return plan.nwin_total > 1 ? std::max(low, top) : top;
     }
 
-    // One window group ("piece") of a call: windows [k0, k0 + nw) of the call's local windows, with its own accumulation
-    // and reduction geometry and its offsets into the per-thread / per-block scratch arrays.
-    struct Piece {
-        uint32_t k0, nw;
+    // Accumulation and reduction geometry of one pipeline run over nw windows of n points.
+    struct Geometry {
         uint32_t seg, tpw;                     // accumulation: entries per thread, threads per window
         uint32_t log2L, nblocks1, log2span;    // reduction
-        size_t off_thr, off_blk;               // sums of nw*tpw, nw*nblocks1 over the earlier pieces
     };
 
-    // How the call's windows are cut into pieces. The pieces run the same pipeline (group, accumulate, fix up, reduce)
-    // on alternating streams with their accumulation kernels chained by events, the idea being that the memory-bound
-    // grouping of piece p+1 and the latency-bound reduction of piece p-1 run underneath the accumulation of piece p.
-    // MEASURED (MI355X, BN254 G1, profiles/r02_split_ab.log): it does not pay. One piece 2.12 ms at 2^20, two 2.31-2.36,
-    // three 2.57-2.78; 2^24: 24.4 against 25.9-26.1. The reduction is not idle time that other work can fill: its lone
-    // wave per SIMD already issues at 84 % of the multiplier peak (tools/ubench_fpmul.hip, one block per CU), so
-    // co-resident accumulation waves only take issue slots away from it, and its 256-register workgroups cannot be
-    // placed at all until a CU has drained two thirds of its accumulation waves. The default is therefore ONE piece;
-    // GMSM_SPLIT=2..4 keeps the experiment reproducible.
-    static int plan_pieces(uint32_t nw, size_t n, uint32_t *sizes) {
-        uint32_t want = env_uint("GMSM_SPLIT", 0);
-        if (want == 0) want = 1;
-        if (want > (uint32_t)Workspace::MAX_PIECES) want = Workspace::MAX_PIECES;
-        if (want > nw) want = nw;
-        if (want <= 1) {
-            sizes[0] = nw;
-            return 1;
+    static Geometry plan_geometry(const Context &ctx, uint32_t nw, size_t n, uint32_t NB, bool split_reduce) {
+        Geometry q;
+        // reduction: buckets per level-1 thread, L = 2^log2L: as few as possible (the per-thread running sum is a
+        // serial chain) while all level-1 workgroups are resident at once - one per CU, every one of them runs a single
+        // wave per SIMD - and level 2 gets at most RED2_TPB of them per window. Measured with whole calls: BN254/BLS12-381
+        // G1 and BN254 G2 L = 8, BLS12-381 G2 L = 16, BW6-761 (24 windows) L = 32.
+        const auto blocks1 = [&](uint32_t l2) { return ((size_t)NB + ((size_t)RED_TPB << l2) - 1) / ((size_t)RED_TPB << l2); };
+        uint32_t log2L = tune_uint("GMSM_LOG2L", 0);
+        if (log2L == 0) {
+            if (split_reduce) {
+                // serial kernel: 2L dependent additions on every SIMD; combine: (2 log2 TPB + log2 L + 1) steps per
+                // round of LDS-limited workgroups. Minimise the total number of steps.
+                const size_t wg_per_round = std::max<size_t>(1, (size_t)ctx.num_cus * std::max<size_t>(1, (160 * 1024) / (2 * RED_TPB * sizeof(OpsElem))));
+                uint32_t lg_tpb = 0;
+                for (int t = RED_TPB; t > 1; t >>= 1) ++lg_tpb;
+                size_t best = ~(size_t)0;
+                for (uint32_t l2 = 1; l2 <= 8; ++l2) {
+                    if (blocks1(l2) > (size_t)RED2_TPB) continue;
+                    const size_t serial_threads = (size_t)nw * (((size_t)NB + ((size_t)1 << l2) - 1) >> l2);
+                    const size_t serial_rounds = (serial_threads + (size_t)ctx.num_cus * 256 - 1) / ((size_t)ctx.num_cus * 256);
+                    const size_t rounds = ((size_t)nw * blocks1(l2) + wg_per_round - 1) / wg_per_round;
+                    const size_t steps = serial_rounds * ((size_t)2 << l2) + rounds * (2 * lg_tpb + l2 + 1);
+                    if (steps < best) {
+                        best = steps;
+                        log2L = l2;
+                    }
+                }
+                if (log2L == 0) log2L = 8;
+            } else {
+                // (Letting an eighth of the CUs take a second workgroup to halve L - 17 windows at c = 15 are 272
+                // workgroups at L = 4 - was measured: the doubly occupied CUs run both chains at half speed and
+                // the kernel gets slower, 0.45 against 0.37 ms at 2^16.)
+                log2L = 1;
+                while ((size_t)nw * blocks1(log2L) > (size_t)ctx.num_cus && blocks1(log2L) > 1) ++log2L;
+            }
         }
-        // last piece: GMSM_SPLIT_LAST sixteenths of the windows (default 1/4), the rest spread evenly, larger pieces first
-        const uint32_t last16 = env_uint("GMSM_SPLIT_LAST", 4);
-        uint32_t last = std::max<uint32_t>(1, nw * last16 / 16);
-        if (last > nw - (want - 1)) last = nw - (want - 1);
-        uint32_t rest = nw - last;
-        for (uint32_t p = 0; p + 1 < want; ++p) {
-            const uint32_t left = want - 1 - p;
-            sizes[p] = (rest + left - 1) / left;
-            rest -= sizes[p];
+        while (blocks1(log2L) > (size_t)RED2_TPB) ++log2L;
+        q.log2L = log2L;
+        q.nblocks1 = (uint32_t)blocks1(log2L);
+        q.log2span = log2L;
+        for (int t = RED_TPB; t > 1; t >>= 1) ++q.log2span;
+        // entry-parallel segmented accumulation: seg entries per thread. Every thread does the same work, so the
+        // launch should be a whole number of resident "rounds" of WORKGROUPS: the grid is (blocks per window) x
+        // (windows), so the unit is a 256-thread block per window - nw * ceil(tpw/256) blocks must not exceed
+        // rounds x (CUs x resident blocks). (Counting threads instead put 24 x 11 = 264 blocks on 256 CUs for the
+        // 24 windows of BW6-761: eight blocks ran a second round alone and the kernel took twice as long - PMC:
+        // 1056 waves, each alive for half of the kernel.) Among the round counts that keep seg <= SEG_MAX the
+        // one that fills its last round best is taken.
+        uint32_t seg = tune_uint("GMSM_SEG", 0);
+        if (seg == 0) {
+            const size_t cap_blocks = (size_t)ctx.num_cus * AccWaves<U>::value;
+            const size_t SEG_MAX = tune_uint("GMSM_SEGMAX", 512);  // measured: 512 best at 2^24, 256 at 2^22
+            size_t best_seg = 0, first_r = 0;
+            double best_fill = -1.0;
+            for (size_t r = 1; r < 100000; ++r) {
+                const size_t bpw = r * cap_blocks / nw;  // whole blocks per window in r rounds
+                if (bpw == 0) continue;
+                const size_t sg = std::max<size_t>((n + bpw * 256 - 1) / (bpw * 256), 32);
+                if (sg > SEG_MAX) continue;
+                if (!first_r) first_r = r;
+                const size_t blocks = (size_t)nw * (((n + sg - 1) / sg + 255) / 256);
+                const double fill = (double)blocks / (double)(((blocks + cap_blocks - 1) / cap_blocks) * cap_blocks);
+                if (fill > best_fill + 1e-9) {
+                    best_fill = fill;
+                    best_seg = sg;
+                }
+                if (fill > 0.985 || r >= first_r + 5 || sg == 32) break;
+            }
+            seg = (uint32_t)(best_seg ? best_seg : 32);
         }
-        sizes[want - 1] = last;
-        (void)n;
-        return (int)want;
+        q.seg = seg;
+        q.tpw = (uint32_t)((n + seg - 1) / seg);  // threads per window (upper bound: <= n entries)
+        return q;
     }
 
-    // Launches every kernel of one MultiExp and queues the copy of the window totals into ws.pinned; does not wait.
-    // `stream` carries the call (inputs are ready there; the totals are complete there); the workspace's second stream
-    // runs every other piece and is joined back before the copy. All scratch comes from `ws`, so two workspaces can be in
-    // flight at once.
+    // Launches every kernel of one pipeline run and queues the copy of the window totals into ws.pinned; does not wait.
+    // `stream` carries the call (inputs are ready there; the totals are complete there). All scratch comes from `ws`, so
+    // two workspaces can be in flight at once.
     // d_out != nullptr: the totals stay on the device (copied to d_out in stream order) instead of going to ws.pinned.
+    // (Round 2 could cut the windows of a call into groups on two streams so that the reduction of one group ran under
+    // the accumulation of the next; measured slower in every configuration - profiles/r02_split_ab.log - and removed.)
     static int enqueue_window_sums(Context &ctx, Workspace &ws, const void *d_points, const void *d_scalars, size_t n,
                                    const WindowPlan &plan, hipStream_t stream, const ResidentBases *resident,
                                    void *d_out = nullptr, size_t resident_offset = 0 /* first registered base used */) {
@@ -198,9 +237,7 @@ struct Group {
         ws.pending_timed = false;
         if (nw == 0) return GMSM_OK;
         if (ws.uncollected) {  // stage events of an enqueue-only call (nobody waited for it): pick them up now
-            bool done = ws.timed_pieces > 0;
-            for (int p = 0; p < ws.timed_pieces; ++p) done = done && hipEventQuery(ws.events[p][T_END]) == hipSuccess;
-            if (done) StageTimer::collect(ws);
+            if (ws.timed && hipEventQuery(ws.events[T_END]) == hipSuccess) StageTimer::collect(ws);
             ws.uncollected = false;
         }
         // The workspace may still be in use by work enqueued earlier on another stream: order behind it.
@@ -222,100 +259,12 @@ struct Group {
         constexpr size_t REC = sizeof(typename Ops::Mem);  // bucket / partial record (lazy representation on the fast path)
         static_assert(sizeof(typename Ops::Mem) == sizeof(typename OpsNI::Mem), "one record format per group");
 
-        const bool split_reduce = env_uint("GMSM_SPLIT_REDUCE", SPLIT_REDUCE_DEFAULT ? 1 : 0) != 0;
-        // ---- pieces and their geometry
-        uint32_t psize[Workspace::MAX_PIECES];
-        const int npieces = plan_pieces(nw, n, psize);
-        Piece pc[Workspace::MAX_PIECES];
-        {
-            uint32_t k0 = 0;
-            size_t off_thr = 0, off_blk = 0;
-            for (int p = 0; p < npieces; ++p) {
-                Piece &q = pc[p];
-                q.k0 = k0;
-                q.nw = psize[p];
-                // reduction: buckets per level-1 thread, L = 2^log2L: as few as possible (the per-thread running sum is a
-                // serial chain) while all level-1 workgroups of the piece are resident at once - one per CU, every one of
-                // them runs a single wave per SIMD - and level 2 gets at most RED2_TPB of them per window. Measured with
-                // whole calls: BN254/BLS12-381 G1 and BN254 G2 L = 8, BLS12-381 G2 L = 16, BW6-761 (24 windows) L = 32.
-                const auto blocks1 = [&](uint32_t l2) { return ((size_t)NB + ((size_t)RED_TPB << l2) - 1) / ((size_t)RED_TPB << l2); };
-                uint32_t log2L = env_uint("GMSM_LOG2L", 0);
-                if (log2L == 0) {
-                    if (split_reduce) {
-                        // serial kernel: 2L dependent additions on every SIMD; combine: (2 log2 TPB + log2 L + 1) steps per
-                        // round of LDS-limited workgroups. Minimise the total number of steps.
-                        const size_t wg_per_round = std::max<size_t>(1, (size_t)ctx.num_cus * std::max<size_t>(1, (160 * 1024) / (2 * RED_TPB * sizeof(OpsElem))));
-                        uint32_t lg_tpb = 0;
-                        for (int t = RED_TPB; t > 1; t >>= 1) ++lg_tpb;
-                        size_t best = ~(size_t)0;
-                        for (uint32_t l2 = 1; l2 <= 8; ++l2) {
-                            if (blocks1(l2) > (size_t)RED2_TPB) continue;
-                            const size_t serial_threads = (size_t)q.nw * (((size_t)NB + ((size_t)1 << l2) - 1) >> l2);
-                            const size_t serial_rounds = (serial_threads + (size_t)ctx.num_cus * 256 - 1) / ((size_t)ctx.num_cus * 256);
-                            const size_t rounds = ((size_t)q.nw * blocks1(l2) + wg_per_round - 1) / wg_per_round;
-                            const size_t steps = serial_rounds * ((size_t)2 << l2) + rounds * (2 * lg_tpb + l2 + 1);
-                            if (steps < best) {
-                                best = steps;
-                                log2L = l2;
-                            }
-                        }
-                        if (log2L == 0) log2L = 8;
-                    } else {
-                        // (Letting an eighth of the CUs take a second workgroup to halve L - 17 windows at c = 15 are 272
-                        // workgroups at L = 4 - was measured: the doubly occupied CUs run both chains at half speed and
-                        // the kernel gets slower, 0.45 against 0.37 ms at 2^16.)
-                        log2L = 1;
-                        while ((size_t)q.nw * blocks1(log2L) > (size_t)ctx.num_cus && blocks1(log2L) > 1) ++log2L;
-                    }
-                }
-                while (blocks1(log2L) > (size_t)RED2_TPB) ++log2L;
-                q.log2L = log2L;
-                q.nblocks1 = (uint32_t)blocks1(log2L);
-                q.log2span = log2L;
-                for (int t = RED_TPB; t > 1; t >>= 1) ++q.log2span;
-                // entry-parallel segmented accumulation: seg entries per thread. Every thread does the same work, so the
-                // launch should be a whole number of resident "rounds" of WORKGROUPS: the grid is (blocks per window) x
-                // (windows), so the unit is a 256-thread block per window - nw * ceil(tpw/256) blocks must not exceed
-                // rounds x (CUs x resident blocks). (Counting threads instead put 24 x 11 = 264 blocks on 256 CUs for the
-                // 24 windows of BW6-761: eight blocks ran a second round alone and the kernel took twice as long - PMC:
-                // 1056 waves, each alive for half of the kernel.) Among the round counts that keep seg <= SEG_MAX the
-                // one that fills its last round best is taken.
-                uint32_t seg = env_uint("GMSM_SEG", 0);
-                if (seg == 0) {
-                    const size_t cap_blocks = (size_t)ctx.num_cus * AccWaves<U>::value;
-                    const size_t SEG_MAX = env_uint("GMSM_SEGMAX", 512);  // measured: 512 best at 2^24, 256 at 2^22
-                    size_t best_seg = 0, first_r = 0;
-                    double best_fill = -1.0;
-                    for (size_t r = 1; r < 100000; ++r) {
-                        const size_t bpw = r * cap_blocks / q.nw;  // whole blocks per window in r rounds
-                        if (bpw == 0) continue;
-                        const size_t sg = std::max<size_t>((n + bpw * 256 - 1) / (bpw * 256), 32);
-                        if (sg > SEG_MAX) continue;
-                        if (!first_r) first_r = r;
-                        const size_t blocks = (size_t)q.nw * (((n + sg - 1) / sg + 255) / 256);
-                        const double fill = (double)blocks / (double)(((blocks + cap_blocks - 1) / cap_blocks) * cap_blocks);
-                        if (fill > best_fill + 1e-9) {
-                            best_fill = fill;
-                            best_seg = sg;
-                        }
-                        if (fill > 0.985 || r >= first_r + 5 || sg == 32) break;
-                    }
-                    seg = (uint32_t)(best_seg ? best_seg : 32);
-                }
-                q.seg = seg;
-                q.tpw = (uint32_t)((n + seg - 1) / seg);  // threads per window (upper bound: <= n entries)
-                q.off_thr = off_thr;
-                q.off_blk = off_blk;
-                off_thr += (size_t)q.nw * q.tpw;
-                off_blk += (size_t)q.nw * q.nblocks1;
-                k0 += q.nw;
-            }
-        }
-        const Piece &lastp = pc[npieces - 1];
-        const size_t tot_thr = lastp.off_thr + (size_t)lastp.nw * lastp.tpw;
-        const size_t tot_blk = lastp.off_blk + (size_t)lastp.nw * lastp.nblocks1;
+        const bool split_reduce = tune_uint("GMSM_SPLIT_REDUCE", SPLIT_REDUCE_DEFAULT ? 1 : 0) != 0;
+        const Geometry q = plan_geometry(ctx, nw, n, NB, split_reduce);
+        const size_t tot_thr = (size_t)nw * q.tpw;
+        const size_t tot_blk = (size_t)nw * q.nblocks1;
 
-        // ---- grouping geometry (the same for every piece)
+        // ---- grouping geometry
         uint32_t log2NB = 0;
         while ((1u << log2NB) < NB) ++log2NB;
         uint32_t log2n = 0;
@@ -323,7 +272,7 @@ struct Group {
         const uint32_t lidx = log2n + 1;  // bits of (index << 1 | negate)
         // target partition population 2^part_log2 (measured, BN254 G1: 2^13 is best up to 2^21 points - more
         // workgroups for the fine pass; 2^15 from 2^24 on - 128-byte runs out of the coarse pass)
-        const uint32_t part_log2 = env_uint("GMSM_PART_LOG2", log2n <= 21 ? 13 : log2n >= 24 ? 15 : 14);
+        const uint32_t part_log2 = tune_uint("GMSM_PART_LOG2", log2n <= 21 ? 13 : log2n >= 24 ? 15 : 14);
         int fb = (int)part_log2 + (int)log2NB - (int)log2n;
         if (fb > (int)log2NB) fb = (int)log2NB;
         if (fb > 15) fb = 15;  // the fine pass keeps 2^fb counters in LDS (128 KiB): windows wider than 16 bits on few points
@@ -342,11 +291,11 @@ struct Group {
         // staging slots of the fine pass: up to 96 KiB next to the 2^fbits counters; larger partitions go direct
         const size_t fine_cnt_bytes = (size_t)4 << fbits;
         const uint32_t stage_cap = fine_cnt_bytes >= 156 * 1024 ? 0u
-                                   : (uint32_t)std::min<size_t>(env_uint("GMSM_STAGE_CAP", part_log2 >= 15 ? 39000 : 24576),
+                                   : (uint32_t)std::min<size_t>(tune_uint("GMSM_STAGE_CAP", part_log2 >= 15 ? 39000 : 24576),
                                                               (156 * 1024 - fine_cnt_bytes) / 4);
         if (fine_cnt_bytes + (size_t)stage_cap * 4 > 160 * 1024)  // cannot happen with fb <= 15; a failed launch must not
             return fail(GMSM_ERR_ARG, "window geometry: fine-sort counters exceed the LDS");  // leave garbage for the next kernels
-        const bool d16 = max_digit_code(plan) < 65536 && env_uint("GMSM_DIGIT32", 0) == 0;
+        const bool d16 = max_digit_code(plan) < 65536;
         const size_t dsz = d16 ? 2 : 4;
 
         // ---- scratch
@@ -356,10 +305,8 @@ struct Group {
         if ((rc = ws.starts.ensure((size_t)nw * (NB + 1) * 4))) return rc;
         if ((rc = ws.buckets.ensure((size_t)nw * NB * REC))) return rc;
         if ((rc = ws.partials.ensure(tot_blk * 2 * REC))) return rc;
-        size_t tot_pre = 0;  // (S, W) pairs of k_reduce_serial, all pieces
-        if (split_reduce)
-            for (int p = 0; p < npieces; ++p) tot_pre += (size_t)pc[p].nw * (((size_t)NB + ((size_t)1 << pc[p].log2L) - 1) >> pc[p].log2L);
-        if ((rc = ws.red_pre.ensure(tot_pre * 2 * REC))) return rc;
+        const uint32_t T = (uint32_t)(((size_t)NB + ((size_t)1 << q.log2L) - 1) >> q.log2L);  // (S, W) pairs per window of k_reduce_serial
+        if (split_reduce && (rc = ws.red_pre.ensure((size_t)nw * T * 2 * REC))) return rc;
         if ((rc = ws.totals.ensure((size_t)nw * sizeof(Ext)))) return rc;
         if ((rc = ws.ensure_pinned((size_t)nw * sizeof(Ext)))) return rc;
         if ((rc = ws.blockhist.ensure((size_t)nw * pchunks * nparts * 4))) return rc;
@@ -367,14 +314,14 @@ struct Group {
         if ((rc = ws.seg_partials.ensure(tot_thr * 2 * REC))) return rc;
         if ((rc = ws.seg_flags.ensure(tot_thr * 4))) return rc;
         if ((rc = ws.seg_bucket.ensure(tot_thr * 4))) return rc;
-        // long-chain list of the fixup (k_fixup_seg appends, k_fixup_long consumes): one counter per window slot (a piece
-        // uses the slot of its first window; k_part_rowscan zeroes them) + at most one entry per FIXUP_MAXWALK threads
+        // long-chain list of the fixup (k_fixup_seg appends, k_fixup_long consumes): one counter (slot of the first window;
+        // k_part_rowscan zeroes it) + at most one entry per FIXUP_MAXWALK threads
         const size_t list_cap = tot_thr / FIXUP_MAXWALK + nw + 1;
         if ((rc = ws.seg_lvl.ensure((size_t)nw * 4 + 16 + list_cap * sizeof(LongChain)))) return rc;
-        uint32_t *long_flag_all = (uint32_t *)ws.seg_lvl.ptr;                                  // [nw] counters
-        LongChain *long_list_all = (LongChain *)((char *)ws.seg_lvl.ptr + (((size_t)nw * 4 + 15) / 16) * 16);
-        uint32_t *bh_all = (uint32_t *)ws.blockhist.ptr, *part_base_all = (uint32_t *)ws.counts.ptr;
-        uint32_t *part_pop_all = part_base_all + (size_t)nw * (nparts + 1);
+        uint32_t *long_flag = (uint32_t *)ws.seg_lvl.ptr;                                  // [nw] counters, [0] is used
+        LongChain *long_list = (LongChain *)((char *)ws.seg_lvl.ptr + (((size_t)nw * 4 + 15) / 16) * 16);
+        uint32_t *bh = (uint32_t *)ws.blockhist.ptr, *part_base = (uint32_t *)ws.counts.ptr;
+        uint32_t *part_pop = part_base + (size_t)nw * (nparts + 1);
 
         if ((rc = ctx.allow_lds((const void *)k_part_hist<uint16_t>, 160 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_part_hist<uint32_t>, 160 * 1024))) return rc;
@@ -388,13 +335,12 @@ struct Group {
             if constexpr (GMSM_COMBINE_LDS != 0)
                 if ((rc = ctx.allow_lds((const void *)k_reduce_combine_lds<OpsSerial, RED_TPB>, (int)((2 * RED_TPB + 1) * sizeof(OpsElem))))) return rc;
         }
-        if ((rc = ctx.allow_lds((const void *)k_reduce2<Ops, RED2_TPB>, (int)(2 * RED2_TPB * sizeof(OpsElem))))) return rc;
 
         StageTimer timer(ws);
-        ws.timed_pieces = npieces;
-        // ---- 0. inputs, once for all pieces: rewrite the bases into the lazy Montgomery domain + infinity flags (unless
-        // registered earlier), signed-digit decomposition of every scalar
-        timer.mark(0, T_DECOMPOSE, stream);
+        ws.timed = timer.on;
+        // ---- 0. inputs: rewrite the bases into the lazy Montgomery domain + infinity flags (unless registered earlier),
+        // signed-digit decomposition of every scalar
+        timer.mark(T_DECOMPOSE, stream);
         const uint8_t *skip = nullptr;
         const void *upoints = nullptr;
         if (resident) {
@@ -416,123 +362,82 @@ struct Group {
         else
             hipLaunchKernelGGL((k_decompose<FrP, uint32_t>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                                (const uint32_t *)d_scalars, n, plan, (uint32_t *)ws.digits.ptr, skip);
-        if (npieces > 1) {
-            HIP_TRY(hipEventRecord(ws.ev_fork, stream));
-            HIP_TRY(hipStreamWaitEvent(ws.stream2, ws.ev_fork, 0));
-        }
 
-        size_t pre_off = 0;
-        for (int p = 0; p < npieces; ++p) {
-            const Piece &q = pc[p];
-            hipStream_t st = (p & 1) ? ws.stream2 : stream;
-            const uint32_t k0 = q.k0, nwp = q.nw;
-            // this piece's slices of the window-major arrays
-            const char *digits = (const char *)ws.digits.ptr + (size_t)k0 * n * dsz;
-            uint32_t *sorted = (uint32_t *)ws.sorted.ptr + (size_t)k0 * n;
-            uint32_t *parted = (uint32_t *)ws.parted.ptr + (size_t)k0 * n;
-            uint32_t *starts = (uint32_t *)ws.starts.ptr + (size_t)k0 * (NB + 1);
-            uint32_t *bh = bh_all + (size_t)k0 * pchunks * nparts;
-            uint32_t *part_base = part_base_all + (size_t)k0 * (nparts + 1);
-            uint32_t *part_pop = part_pop_all + (size_t)k0 * nparts;
-            char *buckets = (char *)ws.buckets.ptr + (size_t)k0 * NB * REC;
-            char *seg_partials = (char *)ws.seg_partials.ptr + q.off_thr * 2 * REC;
-            uint32_t *seg_flags = (uint32_t *)ws.seg_flags.ptr + q.off_thr;
-            uint32_t *seg_bucket = (uint32_t *)ws.seg_bucket.ptr + q.off_thr;
-            uint32_t *long_flag = long_flag_all + k0;                                   // this piece's chain counter
-            LongChain *long_list = long_list_all + q.off_thr / FIXUP_MAXWALK + k0;      // disjoint slices per piece
-            char *partials = (char *)ws.partials.ptr + q.off_blk * 2 * REC;
-            char *totals = (char *)ws.totals.ptr + (size_t)k0 * sizeof(Ext);
+        const void *digits = ws.digits.ptr;
+        uint32_t *sorted = (uint32_t *)ws.sorted.ptr, *parted = (uint32_t *)ws.parted.ptr, *starts = (uint32_t *)ws.starts.ptr;
+        char *buckets = (char *)ws.buckets.ptr, *seg_partials = (char *)ws.seg_partials.ptr;
+        uint32_t *seg_flags = (uint32_t *)ws.seg_flags.ptr, *seg_bucket = (uint32_t *)ws.seg_bucket.ptr;
+        char *partials = (char *)ws.partials.ptr, *totals = (char *)ws.totals.ptr;
 
-            // ---- 1. group the point references of every window by bucket
-            timer.mark(p, T_HIST, st);
-            if (d16)
-                hipLaunchKernelGGL(k_part_hist<uint16_t>, dim3(pchunks, nwp), dim3(1024), (size_t)nparts * 4, st,
-                                   (const uint16_t *)digits, n, nparts, fbits, pchunk_len, bh);
-            else
-                hipLaunchKernelGGL(k_part_hist<uint32_t>, dim3(pchunks, nwp), dim3(1024), (size_t)nparts * 4, st,
-                                   (const uint32_t *)digits, n, nparts, fbits, pchunk_len, bh);
-            timer.mark(p, T_SCAN, st);
-            hipLaunchKernelGGL(k_part_colscan, dim3((nparts + 31) / 32, nwp), dim3(256), 0, st, bh, pchunks, nparts, part_pop);
-            hipLaunchKernelGGL(k_part_rowscan, dim3(nwp), dim3(1024), 0, st, part_pop, nparts, part_base, long_flag);
-            timer.mark(p, T_SCATTER, st);
-            if (d16)
-                hipLaunchKernelGGL(k_part_scatter<uint16_t>, dim3(pchunks, nwp), dim3(1024), scatter_lds, st,
-                                   (const uint16_t *)digits, n, nparts, fbits, lidx, pchunk_len, bh, part_base, parted);
-            else
-                hipLaunchKernelGGL(k_part_scatter<uint32_t>, dim3(pchunks, nwp), dim3(1024), scatter_lds, st,
-                                   (const uint32_t *)digits, n, nparts, fbits, lidx, pchunk_len, bh, part_base, parted);
-            hipLaunchKernelGGL(k_fine_sort, dim3(nparts, nwp), dim3(1024), ((size_t)4 << fbits) + (size_t)stage_cap * 4, st,
-                               parted, n, NB, fbits, lidx, part_base, sorted, starts, stage_cap);
-            // ---- 2. bucket accumulation, after the previous piece's
-            timer.mark(p, T_WAIT, st);
-            if (p > 0) HIP_TRY(hipStreamWaitEvent(st, ws.ev_acc[p - 1], 0));
-            timer.mark(p, T_ACCUMULATE, st);
-            hipLaunchKernelGGL((k_accumulate_seg<U>), dim3((q.tpw + 255) / 256, nwp), dim3(256), 0, st, upoints, n, NB, q.seg,
-                               starts, sorted, buckets, seg_partials, seg_flags, seg_bucket, q.tpw);
-            if (p + 1 < npieces) HIP_TRY(hipEventRecord(ws.ev_acc[p], st));
-            timer.mark(p, T_FIXUP, st);
-            hipLaunchKernelGGL((k_fixup_seg<FixOps>), dim3((q.tpw + 255) / 256, nwp), dim3(256), 0, st, NB, seg_partials,
-                               (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets, long_flag, long_list);
-            hipLaunchKernelGGL((k_fixup_long<FixLongOps, FIXLONG_ONE_SITE>), dim3(2 * ctx.num_cus), dim3(256), 256 * sizeof(OpsElem), st, NB, seg_partials,
-                               (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets,
-                               (const uint32_t *)long_flag, (const LongChain *)long_list);
-            // ---- 3. bucket reduction -> window totals (empty buckets are never written: the reduction consults starts[])
-            timer.mark(p, T_REDUCE, st);
-            {
-                // level 1 doubles its S_blk log2span times in an otherwise idle wave (256-thread blocks only): level 2 then
-                // has no serial doubling tail (11 of its 20 steps at c = 16)
-                // (k_reduce_combine_lds prescales for every workgroup size)
-                const bool lds_combine = GMSM_COMBINE_LDS != 0 && COMBINE_INLINE && split_reduce;
-                const uint32_t prescale = ((RED_TPB >= 256 || lds_combine) && env_uint("GMSM_PRESCALE", 1)) ? q.log2span : 0u;
-                const void *pre = nullptr;
-                uint32_t T = 0;
-                if (split_reduce) {
-                    T = (uint32_t)(((size_t)NB + ((size_t)1 << q.log2L) - 1) >> q.log2L);
-                    char *pre_w = (char *)ws.red_pre.ptr + pre_off * 2 * REC;
-                    pre_off += (size_t)nwp * T;
-                    hipLaunchKernelGGL((k_reduce_serial<OpsSerial>), dim3((T + 255) / 256, nwp), dim3(256), 0, st, buckets, NB,
-                                       q.log2L, T, starts, pre_w);
-                    pre = pre_w;
-                }
-                bool combined = false;
-                if constexpr (COMBINE_INLINE) {
-                    if (split_reduce) {
-                        if constexpr (GMSM_COMBINE_LDS != 0)
-                            hipLaunchKernelGGL((k_reduce_combine_lds<OpsSerial, RED_TPB>), dim3(q.nblocks1, nwp), dim3(RED_TPB),
-                                               (2 * RED_TPB + 1) * sizeof(OpsElem), st, q.log2L, partials, prescale, pre, T);
-                        else
-                            hipLaunchKernelGGL((k_reduce_combine<OpsSerial, RED_TPB>), dim3(q.nblocks1, nwp), dim3(RED_TPB),
-                                               2 * RED_TPB * sizeof(OpsElem), st, q.log2L, partials, prescale, pre, T);
-                        combined = true;
-                    }
-                }
-                if (!combined)
-                    hipLaunchKernelGGL((k_reduce1<Ops, RED_TPB>), dim3(q.nblocks1, nwp), dim3(RED_TPB), 2 * RED_TPB * sizeof(OpsElem), st,
-                                       buckets, NB, q.log2L, partials, starts, prescale, pre, T);
-                bool l2 = false;
-                if constexpr (QUAD_REDUCE) {
-                    // level 2 on quads of lanes (4 lanes share the products of one addition). Level 1 stays
-                    // on single lanes: a quad version needs 4x the lanes at ~230 VGPRs each, i.e. several rounds of
-                    // workgroups per CU - measured 0.57 ms against 0.37 ms.
-                    if (env_uint("GMSM_QUAD", 1) >= 1) {
-                        uint32_t active = 2;
-                        while (active < q.nblocks1) active <<= 1;
-                        hipLaunchKernelGGL((k_reduce2_quad<U, QUAD_INL>), dim3(nwp), dim3(4 * active), active * sizeof(OpsElem),
-                                           st, partials, q.nblocks1, q.log2span - prescale, active, totals);
-                        l2 = true;
-                    }
-                }
-                if (!l2)
-                    hipLaunchKernelGGL((k_reduce2<Ops, RED2_TPB>), dim3(nwp), dim3(RED2_TPB), 2 * RED2_TPB * sizeof(OpsElem), st,
-                                       partials, q.nblocks1, q.log2span - prescale, totals);
+        // ---- 1. group the point references of every window by bucket
+        timer.mark(T_HIST, stream);
+        if (d16)
+            hipLaunchKernelGGL(k_part_hist<uint16_t>, dim3(pchunks, nw), dim3(1024), (size_t)nparts * 4, stream,
+                               (const uint16_t *)digits, n, nparts, fbits, pchunk_len, bh);
+        else
+            hipLaunchKernelGGL(k_part_hist<uint32_t>, dim3(pchunks, nw), dim3(1024), (size_t)nparts * 4, stream,
+                               (const uint32_t *)digits, n, nparts, fbits, pchunk_len, bh);
+        timer.mark(T_SCAN, stream);
+        hipLaunchKernelGGL(k_part_colscan, dim3((nparts + 31) / 32, nw), dim3(256), 0, stream, bh, pchunks, nparts, part_pop);
+        hipLaunchKernelGGL(k_part_rowscan, dim3(nw), dim3(1024), 0, stream, part_pop, nparts, part_base, long_flag);
+        timer.mark(T_SCATTER, stream);
+        if (d16)
+            hipLaunchKernelGGL(k_part_scatter<uint16_t>, dim3(pchunks, nw), dim3(1024), scatter_lds, stream,
+                               (const uint16_t *)digits, n, nparts, fbits, lidx, pchunk_len, bh, part_base, parted);
+        else
+            hipLaunchKernelGGL(k_part_scatter<uint32_t>, dim3(pchunks, nw), dim3(1024), scatter_lds, stream,
+                               (const uint32_t *)digits, n, nparts, fbits, lidx, pchunk_len, bh, part_base, parted);
+        hipLaunchKernelGGL(k_fine_sort, dim3(nparts, nw), dim3(1024), ((size_t)4 << fbits) + (size_t)stage_cap * 4, stream,
+                           parted, n, NB, fbits, lidx, part_base, sorted, starts, stage_cap);
+        // ---- 2. bucket accumulation
+        timer.mark(T_ACCUMULATE, stream);
+        hipLaunchKernelGGL((k_accumulate_seg<U>), dim3((q.tpw + 255) / 256, nw), dim3(256), 0, stream, upoints, n, NB, q.seg,
+                           starts, sorted, buckets, seg_partials, seg_flags, seg_bucket, q.tpw);
+        timer.mark(T_FIXUP, stream);
+        hipLaunchKernelGGL((k_fixup_seg<FixOps>), dim3((q.tpw + 255) / 256, nw), dim3(256), 0, stream, NB, seg_partials,
+                           (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets, long_flag, long_list);
+        hipLaunchKernelGGL((k_fixup_long<FixLongOps, FIXLONG_ONE_SITE>), dim3(2 * ctx.num_cus), dim3(256), 256 * sizeof(OpsElem), stream, NB, seg_partials,
+                           (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets,
+                           (const uint32_t *)long_flag, (const LongChain *)long_list);
+        // ---- 3. bucket reduction -> window totals (empty buckets are never written: the reduction consults starts[])
+        timer.mark(T_REDUCE, stream);
+        {
+            // level 1 doubles its S_blk log2span times in an otherwise idle wave (256-thread blocks only): level 2 then
+            // has no serial doubling tail (11 of its 20 steps at c = 16)
+            // (k_reduce_combine_lds prescales for every workgroup size)
+            const bool lds_combine = GMSM_COMBINE_LDS != 0 && COMBINE_INLINE && split_reduce;
+            const uint32_t prescale = (RED_TPB >= 256 || lds_combine) ? q.log2span : 0u;
+            const void *pre = nullptr;
+            if (split_reduce) {
+                hipLaunchKernelGGL((k_reduce_serial<OpsSerial>), dim3((T + 255) / 256, nw), dim3(256), 0, stream, buckets, NB,
+                                   q.log2L, T, starts, ws.red_pre.ptr);
+                pre = ws.red_pre.ptr;
             }
-            timer.mark(p, T_END, st);
+            bool combined = false;
+            if constexpr (COMBINE_INLINE) {
+                if (split_reduce) {
+                    if constexpr (GMSM_COMBINE_LDS != 0)
+                        hipLaunchKernelGGL((k_reduce_combine_lds<OpsSerial, RED_TPB>), dim3(q.nblocks1, nw), dim3(RED_TPB),
+                                           (2 * RED_TPB + 1) * sizeof(OpsElem), stream, q.log2L, partials, prescale, pre, T);
+                    else
+                        hipLaunchKernelGGL((k_reduce_combine<OpsSerial, RED_TPB>), dim3(q.nblocks1, nw), dim3(RED_TPB),
+                                           2 * RED_TPB * sizeof(OpsElem), stream, q.log2L, partials, prescale, pre, T);
+                    combined = true;
+                }
+            }
+            if (!combined)
+                hipLaunchKernelGGL((k_reduce1<Ops, RED_TPB>), dim3(q.nblocks1, nw), dim3(RED_TPB), 2 * RED_TPB * sizeof(OpsElem), stream,
+                                   buckets, NB, q.log2L, partials, starts, prescale, pre, T);
+            // level 2 on quads of lanes (4 lanes share the products of one addition). Level 1 stays on single lanes: a
+            // quad version needs 4x the lanes at ~230 VGPRs each, i.e. several rounds of workgroups per CU - measured
+            // 0.57 ms against 0.37 ms.
+            uint32_t active = 2;
+            while (active < q.nblocks1) active <<= 1;
+            hipLaunchKernelGGL((k_reduce2_quad<U, QUAD_INL>), dim3(nw), dim3(4 * active), active * sizeof(OpsElem),
+                               stream, partials, q.nblocks1, q.log2span - prescale, active, totals);
         }
+        timer.mark(T_END, stream);
         HIP_TRY(hipGetLastError());
-        if (npieces > 1) {  // everything queued on the second stream is finished before the totals leave
-            HIP_TRY(hipEventRecord(ws.ev_join, ws.stream2));
-            HIP_TRY(hipStreamWaitEvent(stream, ws.ev_join, 0));
-        }
         if (d_out)
             HIP_TRY(hipMemcpyAsync(d_out, ws.totals.ptr, (size_t)nw * sizeof(Ext), hipMemcpyDeviceToDevice, stream));
         else
@@ -692,7 +597,7 @@ struct Group {
             return GMSM_OK;
         }
         // table size against additions per scalar: 2^7 x 32 windows up to 2^21 scalars, 2^10 x 24 beyond (BN254)
-        const unsigned c = env_uint("GMSM_FB_C", n < ((size_t)1 << 21) ? 8 : 11);
+        const unsigned c = tune_uint("GMSM_FB_C", n < ((size_t)1 << 21) ? 8 : 11);
         if (c < 2 || c > 14) return fail(GMSM_ERR_ARG, "GMSM_FB_C out of range (2..14)");
         const WindowPlan plan = make_plan(c, 0, 1);
         std::vector<Aff> table;
@@ -840,17 +745,17 @@ struct Group {
         return GMSM_OK;
     }
 
-    // (*G1Jac).Fold (multiexp.go:331-340): scalars 1, g, g^2, ... (Montgomery fr products on the host), then MultiExp.
-    static int fold_host(const uint64_t *points, size_t n, const uint64_t *coeff, int nb_tasks, J *out) {
+    // (*G1Jac).Fold (multiexp.go:331-340): the scalars 1, g, g^2, ... (Montgomery fr products on the host); the engine then
+    // runs the MultiExp entry over them.
+    static void fold_powers(const uint64_t *coeff, size_t n, uint64_t *out_scalars) {
         using Fr = Fp<FrP>;
-        std::vector<Fr> scalars(n);
+        Fr *scalars = reinterpret_cast<Fr *>(out_scalars);
         Fr g, s = Fr::one();
         memcpy(&g, coeff, sizeof g);
         for (size_t i = 0; i < n; ++i) {
             scalars[i] = s;
             s = fp_mul(s, g);
         }
-        return multiexp_host(points, n, reinterpret_cast<const uint64_t *>(scalars.data()), n, nb_tasks, out);
     }
 
     // Number of point ranges a host-buffer MultiExp is cut into so that the H2D copy of range k+1 runs under the
@@ -874,18 +779,17 @@ struct Group {
         return (unsigned)std::min<size_t>(64, n >> 22);
     }
 
-    // MultiExp with the scalars (and, unless `resident`, the points) in host memory. `first` is leased by the caller;
-    // a second workspace is borrowed when one is free, otherwise the ranges run one after the other.
-    static int multiexp_from_host(Context &ctx, Workspace &first, const uint64_t *points, const ResidentBases *resident,
-                                  const uint64_t *scalars, size_t n, J *out) {
-        unsigned nr = host_ranges(n, points != nullptr);
-        const size_t run = max_run_points();
-        if ((n + nr - 1) / nr > run) nr = (unsigned)((n + run - 1) / run);
+    // Window totals of a MultiExp whose scalars (and, unless `resident`, points) are in host memory: the windows of `plan`
+    // over points [0, n) (registered bases: [resident_base, resident_base + n)), cut into point ranges whose copies run
+    // under the pipeline of the previous range; out_totals receives plan.nwin_local totals (the ranges' totals added on the
+    // host, g1JacExtended.add). `first` is leased by the caller; a second workspace is borrowed when one is free,
+    // otherwise the ranges run one after the other.
+    static int window_sums_from_host(Context &ctx, Workspace &first, const uint64_t *points, const ResidentBases *resident,
+                                     size_t resident_base, const uint64_t *scalars, size_t n, const WindowPlan &plan,
+                                     unsigned nr, Ext *out_totals) {
+        const uint32_t nw = plan.nwin_local;
+        if (nw == 0) return GMSM_OK;
         const size_t per = (n + nr - 1) / nr;
-        nr = (unsigned)((n + per - 1) / per);
-        const unsigned c = choose_c(FR_BITS, AFF_BYTES, per);  // one c for every range: the totals must line up
-        WindowPlan plan = make_plan(c, 0, 1);
-        const uint32_t nw = plan.nwin_total;
         Workspace *w[2] = {&first, nr > 1 ? ctx.acquire(false) : nullptr};
         const unsigned nws = w[1] ? 2 : 1;
         std::vector<Ext> sets((size_t)nr * nw);
@@ -913,7 +817,9 @@ struct Group {
                     }
                     dp = ws.h2d_points.ptr;
                 }
-                if ((rc = enqueue_window_sums(ctx, ws, dp, ws.h2d_scalars.ptr, len, plan, ws.stream, resident, nullptr, lo))) break;
+                if ((rc = enqueue_window_sums(ctx, ws, dp, ws.h2d_scalars.ptr, len, plan, ws.stream, resident, nullptr,
+                                              resident_base + lo)))
+                    break;
                 ++submitted;
             }
             if (rc) break;
@@ -928,8 +834,51 @@ struct Group {
             (void)hipStreamSynchronize(first.stream);
             return rc;
         }
-        *out = nr == 1 ? fold(sets.data(), c) : fold_sets(sets.data(), nr, c);
+        for (uint32_t k = 0; k < nw; ++k) {
+            Ext t = sets[k];
+            for (unsigned r = 1; r < nr; ++r) xyzz_add(t, sets[(size_t)r * nw + k]);
+            out_totals[k] = t;
+        }
         return GMSM_OK;
+    }
+
+    // Point ranges of a host-buffer call over n points: host_ranges(), more if one of them would exceed a pipeline run.
+    static unsigned host_range_count(size_t n, bool with_points) {
+        unsigned nr = host_ranges(n, with_points);
+        const size_t run = max_run_points();
+        if ((n + nr - 1) / nr > run) nr = (unsigned)((n + run - 1) / run);
+        const size_t per = (n + nr - 1) / nr;
+        return (unsigned)((n + per - 1) / per);
+    }
+
+    // MultiExp with the scalars (and, unless `resident`, the points) in host memory.
+    static int multiexp_from_host(Context &ctx, Workspace &first, const uint64_t *points, const ResidentBases *resident,
+                                  const uint64_t *scalars, size_t n, J *out) {
+        const unsigned nr = host_range_count(n, points != nullptr);
+        const unsigned c = choose_c(FR_BITS, AFF_BYTES, (n + nr - 1) / nr);  // one c for every range: the totals must line up
+        WindowPlan plan = make_plan(c, 0, 1);
+        std::vector<Ext> totals(plan.nwin_total);
+        int rc = window_sums_from_host(ctx, first, points, resident, 0, scalars, n, plan, nr, totals.data());
+        if (rc) return rc;
+        *out = fold(totals.data(), c);
+        return GMSM_OK;
+    }
+
+    // One rank's piece of a MultiExp sharded over several devices by the library itself (gmsm_multiexp_sharded and the
+    // drop-in entries on a multi-GPU node; gmsm_engine.hip): host scalars [0, n) and host points or registered bases
+    // [resident_base, resident_base + n), windows win_first, win_first + win_stride, ... of the c-bit decomposition;
+    // out_xyzz = the nwin_local window totals. Runs on ctx's device; leases its own workspace.
+    static int shard_piece(Context &ctx, const uint64_t *points, const ResidentBases *resident, size_t resident_base,
+                           const uint64_t *scalars, size_t n, unsigned c, unsigned win_first, unsigned win_stride,
+                           Ext *out_xyzz) {
+        WindowPlan plan = make_plan(c, win_first, win_stride);
+        if (n == 0) {
+            for (uint32_t k = 0; k < plan.nwin_local; ++k) out_xyzz[k] = Ext::infinity();
+            return GMSM_OK;
+        }
+        GMSM_LEASE_OR_FAIL(lease, ctx);
+        return window_sums_from_host(ctx, *lease.w, points, resident, resident_base, scalars, n, plan,
+                                     host_range_count(n, points != nullptr), out_xyzz);
     }
 
     static int multiexp_host(const uint64_t *points, size_t n_points, const uint64_t *scalars, size_t n_scalars,
@@ -1168,6 +1117,13 @@ struct VTableOf {
         memcpy(out_jac, &j, sizeof j);
         return GMSM_OK;
     }
+    static int shard_piece(Context &ctx, const uint64_t *points, const ResidentBases *resident, size_t resident_base,
+                           const uint64_t *scalars, size_t n, unsigned c, unsigned win_first, unsigned win_stride,
+                           uint64_t *out_xyzz) {
+        return G::shard_piece(ctx, points, resident, resident_base, scalars, n, c, win_first, win_stride,
+                              reinterpret_cast<typename G::Ext *>(out_xyzz));
+    }
+    static unsigned host_piece_ranges(size_t n, bool with_points) { return G::host_range_count(n, with_points); }
     static int window_sums(Context &ctx, const void *d_points, const void *d_scalars, size_t n, unsigned c,
                            unsigned win_first, unsigned win_stride, hipStream_t stream, uint64_t *out_xyzz,
                            const ResidentBases *resident) {
@@ -1197,13 +1153,7 @@ struct VTableOf {
         typename G::J j = G::fold_sets(reinterpret_cast<const typename G::Ext *>(xyzz_sets), nsets, c);
         memcpy(out_jac, &j, sizeof j);
     }
-    static int fold_points(const uint64_t *points, size_t n, const uint64_t *coeff, int nb_tasks, uint64_t *out_jac) {
-        typename G::J j;
-        int rc = G::fold_host(points, n, coeff, nb_tasks, &j);
-        if (rc) return rc;
-        memcpy(out_jac, &j, sizeof j);
-        return GMSM_OK;
-    }
+    static void fold_powers(const uint64_t *coeff, size_t n, uint64_t *out_scalars) { G::fold_powers(coeff, n, out_scalars); }
     // host or device scalars / results; exactly one of each pair is given
     static int batch_scalar_mul(Context &ctx, const uint64_t *base, const uint64_t *scalars, const void *d_scalars, size_t n,
                                 hipStream_t caller_stream, uint64_t *out, void *d_out) {
@@ -1324,7 +1274,7 @@ struct VTableOf {
         static const GroupVTable vt = {G::FR_BITS,      G::AFF_BYTES,   G::SCALAR_BYTES, sizeof(typename G::J),
                                        sizeof(typename G::Ext), &multiexp_host, &multiexp_device, &window_sums,
                                        &fold,           &jac_to_affine, &debug_decompose, &debug_field_op,
-                                       &debug_group_op, &generate_points, &register_bases, &submit, &collect, &window_sums_enqueue, &fold_sets, &fold_points, &multiexp_bases_host, &batch_scalar_mul, &batch_jac_to_affine, &decode_raw, &validate_points, &fft_domain_new, &fft_run, &fft_bit_reverse};
+                                       &debug_group_op, &generate_points, &register_bases, &submit, &collect, &window_sums_enqueue, &fold_sets, &fold_powers, &multiexp_bases_host, &batch_scalar_mul, &batch_jac_to_affine, &decode_raw, &validate_points, &fft_domain_new, &fft_run, &fft_bit_reverse, &shard_piece, &host_piece_ranges};
         return &vt;
     }
 };

@@ -647,7 +647,7 @@ __global__ void __launch_bounds__(256) k_fixup_long(uint32_t nbuckets, const voi
 // Weighted sum  sum_k (k+1) B_k  of a window, as a two-level segmented running sum:
 //   level 1 (k_reduce1): each thread owns L consecutive buckets (running sum, multiexp_jacobian.go:44-52 restricted to
 //   its segment), then the block combines its threads' (S_t, W_t) with a suffix scan in LDS;
-//   level 2 (k_reduce2): one block per window combines the level-1 block results the same way.
+//   level 2 (k_reduce2_quad): one block per window combines the level-1 block results, four lanes per addition.
 // Identity used:  sum_{k in [base, base+T*L)} (k-base+1) B_k = sum_t W_t + L * sum_{t>=1} Suf_t,
 //   S_t = sum of segment t, W_t = sum_{k in seg t} (k-lo_t+1) B_k, Suf_t = sum_{t'>=t} S_t'.
 // The whole reduction of a workgroup is ONE loop with ONE call site of the XYZZ addition (and one of the doubling): an
@@ -965,28 +965,6 @@ __global__ void __launch_bounds__(TPB) k_reduce_combine_lds(uint32_t log2L, void
         A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 0, PARK[0]);
         A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 1, TOT[0]);
     }
-}
-
-// grid = nwin_local, block = TPB >= nblocks1 threads. Thread j holds level-1 block j: (S_j, W_j) covering
-// TPB1*L buckets = 2^log2span. window_total[k] = sum_j W_j + span * sum_j j*S_j.
-template <class A, int TPB>
-__global__ void __launch_bounds__(TPB) k_reduce2(const void *__restrict__ in1, uint32_t nblocks1, uint32_t log2span,
-                                                 void *__restrict__ window_totals) {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    using E = typename A::Elem;
-    E *lds = reinterpret_cast<E *>(lds_raw);
-    const uint32_t k = blockIdx.x, t = threadIdx.x;
-    E S = A::infinity(), W = A::infinity();
-    if (t < nblocks1) {
-        S = A::load(in1, ((size_t)k * nblocks1 + t) * 2 + 0);
-        W = A::load(in1, ((size_t)k * nblocks1 + t) * 2 + 1);
-    }
-    E S_out = A::infinity(), W_out = A::infinity();
-    uint32_t active = 2;
-    while (active < nblocks1) active <<= 1;
-    auto no_buckets = [&](uint32_t) -> E { return A::infinity(); };
-    reduce_program<A, TPB>(no_buckets, 0u, S, W, log2span, active, 0u, lds, S_out, W_out);
-    if (t == 0) A::store_final(window_totals, k, W_out);
 }
 
 // ------------------------------------------------------------------ lane-cooperative addition

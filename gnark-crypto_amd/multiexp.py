@@ -34,6 +34,32 @@ def _ptr(a):
     return a.ctypes.data_as(_lib.ctypes.c_void_p)
 
 
+SHARD_MODES = {"auto": 0, "points": 1, "windows": 2}
+
+
+def _dev_array(devices):
+    """list of device indices (one per logical rank) -> (int*, count) for the C ABI; None -> (NULL, 0)."""
+    if not devices:
+        return None, 0
+    arr = (_lib.ctypes.c_int * len(devices))(*[int(d) for d in devices])
+    return arr, len(devices)
+
+
+def set_devices(devices=None):
+    """gmsm_set_devices: the devices the drop-in entries spread a MultiExp over (None / [] = every visible device)."""
+    dev, nd = _dev_array(devices)
+    rc = _lib.load().gmsm_set_devices(dev, nd)
+    if rc:
+        raise RuntimeError("gmsm: " + _lib.last_error())
+
+
+def get_devices():
+    L = _lib.load()
+    buf = (_lib.ctypes.c_int * 64)()
+    n = L.gmsm_get_devices(buf, 64)
+    return [buf[i] for i in range(min(n, 64))]
+
+
 class _Group:
     group = None  # "g1" / "g2"
 
@@ -66,6 +92,29 @@ class _Group:
         rc = L.gmsm_multiexp(self.gid, _ptr(points), points.shape[0], _ptr(scalars), scalars.shape[0],
                              int(config.NbTasks), _ptr(out))
         return (out, None) if rc == 0 else (None, self._error(rc))
+
+    def MultiExpSharded(self, points, scalars, config=MultiExpConfig(), devices=None, mode="auto"):
+        """gmsm_multiexp_sharded: the same MultiExp spread over several devices inside the library (one host thread per
+        logical rank; `devices` = one entry per rank, None = the configured list). Returns (jacobian_limbs, None) or
+        (None, error)."""
+        L = _lib.load()
+        points, scalars = self._check(points, scalars)
+        out = np.zeros(self.jac_limbs, dtype=np.uint64)
+        dev, nd = _dev_array(devices)
+        rc = L.gmsm_multiexp_sharded(self.gid, _ptr(points), points.shape[0], _ptr(scalars), scalars.shape[0],
+                                     int(config.NbTasks), dev, nd, SHARD_MODES[mode], _ptr(out))
+        return (out, None) if rc == 0 else (None, self._error(rc))
+
+    def register_bases_sharded(self, points, devices=None):
+        """gmsm_bases_register_sharded: full copies of the bases on every distinct device of the list."""
+        L = _lib.load()
+        points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, self.aff_limbs)
+        handle = _lib.ctypes.c_uint64(0)
+        dev, nd = _dev_array(devices)
+        rc = L.gmsm_bases_register_sharded(self.gid, _ptr(points), points.shape[0], dev, nd, _lib.ctypes.byref(handle))
+        if rc:
+            raise RuntimeError(self._error(rc))
+        return ResidentBases(self, handle.value, points.shape[0])
 
     def _fold_jac(self, points, combination_coeff, config):
         """(*G1Jac).Fold (multiexp.go:331): sum_i points[i] * coeff^i; returns (jacobian_limbs, None) or (None, error)."""
@@ -313,6 +362,16 @@ class ResidentBases:
         scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, g.fr_limbs)
         out = np.zeros(g.jac_limbs, dtype=np.uint64)
         rc = L.gmsm_multiexp_bases(self.handle, _ptr(scalars), scalars.shape[0], int(config.NbTasks), _ptr(out))
+        return (out, None) if rc == 0 else (None, g._error(rc))
+
+    def MultiExpSharded(self, scalars, config=MultiExpConfig(), mode="auto"):
+        """gmsm_multiexp_bases_sharded (handles of register_bases_sharded only): explicit decomposition."""
+        L = _lib.load()
+        g = self.group
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, g.fr_limbs)
+        out = np.zeros(g.jac_limbs, dtype=np.uint64)
+        rc = L.gmsm_multiexp_bases_sharded(self.handle, _ptr(scalars), scalars.shape[0], int(config.NbTasks),
+                                           SHARD_MODES[mode], _ptr(out))
         return (out, None) if rc == 0 else (None, g._error(rc))
 
     def multiexp_device(self, d_scalars, n, stream=0):

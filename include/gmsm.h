@@ -24,6 +24,9 @@
  *
  * Threading: every entry point is re-entrant and may be called concurrently from any OS thread (goroutines
  * migrate); per device two calls run at a time, further callers wait their turn.
+ * Several GPUs: on a node with more than one visible device the drop-in entries spread every MultiExp of 2^17 points or
+ * more over all of them (point slices, one host thread per device, one fold; see gmsm_multiexp_sharded) unless
+ * gmsm_set_device pinned the process to one device or gmsm_set_devices / GMSM_DEVICES chose a subset.
  * Limits: n < 2^31. One pipeline run takes up to 2^27 points; the MultiExp entries split larger inputs into point
  * ranges themselves, gmsm_window_sums_* and gmsm_multiexp_bases_submit refuse them (GMSM_ERR_ARG).
  * Ownership: the caller owns all buffers; host pointers are not retained after return.
@@ -85,6 +88,35 @@ int gmsm_multiexp_affine(int group, const uint64_t *points, size_t n_points, con
 int gmsm_fold(int group, const uint64_t *points, size_t n_points, const uint64_t *combination_coeff, int nb_tasks,
               uint64_t *out_jac);
 
+/* ---- one MultiExp over several GPUs of the node, inside the library.  The reference spreads a
+ *      MultiExp over the cores of the machine - one worker per c-bit window collected on a channel
+ *      (ecc/bn254/multiexp.go:148-209), and a split of the points in two halves whose results are added (:98-140) -; here
+ *      the workers are the devices: one host thread per logical rank runs its piece on its device, the ranks' window totals
+ *      (<= 64 extended-Jacobian points each) come back through each device's pinned result buffer and the calling thread
+ *      runs the one fold (multiexp.go:302-315).  Same arguments, layouts, return codes and result as gmsm_multiexp.
+ *      devices / n_devices: one entry per logical rank, a device may appear more than once (two ranks on one device use
+ *      both of its workspaces); NULL / 0 = the configured list (gmsm_set_devices, else GMSM_DEVICES, else every visible
+ *      device).  mode: 0 auto (= 1), 1 points - rank r takes points [r n/G, (r+1) n/G) and all windows; every device
+ *      copies only its slice over its own PCIe link -, 2 windows - rank r takes windows r, r+G, ... of all points (the
+ *      reference's per-window workers; every rank needs all bases).  Ranks whose slice would fall below 2^16 points are
+ *      left out.  gmsm_<curve>_g{1,2}_multiexp, gmsm_multiexp, gmsm_multiexp_affine and gmsm_fold call this themselves
+ *      when more than one device is configured. ---- */
+int gmsm_multiexp_sharded(int group, const uint64_t *points, size_t n_points, const uint64_t *scalars, size_t n_scalars,
+                          int nb_tasks, const int *devices, int n_devices, int mode, uint64_t *out_jac);
+/* Resident bases on several devices: the n bases are uploaded (all devices at once, each over its own link) and
+ * rewritten once on every distinct device of the list - full copies, so that any prefix can be cut evenly over the ranks.
+ * The handle is accepted by gmsm_multiexp_bases (host scalars; sharded like gmsm_multiexp_sharded, mode auto),
+ * gmsm_multiexp_bases_sharded (explicit mode) and gmsm_bases_release; the device-pointer entries take single-device
+ * handles only. */
+int gmsm_bases_register_sharded(int group, const uint64_t *points, size_t n, const int *devices, int n_devices,
+                                uint64_t *out_handle);
+int gmsm_multiexp_bases_sharded(uint64_t handle, const uint64_t *scalars, size_t n_scalars, int nb_tasks, int mode,
+                                uint64_t *out_jac);
+/* The devices the drop-in entries shard over (one entry per logical rank); count = 0 restores the default (every
+ * visible device).  gmsm_get_devices returns the number of configured ranks and writes up to max_devices of them. */
+int gmsm_set_devices(const int *devices, int count);
+int gmsm_get_devices(int *out_devices, int max_devices);
+
 /* ---- device-resident entries (bases/scalars already in HBM: the SRS-resident fast path).
  *      d_points / d_scalars are device pointers with the layouts above; hip_stream is the hipStream_t the inputs were
  *      produced on (NULL = default stream): the engine runs on a private stream ordered after the work queued there;
@@ -118,7 +150,9 @@ int gmsm_multiexp_bases_device(uint64_t handle, const void *d_scalars, size_t n_
 int gmsm_multiexp_bases_submit(uint64_t handle, const void *d_scalars, size_t n_scalars, void *hip_stream,
                                uint64_t *out_ticket);
 int gmsm_multiexp_collect(uint64_t ticket, uint64_t *out_jac);
-/* k MultiExp over the same registered bases in one blocking call (one commitment per polynomial with a fixed SRS:
+/* (a ticket takes at most 2^27 points, and so does every vector of gmsm_multiexp_bases_batch below: submit refuses more
+ * with GMSM_ERR_ARG; the blocking single-vector entries split larger inputs themselves)
+ * k MultiExp over the same registered bases in one blocking call (one commitment per polynomial with a fixed SRS:
  * kzg.Commit, ecc/bn254/kzg/kzg.go:159-176; BatchOpenSinglePoint :246): scalars = k x n fr.Element, contiguous, either on
  * the host (`scalars`) or on the device (`d_scalars`, produced on hip_stream); out_jac = k Jacobian results. Two of
  * the k calls are in flight at a time; host scalars of vector i+1 are copied while vector i is being accumulated. */
@@ -231,11 +265,9 @@ int gmsm_generate_points(int group, const uint64_t *base_affine, const uint64_t 
 /* Per-stage device timing with HIP events on the launch streams. gmsm_set_profiling(1) resets and enables the
  * accumulators; gmsm_get_stage_times copies the summed milliseconds of up to max_stages stages
  * (0 base rewrite + decompose, 1 histogram, 2 scans, 3 scatter + fine sort, 4 bucket accumulation kernel, 5 split-bucket
- * fixup, 6 bucket reduction, 7 time a window group's stream waited for the previous group's accumulation kernel) and the
- * number of pipeline runs they cover; returns the number of stages written. One MultiExp runs as up to four window
- * groups whose pipelines overlap on two streams, so the stage sums exceed the wall time of the call;
- * gmsm_get_stage_launches gives how many stage instances (window groups) each sum covers - for stage 4 that is the
- * number of k_accumulate_seg launches. */
+ * fixup, 6 bucket reduction, 7 reserved = 0) and the number of pipeline runs they cover; returns the number of stages
+ * written. gmsm_get_stage_launches gives how many stage instances each sum covers - for stage 4 that is the number of
+ * k_accumulate_seg launches. */
 void gmsm_set_profiling(int on);
 int gmsm_get_stage_times(double *out_ms, int max_stages, unsigned long *out_calls);
 int gmsm_get_stage_launches(unsigned long *out_launches, int max_stages);
@@ -244,7 +276,9 @@ int gmsm_device_count(void);
 /* Device used by later calls of this thread AND process-wide default for threads that never called it (a goroutine
  * that is moved to another OS thread keeps its device as long as the process uses one device; a process that drives
  * several devices from several threads must pin them, runtime.LockOSThread). Entries that take device pointers or a
- * bases handle do not depend on it: they run on the device that owns the pointer / the registered bases. */
+ * bases handle do not depend on it: they run on the device that owns the pointer / the registered bases.
+ * Calling it also pins the drop-in entries to ONE device: they no longer spread a MultiExp over the node's GPUs
+ * (gmsm_set_devices(NULL, 0) undoes that). */
 int gmsm_set_device(int device);
 /* text of the calling thread's last failure; a thread that never failed gets the most recent failure of the process
  * (a cgo caller may be rescheduled onto another OS thread between the failing call and this one) */

@@ -13,7 +13,7 @@ import torch
 
 sys.path.insert(0, ".")
 gm = importlib.import_module("gnark-crypto_amd")
-STAGES = ["decompose", "histogram", "scans", "scatter", "accumulate", "fixup", "reduce", "wait_prev_group"]
+STAGES = ["decompose", "histogram", "scans", "scatter", "accumulate", "fixup", "reduce", "reserved"]
 
 
 def main():
