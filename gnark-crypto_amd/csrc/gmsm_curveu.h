@@ -499,26 +499,6 @@ struct UnsatOpsNI {
     }
 };
 
-// Out-of-line group operations with INLINED field products inside them: ONE copy of the addition (and of the doubling)
-// per translation unit, shared by every kernel and call site that uses this policy. For the wide element types (Fp2,
-// 28-limb field) UnsatOpsNI pays a call - with its operands through scratch - for every one of the 14 products of an
-// addition; here the call is paid once per addition (two operands of 0.2-0.5 KB through scratch against 6-22 thousand
-// multiply-adds), and the body is the same straight-line code k_reduce_serial runs inlined.
-template <class U>
-struct UnsatOpsMid {
-    using Mem = XYZZL<U>;
-    using Final = XYZZ<typename LzTraits<U>::Sat>;
-    using Elem = UnsatElem<U>;
-    __device__ static __forceinline__ Elem infinity() { return unsat_infinity<U>(); }
-    __device__ static __forceinline__ Elem load(const void *base, size_t i) { return unsat_load<U>(base, i); }
-    __device__ static __forceinline__ void store(void *base, size_t i, const Elem &e) { lazy_store<U>(base, i, e.v, e.inf); }
-    __device__ static __noinline__ void store_final(void *base, size_t i, const Elem &e) { unsat_store_final<U, false>(base, i, e); }
-    __device__ static __noinline__ void add(Elem &p, const Elem &q) { lz_padd<true>(p.v, p.inf, q.v, q.inf); }
-    __device__ static __noinline__ void dbl(Elem &p) {
-        if (!p.inf) p.v = lz_pdbl<true>(p.v);
-    }
-};
-
 #endif  // __HIPCC__
 
 }  // namespace gmsm

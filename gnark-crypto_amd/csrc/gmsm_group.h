@@ -37,58 +37,25 @@ struct Group {
     // unsaturated-limb accumulation (gmsm_fieldu.h) for groups whose coordinates live in Fp; Fp2 groups use the generic
     // saturated kernel
     using U = typename LazyOf<F>::type;  // lazy element type: FpU<P> for Fp coordinates, Fp2U<P> for Fp2 coordinates
-    // fully inlined group operations in k_fixup_seg / k_reduce* only where one XYZZ addition is small enough (9- and
-    // 14-limb prime fields); Fp2 and the 28-limb field use the out-of-line forms (a single inlined Fp2 or BW6-761
-    // addition is 60-350 KB of code: instruction-cache misses and minutes of compile time)
-#ifndef GMSM_INLINE_ALL_OPS
-#define GMSM_INLINE_ALL_OPS 0
-#endif
-    static constexpr bool INLINE_OPS = GMSM_INLINE_ALL_OPS || sizeof(U) <= 14 * 4;
-#ifndef GMSM_COMBINE_INLINE
-#define GMSM_COMBINE_INLINE -1  // -1: per element type (below); 0 / 1 force it off / on for A/B builds
-#endif
-#ifndef GMSM_COMBINE_LDS
-#define GMSM_COMBINE_LDS 0     // 1: the inlined combine keeps its per-thread state in LDS (k_reduce_combine_lds; A/B builds)
-#endif
-#ifndef GMSM_FIXLONG_INLINE
-#define GMSM_FIXLONG_INLINE 0  // 1: k_fixup_long<UnsatOps, ONE_SITE> for the wide element types (A/B builds)
-#endif
-#ifndef GMSM_QUAD_INLINE
-#define GMSM_QUAD_INLINE 0     // 1: the lane-quad level 2 inlines its field products for the wide element types too (A/B builds)
-#endif
-#ifndef GMSM_WIDE_OPS_MID
-#define GMSM_WIDE_OPS_MID 0  // 1: UnsatOpsMid (additions out of line, products inlined inside them) - A/B builds only.
-                            // BN254 G2 runs correctly with it; for the 28-word element types the function body exceeds
-                            // the reach of s_cbranch and LLVM's long-branch expansion goes through s[30:31], the return
-                            // address: the call never returns (tools/check_long_branch.py)
-#endif
-    template <bool Fast, class Dummy = void> struct OpsSel {
-        using type = typename std::conditional<GMSM_WIDE_OPS_MID != 0, UnsatOpsMid<U>, UnsatOpsNI<U>>::type;
-    };
-    template <class Dummy> struct OpsSel<true, Dummy> { using type = UnsatOps<U>; };
-    using Ops = typename OpsSel<INLINE_OPS>::type;     // arithmetic of k_fixup_seg and the reduction kernels
-    using OpsNI = UnsatOpsNI<U>;                       // small-code variant for k_fixup_level
+    // Arithmetic policy of the fix-up and reduction kernels: group operations fully inlined where one XYZZ addition is
+    // small enough (9- and 14-limb prime fields); Fp2 and the 28-limb field use the out-of-line forms in kernels with
+    // several call sites (a single inlined Fp2 or BW6-761 addition is 60-350 KB of code) and inline the group law only
+    // where a kernel has ONE call site of the addition (k_fixup_seg, k_reduce_serial).
+    static constexpr bool INLINE_OPS = sizeof(U) <= 14 * 4;
+    using Ops = typename std::conditional<INLINE_OPS, UnsatOps<U>, UnsatOpsNI<U>>::type;
     using OpsElem = typename Ops::Elem;
-    static_assert((2 * (sizeof(XYZZ<F>) > 256 ? 128 : 256) + 1) * sizeof(OpsElem) <= 160 * 1024, "reduction LDS budget");
-    static constexpr int RED_TPB = sizeof(XYZZ<F>) > 256 ? 128 : 256;  // 2*TPB*sizeof(Elem) of LDS must fit 160 KiB
-    static constexpr int RED2_TPB = 64;  // level-1 workgroups per window that level 2 (k_reduce2_quad) takes
+    using OpsSerial = UnsatOps<U>;   // k_reduce_serial, k_fixup_seg: one call site, inlined for every element type
+    static constexpr int RED_TPB = 256;  // threads of a fused level-1 workgroup (k_reduce1): 2*TPB*sizeof(Elem) of LDS
+    static constexpr int RED2_TPB = 64;  // level-1 workgroups per window that level 2 (k_reduce2_q) takes
     // Every element type except the 9-limb prime field runs the serial part of reduction level 1 as its own kernel
-    // (k_reduce_serial, group law inlined, no LDS): measured reduce times fused / split - BW6-761 G1 8.87 / 6.14 ms,
-    // BLS12-381 G2 5.60 / 4.42, BN254 G2 2.60 / 1.99, BLS12-381 G1 0.98 / 0.84, BN254 G1 0.365 / 0.511 (stays fused).
-    // GMSM_SPLIT_REDUCE=0/1 overrides for A/B measurements.
-    static constexpr bool SPLIT_REDUCE_DEFAULT = sizeof(U) > 9 * 4;
-    using OpsSerial = UnsatOps<U>;
-    // The element types whose `Ops` are out of line (Fp2, 28 limbs) still inline the group law where a kernel has a
-    // SINGLE call site of the addition: k_fixup_seg, and the combine step of the split reduction as its own kernel
-    // (k_reduce_combine) instead of the two-program k_reduce1. Measured with an A/B library (profiles/
-    // r02_window_sweeps.log, gpu_r2q): BN254 G2 2^20 6.97 -> 6.52 ms (reduce 1.8 -> 1.38), BW6-761 fix-up 1.45 -> 0.77 ms,
-    // BLS12-381 G2 fix-up 0.34 -> 0.1 ms; the combine of the 28-word types itself does not get faster (its five live
-    // XYZZ values spill either way).
-    static constexpr bool COMBINE_INLINE = GMSM_COMBINE_INLINE < 0 ? !INLINE_OPS : (GMSM_COMBINE_INLINE != 0);
-    using FixOps = typename std::conditional<COMBINE_INLINE, OpsSerial, Ops>::type;
-    static constexpr bool FIXLONG_ONE_SITE = GMSM_FIXLONG_INLINE != 0 && !INLINE_OPS;
-    using FixLongOps = typename std::conditional<FIXLONG_ONE_SITE, OpsSerial, Ops>::type;
-    static constexpr bool QUAD_INL = INLINE_OPS || GMSM_QUAD_INLINE != 0;
+    // (k_reduce_serial, group law inlined, no LDS) and combines the threads' (S, W) pairs on lane quads with the
+    // operands in LDS (k_combine_q, gmsm_quad.h): COMBINE_N pairs per workgroup of 4 * COMBINE_N threads. Measured reduce
+    // times fused / split with a one-lane combine (round 2): BW6-761 G1 8.87 / 6.14 ms, BLS12-381 G2 5.60 / 4.42, BN254 G2
+    // 2.60 / 1.99, BLS12-381 G1 0.98 / 0.84, BN254 G1 0.365 / 0.511 (stays fused).
+    static constexpr bool SPLIT_REDUCE = sizeof(U) > 9 * 4;
+    static constexpr int COMBINE_N = 64;
+    static_assert((2 * RED_TPB) * sizeof(OpsElem) <= 160 * 1024 || SPLIT_REDUCE, "fused reduction LDS budget");
+    static_assert((2 * COMBINE_N + 1) * sizeof(QRec<U>) <= 160 * 1024, "quad combine LDS budget");
 
     static WindowPlan make_plan(unsigned c, unsigned win_first, unsigned win_stride) {
         WindowPlan p;
@@ -149,38 +116,38 @@ struct Group {
         uint32_t log2L, nblocks1, log2span;    // reduction
     };
 
-    static Geometry plan_geometry(const Context &ctx, uint32_t nw, size_t n, uint32_t NB, bool split_reduce) {
+    static Geometry plan_geometry(const Context &ctx, uint32_t nw, size_t n, uint32_t NB) {
         Geometry q;
-        // reduction: buckets per level-1 thread, L = 2^log2L: as few as possible (the per-thread running sum is a
-        // serial chain) while all level-1 workgroups are resident at once - one per CU, every one of them runs a single
-        // wave per SIMD - and level 2 gets at most RED2_TPB of them per window. Measured with whole calls: BN254/BLS12-381
-        // G1 and BN254 G2 L = 8, BLS12-381 G2 L = 16, BW6-761 (24 windows) L = 32.
-        const auto blocks1 = [&](uint32_t l2) { return ((size_t)NB + ((size_t)RED_TPB << l2) - 1) / ((size_t)RED_TPB << l2); };
+        // reduction: buckets per level-1 thread, L = 2^log2L, and the number of level-1 workgroups per window (at most
+        // RED2_TPB of them: one quad of level 2 each).
+        constexpr size_t SPAN1 = SPLIT_REDUCE ? COMBINE_N : RED_TPB;  // threads' results one level-1 workgroup combines
+        const auto blocks1 = [&](uint32_t l2) { return ((size_t)NB + (SPAN1 << l2) - 1) / (SPAN1 << l2); };
         uint32_t log2L = tune_uint("GMSM_LOG2L", 0);
         if (log2L == 0) {
-            if (split_reduce) {
-                // serial kernel: 2L dependent additions on every SIMD; combine: (2 log2 TPB + log2 L + 1) steps per
-                // round of LDS-limited workgroups. Minimise the total number of steps.
-                const size_t wg_per_round = std::max<size_t>(1, (size_t)ctx.num_cus * std::max<size_t>(1, (160 * 1024) / (2 * RED_TPB * sizeof(OpsElem))));
-                uint32_t lg_tpb = 0;
-                for (int t = RED_TPB; t > 1; t >>= 1) ++lg_tpb;
+            if (SPLIT_REDUCE) {
+                // serial kernel: 2L dependent one-lane additions on every SIMD, as many rounds as the threads need;
+                // combine: 2 log2 N + log2 L + 1 quad steps (a quad step is about a third of a one-lane addition) per
+                // round of workgroups - one per CU, its 4 N threads hold the registers of a whole CU for the wide types.
+                // Minimise the total in units of one-lane additions.
                 size_t best = ~(size_t)0;
                 for (uint32_t l2 = 1; l2 <= 8; ++l2) {
                     if (blocks1(l2) > (size_t)RED2_TPB) continue;
                     const size_t serial_threads = (size_t)nw * (((size_t)NB + ((size_t)1 << l2) - 1) >> l2);
                     const size_t serial_rounds = (serial_threads + (size_t)ctx.num_cus * 256 - 1) / ((size_t)ctx.num_cus * 256);
-                    const size_t rounds = ((size_t)nw * blocks1(l2) + wg_per_round - 1) / wg_per_round;
-                    const size_t steps = serial_rounds * ((size_t)2 << l2) + rounds * (2 * lg_tpb + l2 + 1);
-                    if (steps < best) {
-                        best = steps;
+                    const size_t rounds = ((size_t)nw * blocks1(l2) + ctx.num_cus - 1) / ctx.num_cus;
+                    const size_t cost3 = 3 * serial_rounds * ((size_t)2 << l2) + rounds * (2 * 6 + l2 + 1);
+                    if (cost3 < best) {
+                        best = cost3;
                         log2L = l2;
                     }
                 }
                 if (log2L == 0) log2L = 8;
             } else {
-                // (Letting an eighth of the CUs take a second workgroup to halve L - 17 windows at c = 15 are 272
-                // workgroups at L = 4 - was measured: the doubly occupied CUs run both chains at half speed and
-                // the kernel gets slower, 0.45 against 0.37 ms at 2^16.)
+                // fused (k_reduce1): as few buckets per thread as possible (the per-thread running sum is a serial chain)
+                // while all level-1 workgroups are resident at once - one per CU, every one of them runs a single wave
+                // per SIMD. (Letting an eighth of the CUs take a second workgroup to halve L - 17 windows at c = 15 are
+                // 272 workgroups at L = 4 - was measured: the doubly occupied CUs run both chains at half speed and the
+                // kernel gets slower, 0.45 against 0.37 ms at 2^16.)
                 log2L = 1;
                 while ((size_t)nw * blocks1(log2L) > (size_t)ctx.num_cus && blocks1(log2L) > 1) ++log2L;
             }
@@ -189,7 +156,7 @@ struct Group {
         q.log2L = log2L;
         q.nblocks1 = (uint32_t)blocks1(log2L);
         q.log2span = log2L;
-        for (int t = RED_TPB; t > 1; t >>= 1) ++q.log2span;
+        for (size_t t = SPAN1; t > 1; t >>= 1) ++q.log2span;
         // entry-parallel segmented accumulation: seg entries per thread. Every thread does the same work, so the
         // launch should be a whole number of resident "rounds" of WORKGROUPS: the grid is (blocks per window) x
         // (windows), so the unit is a 256-thread block per window - nw * ceil(tpw/256) blocks must not exceed
@@ -257,10 +224,9 @@ struct Group {
         if (n >= ((size_t)1 << 31)) return fail(GMSM_ERR_ARG, "n must be < 2^31");
         const uint32_t NB = plan.nbuckets;
         constexpr size_t REC = sizeof(typename Ops::Mem);  // bucket / partial record (lazy representation on the fast path)
-        static_assert(sizeof(typename Ops::Mem) == sizeof(typename OpsNI::Mem), "one record format per group");
 
-        const bool split_reduce = tune_uint("GMSM_SPLIT_REDUCE", SPLIT_REDUCE_DEFAULT ? 1 : 0) != 0;
-        const Geometry q = plan_geometry(ctx, nw, n, NB, split_reduce);
+        constexpr bool split_reduce = SPLIT_REDUCE;
+        const Geometry q = plan_geometry(ctx, nw, n, NB);
         const size_t tot_thr = (size_t)nw * q.tpw;
         const size_t tot_blk = (size_t)nw * q.nblocks1;
 
@@ -328,13 +294,13 @@ struct Group {
         if ((rc = ctx.allow_lds((const void *)k_part_scatter<uint16_t>, 152 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_part_scatter<uint32_t>, 152 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_fine_sort, 160 * 1024))) return rc;
-        if ((rc = ctx.allow_lds((const void *)k_fixup_long<FixLongOps, FIXLONG_ONE_SITE>, (int)(256 * sizeof(OpsElem))))) return rc;
-        if ((rc = ctx.allow_lds((const void *)k_reduce1<Ops, RED_TPB>, (int)(2 * RED_TPB * sizeof(OpsElem))))) return rc;
-        if constexpr (COMBINE_INLINE) {
-            if ((rc = ctx.allow_lds((const void *)k_reduce_combine<OpsSerial, RED_TPB>, (int)(2 * RED_TPB * sizeof(OpsElem))))) return rc;
-            if constexpr (GMSM_COMBINE_LDS != 0)
-                if ((rc = ctx.allow_lds((const void *)k_reduce_combine_lds<OpsSerial, RED_TPB>, (int)((2 * RED_TPB + 1) * sizeof(OpsElem))))) return rc;
+        if ((rc = ctx.allow_lds((const void *)k_fixup_long<Ops>, (int)(256 * sizeof(OpsElem))))) return rc;
+        if constexpr (SPLIT_REDUCE) {
+            if ((rc = ctx.allow_lds((const void *)k_combine_q<U, true, COMBINE_N>, (int)((2 * COMBINE_N + 1) * sizeof(QRec<U>))))) return rc;
+        } else {
+            if ((rc = ctx.allow_lds((const void *)k_reduce1<Ops, RED_TPB>, (int)(2 * RED_TPB * sizeof(OpsElem))))) return rc;
         }
+        if ((rc = ctx.allow_lds((const void *)k_reduce2_q<U, true>, (int)(2 * RED2_TPB * sizeof(QRec<U>))))) return rc;
 
         StageTimer timer(ws);
         ws.timed = timer.on;
@@ -394,47 +360,33 @@ struct Group {
         hipLaunchKernelGGL((k_accumulate_seg<U>), dim3((q.tpw + 255) / 256, nw), dim3(256), 0, stream, upoints, n, NB, q.seg,
                            starts, sorted, buckets, seg_partials, seg_flags, seg_bucket, q.tpw);
         timer.mark(T_FIXUP, stream);
-        hipLaunchKernelGGL((k_fixup_seg<FixOps>), dim3((q.tpw + 255) / 256, nw), dim3(256), 0, stream, NB, seg_partials,
+        hipLaunchKernelGGL((k_fixup_seg<OpsSerial>), dim3((q.tpw + 255) / 256, nw), dim3(256), 0, stream, NB, seg_partials,
                            (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets, long_flag, long_list);
-        hipLaunchKernelGGL((k_fixup_long<FixLongOps, FIXLONG_ONE_SITE>), dim3(2 * ctx.num_cus), dim3(256), 256 * sizeof(OpsElem), stream, NB, seg_partials,
+        hipLaunchKernelGGL((k_fixup_long<Ops>), dim3(2 * ctx.num_cus), dim3(256), 256 * sizeof(OpsElem), stream, NB, seg_partials,
                            (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets,
                            (const uint32_t *)long_flag, (const LongChain *)long_list);
         // ---- 3. bucket reduction -> window totals (empty buckets are never written: the reduction consults starts[])
         timer.mark(T_REDUCE, stream);
         {
-            // level 1 doubles its S_blk log2span times in an otherwise idle wave (256-thread blocks only): level 2 then
-            // has no serial doubling tail (11 of its 20 steps at c = 16)
-            // (k_reduce_combine_lds prescales for every workgroup size)
-            const bool lds_combine = GMSM_COMBINE_LDS != 0 && COMBINE_INLINE && split_reduce;
-            const uint32_t prescale = (RED_TPB >= 256 || lds_combine) ? q.log2span : 0u;
-            const void *pre = nullptr;
-            if (split_reduce) {
+            // level 1 leaves S_blk already multiplied by the width of the level-2 spans (an otherwise idle wave / quad
+            // doubles it log2span times while the trees run): level 2 then has no serial doubling tail (11 of its 20
+            // steps at c = 16)
+            const uint32_t prescale = q.log2span;
+            if constexpr (SPLIT_REDUCE) {
                 hipLaunchKernelGGL((k_reduce_serial<OpsSerial>), dim3((T + 255) / 256, nw), dim3(256), 0, stream, buckets, NB,
                                    q.log2L, T, starts, ws.red_pre.ptr);
-                pre = ws.red_pre.ptr;
-            }
-            bool combined = false;
-            if constexpr (COMBINE_INLINE) {
-                if (split_reduce) {
-                    if constexpr (GMSM_COMBINE_LDS != 0)
-                        hipLaunchKernelGGL((k_reduce_combine_lds<OpsSerial, RED_TPB>), dim3(q.nblocks1, nw), dim3(RED_TPB),
-                                           (2 * RED_TPB + 1) * sizeof(OpsElem), stream, q.log2L, partials, prescale, pre, T);
-                    else
-                        hipLaunchKernelGGL((k_reduce_combine<OpsSerial, RED_TPB>), dim3(q.nblocks1, nw), dim3(RED_TPB),
-                                           2 * RED_TPB * sizeof(OpsElem), stream, q.log2L, partials, prescale, pre, T);
-                    combined = true;
-                }
-            }
-            if (!combined)
+                hipLaunchKernelGGL((k_combine_q<U, true, COMBINE_N>), dim3(q.nblocks1, nw), dim3(4 * COMBINE_N),
+                                   (2 * COMBINE_N + 1) * sizeof(QRec<U>), stream, q.log2L, partials, prescale,
+                                   (const void *)ws.red_pre.ptr, T);
+            } else {
                 hipLaunchKernelGGL((k_reduce1<Ops, RED_TPB>), dim3(q.nblocks1, nw), dim3(RED_TPB), 2 * RED_TPB * sizeof(OpsElem), stream,
-                                   buckets, NB, q.log2L, partials, starts, prescale, pre, T);
-            // level 2 on quads of lanes (4 lanes share the products of one addition). Level 1 stays on single lanes: a
-            // quad version needs 4x the lanes at ~230 VGPRs each, i.e. several rounds of workgroups per CU - measured
-            // 0.57 ms against 0.37 ms.
+                                   buckets, NB, q.log2L, partials, starts, prescale);
+            }
+            // level 2 on quads of lanes
             uint32_t active = 2;
             while (active < q.nblocks1) active <<= 1;
-            hipLaunchKernelGGL((k_reduce2_quad<U, QUAD_INL>), dim3(nw), dim3(4 * active), active * sizeof(OpsElem),
-                               stream, partials, q.nblocks1, q.log2span - prescale, active, totals);
+            hipLaunchKernelGGL((k_reduce2_q<U, true>), dim3(nw), dim3(4 * active), 2 * active * sizeof(QRec<U>), stream,
+                               partials, q.nblocks1, q.log2span - prescale, active, totals);
         }
         timer.mark(T_END, stream);
         HIP_TRY(hipGetLastError());

@@ -19,6 +19,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gmsm_curveu.h"
+#include "gmsm_quad.h"
 
 namespace gmsm {
 
@@ -567,10 +568,7 @@ __global__ void __launch_bounds__(256) k_fixup_seg(uint32_t nbuckets, const void
 }
 
 // grid = any (grid-stride over the list), block = 256, dynamic LDS = 256 * sizeof(A::Elem).
-// ONE_SITE: the strided sums and the tree run as ONE loop with a single call site of the addition (the operand is a loaded
-// partial sum in the first ceil(m/256) steps and a neighbour's value out of LDS afterwards), so that the wide element types
-// can inline the group law here as well (A = UnsatOps). A/B form (-DGMSM_FIXLONG_INLINE=1), not yet through the GPU suite.
-template <class A, bool ONE_SITE = false>
+template <class A>
 __global__ void __launch_bounds__(256) k_fixup_long(uint32_t nbuckets, const void *__restrict__ partials,
                                                     const uint32_t *__restrict__ pflags, const uint32_t *__restrict__ pbucket,
                                                     uint32_t threads_per_win, void *__restrict__ buckets,
@@ -601,42 +599,19 @@ __global__ void __launch_bounds__(256) k_fixup_long(uint32_t nbuckets, const voi
         __syncthreads();
         const uint32_t m = s_len != 0xffffffffu ? s_len : threads_per_win - lc.head;
         E mine = A::infinity();
-        if constexpr (ONE_SITE) {
-            uint32_t active = 256;
-            while (active / 2 >= m && active > 1) active >>= 1;  // smallest power of two >= min(m, 256)
-            const uint32_t nstr = (m + 255u) / 256u;
-            uint32_t ntree = 0;
-            while ((1u << ntree) < active) ++ntree;
-#pragma nounroll
-            for (uint32_t s = 0; s < nstr + ntree; ++s) {
-                E Y = A::infinity();
-                if (s < nstr) {
-                    const uint32_t j = tid + s * 256u;
-                    if (j < m) Y = j == 0 ? A::load(partials, (base + lc.head) * 2 + 1) : A::load(partials, (base + lc.head + j) * 2 + 0);
-                } else {
-                    const uint32_t d = active >> (s - nstr + 1);
-                    if (tid < 2 * d) lds[tid] = mine;
-                    __syncthreads();
-                    if (tid < d) Y = lds[tid + d];
-                    __syncthreads();
-                }
-                A::add(mine, Y);
-            }
-        } else {
-            for (uint32_t j = tid; j < m; j += 256) {
-                const E piece = j == 0 ? A::load(partials, (base + lc.head) * 2 + 1) : A::load(partials, (base + lc.head + j) * 2 + 0);
-                A::add(mine, piece);
-            }
-            uint32_t active = 256;
-            while (active / 2 >= m && active > 1) active >>= 1;  // smallest power of two >= min(m, 256)
-            for (uint32_t d = active >> 1; d >= 1; d >>= 1) {
-                if (tid < 2 * d) lds[tid] = mine;
-                __syncthreads();
-                E other = A::infinity();
-                if (tid < d) other = lds[tid + d];
-                __syncthreads();
-                A::add(mine, other);
-            }
+        for (uint32_t j = tid; j < m; j += 256) {
+            const E piece = j == 0 ? A::load(partials, (base + lc.head) * 2 + 1) : A::load(partials, (base + lc.head + j) * 2 + 0);
+            A::add(mine, piece);
+        }
+        uint32_t active = 256;
+        while (active / 2 >= m && active > 1) active >>= 1;  // smallest power of two >= min(m, 256)
+        for (uint32_t d = active >> 1; d >= 1; d >>= 1) {
+            if (tid < 2 * d) lds[tid] = mine;
+            __syncthreads();
+            E other = A::infinity();
+            if (tid < d) other = lds[tid + d];
+            __syncthreads();
+            A::add(mine, other);
         }
         if (tid == 0) A::store(buckets, (size_t)lc.window * nbuckets + pbucket[base + lc.head], mine);
         __syncthreads();
@@ -647,7 +622,7 @@ __global__ void __launch_bounds__(256) k_fixup_long(uint32_t nbuckets, const voi
 // Weighted sum  sum_k (k+1) B_k  of a window, as a two-level segmented running sum:
 //   level 1 (k_reduce1): each thread owns L consecutive buckets (running sum, multiexp_jacobian.go:44-52 restricted to
 //   its segment), then the block combines its threads' (S_t, W_t) with a suffix scan in LDS;
-//   level 2 (k_reduce2_quad): one block per window combines the level-1 block results, four lanes per addition.
+//   level 2 (k_reduce2_q, gmsm_quad.h): one block per window combines the level-1 block results, four lanes per addition.
 // Identity used:  sum_{k in [base, base+T*L)} (k-base+1) B_k = sum_t W_t + L * sum_{t>=1} Suf_t,
 //   S_t = sum of segment t, W_t = sum_{k in seg t} (k-lo_t+1) B_k, Suf_t = sum_{t'>=t} S_t'.
 // The whole reduction of a workgroup is ONE loop with ONE call site of the XYZZ addition (and one of the doubling): an
@@ -799,15 +774,14 @@ __global__ void __launch_bounds__(256, 1) k_reduce_serial(const void *__restrict
     A::store(pre, ((size_t)k * T + g) * 2 + 1, tot);
 }
 
-// grid = (nblocks1, nwin_local), block = TPB threads, each thread L = 2^log2L buckets.
-// out1[(k*nblocks1 + blk)*2 + {0,1}] = (S_blk, W_blk)
-// pre != null: the threads' (S_t, W_t) were produced by k_reduce_serial (T of them per window); this kernel only combines.
+// grid = (nblocks1, nwin_local), block = TPB threads, each thread L = 2^log2L buckets (the fused level 1 of the 9-limb
+// prime field; the other element types run k_reduce_serial + k_combine_q).
+// out1[(k*nblocks1 + blk)*2 + {0,1}] = (2^prescale S_blk, W_blk)
 template <class A, int TPB>
 __global__ void __launch_bounds__(TPB) k_reduce1(const void *__restrict__ buckets, uint32_t nbuckets, uint32_t log2L,
                                                  void *__restrict__ out1,
                                                  const uint32_t *__restrict__ starts /* null: every bucket is stored */,
-                                                 uint32_t prescale /* S_blk is stored as 2^prescale * S_blk */,
-                                                 const void *__restrict__ pre, uint32_t T) {
+                                                 uint32_t prescale) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     using E = typename A::Elem;
     E *lds = reinterpret_cast<E *>(lds_raw);
@@ -822,341 +796,9 @@ __global__ void __launch_bounds__(TPB) k_reduce1(const void *__restrict__ bucket
         return present ? A::load(buckets, (size_t)k * nbuckets + b) : A::infinity();
     };
     E S_out = A::infinity(), W_out = A::infinity();
-    if (pre != nullptr) {
-        const uint32_t g = blk * TPB + t;
-        E S = A::infinity(), W = A::infinity();
-        if (g < T) {
-            S = A::load(pre, ((size_t)k * T + g) * 2 + 0);
-            W = A::load(pre, ((size_t)k * T + g) * 2 + 1);
-        }
-        reduce_program<A, TPB>(load_bucket, 0u, S, W, log2L, (uint32_t)TPB, prescale, lds, S_out, W_out);
-    } else {
-        reduce_program<A, TPB>(load_bucket, L, A::infinity(), A::infinity(), log2L, (uint32_t)TPB, prescale, lds, S_out, W_out);
-    }
+    reduce_program<A, TPB>(load_bucket, L, A::infinity(), A::infinity(), log2L, (uint32_t)TPB, prescale, lds, S_out, W_out);
     if (t == (prescale != 0 && TPB >= 256 ? 64u : 0u)) A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 0, S_out);
     if (t == 0) A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 1, W_out);
-}
-
-// The combine step of level 1 alone, for the split reduction (k_reduce_serial has produced the threads' (S_t, W_t)): the
-// same program as k_reduce1 without its serial phase, so that the kernel holds exactly ONE call site of the addition and
-// one of the doubling and can afford to INLINE them even for the widest element types (the fused k_reduce1 holds two
-// copies of the program - with and without `pre` - and uses the out-of-line policy for those types: 180 us per step for
-// BW6-761 against 43 us for an inlined addition at the multiplier rate). Used for the element types whose policy is
-// out of line (Group::COMBINE_INLINE).
-template <class A, int TPB>
-__global__ void __launch_bounds__(TPB) k_reduce_combine(uint32_t log2L, void *__restrict__ out1, uint32_t prescale,
-                                                        const void *__restrict__ pre, uint32_t T) {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    using E = typename A::Elem;
-    E *lds = reinterpret_cast<E *>(lds_raw);
-    const uint32_t k = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
-    const uint32_t g = blk * TPB + t;
-    E S = A::infinity(), W = A::infinity();
-    if (g < T) {
-        S = A::load(pre, ((size_t)k * T + g) * 2 + 0);
-        W = A::load(pre, ((size_t)k * T + g) * 2 + 1);
-    }
-    E S_out = A::infinity(), W_out = A::infinity();
-    auto no_buckets = [&](uint32_t) -> E { return A::infinity(); };
-    reduce_program<A, TPB>(no_buckets, 0u, S, W, log2L, (uint32_t)TPB, prescale, lds, S_out, W_out);
-    if (t == (prescale != 0 && TPB >= 256 ? 64u : 0u)) A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 0, S_out);
-    if (t == 0) A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 1, W_out);
-}
-
-// The same combine with the per-thread state in LDS instead of registers (A/B form, -DGMSM_COMBINE_LDS=1, not yet through
-// the GPU suite). reduce_program keeps run / tot / suf / mine and the two operands alive across its one call site of the
-// addition: five or six extended-Jacobian values, 3 KB of scratch per lane for the 28-word element types. Here a step
-// reads its two operands from LDS, adds, and writes the result back, so only X and Y (and the addition's temporaries)
-// are live at the call - the register picture of k_reduce_serial, which runs at the multiplier rate.
-//   SUF[t]  S_t, then its inclusive suffix sums (Hillis-Steele in place: all reads of a step, barrier, all writes)
-//   TOT[t]  W_t
-//   trees   lower half of the threads over SUF[1..] (U = sum_{t>=1} Suf_t; slot 0 is read as infinity in the first
-//           step), upper half over TOT, both in place;  PARK = S_blk, saved by thread 0 when the scan ends
-//   finish  thread 0: U <- 2^log2L U, W <- W + U
-// prescale > 0: thread TPB/4, idle from the second tree step on, doubles PARK once per step (log2 TPB - 1 tree steps and
-// log2L + 1 finishing steps are left: exactly log2span = log2L + log2 TPB doublings fit, for every TPB - the fused
-// k_reduce1 only does this for 256-thread workgroups).
-// dynamic LDS = (2 * TPB + 1) * sizeof(A::Elem).
-template <class A, int TPB>
-__global__ void __launch_bounds__(TPB) k_reduce_combine_lds(uint32_t log2L, void *__restrict__ out1, uint32_t prescale,
-                                                            const void *__restrict__ pre, uint32_t T) {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    using E = typename A::Elem;
-    E *SUF = reinterpret_cast<E *>(lds_raw), *TOT = SUF + TPB, *PARK = SUF + 2 * TPB;
-    const uint32_t k = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
-    const uint32_t g = blk * TPB + t;
-    {
-        E S = A::infinity(), W = A::infinity();
-        if (g < T) {
-            S = A::load(pre, ((size_t)k * T + g) * 2 + 0);
-            W = A::load(pre, ((size_t)k * T + g) * 2 + 1);
-        }
-        SUF[t] = S;
-        TOT[t] = W;
-    }
-    __syncthreads();
-    uint32_t lg = 0;
-    while ((1u << lg) < (uint32_t)TPB) ++lg;
-    const uint32_t n_scan = lg, n_tree = lg, n_fin = log2L + 1, total = n_scan + n_tree + n_fin;
-    const bool upper = t >= TPB / 2;
-    const uint32_t tt = upper ? t - TPB / 2 : t;
-    const bool doubler = prescale != 0 && t == TPB / 4;
-    uint32_t dbl_left = prescale;
-#pragma nounroll
-    for (uint32_t s = 0; s < total; ++s) {
-        E X = A::infinity(), Y = A::infinity();
-        int dest = -1;  // 0: SUF[t]  1: tree slot arr[tt]  2: SUF[0] (finish doubling)  3: TOT[0] (finish add)  4: PARK
-        bool do_dbl = false;
-        if (s < n_scan) {
-            const uint32_t d = 1u << s;
-            X = SUF[t];
-            if (t + d < (uint32_t)TPB) Y = SUF[t + d];
-            dest = 0;
-        } else if (s < n_scan + n_tree) {
-            const uint32_t step = s - n_scan, d = (uint32_t)TPB >> (step + 1);
-            E *arr = upper ? TOT : SUF;
-            if (tt < d) {
-                if (!(step == 0 && !upper && tt == 0)) X = arr[tt];  // U excludes Suf_0 (= S_blk, parked)
-                Y = arr[tt + d];
-                dest = 1;
-            } else if (doubler && step >= 1 && dbl_left > 0) {
-                X = PARK[0];
-                do_dbl = true;
-                dest = 4;
-                --dbl_left;
-            }
-        } else {
-            const uint32_t step = s - n_scan - n_tree;
-            if (t == 0) {
-                if (step < log2L) {
-                    X = SUF[0];
-                    do_dbl = true;
-                    dest = 2;
-                } else {
-                    X = TOT[0];
-                    Y = SUF[0];
-                    dest = 3;
-                }
-            } else if (doubler && dbl_left > 0) {
-                X = PARK[0];
-                do_dbl = true;
-                dest = 4;
-                --dbl_left;
-            }
-        }
-        __syncthreads();  // every read of this step is done
-        if (do_dbl) A::dbl(X);
-        else if (dest >= 0) A::add(X, Y);
-        if (dest == 0) {
-            SUF[t] = X;
-            if (s + 1 == n_scan && t == 0) PARK[0] = X;  // S_blk
-        } else if (dest == 1) {
-            (upper ? TOT : SUF)[tt] = X;
-        } else if (dest == 2) {
-            SUF[0] = X;
-        } else if (dest == 3) {
-            TOT[0] = X;
-        } else if (dest == 4) {
-            PARK[0] = X;
-        }
-        __syncthreads();
-    }
-    if (t == 0) {
-        A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 0, PARK[0]);
-        A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 1, TOT[0]);
-    }
-}
-
-// ------------------------------------------------------------------ lane-cooperative addition
-// The latency-bound tail of the bucket reduction runs ONE wave per SIMD whose dependent multiplies cannot hide each
-// other's latency: an XYZZ addition (12 M + 2 S, add-2008-s, g1.go:736-788) takes ~8.6 us there for BN254 G1 and ~50 us
-// over Fp2. Its 14 products fall into 4 dependency levels of <= 4 independent products, so 4 adjacent lanes (a "quad")
-// that hold the SAME two operands each compute one product per level and exchange the results with ds_bpermute: 4
-// multiply-times instead of 14. Same formulas and operand classes as add_u / add_g (gmsm_curveu.h), squares taken as
-// plain products. All control flow is uniform inside a quad (every lane sees identical data).
-template <class P>
-__device__ __forceinline__ FpU<P> quad_pick(uint32_t r, const FpU<P> &a0, const FpU<P> &a1, const FpU<P> &a2,
-                                            const FpU<P> &a3) {
-    FpU<P> o;
-#pragma unroll
-    for (int i = 0; i < P::UL; ++i) {
-        const uint32_t lo = (r & 1u) ? a1.l[i] : a0.l[i];
-        const uint32_t hi = (r & 1u) ? a3.l[i] : a2.l[i];
-        o.l[i] = (r & 2u) ? hi : lo;
-    }
-    return o;
-}
-template <class P>
-__device__ __forceinline__ Fp2U<P> quad_pick(uint32_t r, const Fp2U<P> &a0, const Fp2U<P> &a1, const Fp2U<P> &a2,
-                                             const Fp2U<P> &a3) {
-    return Fp2U<P>{quad_pick(r, a0.a0, a1.a0, a2.a0, a3.a0), quad_pick(r, a0.a1, a1.a1, a2.a1, a3.a1)};
-}
-template <class P>
-__device__ __forceinline__ void quad_gather(const FpU<P> &mine, uint32_t lane, FpU<P> &g0, FpU<P> &g1, FpU<P> &g2, FpU<P> &g3) {
-    const int base = (int)(lane & ~3u);
-#pragma unroll
-    for (int i = 0; i < P::UL; ++i) {
-        g0.l[i] = (uint32_t)__shfl((int)mine.l[i], base + 0, 64);
-        g1.l[i] = (uint32_t)__shfl((int)mine.l[i], base + 1, 64);
-        g2.l[i] = (uint32_t)__shfl((int)mine.l[i], base + 2, 64);
-        g3.l[i] = (uint32_t)__shfl((int)mine.l[i], base + 3, 64);
-    }
-}
-template <class P>
-__device__ __forceinline__ void quad_gather(const Fp2U<P> &mine, uint32_t lane, Fp2U<P> &g0, Fp2U<P> &g1, Fp2U<P> &g2,
-                                            Fp2U<P> &g3) {
-    quad_gather(mine.a0, lane, g0.a0, g1.a0, g2.a0, g3.a0);
-    quad_gather(mine.a1, lane, g0.a1, g1.a1, g2.a1, g3.a1);
-}
-
-// p += q on a quad; `lane` = lane index inside the wavefront. Every lane of the quad passes the same p, q and gets the
-// same result. Prime field: the bound-tracked formulas of add_u.
-template <bool INL, class P>
-__device__ __forceinline__ void lz_padd_quad(XYZZL<FpU<P>> &p, bool &pinf, const XYZZL<FpU<P>> &q, bool qinf, uint32_t lane) {
-    if (qinf) return;
-    if (pinf) {
-        p = q;
-        pinf = false;
-        return;
-    }
-    const uint32_t r = lane & 3u;
-    FpU<P> g0, g1, g2, g3;
-    // level 1: U2 = q.x p.zz, U1 = p.x q.zz, S2 = q.y p.zzz, S1 = p.y q.zzz                     (each < 2)
-    quad_gather(fmul<INL>(quad_pick(r, q.x, p.x, q.y, p.y), quad_pick(r, p.zz, q.zz, p.zzz, q.zzz)), lane, g0, g1, g2, g3);
-    const FpU<P> U1 = g1, S1 = g3;
-    const FpU<P> A = fpu_sub<P, 4>(g0, g1);   // < 6
-    const FpU<P> B = fpu_sub<P, 4>(g2, g3);   // < 6
-    // level 2: PP = A^2, BB = B^2, T1 = p.zz q.zz, T2 = p.zzz q.zzz                              (each < 2)
-    quad_gather(fmul<INL>(quad_pick(r, A, B, p.zz, p.zzz), quad_pick(r, A, B, q.zz, q.zzz)), lane, g0, g1, g2, g3);
-    const FpU<P> PP = g0, BB = g1, T1 = g2, T2 = g3;
-    if (fpu_prod_is_zero(PP)) {  // same x: P + P or P - P (rare) -> the one-lane code, redundantly on the four lanes
-        add_u<P, false>(p, pinf, q, qinf);
-        return;
-    }
-    // level 3: PPP = A PP, Q = U1 PP, ZZ3 = T1 PP (lane 3 repeats lane 2)
-    quad_gather(fmul<INL>(quad_pick(r, A, U1, T1, T1), PP), lane, g0, g1, g2, g3);
-    const FpU<P> PPP = g0, Q = g1, ZZ3 = g2;
-    const FpU<P> X3 = fpu_sub<P, 4>(fpu_sub<P, 4>(BB, PPP), fpu_dbl(Q));  // < 2 + 4 + 4
-    // level 4: V = S1 PPP, ZZZ3 = T2 PPP, Y' = (Q - X3) B (lane 3 repeats lane 0)
-    quad_gather(fmul<INL>(quad_pick(r, S1, T2, fpu_sub<P, 16>(Q, X3), S1), quad_pick(r, PPP, PPP, B, PPP)), lane, g0, g1, g2, g3);
-    p.y = fpu_sub<P, 4>(g2, g0);  // < 6
-    p.x = X3;
-    p.zz = ZZ3;
-    p.zzz = g1;
-}
-// Fp2 (reduced class [0,4q)): the formulas of add_g.
-template <bool INL, class P>
-__device__ __forceinline__ void lz_padd_quad(XYZZL<Fp2U<P>> &p, bool &pinf, const XYZZL<Fp2U<P>> &q, bool qinf, uint32_t lane) {
-    using U = Fp2U<P>;
-    if (qinf) return;
-    if (pinf) {
-        p = q;
-        pinf = false;
-        return;
-    }
-    const uint32_t r = lane & 3u;
-    U g0, g1, g2, g3;
-    quad_gather(lz_mul<INL>(quad_pick(r, q.x, p.x, q.y, p.y), quad_pick(r, p.zz, q.zz, p.zzz, q.zzz)), lane, g0, g1, g2, g3);
-    const U U1 = g1, S1 = g3;
-    const U A = lz_sub(g0, g1), B = lz_sub(g2, g3);
-    if (lz_is_zero(A)) {
-        add_g<U, false>(p, pinf, q, qinf);
-        return;
-    }
-    quad_gather(lz_mul<INL>(quad_pick(r, A, B, p.zz, p.zzz), quad_pick(r, A, B, q.zz, q.zzz)), lane, g0, g1, g2, g3);
-    const U PP = g0, BB = g1, T1 = g2, T2 = g3;
-    quad_gather(lz_mul<INL>(quad_pick(r, A, U1, T1, T1), PP), lane, g0, g1, g2, g3);
-    const U PPP = g0, Q = g1, ZZ3 = g2;
-    const U X3 = lz_sub(lz_sub(BB, PPP), lz_dbl(Q));
-    quad_gather(lz_mul<INL>(quad_pick(r, S1, T2, lz_sub(Q, X3), S1), quad_pick(r, PPP, PPP, B, PPP)), lane, g0, g1, g2, g3);
-    p.y = lz_sub(g2, g0);
-    p.x = X3;
-    p.zz = ZZ3;
-    p.zzz = g1;
-}
-
-// r = [2]q on a quad (dbl-2008-s-1, a = 0; same operands as double_u / double_g): 9 products in 3 levels.
-template <bool INL, class P>
-__device__ __forceinline__ XYZZL<FpU<P>> lz_pdbl_quad(const XYZZL<FpU<P>> &q, uint32_t lane) {
-    const uint32_t r = lane & 3u;
-    FpU<P> g0, g1, g2, g3;
-    const FpU<P> Uy = fpu_dbl(q.y);  // < 14
-    quad_gather(fmul<INL>(quad_pick(r, Uy, q.x, Uy, q.x), quad_pick(r, Uy, q.x, Uy, q.x)), lane, g0, g1, g2, g3);  // V, XX
-    const FpU<P> V = g0, XX = g1;
-    const FpU<P> M = fpu_add(fpu_add(XX, XX), XX);  // < 6
-    quad_gather(fmul<INL>(quad_pick(r, Uy, q.x, V, M), quad_pick(r, V, V, q.zz, M)), lane, g0, g1, g2, g3);  // W, S, ZZ3, M^2
-    const FpU<P> W = g0, S = g1, ZZ3 = g2;
-    XYZZL<FpU<P>> o;
-    o.x = fpu_sub<P, 4>(g3, fpu_dbl(S));  // < 6
-    quad_gather(fmul<INL>(quad_pick(r, W, W, fpu_sub<P, 16>(S, o.x), W), quad_pick(r, q.y, q.zzz, M, q.y)), lane, g0, g1, g2, g3);
-    o.y = fpu_sub<P, 4>(g2, g0);  // < 6
-    o.zz = ZZ3;
-    o.zzz = g1;
-    return o;
-}
-template <bool INL, class P>
-__device__ __forceinline__ XYZZL<Fp2U<P>> lz_pdbl_quad(const XYZZL<Fp2U<P>> &q, uint32_t lane) {
-    using U = Fp2U<P>;
-    const uint32_t r = lane & 3u;
-    U g0, g1, g2, g3;
-    const U Uy = lz_dbl(q.y);
-    quad_gather(lz_mul<INL>(quad_pick(r, Uy, q.x, Uy, q.x), quad_pick(r, Uy, q.x, Uy, q.x)), lane, g0, g1, g2, g3);
-    const U V = g0, XX = g1;
-    const U M = lz_add(lz_dbl(XX), XX);
-    quad_gather(lz_mul<INL>(quad_pick(r, Uy, q.x, V, M), quad_pick(r, V, V, q.zz, M)), lane, g0, g1, g2, g3);
-    const U W = g0, S = g1, ZZ3 = g2;
-    XYZZL<U> o;
-    o.x = lz_sub(g3, lz_dbl(S));
-    quad_gather(lz_mul<INL>(quad_pick(r, W, W, lz_sub(S, o.x), W), quad_pick(r, q.y, q.zzz, M, q.y)), lane, g0, g1, g2, g3);
-    o.y = lz_sub(g2, g0);
-    o.zz = ZZ3;
-    o.zzz = g1;
-    return o;
-}
-
-// Level 2 of the bucket reduction on quads: grid = nwin_local, block = 4 * active threads (active = power of two >=
-// nblocks1, <= 64). Quad j holds level-1 block j: (S_j, W_j), S_j already multiplied by the span when level 1 prescaled
-// it. window_total = sum_j W_j + 2^log2span * sum_{j>=1} Suf_j, Suf = suffix sums of S: suffix scan (log2 active quad
-// steps), quad doublings only if log2span != 0, one step W_j + Suf_j, tree (log2 active steps).
-template <class U, bool INL>
-__global__ void __launch_bounds__(256) k_reduce2_quad(const void *__restrict__ in1, uint32_t nblocks1, uint32_t log2span,
-                                                      uint32_t active, void *__restrict__ window_totals) {
-    using E = UnsatElem<U>;
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    E *lds = reinterpret_cast<E *>(lds_raw);  // [active]
-    const uint32_t k = blockIdx.x, t = threadIdx.x, j = t >> 2, lane = t & 63u;
-    E S = unsat_infinity<U>(), W = unsat_infinity<U>();
-    if (j < nblocks1) {
-        S = unsat_load<U>(in1, ((size_t)k * nblocks1 + j) * 2 + 0);
-        W = unsat_load<U>(in1, ((size_t)k * nblocks1 + j) * 2 + 1);
-    }
-    // inclusive suffix scan of S over the quads
-#pragma nounroll
-    for (uint32_t d = 1; d < active; d <<= 1) {
-        if ((t & 3u) == 0) lds[j] = S;
-        __syncthreads();
-        E Y = unsat_infinity<U>();
-        if (j + d < active) Y = lds[j + d];
-        __syncthreads();
-        lz_padd_quad<INL>(S.v, S.inf, Y.v, Y.inf, lane);
-    }
-    // U-part of quad j: Suf_j for j >= 1, scaled by what is left of the span
-    if (j == 0) S = unsat_infinity<U>();
-#pragma nounroll
-    for (uint32_t s = 0; s < log2span; ++s)
-        if (!S.inf) S.v = lz_pdbl_quad<INL>(S.v, lane);
-    lz_padd_quad<INL>(W.v, W.inf, S.v, S.inf, lane);
-    // tree over the quads
-#pragma nounroll
-    for (uint32_t d = active >> 1; d >= 1; d >>= 1) {
-        if ((t & 3u) == 0) lds[j] = W;
-        __syncthreads();
-        E Y = unsat_infinity<U>();
-        if (j < d) Y = lds[j + d];
-        __syncthreads();
-        lz_padd_quad<INL>(W.v, W.inf, Y.v, Y.inf, lane);
-    }
-    if (t == 0) unsat_store_final<U, false>(window_totals, k, W);
 }
 
 }  // namespace gmsm

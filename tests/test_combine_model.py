@@ -1,81 +1,119 @@
-"""Lockstep model of the level-1 combine programs of the bucket reduction (gmsm_kernels.h: reduce_program's combine
-phases and k_reduce_combine_lds) over the additive group Z (add = +, dbl = *2, infinity = 0): the step machine - suffix
-scan in place, the two trees, the parked block sum with its prescaling doublings, the finish - must produce
-W_blk = sum W_t + L * sum_{t>=1} Suf_t and S_blk = 2^prescale * sum S_t (the identity of multiexp_jacobian.go:44-52
-cut into segments). Pure Python; it pins the index arithmetic of the device code, which the GPU suite then runs."""
+"""Lockstep model of the quad step machines of the bucket reduction (gmsm_quad.h: k_combine_q, the level-1 combine of the
+split reduction, and k_reduce2_q, level 2) over the additive group Z (add = +, dbl = *2, infinity = None): every step
+is "all quads read their operands - barrier - compute and store - barrier", records may be one quad's destination and
+another quad's source in the same step, and the result must be
+    W_blk = sum W_t + L * sum_{t>=1} Suf_t,   S_blk = 2^prescale * sum S_t        (level 1)
+    total = sum_j W_j + 2^log2span * sum_{j>=1} Suf_j                              (level 2)
+- the identity of multiexp_jacobian.go:44-52 cut into segments. Pure Python; it pins the index arithmetic, the parking of
+S_blk and the schedule of the prescaling doublings of the device code, which the GPU suite then runs on curve points."""
 import random
 
 
-def combine_lds(TPB, log2L, prescale, S, W):
-    SUF, TOT, PARK = list(S), list(W), [0]
-    lg = TPB.bit_length() - 1
-    n_scan = n_tree = lg
-    total = n_scan + n_tree + log2L + 1
+def add(x, y):  # group law with infinity
+    if y is None:
+        return x
+    if x is None:
+        return y
+    return x + y
+
+
+def dbl(x):
+    return None if x is None else 2 * x
+
+
+def val(x):
+    return 0 if x is None else x
+
+
+def combine_q(N, log2L, prescale, S, W):
+    """k_combine_q<U, INL, N>: quad j holds pair j."""
+    S, W = list(S), list(W)
+    lg = N.bit_length() - 1
+    for s in range(lg):  # suffix scan, in place
+        d = 1 << s
+        loaded = [(j, S[j], S[j + d]) for j in range(N) if j + d < N]      # quad_add_load of every active quad
+        for j, x, y in loaded:                                               # after the barrier
+            S[j] = add(x, y)
+    park = S[0]
+    S[0] = None
     dbl_left = prescale
-    for s in range(total):
-        ops = []
-        for t in range(TPB):
-            upper = t >= TPB // 2
-            tt = t - TPB // 2 if upper else t
-            doubler = prescale != 0 and t == TPB // 4
-            X = Y = 0
-            dest, do_dbl = -1, False
-            if s < n_scan:
-                d = 1 << s
-                X = SUF[t]
-                if t + d < TPB:
-                    Y = SUF[t + d]
-                dest = 0
-            elif s < n_scan + n_tree:
-                step = s - n_scan
-                d = TPB >> (step + 1)
-                arr = TOT if upper else SUF
-                if tt < d:
-                    if not (step == 0 and not upper and tt == 0):
-                        X = arr[tt]
-                    Y = arr[tt + d]
-                    dest = 1
-                elif doubler and step >= 1 and dbl_left > 0:
-                    X, do_dbl, dest = PARK[0], True, 4
-                    dbl_left -= 1
-            else:
-                step = s - n_scan - n_tree
-                if t == 0:
-                    if step < log2L:
-                        X, do_dbl, dest = SUF[0], True, 2
-                    else:
-                        X, Y, dest = TOT[0], SUF[0], 3
-                elif doubler and dbl_left > 0:
-                    X, do_dbl, dest = PARK[0], True, 4
-                    dbl_left -= 1
-            ops.append((t, upper, tt, X, Y, dest, do_dbl))
-        for t, upper, tt, X, Y, dest, do_dbl in ops:  # after the barrier: compute, write back
-            X = 2 * X if do_dbl else (X + Y if dest >= 0 else X)
-            if dest == 0:
-                SUF[t] = X
-                if s + 1 == n_scan and t == 0:
-                    PARK[0] = X
-            elif dest == 1:
-                (TOT if upper else SUF)[tt] = X
-            elif dest == 2:
-                SUF[0] = X
-            elif dest == 3:
-                TOT[0] = X
-            elif dest == 4:
-                PARK[0] = X
+    n_tree, n_fin = lg, log2L + 1
+    for s in range(n_tree + n_fin):
+        loaded, fin_dbl = [], False
+        for j in range(N):
+            upper = j >= N // 2
+            jj = j - N // 2 if upper else j
+            arr = W if upper else S
+            if s < n_tree:
+                d = N >> (s + 1)
+                if d >= 1 and jj < d:
+                    loaded.append((arr, jj, arr[jj], arr[jj + d]))
+            elif j == 0:
+                step = s - n_tree
+                if step < log2L:
+                    fin_dbl = True
+                else:
+                    loaded.append((W, 0, W[0], S[0]))
+            if j == N - 1 and s == 0:
+                assert upper and jj < (N >> 1), "quad N-1 is busy in the first tree step"
+        for arr, jj, x, y in loaded:
+            arr[jj] = add(x, y)
+        if fin_dbl:
+            S[0] = dbl(S[0])
+        if s >= 1 and dbl_left > 0:  # the doubler (quad N-1)
+            jj = N // 2 - 1
+            assert s >= n_tree or jj >= (N >> (s + 1)), "the doubler must be free"
+            park = dbl(park)
+            dbl_left -= 1
     assert dbl_left == 0
-    return PARK[0], TOT[0]
+    return park, W[0]
 
 
-def test_combine_program_identity():
+def reduce2_q(active, nblocks1, log2span, S, W):
+    """k_reduce2_q: quad j holds level-1 block j (j < nblocks1, the rest infinity)."""
+    S = [S[j] if j < nblocks1 else None for j in range(active)]
+    W = [W[j] if j < nblocks1 else None for j in range(active)]
+    d = 1
+    while d < active:
+        loaded = [(j, S[j], S[j + d]) for j in range(active) if j + d < active]
+        for j, x, y in loaded:
+            S[j] = add(x, y)
+        d <<= 1
+    S[0] = None
+    for _ in range(log2span):
+        S = [dbl(x) for x in S]
+    W = [add(W[j], S[j]) for j in range(active)]
+    d = active >> 1
+    while d >= 1:
+        loaded = [(j, W[j], W[j + d]) for j in range(d)]
+        for j, x, y in loaded:
+            W[j] = add(x, y)
+        d >>= 1
+    return W[0]
+
+
+def test_combine_q_identity():
     rng = random.Random(20260925)
-    for TPB in (128, 256):
-        for log2L in (1, 3, 4, 5, 8):
-            for prescale in (0, log2L + TPB.bit_length() - 1):  # log2span = log2L + log2 TPB, as the host passes it
+    for N in (16, 32, 64, 128):
+        lg = N.bit_length() - 1
+        for log2L in (1, 2, 3, 4, 8):
+            for prescale in (0, log2L + lg):  # log2span = log2L + log2 N, as the host passes it
                 for _ in range(10):
-                    S = [rng.randrange(1 << 40) if rng.random() < 0.8 else 0 for _ in range(TPB)]
-                    W = [rng.randrange(1 << 40) for _ in range(TPB)]
-                    s_blk, w_blk = combine_lds(TPB, log2L, prescale, S, W)
-                    suf = [sum(S[t:]) for t in range(TPB)]
-                    assert w_blk == sum(W) + (1 << log2L) * sum(suf[1:])
-                    assert s_blk == sum(S) << prescale
+                    S = [rng.randrange(1, 1 << 40) if rng.random() < 0.8 else None for _ in range(N)]
+                    W = [rng.randrange(1, 1 << 40) if rng.random() < 0.9 else None for _ in range(N)]
+                    s_blk, w_blk = combine_q(N, log2L, prescale, S, W)
+                    suf = [sum(val(x) for x in S[t:]) for t in range(N)]
+                    assert val(w_blk) == sum(val(x) for x in W) + (1 << log2L) * sum(suf[1:])
+                    assert val(s_blk) == sum(val(x) for x in S) << prescale
+
+
+def test_reduce2_q_identity():
+    rng = random.Random(7)
+    for active in (2, 4, 16, 64):
+        for nblocks1 in {1, 2, active // 2 + 1, active} & set(range(1, active + 1)):
+            for log2span in (0, 3, 11):
+                S = [rng.randrange(1, 1 << 40) if rng.random() < 0.8 else None for _ in range(active)]
+                W = [rng.randrange(1, 1 << 40) for _ in range(active)]
+                got = reduce2_q(active, nblocks1, log2span, S, W)
+                suf = [sum(val(x) for x in S[j:nblocks1]) for j in range(nblocks1)]
+                assert val(got) == sum(val(x) for x in W[:nblocks1]) + (1 << log2span) * sum(suf[1:])
