@@ -1,9 +1,7 @@
-// Extended-Jacobian group law on the unsaturated ("lazy") field representation of gmsm_fieldu.h, plus the two
-// arithmetic policies the bucket kernels are written against:
-//   UnsatOps<U>    -- group operations inlined into the kernel (9- and 14-limb prime fields)
-//   UnsatOpsNI<U>  -- out-of-line group operations on the out-of-line multiplier (Fp2, 28-limb field, k_fixup_level)
-// Both present the same interface (Elem, load/store of the lazy XYZZ record in memory, store_final, add, dbl), so the
-// fixup and reduction kernels are written once for every element type U (FpU<P> or Fp2U<P>).
+// Extended-Jacobian group law on the unsaturated ("lazy") field representation of gmsm_fieldu.h, plus the arithmetic
+// policy UnsatOps<U> the one-lane bucket kernels (k_fixup_seg, k_reduce_serial) are written against: Elem, load/store of
+// the lazy XYZZ record in memory, store_final, add, dbl - once for every element type U (FpU<P> or Fp2U<P>). The kernels
+// that combine few elements use the lane-quad forms of gmsm_quad.h instead.
 //
 // Same group semantics as the reference's g1JacExtended (ecc/bn254/g1.go:682-985): every special case is kept
 // (inf + P, P + inf, P + P -> doubling, P + (-P) -> infinity). Value bounds are stated in multiples of q and hold for
@@ -466,7 +464,7 @@ __device__ __forceinline__ UnsatElem<U> unsat_infinity() {
     return e;
 }
 
-// Fully inlined policy: fastest when the kernel holds few call sites (k_fixup_seg, k_reduce1/2).
+// Fully inlined policy: for kernels with ONE call site of the addition (k_fixup_seg, k_reduce_serial).
 template <class U>
 struct UnsatOps {
     using Mem = XYZZL<U>;                              // bucket / partial record in HBM
@@ -479,23 +477,6 @@ struct UnsatOps {
     __device__ static __forceinline__ void add(Elem &p, const Elem &q) { lz_padd<true>(p.v, p.inf, q.v, q.inf); }
     __device__ static __forceinline__ void dbl(Elem &p) {
         if (!p.inf) p.v = lz_pdbl<true>(p.v);
-    }
-};
-
-// Out-of-line policy on the out-of-line multiplier: smallest code. k_fixup_level has five call sites of the group
-// operations inside one loop.
-template <class U>
-struct UnsatOpsNI {
-    using Mem = XYZZL<U>;
-    using Final = XYZZ<typename LzTraits<U>::Sat>;
-    using Elem = UnsatElem<U>;
-    __device__ static __forceinline__ Elem infinity() { return unsat_infinity<U>(); }
-    __device__ static __forceinline__ Elem load(const void *base, size_t i) { return unsat_load<U>(base, i); }
-    __device__ static __forceinline__ void store(void *base, size_t i, const Elem &e) { lazy_store<U>(base, i, e.v, e.inf); }
-    __device__ static __noinline__ void store_final(void *base, size_t i, const Elem &e) { unsat_store_final<U, false>(base, i, e); }
-    __device__ static __noinline__ void add(Elem &p, const Elem &q) { lz_padd<false>(p.v, p.inf, q.v, q.inf); }
-    __device__ static __noinline__ void dbl(Elem &p) {
-        if (!p.inf) p.v = lz_pdbl<false>(p.v);
     }
 };
 

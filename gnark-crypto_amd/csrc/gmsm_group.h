@@ -37,24 +37,28 @@ struct Group {
     // unsaturated-limb accumulation (gmsm_fieldu.h) for groups whose coordinates live in Fp; Fp2 groups use the generic
     // saturated kernel
     using U = typename LazyOf<F>::type;  // lazy element type: FpU<P> for Fp coordinates, Fp2U<P> for Fp2 coordinates
-    // Arithmetic policy of the fix-up and reduction kernels: group operations fully inlined where one XYZZ addition is
-    // small enough (9- and 14-limb prime fields); Fp2 and the 28-limb field use the out-of-line forms in kernels with
-    // several call sites (a single inlined Fp2 or BW6-761 addition is 60-350 KB of code) and inline the group law only
-    // where a kernel has ONE call site of the addition (k_fixup_seg, k_reduce_serial).
-    static constexpr bool INLINE_OPS = sizeof(U) <= 14 * 4;
-    using Ops = typename std::conditional<INLINE_OPS, UnsatOps<U>, UnsatOpsNI<U>>::type;
-    using OpsElem = typename Ops::Elem;
-    using OpsSerial = UnsatOps<U>;   // k_reduce_serial, k_fixup_seg: one call site, inlined for every element type
-    static constexpr int RED_TPB = 256;  // threads of a fused level-1 workgroup (k_reduce1): 2*TPB*sizeof(Elem) of LDS
-    static constexpr int RED2_TPB = 64;  // level-1 workgroups per window that level 2 (k_reduce2_q) takes
-    // Every element type except the 9-limb prime field runs the serial part of reduction level 1 as its own kernel
-    // (k_reduce_serial, group law inlined, no LDS) and combines the threads' (S, W) pairs on lane quads with the
-    // operands in LDS (k_combine_q, gmsm_quad.h): COMBINE_N pairs per workgroup of 4 * COMBINE_N threads. Measured reduce
-    // times fused / split with a one-lane combine (round 2): BW6-761 G1 8.87 / 6.14 ms, BLS12-381 G2 5.60 / 4.42, BN254 G2
-    // 2.60 / 1.99, BLS12-381 G1 0.98 / 0.84, BN254 G1 0.365 / 0.511 (stays fused).
-    static constexpr bool SPLIT_REDUCE = sizeof(U) > 9 * 4;
+    // Group operations are inlined where a kernel has ONE call site of the addition (k_accumulate_seg, k_fixup_seg,
+    // k_reduce_serial: a single inlined Fp2 or BW6-761 addition is 60-350 KB of code); everything that combines few
+    // elements (long chains, the reduction's combine and level 2) runs on lane quads with the operands in LDS (gmsm_quad.h).
+    static constexpr bool INLINE_OPS = sizeof(U) <= 14 * 4;  // fixed-base / normalisation kernels: inline their products
+    using OpsSerial = UnsatOps<U>;
+    using OpsElem = typename OpsSerial::Elem;
+    // Level 1 of the bucket reduction = k_reduce_serial (one thread per L buckets, no LDS) + k_combine_q (COMBINE_N
+    // (S, W) pairs per workgroup of 4 * COMBINE_N threads); level 2 = k_reduce2_q, at most RED2_TPB level-1 results per window.
     static constexpr int COMBINE_N = 64;
-    static_assert((2 * RED_TPB) * sizeof(OpsElem) <= 160 * 1024 || SPLIT_REDUCE, "fused reduction LDS budget");
+    static constexpr int RED2_TPB = 64;
+    // The serial part itself runs on quads (k_reduce_serial_q) for every element type but the 9-limb prime field.
+    // Measured reduce times one-lane / quad serial (same box): BW6-761 2^20 1.85 / 1.13 ms, BLS12-381 G2 2^22 2.17 / 1.61,
+    // BN254 G2 2^20 0.955 / 0.906, BLS12-381 G1 2^22 0.675 / 0.601 (2^16: 0.688 / 0.611).
+#ifndef GMSM_SERIAL_QUAD_WORDS
+#define GMSM_SERIAL_QUAD_WORDS 14
+#endif
+    static constexpr bool SERIAL_QUAD = sizeof(U) >= GMSM_SERIAL_QUAD_WORDS * 4;
+    // k_fixup_seg: followers a chain head adds itself (one-lane additions); longer chains go to k_fixup_long (quads, one
+    // workgroup per chain). Handing chains of 3+ links to the quads for the wide types was measured: no gain at 2^20
+    // (BW6-761 fixup 0.75 ms either way - it is 322 K two-link chains in five rounds of 512-register workgroups), and 2^16
+    // got slower (0.68 -> 2.6 ms: thousands of short chains, one workgroup each).
+    static constexpr uint32_t FIX_MAXWALK = FIXUP_MAXWALK;
     static_assert((2 * COMBINE_N + 1) * sizeof(QRec<U>) <= 160 * 1024, "quad combine LDS budget");
 
     static WindowPlan make_plan(unsigned c, unsigned win_first, unsigned win_stride) {
@@ -120,37 +124,28 @@ struct Group {
         Geometry q;
         // reduction: buckets per level-1 thread, L = 2^log2L, and the number of level-1 workgroups per window (at most
         // RED2_TPB of them: one quad of level 2 each).
-        constexpr size_t SPAN1 = SPLIT_REDUCE ? COMBINE_N : RED_TPB;  // threads' results one level-1 workgroup combines
+        constexpr size_t SPAN1 = COMBINE_N;  // threads' results one level-1 workgroup combines
         const auto blocks1 = [&](uint32_t l2) { return ((size_t)NB + (SPAN1 << l2) - 1) / (SPAN1 << l2); };
         uint32_t log2L = tune_uint("GMSM_LOG2L", 0);
         if (log2L == 0) {
-            if (SPLIT_REDUCE) {
-                // serial kernel: 2L dependent one-lane additions on every SIMD, as many rounds as the threads need;
-                // combine: 2 log2 N + log2 L + 1 quad steps (a quad step is about a third of a one-lane addition) per
-                // round of workgroups - one per CU, its 4 N threads hold the registers of a whole CU for the wide types.
-                // Minimise the total in units of one-lane additions.
-                size_t best = ~(size_t)0;
-                for (uint32_t l2 = 1; l2 <= 8; ++l2) {
-                    if (blocks1(l2) > (size_t)RED2_TPB) continue;
-                    const size_t serial_threads = (size_t)nw * (((size_t)NB + ((size_t)1 << l2) - 1) >> l2);
-                    const size_t serial_rounds = (serial_threads + (size_t)ctx.num_cus * 256 - 1) / ((size_t)ctx.num_cus * 256);
-                    const size_t rounds = ((size_t)nw * blocks1(l2) + ctx.num_cus - 1) / ctx.num_cus;
-                    const size_t cost3 = 3 * serial_rounds * ((size_t)2 << l2) + rounds * (2 * 6 + l2 + 1);
-                    if (cost3 < best) {
-                        best = cost3;
-                        log2L = l2;
-                    }
+            // serial kernel: 2L dependent one-lane additions on every SIMD, as many rounds as the threads need;
+            // combine: 2 log2 N + log2 L + 1 quad steps (a quad step is about a third of a one-lane addition) per
+            // round of workgroups, one per CU. Minimise the total in units of one-lane additions.
+            size_t best = ~(size_t)0;
+            for (uint32_t l2 = 1; l2 <= 8; ++l2) {
+                if (blocks1(l2) > (size_t)RED2_TPB) continue;
+                const size_t serial_threads = (size_t)nw * (((size_t)NB + ((size_t)1 << l2) - 1) >> l2);
+                // lanes of the serial kernel: one per thread, or a quad per thread at a third of the step time
+                const size_t serial_lanes = SERIAL_QUAD ? 4 * serial_threads : serial_threads;
+                const size_t serial_rounds = (serial_lanes + (size_t)ctx.num_cus * 256 - 1) / ((size_t)ctx.num_cus * 256);
+                const size_t rounds = ((size_t)nw * blocks1(l2) + ctx.num_cus - 1) / ctx.num_cus;
+                const size_t cost3 = (SERIAL_QUAD ? 1 : 3) * serial_rounds * ((size_t)2 << l2) + rounds * (2 * 6 + l2 + 1);
+                if (cost3 < best) {
+                    best = cost3;
+                    log2L = l2;
                 }
-                if (log2L == 0) log2L = 8;
-            } else {
-                // fused (k_reduce1): as few buckets per thread as possible (the per-thread running sum is a serial chain)
-                // while all level-1 workgroups are resident at once - one per CU, every one of them runs a single wave
-                // per SIMD. (Letting an eighth of the CUs take a second workgroup to halve L - 17 windows at c = 15 are
-                // 272 workgroups at L = 4 - was measured: the doubly occupied CUs run both chains at half speed and the
-                // kernel gets slower, 0.45 against 0.37 ms at 2^16.)
-                log2L = 1;
-                while ((size_t)nw * blocks1(log2L) > (size_t)ctx.num_cus && blocks1(log2L) > 1) ++log2L;
             }
+            if (log2L == 0) log2L = 8;
         }
         while (blocks1(log2L) > (size_t)RED2_TPB) ++log2L;
         q.log2L = log2L;
@@ -223,9 +218,8 @@ struct Group {
         }
         if (n >= ((size_t)1 << 31)) return fail(GMSM_ERR_ARG, "n must be < 2^31");
         const uint32_t NB = plan.nbuckets;
-        constexpr size_t REC = sizeof(typename Ops::Mem);  // bucket / partial record (lazy representation on the fast path)
+        constexpr size_t REC = sizeof(typename OpsSerial::Mem);  // bucket / partial record (lazy representation on the fast path)
 
-        constexpr bool split_reduce = SPLIT_REDUCE;
         const Geometry q = plan_geometry(ctx, nw, n, NB);
         const size_t tot_thr = (size_t)nw * q.tpw;
         const size_t tot_blk = (size_t)nw * q.nblocks1;
@@ -272,7 +266,7 @@ struct Group {
         if ((rc = ws.buckets.ensure((size_t)nw * NB * REC))) return rc;
         if ((rc = ws.partials.ensure(tot_blk * 2 * REC))) return rc;
         const uint32_t T = (uint32_t)(((size_t)NB + ((size_t)1 << q.log2L) - 1) >> q.log2L);  // (S, W) pairs per window of k_reduce_serial
-        if (split_reduce && (rc = ws.red_pre.ensure((size_t)nw * T * 2 * REC))) return rc;
+        if ((rc = ws.red_pre.ensure((size_t)nw * T * 2 * REC))) return rc;
         if ((rc = ws.totals.ensure((size_t)nw * sizeof(Ext)))) return rc;
         if ((rc = ws.ensure_pinned((size_t)nw * sizeof(Ext)))) return rc;
         if ((rc = ws.blockhist.ensure((size_t)nw * pchunks * nparts * 4))) return rc;
@@ -282,7 +276,7 @@ struct Group {
         if ((rc = ws.seg_bucket.ensure(tot_thr * 4))) return rc;
         // long-chain list of the fixup (k_fixup_seg appends, k_fixup_long consumes): one counter (slot of the first window;
         // k_part_rowscan zeroes it) + at most one entry per FIXUP_MAXWALK threads
-        const size_t list_cap = tot_thr / FIXUP_MAXWALK + nw + 1;
+        const size_t list_cap = tot_thr / FIX_MAXWALK + nw + 1;
         if ((rc = ws.seg_lvl.ensure((size_t)nw * 4 + 16 + list_cap * sizeof(LongChain)))) return rc;
         uint32_t *long_flag = (uint32_t *)ws.seg_lvl.ptr;                                  // [nw] counters, [0] is used
         LongChain *long_list = (LongChain *)((char *)ws.seg_lvl.ptr + (((size_t)nw * 4 + 15) / 16) * 16);
@@ -294,12 +288,10 @@ struct Group {
         if ((rc = ctx.allow_lds((const void *)k_part_scatter<uint16_t>, 152 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_part_scatter<uint32_t>, 152 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_fine_sort, 160 * 1024))) return rc;
-        if ((rc = ctx.allow_lds((const void *)k_fixup_long<Ops>, (int)(256 * sizeof(OpsElem))))) return rc;
-        if constexpr (SPLIT_REDUCE) {
-            if ((rc = ctx.allow_lds((const void *)k_combine_q<U, true, COMBINE_N>, (int)((2 * COMBINE_N + 1) * sizeof(QRec<U>))))) return rc;
-        } else {
-            if ((rc = ctx.allow_lds((const void *)k_reduce1<Ops, RED_TPB>, (int)(2 * RED_TPB * sizeof(OpsElem))))) return rc;
-        }
+        if ((rc = ctx.allow_lds((const void *)k_fixup_long<U>, (int)(128 * sizeof(QRec<U>))))) return rc;
+        if ((rc = ctx.allow_lds((const void *)k_combine_q<U, true, COMBINE_N>, (int)((2 * COMBINE_N + 1) * sizeof(QRec<U>))))) return rc;
+        if constexpr (SERIAL_QUAD)
+            if ((rc = ctx.allow_lds((const void *)k_reduce_serial_q<U>, (int)(192 * sizeof(QRec<U>))))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_reduce2_q<U, true>, (int)(2 * RED2_TPB * sizeof(QRec<U>))))) return rc;
 
         StageTimer timer(ws);
@@ -361,8 +353,8 @@ struct Group {
                            starts, sorted, buckets, seg_partials, seg_flags, seg_bucket, q.tpw);
         timer.mark(T_FIXUP, stream);
         hipLaunchKernelGGL((k_fixup_seg<OpsSerial>), dim3((q.tpw + 255) / 256, nw), dim3(256), 0, stream, NB, seg_partials,
-                           (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets, long_flag, long_list);
-        hipLaunchKernelGGL((k_fixup_long<Ops>), dim3(2 * ctx.num_cus), dim3(256), 256 * sizeof(OpsElem), stream, NB, seg_partials,
+                           (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets, long_flag, long_list, FIX_MAXWALK);
+        hipLaunchKernelGGL((k_fixup_long<U>), dim3(2 * ctx.num_cus), dim3(256), 128 * sizeof(QRec<U>), stream, NB, seg_partials,
                            (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets,
                            (const uint32_t *)long_flag, (const LongChain *)long_list);
         // ---- 3. bucket reduction -> window totals (empty buckets are never written: the reduction consults starts[])
@@ -372,16 +364,15 @@ struct Group {
             // doubles it log2span times while the trees run): level 2 then has no serial doubling tail (11 of its 20
             // steps at c = 16)
             const uint32_t prescale = q.log2span;
-            if constexpr (SPLIT_REDUCE) {
+            if constexpr (SERIAL_QUAD)
+                hipLaunchKernelGGL((k_reduce_serial_q<U>), dim3((T + 63) / 64, nw), dim3(256), 192 * sizeof(QRec<U>), stream, buckets,
+                                   NB, q.log2L, T, starts, ws.red_pre.ptr);
+            else
                 hipLaunchKernelGGL((k_reduce_serial<OpsSerial>), dim3((T + 255) / 256, nw), dim3(256), 0, stream, buckets, NB,
                                    q.log2L, T, starts, ws.red_pre.ptr);
-                hipLaunchKernelGGL((k_combine_q<U, true, COMBINE_N>), dim3(q.nblocks1, nw), dim3(4 * COMBINE_N),
-                                   (2 * COMBINE_N + 1) * sizeof(QRec<U>), stream, q.log2L, partials, prescale,
-                                   (const void *)ws.red_pre.ptr, T);
-            } else {
-                hipLaunchKernelGGL((k_reduce1<Ops, RED_TPB>), dim3(q.nblocks1, nw), dim3(RED_TPB), 2 * RED_TPB * sizeof(OpsElem), stream,
-                                   buckets, NB, q.log2L, partials, starts, prescale);
-            }
+            hipLaunchKernelGGL((k_combine_q<U, true, COMBINE_N>), dim3(q.nblocks1, nw), dim3(4 * COMBINE_N),
+                               (2 * COMBINE_N + 1) * sizeof(QRec<U>), stream, q.log2L, partials, prescale,
+                               (const void *)ws.red_pre.ptr, T);
             // level 2 on quads of lanes
             uint32_t active = 2;
             while (active < q.nblocks1) active <<= 1;

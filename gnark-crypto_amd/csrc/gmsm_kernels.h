@@ -518,13 +518,14 @@ __global__ void __launch_bounds__(256, AccWaves<U>::value) k_accumulate_seg(cons
 struct LongChain {
     uint32_t window, head;  // window index inside the launch, head thread (the chain's destination is pbucket[head])
 };
-constexpr uint32_t FIXUP_MAXWALK = 8;
+constexpr uint32_t FIXUP_MAXWALK = 8;  // upper limit of the `maxwalk` argument of k_fixup_seg
 
 template <class A>
 __global__ void __launch_bounds__(256) k_fixup_seg(uint32_t nbuckets, const void *__restrict__ partials,
                                                    const uint32_t *__restrict__ pflags, const uint32_t *__restrict__ pbucket,
                                                    uint32_t threads_per_win, void *__restrict__ buckets,
-                                                   uint32_t *__restrict__ long_count, LongChain *__restrict__ long_list) {
+                                                   uint32_t *__restrict__ long_count, LongChain *__restrict__ long_list,
+                                                   uint32_t maxwalk /* followers a head adds itself; longer chains -> list */) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
     if (t >= threads_per_win) return;
     const size_t base = (size_t)k * threads_per_win;
@@ -541,14 +542,14 @@ __global__ void __launch_bounds__(256) k_fixup_seg(uint32_t nbuckets, const void
     bool closed = false;
     {
         uint32_t fu = f;
-        for (uint32_t u = t + 1; u < threads_per_win && u <= t + FIXUP_MAXWALK; ++u) {
+        for (uint32_t u = t + 1; u < threads_per_win && u <= t + maxwalk; ++u) {
             if (u != t + 1) fu = pflags[base + u];
             if (!(fu & SegFlags::HAS_P0) || !(fu & SegFlags::P0_OPEN_RIGHT)) {
                 closed = true;
                 break;
             }
         }
-        if (!closed && t + FIXUP_MAXWALK + 1 >= threads_per_win) closed = true;  // runs off the end of the window: short
+        if (!closed && t + maxwalk + 1 >= threads_per_win) closed = true;  // runs off the end of the window: short
     }
     if (!closed) {
         const uint32_t slot = atomicAdd(long_count, 1u);
@@ -567,18 +568,21 @@ __global__ void __launch_bounds__(256) k_fixup_seg(uint32_t nbuckets, const void
     A::store(buckets, (size_t)k * nbuckets + dest, acc);
 }
 
-// grid = any (grid-stride over the list), block = 256, dynamic LDS = 256 * sizeof(A::Elem).
-template <class A>
+// grid = any (grid-stride over the list), block = 256 = 64 quads, dynamic LDS = 128 * sizeof(QRec<U>).
+// Additions on lane quads with the operands in LDS (gmsm_quad.h): quad j first adds up the partial sums j, j + 64, ... of
+// the chain (each fetched into the quad's staging record, one coordinate per lane), then a tree over the 64 quads - for a
+// chain of m links m/64 + 6 quad steps instead of m one-lane additions. (Round 2 ran this with one-lane additions out of
+// line: 2.9 KB of scratch per lane for the 28-limb field, 0.77 ms for the 256 nine-link chains of BW6-761's top window.)
+template <class U>
 __global__ void __launch_bounds__(256) k_fixup_long(uint32_t nbuckets, const void *__restrict__ partials,
                                                     const uint32_t *__restrict__ pflags, const uint32_t *__restrict__ pbucket,
                                                     uint32_t threads_per_win, void *__restrict__ buckets,
                                                     const uint32_t *__restrict__ long_count,
                                                     const LongChain *__restrict__ long_list) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    using E = typename A::Elem;
-    E *lds = reinterpret_cast<E *>(lds_raw);
+    QRec<U> *acc = reinterpret_cast<QRec<U> *>(lds_raw), *stage = acc + 64;
     __shared__ uint32_t s_len;
-    const uint32_t tid = threadIdx.x, count = *long_count;
+    const uint32_t tid = threadIdx.x, j = tid >> 2, lane = tid & 63u, count = *long_count;
     for (uint32_t c = blockIdx.x; c < count; c += gridDim.x) {
         const LongChain lc = long_list[c];
         const size_t base = (size_t)lc.window * threads_per_win;
@@ -598,153 +602,43 @@ __global__ void __launch_bounds__(256) k_fixup_long(uint32_t nbuckets, const voi
         }
         __syncthreads();
         const uint32_t m = s_len != 0xffffffffu ? s_len : threads_per_win - lc.head;
-        E mine = A::infinity();
-        for (uint32_t j = tid; j < m; j += 256) {
-            const E piece = j == 0 ? A::load(partials, (base + lc.head) * 2 + 1) : A::load(partials, (base + lc.head + j) * 2 + 0);
-            A::add(mine, piece);
+        // strided sums: link i of the chain is P1[head] for i = 0 and P0[head + i] otherwise
+        if ((tid & 3u) == 0) acc[j].inf = 1u;
+        for (uint32_t i0 = 0; i0 < m; i0 += 64) {
+            const uint32_t i = i0 + j;
+            quad_rec_load<U>(&stage[j], partials, i == 0 ? (base + lc.head) * 2 + 1 : (base + lc.head + i) * 2 + 0, i < m, lane);
+            __syncthreads();  // the lanes of a quad exchange coordinates through the record: stores before loads
+            const QAddOps<U> o = quad_add_load<U>(&acc[j], &stage[j], lane);  // both records belong to this quad
+            quad_add_store<U, true>(&acc[j], o, i < m, lane);
         }
-        uint32_t active = 256;
-        while (active / 2 >= m && active > 1) active >>= 1;  // smallest power of two >= min(m, 256)
+        __syncthreads();
+        uint32_t active = 64;
+        while (active / 2 >= m && active > 1) active >>= 1;  // smallest power of two >= min(m, 64)
+#pragma nounroll
         for (uint32_t d = active >> 1; d >= 1; d >>= 1) {
-            if (tid < 2 * d) lds[tid] = mine;
+            const bool act = j < d;
+            const QAddOps<U> o = quad_add_load<U>(&acc[j], &acc[act ? j + d : j], lane);
             __syncthreads();
-            E other = A::infinity();
-            if (tid < d) other = lds[tid + d];
+            quad_add_store<U, true>(&acc[j], o, act, lane);
             __syncthreads();
-            A::add(mine, other);
         }
-        if (tid == 0) A::store(buckets, (size_t)lc.window * nbuckets + pbucket[base + lc.head], mine);
+        if (j == 0) quad_rec_store<U>(buckets, (size_t)lc.window * nbuckets + pbucket[base + lc.head], &acc[0], lane);
         __syncthreads();
     }
 }
 
 // ------------------------------------------------------------------ bucket reduction
 // Weighted sum  sum_k (k+1) B_k  of a window, as a two-level segmented running sum:
-//   level 1 (k_reduce1): each thread owns L consecutive buckets (running sum, multiexp_jacobian.go:44-52 restricted to
-//   its segment), then the block combines its threads' (S_t, W_t) with a suffix scan in LDS;
-//   level 2 (k_reduce2_q, gmsm_quad.h): one block per window combines the level-1 block results, four lanes per addition.
-// Identity used:  sum_{k in [base, base+T*L)} (k-base+1) B_k = sum_t W_t + L * sum_{t>=1} Suf_t,
-//   S_t = sum of segment t, W_t = sum_{k in seg t} (k-lo_t+1) B_k, Suf_t = sum_{t'>=t} S_t'.
-// The whole reduction of a workgroup is ONE loop with ONE call site of the XYZZ addition (and one of the doubling): an
-// inlined addition is ~25 KB of straight-line code, and every additional call site that runs only a few times pays a
-// cold instruction fetch of that size (k_reduce2 spent half of its 225 us that way). Each step selects its operands
-// (X += Y) from the thread's registers or from LDS:
-//   serial  (2L steps)      even: run += B_j      odd: tot += run           (multiexp_jacobian.go:44-52 on L buckets)
-//   scan    (log2 active)   suf += suf[t + d]                               (inclusive suffix sums of S_t = run)
-//   trees   (log2 active)   lower half of the threads: U-tree over Suf_t (t >= 1); upper half: W-tree over tot
-//   finish  (log2L + 1)     thread 0: U = 2^log2L * U, then W += U
-// Identity:  sum_{k in [base, base+T*L)} (k-base+1) B_k = sum_t W_t + L * sum_{t>=1} Suf_t.
-// `active` (power of two, 2 <= active <= TPB): threads t >= active hold infinity.
-// prescale > 0 (level 1 only, TPB >= 256): the block's S is also needed multiplied by the width of the level-2 spans,
-// 2^prescale. Those doublings used to be level 2's serial tail (11 of its 20 steps at c = 16); here thread 64 - whose
-// wave has nothing left to do after the first tree step - performs them while the trees and the finish run, and S_out
-// of THAT thread is the scaled sum. prescale must not exceed the log2(active) - 1 + log2L + 1 steps that remain.
-template <class A, int TPB, class LoadFn>
-__device__ __forceinline__ void reduce_program(LoadFn load_bucket, uint32_t L, typename A::Elem run, typename A::Elem tot,
-                                               uint32_t log2L, uint32_t active, uint32_t prescale, typename A::Elem *lds,
-                                               typename A::Elem &S_out, typename A::Elem &W_out) {
-    using E = typename A::Elem;
-    const uint32_t t = threadIdx.x;
-    E *ldsA = lds, *ldsB = lds + TPB;
-    uint32_t lg = 0;
-    while ((1u << lg) < active) ++lg;
-    const uint32_t n_serial = 2 * L, n_scan = lg, n_tree = lg, n_fin = log2L + 1;
-    const uint32_t total = n_serial + n_scan + n_tree + n_fin;
-    const bool upper = t >= TPB / 2;
-    const uint32_t tt = upper ? t - TPB / 2 : t;
-    E suf = A::infinity(), mine = A::infinity();
-    constexpr uint32_t DOUBLER = 64;
-    const bool doubler = TPB >= 256 && prescale != 0 && t == DOUBLER;
-    uint32_t dbl_left = prescale;
-#pragma nounroll
-    for (uint32_t s = 0; s < total; ++s) {
-        E X = A::infinity(), Y = A::infinity();
-        int dest = -1;  // 0 run, 1 tot, 2 suf, 3 mine
-        bool do_dbl = false;
-        if (doubler && s > n_serial + n_scan) {  // from the second tree step on this thread's registers are free
-            if (s == n_serial + n_scan + 1) suf = ldsA[TPB - 1];  // S, parked there by thread 0 (below)
-            if (dbl_left > 0) {
-                do_dbl = true;
-                --dbl_left;
-            }
-        }
-        if (s < n_serial) {
-            if ((s & 1u) == 0) {
-                X = run;
-                Y = load_bucket(L - 1 - (s >> 1));
-                dest = 0;
-            } else {
-                X = tot;
-                Y = run;
-                dest = 1;
-            }
-        } else if (s < n_serial + n_scan) {
-            const uint32_t step = s - n_serial, d = 1u << step;
-            if (step == 0) {
-                suf = run;
-                ldsA[t] = run;
-                __syncthreads();
-            }
-            X = suf;
-            if (t + d < active) Y = ldsA[t + d];
-            dest = 2;
-        } else if (s < n_serial + n_scan + n_tree) {
-            const uint32_t step = s - n_serial - n_scan;
-            if (step == 0) {  // tree inputs: U_t = Suf_t for t >= 1, W_t = tot
-                if (t == 0) S_out = suf;
-                __syncthreads();
-                ldsA[t] = t >= 1 ? suf : A::infinity();
-                ldsB[t] = tot;
-                __syncthreads();
-                E *arr0 = upper ? ldsB : ldsA;
-                mine = tt < active ? arr0[tt] : A::infinity();
-            }
-            const uint32_t d = active >> (step + 1);
-            E *arr = upper ? ldsB : ldsA;
-            X = mine;
-            if (tt < d) Y = arr[tt + d];
-            dest = 3;
-        } else {
-            const uint32_t step = s - n_serial - n_scan - n_tree;
-            if (step == 0) {  // hand the W total (upper half, tt == 0) to thread 0
-                __syncthreads();
-                if (upper && tt == 0) ldsB[0] = mine;
-                __syncthreads();
-                if (t == 0) {
-                    suf = mine;      // U total, reuse the register
-                    tot = ldsB[0];   // W total
-                }
-            }
-            if (step < log2L) {
-                do_dbl = do_dbl || (t == 0);
-            } else if (t == 0) {
-                X = tot;
-                Y = suf;
-                dest = 1;
-            }
-        }
-        __syncthreads();  // all LDS reads of this step are done
-        if (do_dbl) A::dbl(suf);
-        else if (dest >= 0) A::add(X, Y);
-        if (dest == 0) run = X;
-        else if (dest == 1) tot = X;
-        else if (dest == 2) {
-            suf = X;
-            ldsA[t] = suf;
-        } else if (dest == 3) {
-            mine = X;
-            E *arr = upper ? ldsB : ldsA;
-            if (tt < (active >> 1)) arr[tt] = mine;
-            // first tree step: slot TPB-1 has been consumed, park S there for the doubler
-            if (TPB >= 256 && prescale != 0 && t == 0 && s == n_serial + n_scan) ldsA[TPB - 1] = suf;
-        }
-        __syncthreads();
-    }
-    W_out = tot;  // meaningful in thread 0
-    if (doubler) S_out = suf;  // 2^prescale * S
-}
+//   level 1: each thread of k_reduce_serial owns L consecutive buckets (running sum, multiexp_jacobian.go:44-52 restricted
+//   to its segment) and leaves S_t = sum of the segment, W_t = sum_{k in seg t} (k-lo_t+1) B_k; k_combine_q (gmsm_quad.h)
+//   combines N consecutive (S_t, W_t) with a suffix scan and two trees on lane quads;
+//   level 2 (k_reduce2_q): one block per window combines the level-1 block results the same way.
+// Identity:  sum_{k in [base, base+T*L)} (k-base+1) B_k = sum_t W_t + L * sum_{t>=1} Suf_t,  Suf_t = sum_{t'>=t} S_t'.
+// (Rounds 1-2 fused the serial part and a one-lane combine into one kernel for the 9-limb field - k_reduce1, 36 dependent
+// one-lane additions at c = 16. Split, with the combine on quads, measured 0.29 against 0.34 ms at 2^16 and 0.44 against
+// 0.47 ms at 2^24; equal at 2^20.)
 
-// The serial part of level 1 as a kernel of its own (wide element types): thread g of a window owns the L = 2^log2L
+// The serial part of level 1: thread g of a window owns the L = 2^log2L
 // consecutive buckets [g*L, (g+1)*L) and runs the reference's running sum over them (multiexp_jacobian.go:44-52), leaving
 // S_g = sum B_j and W_g = sum (j+1) B_j in pre[(k*T + g)*2 + {0,1}], T = ceil(nbuckets / L). Fused into k_reduce1 the
 // loop keeps four extended-Jacobian values plus the addition's temporaries alive - for a 28-limb field or Fp2 over 14
@@ -774,31 +668,50 @@ __global__ void __launch_bounds__(256, 1) k_reduce_serial(const void *__restrict
     A::store(pre, ((size_t)k * T + g) * 2 + 1, tot);
 }
 
-// grid = (nblocks1, nwin_local), block = TPB threads, each thread L = 2^log2L buckets (the fused level 1 of the 9-limb
-// prime field; the other element types run k_reduce_serial + k_combine_q).
-// out1[(k*nblocks1 + blk)*2 + {0,1}] = (2^prescale S_blk, W_blk)
-template <class A, int TPB>
-__global__ void __launch_bounds__(TPB) k_reduce1(const void *__restrict__ buckets, uint32_t nbuckets, uint32_t log2L,
-                                                 void *__restrict__ out1,
-                                                 const uint32_t *__restrict__ starts /* null: every bucket is stored */,
-                                                 uint32_t prescale) {
+// The serial part of level 1 on lane quads, for the element types whose one-lane addition is so long (64 us per step for
+// the 28-limb field, out of a 512-register frame with spills) that a window's buckets do not fill the chip with one-lane
+// threads: quad g owns the L = 2^log2L buckets [g L, (g+1) L) and keeps `run` and `tot` in LDS records; a bucket is
+// fetched into the quad's staging record, one coordinate per lane. A quad addition takes about a third of the one-lane
+// time, so with the same number of lanes busy the chain is 4/3.3 as long per bucket - but a window of 2^13 buckets now
+// occupies four times as many lanes, and the number of (S, W) pairs left for the combine is a quarter.
+// Every record belongs to one quad: no workgroup barriers, only the ordering of a wave's own LDS accesses.
+// grid = (ceil(T / 64), nwin), block = 256, dynamic LDS = 192 * sizeof(QRec<U>); output as k_reduce_serial.
+template <class U>
+__global__ void __launch_bounds__(256) k_reduce_serial_q(const void *__restrict__ buckets, uint32_t nbuckets, uint32_t log2L,
+                                                         uint32_t T, const uint32_t *__restrict__ starts,
+                                                         void *__restrict__ pre) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    using E = typename A::Elem;
-    E *lds = reinterpret_cast<E *>(lds_raw);
-    const uint32_t k = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
-    const uint32_t L = 1u << log2L;
-    const uint32_t lo = (blk * TPB + t) * L;
-    const uint32_t *st = starts ? starts + (size_t)k * (nbuckets + 1) : nullptr;
-    auto load_bucket = [&](uint32_t j) -> E {
-        const uint32_t b = lo + j;
-        bool present = b < nbuckets;
-        if (present && st != nullptr) present = st[b + 1] > st[b];
-        return present ? A::load(buckets, (size_t)k * nbuckets + b) : A::infinity();
-    };
-    E S_out = A::infinity(), W_out = A::infinity();
-    reduce_program<A, TPB>(load_bucket, L, A::infinity(), A::infinity(), log2L, (uint32_t)TPB, prescale, lds, S_out, W_out);
-    if (t == (prescale != 0 && TPB >= 256 ? 64u : 0u)) A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 0, S_out);
-    if (t == 0) A::store(out1, ((size_t)k * gridDim.x + blk) * 2 + 1, W_out);
+    QRec<U> *run = reinterpret_cast<QRec<U> *>(lds_raw), *tot = run + 64, *stage = run + 128;
+    const uint32_t tid = threadIdx.x, j = tid >> 2, lane = tid & 63u, k = blockIdx.y;
+    const uint32_t g = blockIdx.x * 64 + j;
+    const uint32_t L = 1u << log2L, lo = g * L;
+    const uint32_t *st = starts + (size_t)k * (nbuckets + 1);
+    if ((tid & 3u) == 0) {
+        run[j].inf = 1u;
+        tot[j].inf = 1u;
+    }
+    quad_lds_fence();
+#pragma nounroll
+    for (uint32_t jj = L; jj-- > 0;) {
+        const uint32_t b = lo + jj;
+        const bool present = g < T && b < nbuckets && st[b + 1] > st[b];  // empty buckets were never written
+        quad_rec_load<U>(&stage[j], buckets, (size_t)k * nbuckets + (present ? b : 0), present, lane);
+        quad_lds_fence();
+        {
+            const QAddOps<U> o = quad_add_load<U>(&run[j], &stage[j], lane);
+            quad_add_store<U, true>(&run[j], o, present, lane);
+        }
+        quad_lds_fence();
+        {
+            const QAddOps<U> o = quad_add_load<U>(&tot[j], &run[j], lane);
+            quad_add_store<U, true>(&tot[j], o, g < T, lane);
+        }
+        quad_lds_fence();
+    }
+    if (g < T) {
+        quad_rec_store<U>(pre, ((size_t)k * T + g) * 2 + 0, &run[j], lane);
+        quad_rec_store<U>(pre, ((size_t)k * T + g) * 2 + 1, &tot[j], lane);
+    }
 }
 
 }  // namespace gmsm

@@ -34,6 +34,11 @@ namespace gmsm {
 
 #if defined(__HIPCC__)
 
+// Orders a wave's own LDS accesses where the lanes of a quad exchange coordinates through a record that no other wave
+// touches (stores of one lane before loads of another): the hardware executes a wave's LDS instructions in order, this
+// keeps the compiler from reordering them.
+__device__ __forceinline__ void quad_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
 template <class U>
 struct QRec {  // one extended-Jacobian value in LDS: x, y, zz, zzz + infinity flag
     U c[4];
@@ -104,8 +109,9 @@ __device__ __forceinline__ QAddOps<U> quad_add_load(const QRec<U> *X, const QRec
     return o;
 }
 
-// X = 2 X in place on a quad (dbl-2008-s-1, a = 0; g1.go:795-817); X not infinity. Only the quad's own record is touched,
-// so no barrier is needed around it.
+// X = 2 X in place on a quad (dbl-2008-s-1, a = 0; g1.go:795-817); X not infinity. Only the quad's own record is touched:
+// no other quad needs a barrier because of it, but the quad's own lanes read coordinates that other lanes of the quad
+// wrote, so a barrier (or the end of the kernel's step) must separate it from the previous and the next access to X.
 //   level   lane 0              lane 1                lane 2               lane 3
 //   1       V = U U (U = 2y)    XX = x x              V = U U              XX = x x        (M = 3 XX)
 //   2       W = U V             S = x V(<-0)          ZZ3 = V zz           MM = M M
@@ -249,8 +255,10 @@ __global__ void __launch_bounds__(256) k_reduce2_q(const void *__restrict__ in1,
     if (j == 0 && (t & 3u) == 0) S[0].inf = 1u;
     __syncthreads();
 #pragma nounroll
-    for (uint32_t s = 0; s < log2span; ++s)
+    for (uint32_t s = 0; s < log2span; ++s) {
         if (!S[j].inf) quad_dbl_inplace<U, INL>(&S[j], lane);
+        __syncthreads();  // the lanes of a quad exchange coordinates through the record: stores before the next loads
+    }
     {
         const QAddOps<U> o = quad_add_load<U>(&W[j], &S[j], lane);
         quad_add_store<U, INL>(&W[j], o, true, lane);  // both records belong to this quad
