@@ -113,7 +113,10 @@ struct Workspace {
     DeviceBuffer seg_partials, seg_flags, seg_bucket;  // split-bucket partial sums of the segmented accumulation
     DeviceBuffer parted;         // coarse-partitioned references (two-level grouping)
     DeviceBuffer digits, sorted, blockhist, counts, starts, buckets, partials, totals;
-    DeviceBuffer red_pre;        // per-thread (S, W) of the split bucket reduction (k_reduce_serial -> k_reduce1)
+    DeviceBuffer red_pre;        // per-thread (S, W) of the bucket reduction (k_reduce_serial -> k_combine_q)
+    DeviceBuffer carry;          // running bucket sums of a multi-range host call (k_merge_buckets)
+    hipStream_t mstream = nullptr;                         // merges + the one reduction of a multi-range call
+    hipEvent_t ev_buckets = nullptr, ev_merged = nullptr;  // a range's buckets are complete / have been merged
     hipEvent_t events[12] = {nullptr};  // stage boundaries of the call in flight when profiling is on
     bool timed = false;                 // events[] were recorded by the last enqueue
     void *pinned = nullptr;             // pinned host buffer for the window totals
@@ -158,7 +161,12 @@ struct Context {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
         num_cus = prop.multiProcessorCount;
-        for (auto &w : ws) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+        for (auto &w : ws) {
+            HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&w.mstream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&w.ev_buckets, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&w.ev_merged, hipEventDisableTiming));
+        }
         return GMSM_OK;
     }
     // Kernels that need more than the default 64 KiB of dynamic LDS: raise the limit once per kernel on this device.

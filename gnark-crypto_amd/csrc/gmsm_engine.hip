@@ -217,18 +217,15 @@ static int multiexp_sharded_run(int group, const uint64_t *points, const std::ma
     if (G == 0) return fail(GMSM_ERR_ARG, "sharded MultiExp: empty device list");
     if (mode == 0) mode = 1;
     if (mode != 1 && mode != 2) return fail(GMSM_ERR_ARG, "sharded MultiExp: mode must be 0 (auto), 1 (points) or 2 (windows)");
-    const bool with_points = points != nullptr;
     unsigned c;
     uint32_t nwin;
     if (mode == 1) {
         G = std::max<size_t>(1, std::min(G, n / SHARD_MIN_SLICE));
         const size_t slice = (n + G - 1) / G;  // the largest slice decides c: the ranks' totals must line up
-        const unsigned nr = vt->host_piece_ranges(slice, with_points);
-        c = choose_c(vt->fr_bits, vt->aff_bytes, (slice + nr - 1) / nr);
+        c = choose_c(vt->fr_bits, vt->aff_bytes, slice);
         nwin = num_windows(vt->fr_bits, c);
     } else {
-        const unsigned nr = vt->host_piece_ranges(n, with_points);
-        c = choose_c(vt->fr_bits, vt->aff_bytes, (n + nr - 1) / nr);
+        c = choose_c(vt->fr_bits, vt->aff_bytes, n);
         nwin = num_windows(vt->fr_bits, c);
         G = std::min<size_t>(G, nwin);
     }

@@ -192,9 +192,12 @@ struct Group {
     // d_out != nullptr: the totals stay on the device (copied to d_out in stream order) instead of going to ws.pinned.
     // (Round 2 could cut the windows of a call into groups on two streams so that the reduction of one group ran under
     // the accumulation of the next; measured slower in every configuration - profiles/r02_split_ab.log - and removed.)
+    // buckets_only: stop after the fix-up - ws.buckets / ws.starts hold the range's bucket sums (a range of a multi-range
+    // host call: k_merge_buckets adds them to the call's running buckets, ONE reduction at the end; enqueue_reduce).
     static int enqueue_window_sums(Context &ctx, Workspace &ws, const void *d_points, const void *d_scalars, size_t n,
                                    const WindowPlan &plan, hipStream_t stream, const ResidentBases *resident,
-                                   void *d_out = nullptr, size_t resident_offset = 0 /* first registered base used */) {
+                                   void *d_out = nullptr, size_t resident_offset = 0 /* first registered base used */,
+                                   bool buckets_only = false) {
         const uint32_t nw = plan.nwin_local;
         ws.pending_timed = false;
         if (nw == 0) return GMSM_OK;
@@ -325,7 +328,6 @@ struct Group {
         uint32_t *sorted = (uint32_t *)ws.sorted.ptr, *parted = (uint32_t *)ws.parted.ptr, *starts = (uint32_t *)ws.starts.ptr;
         char *buckets = (char *)ws.buckets.ptr, *seg_partials = (char *)ws.seg_partials.ptr;
         uint32_t *seg_flags = (uint32_t *)ws.seg_flags.ptr, *seg_bucket = (uint32_t *)ws.seg_bucket.ptr;
-        char *partials = (char *)ws.partials.ptr, *totals = (char *)ws.totals.ptr;
 
         // ---- 1. group the point references of every window by bucket
         timer.mark(T_HIST, stream);
@@ -359,34 +361,62 @@ struct Group {
                            (const uint32_t *)long_flag, (const LongChain *)long_list);
         // ---- 3. bucket reduction -> window totals (empty buckets are never written: the reduction consults starts[])
         timer.mark(T_REDUCE, stream);
-        {
-            // level 1 leaves S_blk already multiplied by the width of the level-2 spans (an otherwise idle wave / quad
-            // doubles it log2span times while the trees run): level 2 then has no serial doubling tail (11 of its 20
-            // steps at c = 16)
-            const uint32_t prescale = q.log2span;
-            if constexpr (SERIAL_QUAD)
-                hipLaunchKernelGGL((k_reduce_serial_q<U>), dim3((T + 63) / 64, nw), dim3(256), 192 * sizeof(QRec<U>), stream, buckets,
-                                   NB, q.log2L, T, starts, ws.red_pre.ptr);
-            else
-                hipLaunchKernelGGL((k_reduce_serial<OpsSerial>), dim3((T + 255) / 256, nw), dim3(256), 0, stream, buckets, NB,
-                                   q.log2L, T, starts, ws.red_pre.ptr);
-            hipLaunchKernelGGL((k_combine_q<U, true, COMBINE_N>), dim3(q.nblocks1, nw), dim3(4 * COMBINE_N),
-                               (2 * COMBINE_N + 1) * sizeof(QRec<U>), stream, q.log2L, partials, prescale,
-                               (const void *)ws.red_pre.ptr, T);
-            // level 2 on quads of lanes
-            uint32_t active = 2;
-            while (active < q.nblocks1) active <<= 1;
-            hipLaunchKernelGGL((k_reduce2_q<U, true>), dim3(nw), dim3(4 * active), 2 * active * sizeof(QRec<U>), stream,
-                               partials, q.nblocks1, q.log2span - prescale, active, totals);
-        }
+        if (!buckets_only) enqueue_reduce_kernels(ctx, ws, q, T, buckets, starts, nw, NB, stream);
         timer.mark(T_END, stream);
         HIP_TRY(hipGetLastError());
-        if (d_out)
-            HIP_TRY(hipMemcpyAsync(d_out, ws.totals.ptr, (size_t)nw * sizeof(Ext), hipMemcpyDeviceToDevice, stream));
-        else
-            HIP_TRY(hipMemcpyAsync(ws.pinned, ws.totals.ptr, (size_t)nw * sizeof(Ext), hipMemcpyDeviceToHost, stream));
+        if (!buckets_only) {
+            if (d_out)
+                HIP_TRY(hipMemcpyAsync(d_out, ws.totals.ptr, (size_t)nw * sizeof(Ext), hipMemcpyDeviceToDevice, stream));
+            else
+                HIP_TRY(hipMemcpyAsync(ws.pinned, ws.totals.ptr, (size_t)nw * sizeof(Ext), hipMemcpyDeviceToHost, stream));
+        }
         if ((rc = end_use(ws, stream))) return rc;
         ws.pending_timed = timer.on;
+        return GMSM_OK;
+    }
+
+    // The three kernels of the bucket reduction: buckets (nw x NB lazy records; starts == nullptr: every record is
+    // stored, infinity as zz = 0) -> ws.totals. Scratch: ws.red_pre, ws.partials.
+    static void enqueue_reduce_kernels(Context &ctx, Workspace &ws, const Geometry &q, uint32_t T, const void *buckets,
+                                       const uint32_t *starts, uint32_t nw, uint32_t NB, hipStream_t stream) {
+        // level 1 leaves S_blk already multiplied by the width of the level-2 spans (an otherwise idle quad doubles it
+        // log2span times while the trees run): level 2 then has no serial doubling tail
+        const uint32_t prescale = q.log2span;
+        if constexpr (SERIAL_QUAD)
+            hipLaunchKernelGGL((k_reduce_serial_q<U>), dim3((T + 63) / 64, nw), dim3(256), 192 * sizeof(QRec<U>), stream, buckets,
+                               NB, q.log2L, T, starts, ws.red_pre.ptr);
+        else
+            hipLaunchKernelGGL((k_reduce_serial<OpsSerial>), dim3((T + 255) / 256, nw), dim3(256), 0, stream, buckets, NB,
+                               q.log2L, T, starts, ws.red_pre.ptr);
+        hipLaunchKernelGGL((k_combine_q<U, true, COMBINE_N>), dim3(q.nblocks1, nw), dim3(4 * COMBINE_N),
+                           (2 * COMBINE_N + 1) * sizeof(QRec<U>), stream, q.log2L, ws.partials.ptr, prescale,
+                           (const void *)ws.red_pre.ptr, T);
+        uint32_t active = 2;
+        while (active < q.nblocks1) active <<= 1;
+        hipLaunchKernelGGL((k_reduce2_q<U, true>), dim3(nw), dim3(4 * active), 2 * active * sizeof(QRec<U>), stream,
+                           ws.partials.ptr, q.nblocks1, q.log2span - prescale, active, ws.totals.ptr);
+        (void)ctx;
+    }
+
+    // The reduction alone, over bucket sums that a multi-range call has merged (every record stored): totals -> ws.pinned.
+    static int enqueue_reduce(Context &ctx, Workspace &ws, const void *buckets, const WindowPlan &plan, size_t n_for_geometry,
+                              hipStream_t stream) {
+        const uint32_t nw = plan.nwin_local, NB = plan.nbuckets;
+        constexpr size_t REC = sizeof(typename OpsSerial::Mem);
+        const Geometry q = plan_geometry(ctx, nw, n_for_geometry, NB);
+        const uint32_t T = (uint32_t)(((size_t)NB + ((size_t)1 << q.log2L) - 1) >> q.log2L);
+        int rc;
+        if ((rc = ws.partials.ensure((size_t)nw * q.nblocks1 * 2 * REC))) return rc;
+        if ((rc = ws.red_pre.ensure((size_t)nw * T * 2 * REC))) return rc;
+        if ((rc = ws.totals.ensure((size_t)nw * sizeof(Ext)))) return rc;
+        if ((rc = ws.ensure_pinned((size_t)nw * sizeof(Ext)))) return rc;
+        if ((rc = ctx.allow_lds((const void *)k_combine_q<U, true, COMBINE_N>, (int)((2 * COMBINE_N + 1) * sizeof(QRec<U>))))) return rc;
+        if constexpr (SERIAL_QUAD)
+            if ((rc = ctx.allow_lds((const void *)k_reduce_serial_q<U>, (int)(192 * sizeof(QRec<U>))))) return rc;
+        if ((rc = ctx.allow_lds((const void *)k_reduce2_q<U, true>, (int)(2 * RED2_TPB * sizeof(QRec<U>))))) return rc;
+        enqueue_reduce_kernels(ctx, ws, q, T, buckets, nullptr, nw, NB, stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(ws.pinned, ws.totals.ptr, (size_t)nw * sizeof(Ext), hipMemcpyDeviceToHost, stream));
         return GMSM_OK;
     }
 
@@ -702,24 +732,25 @@ struct Group {
     }
 
     // Number of point ranges a host-buffer MultiExp is cut into so that the H2D copy of range k+1 runs under the
-    // pipeline of range k (two workspaces, two streams; the ranges' window totals are added on the host, fold_sets).
-    // A range pays the size-independent part of the pipeline again (~0.6 ms: reduction chain, dependent launches), so
-    // small inputs stay whole. Model with T(2^18..2^22) = 0.96 / 1.25 / 2.05 / 3.6 / 6.9 ms and 56 GB/s (96 B/point cold,
-    // 32 B/point with registered bases): cold - 2 ranges from 2^20, ranges of 2^21 from 2^22 on (2^24: 32 ms against
-    // 55 ms serial, PCIe floor 27 ms); registered bases - 2 ranges from 2^20, ranges of 2^22 from 2^23 on. Measured at
-    // 2^20 (profiles/r02_host_ranges.log): cold 3.99 / 3.31 / 3.94 ms with 1 / 2 / 4 ranges, registered bases 2.70 / 2.53 /
-    // 3.11. GMSM_HOST_RANGES overrides.
+    // pipeline of range k (two workspaces, two streams). Round 2 reduced every range on its own and added the totals on
+    // the host: a range then paid the size-independent part of the pipeline again (0.35 ms reduction chain), so 2^20 ran
+    // as 2 ranges (cold 3.99 / 3.31 / 3.94 ms with 1 / 2 / 4 ranges, profiles/r02_host_ranges.log). Now the ranges share one
+    // bucket set and ONE reduction (k_merge_buckets), a range costs its share of the accumulation plus ~0.1 ms, and the
+    // call is cut finer: what is exposed is the copy of the first range and the tail after the last.
+    // GMSM_HOST_RANGES overrides.
     static unsigned host_ranges(size_t n, bool with_points) {
         const unsigned forced = env_uint("GMSM_HOST_RANGES", 0);
         if (forced) return (unsigned)std::min<size_t>(forced, std::max<size_t>(1, n));
-        if (with_points) {
-            if (n < ((size_t)1 << 20)) return 1;
-            if (n < ((size_t)1 << 22)) return 2;
-            return (unsigned)std::min<size_t>(64, n >> 21);
+        // Measured (profiles/r03_host_ranges.log, BN254 G1, cold / warm-bases ms): 2^20 1 range 3.73 / 2.51, 2: 3.19 / 2.23,
+        // 4: 2.95 / 2.31, 8: 3.38 / 2.70; 2^22 4: 9.47 / 6.97, 8: 8.87 / 7.11, 16: 9.69 / 8.26; 2^24 8: 32.5 / 23.5, 16: 31.5 / 23.3,
+        // 32: 31.8 / 25.1 (resident 2.00 / 6.25 / 22.1): a range costs about 0.1 ms of launches and merge.
+        if (with_points) {  // bases + scalars cross PCIe (96 B per BN254 G1 point)
+            if (n < ((size_t)1 << 19)) return 1;
+            if (n < ((size_t)1 << 23)) return (unsigned)std::min<size_t>(8, n >> 18);
+            return 16;
         }
-        if (n < ((size_t)1 << 20)) return 1;
-        if (n < ((size_t)1 << 23)) return 2;  // measured at 2^20: 2.70 -> 2.53 ms (profiles/r02_host_ranges.log)
-        return (unsigned)std::min<size_t>(64, n >> 22);
+        if (n < ((size_t)1 << 20)) return 1;  // scalars only (32 B per point)
+        return (unsigned)std::min<size_t>(16, std::max<size_t>(2, n >> 20));
     }
 
     // Window totals of a MultiExp whose scalars (and, unless `resident`, points) are in host memory: the windows of `plan`
@@ -735,53 +766,72 @@ struct Group {
         const size_t per = (n + nr - 1) / nr;
         Workspace *w[2] = {&first, nr > 1 ? ctx.acquire(false) : nullptr};
         const unsigned nws = w[1] ? 2 : 1;
-        std::vector<Ext> sets((size_t)nr * nw);
+        // More than one range: every range stops after its fix-up, its bucket sums are added to the call's running buckets
+        // (first.carry) on a third stream, and ONE reduction follows the last merge - a range costs its accumulation and
+        // one addition per occupied bucket, not another 0.35 ms reduction chain. With one workspace the ranges and the
+        // merges simply alternate on its stream.
+        hipStream_t ms = nws == 2 ? first.mstream : first.stream;
+        constexpr size_t REC = sizeof(typename OpsSerial::Mem);
         int rc = GMSM_OK;
-        unsigned submitted = 0, collected = 0;
-        while (rc == GMSM_OK && collected < nr) {
-            while (rc == GMSM_OK && submitted < nr && submitted - collected < nws) {
-                Workspace &ws = *w[submitted % nws];
-                const size_t lo = (size_t)submitted * per, len = std::min(per, n - lo);
-                const void *dp = nullptr;
-                // hipMemcpyAsync from pageable memory returns when the caller's buffer has been consumed; the kernels
-                // queued behind it do not wait for the host, so range k computes while range k+1 is being copied
-                if ((rc = ws.h2d_scalars.ensure(len * SCALAR_BYTES))) break;
-                if (hipMemcpyAsync(ws.h2d_scalars.ptr, (const char *)scalars + lo * SCALAR_BYTES, len * SCALAR_BYTES,
-                                   hipMemcpyHostToDevice, ws.stream) != hipSuccess) {
-                    rc = fail(GMSM_ERR_DEVICE, "hipMemcpyAsync(scalars) failed");
-                    break;
-                }
-                if (points) {
-                    if ((rc = ws.h2d_points.ensure(len * AFF_BYTES))) break;
-                    if (hipMemcpyAsync(ws.h2d_points.ptr, (const char *)points + lo * AFF_BYTES, len * AFF_BYTES,
-                                       hipMemcpyHostToDevice, ws.stream) != hipSuccess) {
-                        rc = fail(GMSM_ERR_DEVICE, "hipMemcpyAsync(points) failed");
-                        break;
-                    }
-                    dp = ws.h2d_points.ptr;
-                }
-                if ((rc = enqueue_window_sums(ctx, ws, dp, ws.h2d_scalars.ptr, len, plan, ws.stream, resident, nullptr,
-                                              resident_base + lo)))
-                    break;
-                ++submitted;
-            }
-            if (rc) break;
-            rc = collect_window_sums(*w[collected % nws], w[collected % nws]->stream, nw, sets.data() + (size_t)collected * nw);
-            ++collected;
-        }
-        if (w[1]) {
-            (void)hipStreamSynchronize(w[1]->stream);  // nothing of this call is left running on the borrowed workspace
-            ctx.release(w[1]);
-        }
-        if (rc) {
-            (void)hipStreamSynchronize(first.stream);
+        if (nr > 1 && (rc = first.carry.ensure((size_t)nw * plan.nbuckets * REC))) {
+            if (w[1]) ctx.release(w[1]);
             return rc;
         }
-        for (uint32_t k = 0; k < nw; ++k) {
-            Ext t = sets[k];
-            for (unsigned r = 1; r < nr; ++r) xyzz_add(t, sets[(size_t)r * nw + k]);
-            out_totals[k] = t;
+        for (unsigned r = 0; r < nr && rc == GMSM_OK; ++r) {
+            Workspace &ws = *w[r % nws];
+            const size_t lo = (size_t)r * per, len = std::min(per, n - lo);
+            const void *dp = nullptr;
+            // hipMemcpyAsync from pageable memory returns when the caller's buffer has been consumed; the kernels
+            // queued behind it do not wait for the host, so range k computes while range k+1 is being copied
+            if ((rc = ws.h2d_scalars.ensure(len * SCALAR_BYTES))) break;
+            if (hipMemcpyAsync(ws.h2d_scalars.ptr, (const char *)scalars + lo * SCALAR_BYTES, len * SCALAR_BYTES,
+                               hipMemcpyHostToDevice, ws.stream) != hipSuccess) {
+                rc = fail(GMSM_ERR_DEVICE, "hipMemcpyAsync(scalars) failed");
+                break;
+            }
+            if (points) {
+                if ((rc = ws.h2d_points.ensure(len * AFF_BYTES))) break;
+                if (hipMemcpyAsync(ws.h2d_points.ptr, (const char *)points + lo * AFF_BYTES, len * AFF_BYTES,
+                                   hipMemcpyHostToDevice, ws.stream) != hipSuccess) {
+                    rc = fail(GMSM_ERR_DEVICE, "hipMemcpyAsync(points) failed");
+                    break;
+                }
+                dp = ws.h2d_points.ptr;
+            }
+            if (nr == 1) {
+                rc = enqueue_window_sums(ctx, ws, dp, ws.h2d_scalars.ptr, len, plan, ws.stream, resident, nullptr, resident_base + lo);
+                break;
+            }
+            // the buckets of the range this workspace ran two ranges ago must have been merged before they are overwritten
+            hipError_t he = hipSuccess;
+            if (nws == 2 && r >= 2) he = hipStreamWaitEvent(ws.stream, ws.ev_merged, 0);
+            if (he != hipSuccess) {
+                rc = fail(GMSM_ERR_DEVICE, std::string("hipStreamWaitEvent: ") + hipGetErrorString(he));
+                break;
+            }
+            if ((rc = enqueue_window_sums(ctx, ws, dp, ws.h2d_scalars.ptr, len, plan, ws.stream, resident, nullptr,
+                                          resident_base + lo, /*buckets_only=*/true)))
+                break;
+            if (nws == 2) {
+                he = hipEventRecord(ws.ev_buckets, ws.stream);
+                if (he == hipSuccess) he = hipStreamWaitEvent(ms, ws.ev_buckets, 0);
+            }
+            hipLaunchKernelGGL((k_merge_buckets<OpsSerial>), dim3((plan.nbuckets + 255) / 256, nw), dim3(256), 0, ms, first.carry.ptr,
+                               (const void *)ws.buckets.ptr, (const uint32_t *)ws.starts.ptr, plan.nbuckets, r == 0 ? 1 : 0);
+            if (he == hipSuccess && nws == 2) he = hipEventRecord(ws.ev_merged, ms);
+            if (he == hipSuccess) he = hipGetLastError();
+            if (he != hipSuccess) rc = fail(GMSM_ERR_DEVICE, std::string("multi-range merge: ") + hipGetErrorString(he));
         }
+        if (rc == GMSM_OK && nr > 1) rc = enqueue_reduce(ctx, first, first.carry.ptr, plan, per, ms);
+        if (rc == GMSM_OK && hipStreamSynchronize(ms) != hipSuccess) rc = fail(GMSM_ERR_DEVICE, "hipStreamSynchronize failed");
+        for (unsigned i = 0; i < nws; ++i) {  // nothing of this call is left running on either workspace
+            (void)hipStreamSynchronize(w[i]->stream);
+            if (rc == GMSM_OK && w[i]->pending_timed) StageTimer::collect(*w[i]);
+            w[i]->pending_timed = false;
+        }
+        if (w[1]) ctx.release(w[1]);
+        if (rc) return rc;
+        memcpy(out_totals, first.pinned, (size_t)nw * sizeof(Ext));
         return GMSM_OK;
     }
 
@@ -798,7 +848,7 @@ struct Group {
     static int multiexp_from_host(Context &ctx, Workspace &first, const uint64_t *points, const ResidentBases *resident,
                                   const uint64_t *scalars, size_t n, J *out) {
         const unsigned nr = host_range_count(n, points != nullptr);
-        const unsigned c = choose_c(FR_BITS, AFF_BYTES, (n + nr - 1) / nr);  // one c for every range: the totals must line up
+        const unsigned c = choose_c(FR_BITS, AFF_BYTES, n);  // the ranges share one bucket set and one reduction
         WindowPlan plan = make_plan(c, 0, 1);
         std::vector<Ext> totals(plan.nwin_total);
         int rc = window_sums_from_host(ctx, first, points, resident, 0, scalars, n, plan, nr, totals.data());

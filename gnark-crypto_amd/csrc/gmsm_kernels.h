@@ -653,12 +653,12 @@ __global__ void __launch_bounds__(256, 1) k_reduce_serial(const void *__restrict
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
     if (g >= T) return;
     const uint32_t L = 1u << log2L, lo = g * L;
-    const uint32_t *st = starts + (size_t)k * (nbuckets + 1);
+    const uint32_t *st = starts ? starts + (size_t)k * (nbuckets + 1) : nullptr;  // null: every record is stored
     E run = A::infinity(), tot = A::infinity();
 #pragma nounroll
     for (uint32_t j = L; j-- > 0;) {
         const uint32_t b = lo + j;
-        if (b < nbuckets && st[b + 1] > st[b]) {  // empty buckets were never written
+        if (b < nbuckets && (st == nullptr || st[b + 1] > st[b])) {  // empty buckets were never written
             const E B = A::load(buckets, (size_t)k * nbuckets + b);
             A::add(run, B);
         }
@@ -685,7 +685,7 @@ __global__ void __launch_bounds__(256) k_reduce_serial_q(const void *__restrict_
     const uint32_t tid = threadIdx.x, j = tid >> 2, lane = tid & 63u, k = blockIdx.y;
     const uint32_t g = blockIdx.x * 64 + j;
     const uint32_t L = 1u << log2L, lo = g * L;
-    const uint32_t *st = starts + (size_t)k * (nbuckets + 1);
+    const uint32_t *st = starts ? starts + (size_t)k * (nbuckets + 1) : nullptr;  // null: every record is stored
     if ((tid & 3u) == 0) {
         run[j].inf = 1u;
         tot[j].inf = 1u;
@@ -694,7 +694,7 @@ __global__ void __launch_bounds__(256) k_reduce_serial_q(const void *__restrict_
 #pragma nounroll
     for (uint32_t jj = L; jj-- > 0;) {
         const uint32_t b = lo + jj;
-        const bool present = g < T && b < nbuckets && st[b + 1] > st[b];  // empty buckets were never written
+        const bool present = g < T && b < nbuckets && (st == nullptr || st[b + 1] > st[b]);  // empty buckets were never written
         quad_rec_load<U>(&stage[j], buckets, (size_t)k * nbuckets + (present ? b : 0), present, lane);
         quad_lds_fence();
         {
@@ -711,6 +711,32 @@ __global__ void __launch_bounds__(256) k_reduce_serial_q(const void *__restrict_
     if (g < T) {
         quad_rec_store<U>(pre, ((size_t)k * T + g) * 2 + 0, &run[j], lane);
         quad_rec_store<U>(pre, ((size_t)k * T + g) * 2 + 1, &tot[j], lane);
+    }
+}
+
+// Multi-range host calls (Group::window_sums_from_host): every point range leaves its bucket sums, this kernel adds them to
+// the call's running buckets, and the reduction runs once. One thread per (window, bucket); `init`: the first range
+// initialises the running buckets - every record is stored from here on, infinity as zz = 0.
+// The reference's split of a MultiExp in two halves adds the halves' RESULTS (multiexp.go:98-140); adding bucket by bucket
+// gives the same group element and pays the reduction once.
+template <class A>
+__global__ void __launch_bounds__(256) k_merge_buckets(void *__restrict__ carry, const void *__restrict__ buckets,
+                                                       const uint32_t *__restrict__ starts, uint32_t nbuckets, int init) {
+    using E = typename A::Elem;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (b >= nbuckets) return;
+    const uint32_t *st = starts + (size_t)k * (nbuckets + 1);
+    const bool present = st[b + 1] > st[b];
+    const size_t idx = (size_t)k * nbuckets + b;
+    if (init) {
+        E v = A::infinity();
+        if (present) v = A::load(buckets, idx);
+        A::store(carry, idx, v);
+    } else if (present) {
+        E c = A::load(carry, idx);
+        const E v = A::load(buckets, idx);
+        A::add(c, v);
+        A::store(carry, idx, c);
     }
 }
 
