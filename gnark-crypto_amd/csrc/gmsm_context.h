@@ -79,16 +79,15 @@ struct FftDomain {
     // Device tables. "Lazy domain" = the canonical element 2^(L*W-32N) * factor (gmsm_fft_lazy.h): what the lazy-limb
     // butterflies multiply by.
     DeviceBuffer twiddles_lz, twiddles_inv_lz;  // w^t, w^-t for t < n/2, lazy domain
-    DeviceBuffer twiddles, twiddles_inv;        // the same as plain Montgomery elements: built on demand for the A/B paths
     DeviceBuffer coset, coset_inv_scaled;       // u^i and u^-i / n for i < n (lazy domain), built by the first coset transform
     std::vector<uint64_t> cardinality_inv_lz;   // 1/n, lazy domain
-    bool coset_ready = false, sat_ready = false;
+    bool coset_ready = false;
     std::mutex mu;                            // serialises the lazy coset build and transforms that share the tables
     FftDomain() = default;
     FftDomain(const FftDomain &) = delete;
     FftDomain &operator=(const FftDomain &) = delete;
     ~FftDomain() {
-        DeviceBuffer *bufs[] = {&twiddles_lz, &twiddles_inv_lz, &twiddles, &twiddles_inv, &coset, &coset_inv_scaled};
+        DeviceBuffer *bufs[] = {&twiddles_lz, &twiddles_inv_lz, &coset, &coset_inv_scaled};
         bool any = false;
         for (auto *b : bufs) any = any || b->ptr;
         if (!any) return;

@@ -14,9 +14,7 @@
 // instead of 24), with the twiddles w^t for t < n/2 resident per domain like the reference's precomputed tables. The
 // butterflies run on lazy 29-bit limbs (gmsm_fft_lazy.h: one v_mad_u64_u32 per partial product, values reduced by a
 // top-limb test between products, canonical again on every store), and the coset / 1/n scalings ride on the first
-// load and the last store of the transform instead of being passes of their own. The first version - canonical
-// saturated arithmetic (gmsm_field.h), one launch per stage or per pass - stays as the A/B baseline
-// (GMSM_FFT_LAZY=0, GMSM_FFT_STAGEWISE=1).
+// load and the last store of the transform instead of being passes of their own.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gmsm_context.h"
@@ -84,91 +82,16 @@ __global__ void __launch_bounds__(256) k_fft_scale_const_lz(Fp<FrP> *__restrict_
     fft_store(a, i, Z::store(Z::mul(Z::load(fft_load(a, i)), c)));
 }
 
-// One decimation-in-frequency stage (difFFT, fft.go:198-262): stage s works on blocks of 2*half, half = n >> (s+1):
-//   (a[i], a[i+half]) <- (a[i] + a[i+half], (a[i] - a[i+half]) * w^(j << s)),  j = i mod half.
-template <class FrP>
-__global__ void __launch_bounds__(256) k_fft_dif_stage(Fp<FrP> *__restrict__ a, size_t n, unsigned log2n, unsigned s,
-                                                       const Fp<FrP> *__restrict__ tw) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n / 2) return;
-    const unsigned lh = log2n - 1 - s;  // log2(half)
-    const size_t half = (size_t)1 << lh;
-    const size_t j = idx & (half - 1), i = ((idx >> lh) << (lh + 1)) + j;
-    const Fp<FrP> x = fft_load(a, i), y = fft_load(a, i + half);
-    fft_store(a, i, fp_add(x, y));
-    Fp<FrP> d = fp_sub(x, y);
-    if (j) d = fp_mul(d, fft_load(tw, j << s));  // w^0 = 1 (innerDIFWithTwiddles skips it the same way)
-    fft_store(a, i + half, d);
-}
-
-// One decimation-in-time stage (ditFFT, fft.go:264-330): half = 1 << s,
-//   t = a[i+half] * w^(j * n / (2 half));  (a[i], a[i+half]) <- (a[i] + t, a[i] - t).
-template <class FrP>
-__global__ void __launch_bounds__(256) k_fft_dit_stage(Fp<FrP> *__restrict__ a, size_t n, unsigned log2n, unsigned s,
-                                                       const Fp<FrP> *__restrict__ tw) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n / 2) return;
-    const size_t half = (size_t)1 << s;
-    const size_t j = idx & (half - 1), i = ((idx >> s) << (s + 1)) + j;
-    const Fp<FrP> x = fft_load(a, i);
-    Fp<FrP> t = fft_load(a, i + half);
-    if (j) t = fp_mul(t, fft_load(tw, j << (log2n - 1 - s)));
-    fft_store(a, i, fp_add(x, t));
-    fft_store(a, i + half, fp_sub(x, t));
-}
-
 // Several consecutive radix-2 stages in one pass over HBM. A stage pairs elements whose indices differ in one bit b
-// (DIF walks b downwards from log2n-1, DIT upwards from 0); a pass takes the B stages of bits [bl, bl+B) and a workgroup
-// owns a tile of 2^B x C elements - every value of those B bits x C consecutive values of the low bits (C x 32 bytes
-// contiguous per row, so the strided passes still move whole 128-256-byte runs) - stages it in LDS, runs the B stages
-// with a barrier in between and writes it back: one read and one write of the vector per pass instead of per stage
-// (2^24: 3 passes instead of 24 trips through HBM). Same butterflies, same twiddles w^(j << (log2n-1-b)), j = i mod 2^b,
-// as the per-stage kernels above.
-template <class FrP, bool DIF>
-__global__ void __launch_bounds__(256) k_fft_pass(Fp<FrP> *__restrict__ a, unsigned log2n, unsigned bl, unsigned B, unsigned log2C,
-                                                  const Fp<FrP> *__restrict__ tw) {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    using Fr = Fp<FrP>;
-    Fr *tile = reinterpret_cast<Fr *>(lds_raw);  // [2^B][C]
-    const unsigned C = 1u << log2C, T = blockDim.x, t = threadIdx.x;
-    const size_t ntile_lo = ((size_t)1 << bl) >> log2C;  // tiles along the low bits
-    const size_t lo0 = ((size_t)blockIdx.x % ntile_lo) << log2C, hi = (size_t)blockIdx.x / ntile_lo;
-    const size_t base = (hi << (bl + B)) | lo0;
-    const unsigned elems = (1u << B) << log2C;
-    for (unsigned e = t; e < elems; e += T) {
-        const unsigned mid = e >> log2C, c = e & (C - 1);
-        tile[e] = fft_load(a, base + ((size_t)mid << bl) + c);
-    }
-    __syncthreads();
-    const unsigned nbf = elems >> 1;  // butterflies per stage
-    for (unsigned st = 0; st < B; ++st) {
-        const unsigned bb = DIF ? B - 1 - st : st;  // bit inside the tile; global bit b = bl + bb
-        const unsigned b = bl + bb;
-        for (unsigned q = t; q < nbf; q += T) {
-            const unsigned c = q & (C - 1), p = q >> log2C;
-            const unsigned mid0 = ((p >> bb) << (bb + 1)) | (p & ((1u << bb) - 1)), mid1 = mid0 | (1u << bb);
-            const size_t i = base + ((size_t)mid0 << bl) + c;
-            const size_t j = i & (((size_t)1 << b) - 1);
-            Fr x = tile[(mid0 << log2C) + c], y = tile[(mid1 << log2C) + c];
-            if (DIF) {
-                Fr d = fp_sub(x, y);
-                if (j) d = fp_mul(d, fft_load(tw, j << (log2n - 1 - b)));
-                tile[(mid0 << log2C) + c] = fp_add(x, y);
-                tile[(mid1 << log2C) + c] = d;
-            } else {
-                if (j) y = fp_mul(y, fft_load(tw, j << (log2n - 1 - b)));
-                tile[(mid0 << log2C) + c] = fp_add(x, y);
-                tile[(mid1 << log2C) + c] = fp_sub(x, y);
-            }
-        }
-        __syncthreads();
-    }
-    for (unsigned e = t; e < elems; e += T) {
-        const unsigned mid = e >> log2C, c = e & (C - 1);
-        fft_store(a, base + ((size_t)mid << bl) + c, tile[e]);
-    }
-}
-
+// (DIF walks b downwards from log2n-1, DIT upwards from 0): (a[i], a[i+2^b]) <- (a[i] + a[i+2^b], (a[i] - a[i+2^b]) w^(j <<
+// (log2n-1-b))) for DIF (difFFT, fft.go:198-262; j = i mod 2^b), t = a[i+2^b] w^(...); (a[i] + t, a[i] - t) for DIT (ditFFT,
+// fft.go:264-330). A pass takes the B stages of bits [bl, bl+B) and a workgroup owns a tile of 2^B x C elements - every
+// value of those B bits x C consecutive values of the low bits (C x 32 bytes contiguous per row, so the strided passes
+// still move whole 128-256-byte runs) - stages it in LDS, runs the B stages with a barrier in between and writes it back:
+// one read and one write of the vector per pass instead of per stage (2^24: 3 passes instead of 24 trips through HBM).
+// (Rounds 1-2 kept the first two versions - one launch per stage, and the tiled pass on the canonical saturated field -
+// as A/B baselines: 6.0 and 3.25-3.48 ms at 2^24 against 2.65; removed in round 3.)
+//
 // k_fft_pass on lazy limbs. The tile holds FpU values of the class A2 (36 bytes per BN254 element: an odd number of
 // words, so consecutive elements fall into different LDS banks); `twz` and the scaling tables are in the lazy domain.
 // Scalings of the transform fused into the pass that touches the vector first / last:
@@ -223,6 +146,12 @@ __global__ void __launch_bounds__(256) k_fft_pass_lz(Fp<FrP> *__restrict__ a, un
         fft_store(a, g, Z::store(x));
     }
 }
+
+// (Round 3 tried two radix-2 stages per trip through LDS - "radix 2^2": a thread owns the four elements that differ in
+// two adjacent bits and runs both stages in registers, half the LDS round trips and barriers per butterfly. Slower at every
+// size - 2^24 2.87 against 2.72 ms, 2^20 0.245 against 0.197 with 256 threads; 128 and 512 threads per tile are worse still
+// (profiles/r03_fft_radix4.log): twice the registers (121 against 61) and a quarter of a tile's elements per work item
+// leave fewer waves to cover the twiddle loads. Removed.)
 
 // BitReverse (bitreverse.go:33-45): swap a[i] and a[rev(i)] once per pair
 template <class FrP>
@@ -320,29 +249,6 @@ struct FftField {
         return s;
     }
 
-    // the plain-Montgomery twiddle tables of the first version (A/B paths only)
-    static int ensure_sat_twiddles(hipStream_t stream, FftDomain *d) {
-        if (d->sat_ready) return GMSM_OK;
-        const size_t half = ((size_t)1 << d->log2n) / 2;
-        if (half) {
-            int rc;
-            if ((rc = d->twiddles.ensure(half * sizeof(Fr)))) return rc;
-            if ((rc = d->twiddles_inv.ensure(half * sizeof(Fr)))) return rc;
-            Fr gen, gen_inv;
-            memcpy(&gen, d->generator.data(), sizeof(Fr));
-            memcpy(&gen_inv, d->generator_inv.data(), sizeof(Fr));
-            const unsigned blocks = (unsigned)((half + 255) / 256);
-            hipLaunchKernelGGL((k_fft_pow_table<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(gen), Fr::one(), half,
-                               (Fr *)d->twiddles.ptr);
-            hipLaunchKernelGGL((k_fft_pow_table<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(gen_inv), Fr::one(), half,
-                               (Fr *)d->twiddles_inv.ptr);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipStreamSynchronize(stream));  // shared by later transforms on other streams (see ensure_coset_tables)
-        }
-        d->sat_ready = true;
-        return GMSM_OK;
-    }
-
     // cosetTable = u^i and cosetTableInv (with 1/n folded in) = u^-i / n, built on first use (domain.go:150-160); both in
     // the lazy domain
     static int ensure_coset_tables(hipStream_t stream, FftDomain *d) {
@@ -372,11 +278,10 @@ struct FftField {
         const unsigned log2n = d->log2n;
         const size_t n = (size_t)1 << log2n;
         Fr *a = (Fr *)d_a;
-        const unsigned blocks_n = (unsigned)((n + 255) / 256), blocks_h = (unsigned)((n / 2 + 255) / 256);
+        const unsigned blocks_n = (unsigned)((n + 255) / 256);
         int rc;
         if (coset && (rc = ensure_coset_tables(stream, d))) return rc;
-        const bool stagewise = tune_uint("GMSM_FFT_STAGEWISE", 0) != 0, lazy = tune_uint("GMSM_FFT_LAZY", 1) != 0 && !stagewise;
-        const bool fused = lazy && n > 1;  // the scalings ride on the first / last pass
+        const bool fused = n > 1;  // the scalings ride on the first / last pass
         Fr card_inv_lz;
         memcpy(&card_inv_lz, d->cardinality_inv_lz.data(), sizeof(Fr));
         // the two scalings of the transform (fft.go:43-82, :144-195): DIT input and DIF output are bit-reversed, so the
@@ -405,31 +310,7 @@ struct FftField {
                 bl += Bk;
                 rest -= Bk;
             }
-            if (stagewise) {  // one launch per stage (the first version; kept for A/B)
-                if ((rc = ensure_sat_twiddles(stream, d))) return rc;
-                const Fr *tw = (const Fr *)(inverse ? d->twiddles_inv.ptr : d->twiddles.ptr);
-                for (unsigned s = 0; s < log2n; ++s) {
-                    if (dif) hipLaunchKernelGGL((k_fft_dif_stage<FrP>), dim3(blocks_h), dim3(256), 0, stream, a, n, log2n, s, tw);
-                    else hipLaunchKernelGGL((k_fft_dit_stage<FrP>), dim3(blocks_h), dim3(256), 0, stream, a, n, log2n, s, tw);
-                }
-            } else if (!lazy) {  // LDS-tiled passes on the saturated field (the second version; kept for A/B)
-                if ((rc = ensure_sat_twiddles(stream, d))) return rc;
-                const Fr *tw = (const Fr *)(inverse ? d->twiddles_inv.ptr : d->twiddles.ptr);
-                for (int k = 0; k < np; ++k) {
-                    const Pass &ps = passes[dif ? np - 1 - k : k];
-                    const size_t lds = ((size_t)sizeof(Fr) << ps.B) << ps.log2C;
-                    const size_t tiles = n >> (ps.B + ps.log2C);
-                    if (dif) {
-                        if ((rc = ctx_allow_lds((const void *)k_fft_pass<FrP, true>, 128 * 1024))) return rc;
-                        hipLaunchKernelGGL((k_fft_pass<FrP, true>), dim3((unsigned)tiles), dim3(256), lds, stream, a, log2n, ps.bl, ps.B,
-                                           ps.log2C, tw);
-                    } else {
-                        if ((rc = ctx_allow_lds((const void *)k_fft_pass<FrP, false>, 128 * 1024))) return rc;
-                        hipLaunchKernelGGL((k_fft_pass<FrP, false>), dim3((unsigned)tiles), dim3(256), lds, stream, a, log2n, ps.bl, ps.B,
-                                           ps.log2C, tw);
-                    }
-                }
-            } else {
+            {
                 const Fr *twz = (const Fr *)(inverse ? d->twiddles_inv_lz.ptr : d->twiddles_lz.ptr);
                 for (int k = 0; k < np; ++k) {
                     const Pass &ps = passes[dif ? np - 1 - k : k];

@@ -669,31 +669,48 @@ struct Group {
         return forced ? std::min(cap, forced) : cap;
     }
 
+    // Point ranges of a MultiExp over device-resident inputs. More than one range (a) beyond the cap of one pipeline run
+    // and (b) - experiment, GMSM_DEVICE_RANGES - to keep the bases of a range inside the 256 MiB Infinity Cache while
+    // all windows gather from them.
+    static unsigned device_ranges(size_t n) {
+        const size_t run = max_run_points();
+        unsigned nr = (unsigned)((n + run - 1) / run);
+        const unsigned forced = tune_uint("GMSM_DEVICE_RANGES", 0);
+        if (forced > nr) nr = (unsigned)std::min<size_t>(forced, n);
+        return nr;
+    }
+
     static int multiexp_device(Context &ctx, Workspace &ws, const void *d_points, const void *d_scalars, size_t n,
                                hipStream_t caller_stream, J *out, const ResidentBases *resident = nullptr) {
-        const size_t run = max_run_points();
-        if (n <= run) {
-            const unsigned c = choose_c(FR_BITS, AFF_BYTES, n);
-            WindowPlan plan = make_plan(c, 0, 1);
-            std::vector<Ext> totals(plan.nwin_total);
+        const unsigned nr = device_ranges(n);
+        const unsigned c = choose_c(FR_BITS, AFF_BYTES, n);
+        WindowPlan plan = make_plan(c, 0, 1);
+        std::vector<Ext> totals(plan.nwin_total);
+        if (nr <= 1) {
             int rc = window_sums(ctx, ws, d_points, d_scalars, n, plan, caller_stream, totals.data(), resident);
             if (rc) return rc;
             *out = fold(totals.data(), c);
             return GMSM_OK;
         }
-        const unsigned nruns = (unsigned)((n + run - 1) / run);
-        const size_t per = (n + nruns - 1) / nruns;
-        const unsigned c = choose_c(FR_BITS, AFF_BYTES, per);  // one c for every range: the totals must line up
-        WindowPlan plan = make_plan(c, 0, 1);
-        std::vector<Ext> sets((size_t)nruns * plan.nwin_total);
-        for (unsigned r = 0; r < nruns; ++r) {
+        // Consecutive point ranges on the workspace's stream: each leaves its bucket sums, k_merge_buckets adds them to the
+        // running buckets, one reduction at the end (the reference's split + AddAssign, multiexp.go:98-140, bucket by bucket).
+        constexpr size_t REC = sizeof(typename OpsSerial::Mem);
+        const size_t per = (n + nr - 1) / nr;
+        int rc = order_after(ws, caller_stream);
+        if (rc) return rc;
+        if ((rc = ws.carry.ensure((size_t)plan.nwin_local * plan.nbuckets * REC))) return rc;
+        for (unsigned r = 0; r * per < n; ++r) {
             const size_t lo = (size_t)r * per, len = std::min(per, n - lo);
             const void *dp = d_points ? (const char *)d_points + lo * AFF_BYTES : nullptr;
-            int rc = window_sums(ctx, ws, dp, (const char *)d_scalars + lo * SCALAR_BYTES, len, plan, caller_stream,
-                                 sets.data() + (size_t)r * plan.nwin_total, resident, lo);
-            if (rc) return rc;
+            if ((rc = enqueue_window_sums(ctx, ws, dp, (const char *)d_scalars + lo * SCALAR_BYTES, len, plan, ws.stream, resident,
+                                          nullptr, lo, /*buckets_only=*/true)))
+                return rc;
+            hipLaunchKernelGGL((k_merge_buckets<OpsSerial>), dim3((plan.nbuckets + 255) / 256, plan.nwin_local), dim3(256), 0, ws.stream,
+                               ws.carry.ptr, (const void *)ws.buckets.ptr, (const uint32_t *)ws.starts.ptr, plan.nbuckets, r == 0 ? 1 : 0);
         }
-        *out = fold_sets(sets.data(), nruns, c);
+        if ((rc = enqueue_reduce(ctx, ws, ws.carry.ptr, plan, per, ws.stream))) return rc;
+        if ((rc = collect_window_sums(ws, ws.stream, plan.nwin_local, totals.data()))) return rc;
+        *out = fold(totals.data(), c);
         return GMSM_OK;
     }
 
