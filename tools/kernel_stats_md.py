@@ -20,7 +20,7 @@ def main(args):
           "(HIP events inside libgmsm) is to be compared with the `k_accumulate_seg` row of the matching block.\n")
     for a in args:
         label, d = a.split("=", 1)
-        files = glob.glob(d + "/*kernel_stats.csv")
+        files = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)
         if not files:
             print(f"## {label}\n\n(no kernel_stats.csv under {d})\n")
             continue

@@ -6,8 +6,11 @@ usage: python tools/pmc_traffic.py <key>=<dir> ... > profiles/traffic_r02.json
        each <dir> holds fetch/*counter_collection.csv and write/*counter_collection.csv of one configuration
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB.  On gfx950 FETCH_SIZE under-counts wide coalesced streaming reads by 2x
-(MI355X_MICROARCH.md, HBM section); this kernel reads 16-byte pieces of scattered 64..192-byte records and 4-byte
-sequential entries, a pattern the guide calls uncalibrated: the value is reported as measured."""
+(MI355X_MICROARCH.md, HBM section).  This kernel's traffic is the gather of one 64..192-byte record per lane (plus 4-byte
+sequential entries, ~6 %): calibrated in round 3 with tools/ubench_gather.hip on exactly that pattern - 2^24 lanes x one
+64-byte record out of a 4 GiB table report FETCH_SIZE = 1024.0 MiB for 1024.0 MiB read (factor 1.00), the 16-byte-per-lane
+stream over the same table 2048 MiB for 4096 MiB (the guide's factor 2) - profiles/r03_fetch_calibration.md.  The values
+are therefore reported as measured."""
 import collections
 import csv
 import glob
@@ -25,11 +28,11 @@ def per_launch_mean(path, counter):
 
 
 def main(args):
-    out, detail = {}, {}
+    out, detail, windows = {}, {}, {}
     for a in args:
         key, d = a.split("=", 1)
-        f = glob.glob(d + "/fetch/*counter_collection.csv")
-        w = glob.glob(d + "/write/*counter_collection.csv")
+        f = glob.glob(d + "/fetch/**/*counter_collection.csv", recursive=True)
+        w = glob.glob(d + "/write/**/*counter_collection.csv", recursive=True)
         if not f or not w:
             continue
         fb, nf = per_launch_mean(f[0], "FETCH_SIZE")
@@ -38,10 +41,15 @@ def main(args):
             continue
         out[key] = fb + wb
         detail[key] = {"fetch_bytes": fb, "write_bytes": wb, "launches": [nf, nw]}
+        try:  # window count of the profiled run: bench.py reports the figure only for a run with the same geometry
+            windows[key] = json.load(open(d + "/bench.json"))["config"]["windows"]
+        except (OSError, ValueError, KeyError):
+            pass
     print(json.dumps({"note": "HBM/fabric bytes per k_accumulate_seg launch: rocprofv3 PMC FETCH_SIZE + WRITE_SIZE (separate passes, "
-                              "KiB x 1024) on the round-2 build, one bench.py configuration per pass; FETCH_SIZE as reported (gfx950 may "
-                              "under-count streaming reads by up to 2x, MI355X_MICROARCH.md)",
-                      "k_accumulate_seg": out, "detail": detail}, indent=1))
+                              "KiB x 1024) on the round-3 build with the shipped window table, one bench.py configuration per "
+                              "pass; FETCH_SIZE as reported - calibrated at factor 1.00 for this kernel's 64-byte-per-lane gather "
+                              "(profiles/r03_fetch_calibration.md)",
+                      "k_accumulate_seg": out, "windows": windows, "detail": detail}, indent=1))
 
 
 if __name__ == "__main__":

@@ -9,10 +9,11 @@ run() {  # label, bench args...
   rocprofv3 --kernel-trace --stats -d $out/$label/trace -o t --output-format csv -- python /root/repo/bench.py $Q "$@" > $out/$label/bench.json 2> $out/$label/trace.log
   rocprofv3 --pmc FETCH_SIZE -d $out/$label/fetch -o f --output-format csv -- python /root/repo/bench.py $Q --steps 3 --warmup 1 "$@" > /dev/null 2> $out/$label/fetch.log
   rocprofv3 --pmc WRITE_SIZE -d $out/$label/write -o w --output-format csv -- python /root/repo/bench.py $Q --steps 3 --warmup 1 "$@" > /dev/null 2> $out/$label/write.log
-  rm -f $out/$label/trace/*kernel_trace.csv $out/$label/*/*agent_info.csv
+  find $out/$label -name "*kernel_trace.csv" -delete; find $out/$label -name "*agent_info.csv" -delete
 }
-mkdir -p $out/bn254_g1_20 $out/bn254_g1_24 $out/bls12_381_g1_22 $out/bls12_381_g2_22 $out/bw6_761_g1_20
+mkdir -p $out/bn254_g1_20 $out/bn254_g1_22 $out/bn254_g1_24 $out/bls12_381_g1_22 $out/bls12_381_g2_22 $out/bw6_761_g1_20
 run bn254_g1_20
+run bn254_g1_22 --logn 22 --steps 5
 run bn254_g1_24 --logn 24 --steps 5
 run bls12_381_g1_22 --curve bls12_381 --group g1 --logn 22 --steps 5
 run bls12_381_g2_22 --curve bls12_381 --group g2 --logn 22 --steps 3
