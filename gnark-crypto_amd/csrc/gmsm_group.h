@@ -243,9 +243,10 @@ struct Group {
         if (fb + lidx > 32) fb = 32 - lidx;
         const uint32_t fbits = (uint32_t)fb;
         const uint32_t nparts = NB >> fbits;
-        const uint32_t pchunks = (uint32_t)((n + PART_CHUNK - 1) / PART_CHUNK);  // chunk = one LDS staging buffer
-        const size_t pchunk_len = PART_CHUNK;
-        const size_t scatter_lds = (size_t)nparts * 8 + (size_t)PART_CHUNK * 6;
+        const bool big_chunk = n > ((size_t)1 << 25);
+        const size_t pchunk_len = big_chunk ? PART_CHUNK_BIG : PART_CHUNK;  // chunk = one LDS staging buffer
+        const uint32_t pchunks = (uint32_t)((n + pchunk_len - 1) / pchunk_len);
+        const size_t scatter_lds = (size_t)nparts * 8 + pchunk_len * 6;
         if (scatter_lds > 152 * 1024)  // 32-bit sort entries: bucket bits + index bits; reached beyond 2^27 points at c <= 17
             return fail(GMSM_ERR_ARG, plan.c > 17 ? "window width too large for this many points in one pipeline run (a run takes up to "
                                                     "2^(44-c) points for c > 17): use a smaller c or split by point range"
@@ -288,8 +289,10 @@ struct Group {
 
         if ((rc = ctx.allow_lds((const void *)k_part_hist<uint16_t>, 160 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_part_hist<uint32_t>, 160 * 1024))) return rc;
-        if ((rc = ctx.allow_lds((const void *)k_part_scatter<uint16_t>, 152 * 1024))) return rc;
-        if ((rc = ctx.allow_lds((const void *)k_part_scatter<uint32_t>, 152 * 1024))) return rc;
+        if ((rc = ctx.allow_lds((const void *)k_part_scatter<uint16_t, PART_CHUNK>, 152 * 1024))) return rc;
+        if ((rc = ctx.allow_lds((const void *)k_part_scatter<uint32_t, PART_CHUNK>, 152 * 1024))) return rc;
+        if ((rc = ctx.allow_lds((const void *)k_part_scatter<uint16_t, PART_CHUNK_BIG>, 152 * 1024))) return rc;
+        if ((rc = ctx.allow_lds((const void *)k_part_scatter<uint32_t, PART_CHUNK_BIG>, 152 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_fine_sort, 160 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_fixup_long<U>, (int)(128 * sizeof(QRec<U>))))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_combine_q<U, true, COMBINE_N>, (int)((2 * COMBINE_N + 1) * sizeof(QRec<U>))))) return rc;
@@ -341,12 +344,17 @@ struct Group {
         hipLaunchKernelGGL(k_part_colscan, dim3((nparts + 31) / 32, nw), dim3(256), 0, stream, bh, pchunks, nparts, part_pop);
         hipLaunchKernelGGL(k_part_rowscan, dim3(nw), dim3(1024), 0, stream, part_pop, nparts, part_base, long_flag);
         timer.mark(T_SCATTER, stream);
-        if (d16)
-            hipLaunchKernelGGL(k_part_scatter<uint16_t>, dim3(pchunks, nw), dim3(1024), scatter_lds, stream,
-                               (const uint16_t *)digits, n, nparts, fbits, lidx, pchunk_len, bh, part_base, parted);
-        else
-            hipLaunchKernelGGL(k_part_scatter<uint32_t>, dim3(pchunks, nw), dim3(1024), scatter_lds, stream,
-                               (const uint32_t *)digits, n, nparts, fbits, lidx, pchunk_len, bh, part_base, parted);
+        {
+            const dim3 grid(pchunks, nw), block(1024);
+#define GMSM_SCATTER(D, CH)                                                                                              \
+    hipLaunchKernelGGL((k_part_scatter<D, CH>), grid, block, scatter_lds, stream, (const D *)digits, n, nparts, fbits, lidx, \
+                       pchunk_len, bh, part_base, parted)
+            if (d16 && !big_chunk) GMSM_SCATTER(uint16_t, PART_CHUNK);
+            else if (d16) GMSM_SCATTER(uint16_t, PART_CHUNK_BIG);
+            else if (!big_chunk) GMSM_SCATTER(uint32_t, PART_CHUNK);
+            else GMSM_SCATTER(uint32_t, PART_CHUNK_BIG);
+#undef GMSM_SCATTER
+        }
         hipLaunchKernelGGL(k_fine_sort, dim3(nparts, nw), dim3(1024), ((size_t)4 << fbits) + (size_t)stage_cap * 4, stream,
                            parted, n, NB, fbits, lidx, part_base, sorted, starts, stage_cap);
         // ---- 2. bucket accumulation

@@ -224,12 +224,16 @@ static __global__ void __launch_bounds__(1024) k_part_rowscan(const uint32_t *__
     if (t == T - 1) pb[nparts] = sums[T - 1];
 }
 
-// grid = (nchunks, nwin), block = 1024, chunk_len <= PART_CHUNK. The chunk is first sorted by partition inside LDS
+// grid = (nchunks, nwin), block = 1024, chunk_len <= CHUNK. The chunk is first sorted by partition inside LDS
 // (staging buffer + partition id per slot), then written out slot by slot: consecutive slots of one partition go to
 // consecutive addresses, so every (chunk, partition) run leaves the CU as one burst instead of trickling out 4 bytes at
 // a time over the lifetime of the workgroup (which left L2 writing back partially filled lines: 4.4 ms at 2^24).
-constexpr uint32_t PART_CHUNK = 16384;
-template <class D>
+// Chunk = what one workgroup stages in LDS. 12 K entries (76 KB) let two workgroups share a CU - one counts and scans
+// while the other places and writes: scatter + fine sort 1.93 -> 1.47 ms at 2^24, 0.42 -> 0.35 at 2^22 (A/B in one
+// session, profiles/r03_part_chunk.log). Beyond 2^25 points the coarse pass has 2048 partitions and the longer chunk's
+// longer runs win again (2^26: 9.5 against 10.3 ms): PART_CHUNK_BIG.
+constexpr uint32_t PART_CHUNK = 12288, PART_CHUNK_BIG = 16384;
+template <class D, uint32_t CHUNK>
 __global__ void __launch_bounds__(1024) k_part_scatter(const D *__restrict__ digits, size_t n, uint32_t nparts,
                                                               uint32_t fbits, uint32_t lidx, size_t chunk_len,
                                                               const uint32_t *__restrict__ blockhist,
@@ -238,8 +242,8 @@ __global__ void __launch_bounds__(1024) k_part_scatter(const D *__restrict__ dig
     extern __shared__ uint32_t lds_ps[];
     uint32_t *cnt = lds_ps;                 // [nparts] -> local cursor
     uint32_t *lbase = lds_ps + nparts;      // [nparts] first staging slot of the partition
-    uint32_t *stage = lds_ps + 2 * nparts;  // [PART_CHUNK] entries sorted by partition
-    uint16_t *spid = reinterpret_cast<uint16_t *>(stage + PART_CHUNK);  // [PART_CHUNK] partition of each slot
+    uint32_t *stage = lds_ps + 2 * nparts;  // [CHUNK] entries sorted by partition
+    uint16_t *spid = reinterpret_cast<uint16_t *>(stage + CHUNK);  // [CHUNK] partition of each slot
     __shared__ uint32_t scan_tmp[1];
     const uint32_t chunk = blockIdx.x, k = blockIdx.y, nchunks = gridDim.x, t = threadIdx.x, T = blockDim.x;
     const uint32_t *goff = blockhist + ((size_t)k * nchunks + chunk) * nparts;  // prefix of (chunk, p) inside partition p
@@ -250,7 +254,8 @@ __global__ void __launch_bounds__(1024) k_part_scatter(const D *__restrict__ dig
     const size_t hi = lo + chunk_len < n ? lo + chunk_len : n;
     const D *d = digits + (size_t)k * n;
     const uint32_t fmask = (1u << fbits) - 1u;
-    constexpr int PER = PART_CHUNK / 1024;  // entries per thread, kept in registers between the two passes
+    static_assert(CHUNK % 1024 == 0, "a whole number of entries per thread");
+    constexpr int PER = CHUNK / 1024;  // entries per thread, kept in registers between the two passes
     uint32_t ent[PER];
     uint32_t pid[PER];
 #pragma unroll

@@ -179,3 +179,61 @@ def test_sharding_layout():
                 g[r] = sharding.pack_local(loc, nwin, world, 4)
             tot = sharding.unpack_gathered(g, nwin, world, 4)
             assert (tot[:, 0] == np.arange(nwin)).all()
+
+
+def _wait_worker(rank, world, port, q):
+    """bench.py's host_side_wait: rank 0 works while the others wait on a key of the rendezvous store (no collective)."""
+    try:
+        if ROOT not in sys.path:
+            sys.path.insert(0, ROOT)
+        import time
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import bench
+
+        t0 = time.perf_counter()
+
+        def work():
+            time.sleep(0.5)
+            return {"by": rank}
+
+        out = bench.host_side_wait(dist, rank, "unit_test_key", work)
+        waited = time.perf_counter() - t0
+        ok = (out == {"by": 0}) if rank == 0 else (out is None and waited >= 0.4)
+        q.put((rank, ok, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        q.put((rank, False, repr(e)))
+
+
+def test_bench_host_side_wait_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_wait_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in results), results
+
+
+def test_bench_launcher_asks_for_the_devices_it_needs():
+    """`python bench.py --gpus N` as a plain command becomes the launcher of N ranks; on a machine with fewer devices it
+    says so instead of failing inside a launcher (here: no device at all)."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert r.returncode != 0
+    assert "needs 2 devices" in (r.stderr + r.stdout)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
