@@ -54,12 +54,20 @@ struct Group {
 #define GMSM_SERIAL_QUAD_WORDS 14
 #endif
     static constexpr bool SERIAL_QUAD = sizeof(U) >= GMSM_SERIAL_QUAD_WORDS * 4;
+    // The work-efficient combine (k_combine_we: half the issue work, one step more) where the combine is throughput-bound:
+    // the 9-limb field with at least two workgroups per CU. Measured k_combine_q / k_combine_we reduce times, BN254 G1:
+    // 2^16 0.293 / 0.277 ms, 2^18 0.337 / 0.308, 2^20 0.344 / 0.312, 2^24 0.465 / 0.433 - but 2^12 (a handful of
+    // workgroups: latency) 0.080 / 0.106, and the 14-limb field 0.628 / 0.68 (three workgroups per CU, not four).
+#ifndef GMSM_COMBINE_WE_WORDS
+#define GMSM_COMBINE_WE_WORDS 9
+#endif
+    static constexpr bool COMBINE_WE = sizeof(U) <= GMSM_COMBINE_WE_WORDS * 4;
+    static bool use_combine_we(const Context &ctx, uint32_t workgroups) { return COMBINE_WE && workgroups >= 2u * (uint32_t)ctx.num_cus; }
     // k_fixup_seg: followers a chain head adds itself (one-lane additions); longer chains go to k_fixup_long (quads, one
     // workgroup per chain). Handing chains of 3+ links to the quads for the wide types was measured: no gain at 2^20
     // (BW6-761 fixup 0.75 ms either way - it is 322 K two-link chains in five rounds of 512-register workgroups), and 2^16
     // got slower (0.68 -> 2.6 ms: thousands of short chains, one workgroup each).
     static constexpr uint32_t FIX_MAXWALK = FIXUP_MAXWALK;
-    static_assert((2 * COMBINE_N + 1) * sizeof(QRec<U>) <= 160 * 1024, "quad combine LDS budget");
 
     static WindowPlan make_plan(unsigned c, unsigned win_first, unsigned win_stride) {
         WindowPlan p;
@@ -296,6 +304,8 @@ struct Group {
         if ((rc = ctx.allow_lds((const void *)k_fine_sort, 160 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_fixup_long<U>, (int)(128 * sizeof(QRec<U>))))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_combine_q<U, true, COMBINE_N>, (int)((2 * COMBINE_N + 1) * sizeof(QRec<U>))))) return rc;
+        if constexpr (COMBINE_WE)
+            if ((rc = ctx.allow_lds((const void *)k_combine_we<U, true>, (int)((2 * COMBINE_N + 1) * sizeof(QRec<U>))))) return rc;
         if constexpr (SERIAL_QUAD)
             if ((rc = ctx.allow_lds((const void *)k_reduce_serial_q<U>, (int)(192 * sizeof(QRec<U>))))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_reduce2_q<U, true>, (int)(2 * RED2_TPB * sizeof(QRec<U>))))) return rc;
@@ -396,9 +406,19 @@ struct Group {
         else
             hipLaunchKernelGGL((k_reduce_serial<OpsSerial>), dim3((T + 255) / 256, nw), dim3(256), 0, stream, buckets, NB,
                                q.log2L, T, starts, ws.red_pre.ptr);
-        hipLaunchKernelGGL((k_combine_q<U, true, COMBINE_N>), dim3(q.nblocks1, nw), dim3(4 * COMBINE_N),
-                           (2 * COMBINE_N + 1) * sizeof(QRec<U>), stream, q.log2L, ws.partials.ptr, prescale,
-                           (const void *)ws.red_pre.ptr, T);
+        bool we = false;
+        if constexpr (COMBINE_WE) {
+            if (use_combine_we(ctx, q.nblocks1 * nw)) {
+                hipLaunchKernelGGL((k_combine_we<U, true>), dim3(q.nblocks1, nw), dim3(4 * COMBINE_N),
+                                   (2 * COMBINE_N + 1) * sizeof(QRec<U>), stream, q.log2L, ws.partials.ptr, prescale,
+                                   (const void *)ws.red_pre.ptr, T);
+                we = true;
+            }
+        }
+        if (!we)
+            hipLaunchKernelGGL((k_combine_q<U, true, COMBINE_N>), dim3(q.nblocks1, nw), dim3(4 * COMBINE_N),
+                               (2 * COMBINE_N + 1) * sizeof(QRec<U>), stream, q.log2L, ws.partials.ptr, prescale,
+                               (const void *)ws.red_pre.ptr, T);
         uint32_t active = 2;
         while (active < q.nblocks1) active <<= 1;
         hipLaunchKernelGGL((k_reduce2_q<U, true>), dim3(nw), dim3(4 * active), 2 * active * sizeof(QRec<U>), stream,
@@ -419,6 +439,8 @@ struct Group {
         if ((rc = ws.totals.ensure((size_t)nw * sizeof(Ext)))) return rc;
         if ((rc = ws.ensure_pinned((size_t)nw * sizeof(Ext)))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_combine_q<U, true, COMBINE_N>, (int)((2 * COMBINE_N + 1) * sizeof(QRec<U>))))) return rc;
+        if constexpr (COMBINE_WE)
+            if ((rc = ctx.allow_lds((const void *)k_combine_we<U, true>, (int)((2 * COMBINE_N + 1) * sizeof(QRec<U>))))) return rc;
         if constexpr (SERIAL_QUAD)
             if ((rc = ctx.allow_lds((const void *)k_reduce_serial_q<U>, (int)(192 * sizeof(QRec<U>))))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_reduce2_q<U, true>, (int)(2 * RED2_TPB * sizeof(QRec<U>))))) return rc;

@@ -367,6 +367,86 @@ __global__ void __launch_bounds__(4 * N) k_combine_q(uint32_t log2L, void *__res
     if (j == 1) quad_rec_store<U>(out1, ((size_t)k * gridDim.x + blk) * 2 + 0, PARK, lane);
 }
 
+// ------------------------------------------------------------------ work-efficient level-1 combine (N = 64)
+// k_combine_q computes all 64 suffix sums (Hillis-Steele: 6 steps of 64 additions) only to add them up again. What the
+// block needs is A = sum_t S_t, U = sum_t t S_t and sum_t W_t, and U = sum_l 2^l M_l with M_l = the sum of the S_t whose
+// index has bit l set. Steps 1..6 form, in place, the pair sums per index bit - P^0 = S, P^(l+1)_j = P^l_2j + P^l_(2j+1),
+// P^l_j living in slot j << l - which leave the odd elements P^l_(2j+1) untouched in their slots t = (2j+1) << l; from the
+// step after a level has read them, those slots are summed by a halving tree (M_l ends in slot 1 << l); the W tree runs
+// alongside. Every step has (s + 1) groups of g = 32 >> (s-1) additions: 64, 48, 32, 20, 12, 7 - 3.4 additions per pair
+// instead of 8, and waves without work skip the products. The tail combines the six M_l:
+//   U = (M_0 + 2 M_1) + 4 (M_2 + 2 M_3) + 16 (M_4 + 2 M_5), then L U, then W + L U      (7 + log2L + 1 steps on quads 0..2)
+// while quad 15 doubles the parked A log2span times. 17 steps at L = 8 (k_combine_q: 16), about half the issue work: for
+// the element types whose combine is throughput-bound (several workgroups per CU: the 9- and 14-limb fields).
+// tests/test_combine_model.py runs this step machine over Z. Launch and LDS as k_combine_q<U, INL, 64>.
+template <class U, bool INL>
+__global__ void __launch_bounds__(256) k_combine_we(uint32_t log2L, void *__restrict__ out1, uint32_t prescale,
+                                                    const void *__restrict__ pre, uint32_t T) {
+    constexpr uint32_t N = 64;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    QRec<U> *S = reinterpret_cast<QRec<U> *>(lds_raw), *W = S + N, *PARK = S + 2 * N;
+    const uint32_t k = blockIdx.y, blk = blockIdx.x, t = threadIdx.x, j = t >> 2, lane = t & 63u;
+    const uint32_t g0 = blk * N + j;
+    quad_rec_load<U>(&S[j], pre, ((size_t)k * T + g0) * 2 + 0, g0 < T, lane);
+    quad_rec_load<U>(&W[j], pre, ((size_t)k * T + g0) * 2 + 1, g0 < T, lane);
+    __syncthreads();
+#pragma nounroll
+    for (uint32_t s = 1; s <= 6; ++s) {
+        const uint32_t g = 32u >> (s - 1), G = j / g, i = j % g;
+        const bool act = G <= s;
+        QRec<U> *X = &S[0], *Y = &S[0];
+        if (G == 0) {  // pair sums of level l = s - 1
+            const uint32_t l = s - 1;
+            X = &S[(2 * i) << l];
+            Y = &S[(2 * i + 1) << l];
+        } else if (G < s) {  // tree over the odd elements of level l = G - 1: slot i += slot i + g
+            const uint32_t l = G - 1;
+            X = &S[(2 * i + 1) << l];
+            Y = &S[(2 * (i + g) + 1) << l];
+        } else if (G == s) {  // W tree
+            X = &W[i];
+            Y = &W[i + g];
+        }
+        const QAddOps<U> o = quad_add_load<U>(X, Y, lane);
+        __syncthreads();
+        quad_add_store<U, INL>(X, o, act, lane);
+        __syncthreads();
+    }
+    if (j == 0) {  // park A = S[0] for the prescaling doubler
+        PARK->c[t & 3u] = S[0].c[t & 3u];
+        if ((t & 3u) == 0) PARK->inf = S[0].inf;
+    }
+    __syncthreads();
+    uint32_t dbl_left = prescale;
+    const uint32_t n_tail = 7 + log2L + 1;
+#pragma nounroll
+    for (uint32_t s = 0; s < n_tail; ++s) {
+        // tail program of quads 0, 1, 2 on the slots of M_0..M_5 = S[1], S[2], S[4], S[8], S[16], S[32]
+        int op = 0;  // 0 nothing, 1 double X, 2 X += Y
+        QRec<U> *X = &S[0], *Y = &S[0];
+        if (j < 3) {
+            if (s == 0) { op = 1; X = &S[2u << (2 * j)]; }                                    // 2 M_1, 2 M_3, 2 M_5
+            else if (s == 1) { op = 2; X = &S[1u << (2 * j)]; Y = &S[2u << (2 * j)]; }       // M_0 + 2 M_1, M_2 + 2 M_3, M_4 + 2 M_5
+            else if (s == 2 || s == 3) { if (j >= 1) { op = 1; X = &S[j == 1 ? 4 : 16]; } }   // x4 under way, x16 under way
+            else if (s == 4) { if (j == 0) { op = 2; X = &S[1]; Y = &S[4]; } else if (j == 2) { op = 1; X = &S[16]; } }
+            else if (s == 5) { if (j == 2) { op = 1; X = &S[16]; } }
+            else if (s == 6) { if (j == 0) { op = 2; X = &S[1]; Y = &S[16]; } }             // U complete
+            else if (s < 7 + log2L) { if (j == 0) { op = 1; X = &S[1]; } }                    // L U
+            else if (j == 0) { op = 2; X = &W[0]; Y = &S[1]; }                                // W + L U
+        }
+        const bool park_dbl = j == 15 && dbl_left > 0;
+        const QAddOps<U> o = quad_add_load<U>(X, Y, lane);
+        __syncthreads();
+        quad_add_store<U, INL>(X, o, op == 2, lane);
+        if (op == 1 && !X->inf) quad_dbl_inplace<U, INL>(X, lane);
+        if (park_dbl && !PARK->inf) quad_dbl_inplace<U, INL>(PARK, lane);
+        if (dbl_left > 0) --dbl_left;
+        __syncthreads();
+    }
+    if (j == 0) quad_rec_store<U>(out1, ((size_t)k * gridDim.x + blk) * 2 + 1, &W[0], lane);
+    if (j == 1) quad_rec_store<U>(out1, ((size_t)k * gridDim.x + blk) * 2 + 0, PARK, lane);
+}
+
 #endif  // __HIPCC__
 
 }  // namespace gmsm

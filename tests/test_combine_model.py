@@ -1,5 +1,5 @@
-"""Lockstep model of the quad step machines of the bucket reduction (gmsm_quad.h: k_combine_q, the level-1 combine of the
-split reduction, and k_reduce2_q, level 2) over the additive group Z (add = +, dbl = *2, infinity = None): every step
+"""Lockstep model of the quad step machines of the bucket reduction (gmsm_quad.h: k_combine_q and its work-efficient twin
+k_combine_we, the level-1 combine of the reduction, and k_reduce2_q, level 2) over the additive group Z (add = +, dbl = *2, infinity = None): every step
 is "all quads read their operands - barrier - compute and store - barrier", records may be one quad's destination and
 another quad's source in the same step, and the result must be
     W_blk = sum W_t + L * sum_{t>=1} Suf_t,   S_blk = 2^prescale * sum S_t        (level 1)
@@ -69,6 +69,61 @@ def combine_q(N, log2L, prescale, S, W):
     return park, W[0]
 
 
+def combine_we(log2L, prescale, S, W):
+    """k_combine_we (N = 64): work-efficient form - pair sums per index bit, the odd elements' trees in place, then
+    U = sum_l 2^l M_l by three two-term pairs. Same result as combine_q with 3.4 instead of 8 additions per pair."""
+    N = 64
+    S, W = list(S), list(W)
+    for s in range(1, 7):
+        g = 32 >> (s - 1)
+        loaded = []
+        for q in range(N):
+            G, i = q // g, q % g
+            if G > s:
+                continue
+            if G == 0:
+                l = s - 1
+                loaded.append((S, (2 * i) << l, S[(2 * i) << l], S[(2 * i + 1) << l]))
+            elif G < s:
+                l = G - 1
+                loaded.append((S, (2 * i + 1) << l, S[(2 * i + 1) << l], S[(2 * (i + g) + 1) << l]))
+            else:
+                loaded.append((W, i, W[i], W[i + g]))
+        assert len(loaded) == (s + 1) * g <= N
+        dests = [(id(arr), k) for arr, k, _, _ in loaded]
+        assert len(set(dests)) == len(dests), "two tasks write one record"
+        for arr, k, x, y in loaded:
+            arr[k] = add(x, y)
+    park = S[0]
+    dbl_left = prescale
+    m = lambda l: 1 << l  # slot of M_l
+    tail = [  # (doublings, additions) of each tail step on the slots S[1], S[2], S[4], S[8], S[16], S[32]
+        ([m(1), m(3), m(5)], []),
+        ([], [(m(0), m(1)), (m(2), m(3)), (m(4), m(5))]),
+        ([m(2), m(4)], []),
+        ([m(2), m(4)], []),
+        ([m(4)], [(m(0), m(2))]),
+        ([m(4)], []),
+        ([], [(m(0), m(4))]),
+    ]
+    tail += [([m(0)], [])] * log2L
+    for dbls, adds in tail + [([], [])]:
+        last = (dbls, adds) == ([], [])
+        loaded = [(x, S[x], S[y]) for x, y in adds]
+        assert not (set(dbls) & {x for x, _ in adds}) and not (set(dbls) & {y for _, y in adds})
+        for x, vx, vy in loaded:
+            S[x] = add(vx, vy)
+        for x in dbls:
+            S[x] = dbl(S[x])
+        if last:
+            W[0] = add(W[0], S[1])
+        if dbl_left > 0:
+            park = dbl(park)
+            dbl_left -= 1
+    assert dbl_left == 0, "the prescaling doublings must fit into the tail"
+    return park, W[0]
+
+
 def reduce2_q(active, nblocks1, log2span, S, W):
     """k_reduce2_q: quad j holds level-1 block j (j < nblocks1, the rest infinity)."""
     S = [S[j] if j < nblocks1 else None for j in range(active)]
@@ -105,6 +160,20 @@ def test_combine_q_identity():
                     suf = [sum(val(x) for x in S[t:]) for t in range(N)]
                     assert val(w_blk) == sum(val(x) for x in W) + (1 << log2L) * sum(suf[1:])
                     assert val(s_blk) == sum(val(x) for x in S) << prescale
+
+
+def test_combine_we_identity():
+    rng = random.Random(31)
+    N = 64
+    for log2L in (1, 2, 3, 4, 8):
+        for prescale in (0, log2L + 6):
+            for _ in range(20):
+                S = [rng.randrange(1, 1 << 40) if rng.random() < 0.8 else None for _ in range(N)]
+                W = [rng.randrange(1, 1 << 40) if rng.random() < 0.9 else None for _ in range(N)]
+                s_blk, w_blk = combine_we(log2L, prescale, S, W)
+                suf = [sum(val(x) for x in S[t:]) for t in range(N)]
+                assert val(w_blk) == sum(val(x) for x in W) + (1 << log2L) * sum(suf[1:])
+                assert val(s_blk) == sum(val(x) for x in S) << prescale
 
 
 def test_reduce2_q_identity():
