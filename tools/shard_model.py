@@ -8,7 +8,8 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 gm = importlib.import_module("gnark-crypto_amd")
 
 
