@@ -1,7 +1,8 @@
 """Environment-switch sweep in ONE process: ms per MultiExp and per-stage times for a list of GMSM_* settings.
-usage: python tools/sweep_env.py curve group logn [reps] -- "GMSM_C=20" "GMSM_C=20,GMSM_SPLIT_REDUCE=1,GMSM_LOG2L=6" ...
-An empty string "" is the default configuration. The library reads its GMSM_* switches on every call, so one set of
-device-resident inputs serves every variant. Every variant's affine result is compared with the default's."""
+usage: python tools/sweep_env.py curve group logn [reps] -- "GMSM_C=20" "GMSM_C=17,GMSM_LOG2L=5,GMSM_PART_LOG2=14" ...
+An empty string "" is the default configuration. The library reads its GMSM_* switches on every call (GMSM_C always; the
+tuning knobs only in a -DGMSM_EXPERIMENTS build, tools/build_ab.sh + GMSM_LIB), so one set of device-resident inputs
+serves every variant. Every variant's affine result is compared with the default's."""
 import ctypes
 import importlib
 import os
