@@ -330,7 +330,7 @@ def fft_config(gm, torch, curve="bn254", logn=24, reps=5):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / reps * 1e3
     d.release()
-    passes = 1 + (max(0, logn - 11) + 7) // 8  # gmsm_fft.h: the low 11 bits in one pass, the rest in passes of <= 8
+    passes = 1 + (max(0, logn - 10) + 7) // 8  # gmsm_fft.h: the low 10 bits in one pass, the rest in passes of <= 8
     traffic = passes * 2 * n * 8 * c.fr_limbs
     return {"workload": f"{curve.upper()} fr FFT (DIF) 2^{logn} elements resident in HBM", "ms": ms, "ffts_per_s": 1e3 / ms,
             "butterflies_per_s": n * logn / 2 / (ms * 1e-3), "hbm_passes": passes,

@@ -98,8 +98,15 @@ __global__ void __launch_bounds__(256) k_fft_scale_const_lz(Fp<FrP> *__restrict_
 //   pre  != null : every element is multiplied by pre[pre_rev ? bitrev(i) : i] as it is loaded (coset FFT, fft.go:43-82)
 //   post_mode 1/2: ... by post[i] / post[bitrev(i)] as it is stored (inverse coset FFT, fft.go:153-195)
 //   post_mode 3  : ... by the constant post_c (CardinalityInv, fft.go:144-150)
+// Tile of the contiguous low pass: 2^10 elements (36 KB of LDS for a 32-byte field: four workgroups per CU instead of the
+// two that 2^11 allowed) and 512 threads per tile from 2^22 elements on. Measured, BN254 fr DIF, 2^11 x 256 threads ->
+// 2^10 x 256 / 512: 2^16 0.080 -> 0.061 / 0.053 ms, 2^20 0.197 -> 0.187 / 0.192, 2^24 2.73 -> 2.60 / 2.53
+// (profiles/r03_fft_tiles.log; 2^9 tiles and 1024 threads lose).
+#ifndef GMSM_FFT_LOWB
+#define GMSM_FFT_LOWB 10
+#endif
 template <class FrP, bool DIF>
-__global__ void __launch_bounds__(256) k_fft_pass_lz(Fp<FrP> *__restrict__ a, unsigned log2n, unsigned bl, unsigned B, unsigned log2C,
+__global__ void __launch_bounds__(512) k_fft_pass_lz(Fp<FrP> *__restrict__ a, unsigned log2n, unsigned bl, unsigned B, unsigned log2C,
                                                      const Fp<FrP> *__restrict__ twz, const Fp<FrP> *__restrict__ pre, int pre_rev,
                                                      const Fp<FrP> *__restrict__ post, int post_mode, Fp<FrP> post_c) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -294,9 +301,10 @@ struct FftField {
             hipLaunchKernelGGL((k_fft_scale_table_lz<FrP>), dim3(blocks_n), dim3(256), 0, stream, a, n, log2n, pre, pre_rev);
         if (n > 1) {
             // passes over the bit positions: the lowest LOWB bits as one contiguous pass (tiles of 2^LOWB elements,
-            // C = 1), the rest in passes of <= 8 bits with C = 8 consecutive elements per row. DIF runs the passes
+            // C = 1), the rest in passes of <= 8 bits with C = 8 consecutive elements per row (2^24: 10 + 7 + 7). DIF runs the passes
             // from the top bits down, DIT from the bottom up.
-            constexpr unsigned LOWB = sizeof(Fr) <= 32 ? 11 : 10;  // 2^11 x 36 B = 72 KiB of LDS
+            constexpr unsigned LOWB = sizeof(Fr) <= 32 ? GMSM_FFT_LOWB : GMSM_FFT_LOWB - 1;  // 2^10 x 36 B = 36 KiB of LDS
+            const unsigned tpb = log2n >= 22 ? 512u : 256u;
             static_assert(LOWB <= FFT_MAX_CHAIN, "additions between two reductions to canonical form");
             struct Pass { unsigned bl, B, log2C; } passes[16];
             int np = 0;
@@ -320,11 +328,11 @@ struct FftField {
                     const int post_k = k == np - 1 ? post_mode : 0;
                     if (dif) {
                         if ((rc = ctx_allow_lds((const void *)k_fft_pass_lz<FrP, true>, 128 * 1024))) return rc;
-                        hipLaunchKernelGGL((k_fft_pass_lz<FrP, true>), dim3((unsigned)tiles), dim3(256), lds, stream, a, log2n, ps.bl,
+                        hipLaunchKernelGGL((k_fft_pass_lz<FrP, true>), dim3((unsigned)tiles), dim3(tpb), lds, stream, a, log2n, ps.bl,
                                            ps.B, ps.log2C, twz, pre_k, pre_rev, post, post_k, card_inv_lz);
                     } else {
                         if ((rc = ctx_allow_lds((const void *)k_fft_pass_lz<FrP, false>, 128 * 1024))) return rc;
-                        hipLaunchKernelGGL((k_fft_pass_lz<FrP, false>), dim3((unsigned)tiles), dim3(256), lds, stream, a, log2n, ps.bl,
+                        hipLaunchKernelGGL((k_fft_pass_lz<FrP, false>), dim3((unsigned)tiles), dim3(tpb), lds, stream, a, log2n, ps.bl,
                                            ps.B, ps.log2C, twz, pre_k, pre_rev, post, post_k, card_inv_lz);
                     }
                 }
