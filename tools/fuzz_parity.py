@@ -7,9 +7,10 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
-sys.path.insert(0, "oracle")
-sys.path.insert(0, "tests")
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (_ROOT, os.path.join(_ROOT, "oracle"), os.path.join(_ROOT, "tests")):
+    sys.path.insert(0, _p)
 gm = importlib.import_module("gnark-crypto_amd")
 
 
@@ -28,7 +29,7 @@ def main():
     cases = bad = 0
     while time.time() - t0 < budget:
         n = int(rng.choice([rng.integers(1, 64), rng.integers(64, 5000), rng.integers(5000, nmax)]))
-        kind = int(rng.integers(0, 6))
+        kind = int(rng.integers(0, 8))
         if kind == 0:
             sc = random_scalars(rng, g.curve, n)
         elif kind == 1:  # small values
@@ -42,15 +43,32 @@ def main():
         elif kind == 4:  # sparse: mostly zero
             sc = random_scalars(rng, g.curve, n)
             sc[rng.random(n) < 0.9] = 0
-        else:  # powers of two and r - small
+        elif kind == 5:  # powers of two and r - small
             sc = scalars_from_ints(g.curve, [(1 << int(e)) % g.curve.r if e >= 0 else g.curve.r + int(e)
                                              for e in rng.integers(-5, g.curve.fr_bits, size=n)])
+        else:
+            sc = random_scalars(rng, g.curve, n)
         pts = pts_all[:n]
+        fresh_bases = False
+        if kind == 6:  # one base repeated: P + P in buckets, partial sums and the reduction's combine
+            pts = np.tile(pts_all[int(rng.integers(0, nmax)):][:1], (n, 1))
+            fresh_bases = True
+        elif kind == 7 and n >= 2:  # every base twice, with s and r - s: P - P everywhere, the total is infinity
+            h = n // 2
+            vals = [int.from_bytes(rng.bytes(32), "little") % g.curve.r for _ in range(h)]
+            sc = scalars_from_ints(g.curve, vals + [(g.curve.r - v) % g.curve.r for v in vals] + [0] * (n - 2 * h))
+            pts = np.concatenate([pts_all[:h], pts_all[:h], pts_all[:n - 2 * h]])
+            fresh_bases = True
         want = o.msm_affine(pts, sc, nthreads=8)
-        entry = int(rng.integers(0, 4))
+        entry = 0 if fresh_bases and rng.random() < 0.5 else (4 if fresh_bases else int(rng.integers(0, 5)))
         if entry == 0:
             got, err = g.MultiExp(pts, sc)
             assert err is None
+        elif entry == 4:  # the in-library multi-device entry, 2-5 logical ranks on device 0, either decomposition
+            gj = (gm.G1Jac if which == "g1" else gm.G2Jac)(curve)
+            jac, err = gj.MultiExpSharded(pts, sc, devices=[0] * int(rng.integers(2, 6)), mode=str(rng.choice(["points", "windows"])))
+            assert err is None, err
+            got = g.jac_to_affine(jac)
         elif entry == 1:
             jac, err = rb.MultiExp(sc)
             assert err is None
