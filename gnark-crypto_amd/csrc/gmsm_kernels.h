@@ -8,8 +8,10 @@
 //                      "one goroutine walks all n digits of a window" (multiexp_jacobian.go:26-39)
 //   k_convert_points   rewrite the bases into the lazy Montgomery domain (once per call or per registered SRS)
 //   k_accumulate_seg   bucket accumulation loop             multiexp_jacobian.go:26-39 (addMixed / subMixed)
-//   k_fixup_seg/level  close buckets that were split over several accumulation threads
-//   k_reduce1/2        running-sum bucket reduction         multiexp_jacobian.go:44-52
+//   k_fixup_seg/long   close buckets that were split over several accumulation threads
+//   k_reduce_serial[_q], k_combine_q / k_combine_we, k_reduce2_q (gmsm_quad.h)
+//                      running-sum bucket reduction         multiexp_jacobian.go:44-52
+//   k_merge_buckets    the split of a MultiExp in point ranges  multiexp.go:98-140 (AddAssign, here bucket by bucket)
 //   (host) fold        msmReduceChunkG1Affine               multiexp.go:302-315
 //
 // Digit code (the reference's uint16 digits, multiexp.go:779-800; stored as uint16 whenever every code of the call fits,
@@ -404,7 +406,7 @@ __global__ void __launch_bounds__(256) k_convert_points(const void *__restrict__
 // all scalars equal).  A run of entries that lies completely inside the thread's range is a finished bucket and is
 // stored directly; a run that continues into a neighbouring thread is stored as a partial (slot 0: run open to the
 // left, slot 1: run open only to the right) and k_fixup_seg adds the chain of partials of each split bucket.
-// Buckets without entries are never written: k_reduce1 recognises them from `starts`.
+// Buckets without entries are never written: the reduction (and k_merge_buckets) recognise them from `starts`.
 struct SegFlags {
     static constexpr uint32_t HAS_P0 = 1u;         // first run continues from the previous thread
     static constexpr uint32_t P0_OPEN_RIGHT = 2u;  // ... and also continues into the next thread
@@ -645,7 +647,7 @@ __global__ void __launch_bounds__(256) k_fixup_long(uint32_t nbuckets, const voi
 
 // The serial part of level 1: thread g of a window owns the L = 2^log2L
 // consecutive buckets [g*L, (g+1)*L) and runs the reference's running sum over them (multiexp_jacobian.go:44-52), leaving
-// S_g = sum B_j and W_g = sum (j+1) B_j in pre[(k*T + g)*2 + {0,1}], T = ceil(nbuckets / L). Fused into k_reduce1 the
+// S_g = sum B_j and W_g = sum (j+1) B_j in pre[(k*T + g)*2 + {0,1}], T = ceil(nbuckets / L). Fused with the combine (rounds 1-2) the
 // loop keeps four extended-Jacobian values plus the addition's temporaries alive - for a 28-limb field or Fp2 over 14
 // limbs that is over 600 registers and the kernel ran out of a 3-4 KB per lane scratch frame (BW6-761: 9.1 ms for a 4.8 ms
 // multiplier bill). Here only `run`, `tot` and the loaded bucket are live, the addition is inlined, and the launch is
