@@ -194,6 +194,32 @@ struct Group {
         return q;
     }
 
+    // k_decompose for this plan: the unrolled kernel of the plan's width when it is one of the window table's
+    // (preferred_c), the generic one otherwise (forced and test widths). d16: uint16 digit codes.
+    static void launch_decompose(const void *d_scalars, size_t n, const WindowPlan &plan, bool d16, void *digits,
+                                 const uint8_t *skip, hipStream_t stream) {
+        const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+#define GMSM_DECOMPOSE_C(CC)                                                                                                \
+    case CC:                                                                                                                \
+        if (d16) hipLaunchKernelGGL((k_decompose_c<FrP, uint16_t, CC>), grid, block, 0, stream, (const uint32_t *)d_scalars, n,  \
+                                    plan, (uint16_t *)digits, skip);                                                         \
+        else hipLaunchKernelGGL((k_decompose_c<FrP, uint32_t, CC>), grid, block, 0, stream, (const uint32_t *)d_scalars, n,      \
+                                plan, (uint32_t *)digits, skip);                                                             \
+        return;
+        switch (plan.c) {
+            GMSM_DECOMPOSE_C(8) GMSM_DECOMPOSE_C(9) GMSM_DECOMPOSE_C(10) GMSM_DECOMPOSE_C(12) GMSM_DECOMPOSE_C(13)
+            GMSM_DECOMPOSE_C(14) GMSM_DECOMPOSE_C(15) GMSM_DECOMPOSE_C(16) GMSM_DECOMPOSE_C(17)
+            default: break;
+        }
+#undef GMSM_DECOMPOSE_C
+        if (d16)
+            hipLaunchKernelGGL((k_decompose<FrP, uint16_t>), grid, block, 0, stream, (const uint32_t *)d_scalars, n, plan,
+                               (uint16_t *)digits, skip);
+        else
+            hipLaunchKernelGGL((k_decompose<FrP, uint32_t>), grid, block, 0, stream, (const uint32_t *)d_scalars, n, plan,
+                               (uint32_t *)digits, skip);
+    }
+
     // Launches every kernel of one pipeline run and queues the copy of the window totals into ws.pinned; does not wait.
     // `stream` carries the call (inputs are ready there; the totals are complete there). All scratch comes from `ws`, so
     // two workspaces can be in flight at once.
@@ -330,12 +356,7 @@ struct Group {
         }
         // (A decomposition fused with the coarse histogram was measured and dropped: one workgroup per 16 K-scalar chunk
         // leaves 3/4 of the CUs idle at 2^20, and at 2^24 it only breaks even.)
-        if (d16)
-            hipLaunchKernelGGL((k_decompose<FrP, uint16_t>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                               (const uint32_t *)d_scalars, n, plan, (uint16_t *)ws.digits.ptr, skip);
-        else
-            hipLaunchKernelGGL((k_decompose<FrP, uint32_t>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                               (const uint32_t *)d_scalars, n, plan, (uint32_t *)ws.digits.ptr, skip);
+        launch_decompose(d_scalars, n, plan, d16, ws.digits.ptr, skip, stream);
 
         const void *digits = ws.digits.ptr;
         uint32_t *sorted = (uint32_t *)ws.sorted.ptr, *parted = (uint32_t *)ws.parted.ptr, *starts = (uint32_t *)ws.starts.ptr;
@@ -1115,8 +1136,7 @@ static int debug_decompose_impl(const uint64_t *scalars, size_t n, unsigned c, u
     if ((rc = ws.h2d_scalars.ensure(n * G::SCALAR_BYTES))) return rc;
     if ((rc = ws.digits.ensure((size_t)plan.nwin_total * n * 4))) return rc;
     HIP_TRY(hipMemcpyAsync(ws.h2d_scalars.ptr, scalars, n * G::SCALAR_BYTES, hipMemcpyHostToDevice, ws.stream));
-    hipLaunchKernelGGL((k_decompose<typename G::FrP, uint32_t>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ws.stream,
-                       (const uint32_t *)ws.h2d_scalars.ptr, n, plan, (uint32_t *)ws.digits.ptr, (const uint8_t *)nullptr);
+    G::launch_decompose(ws.h2d_scalars.ptr, n, plan, /*d16=*/false, ws.digits.ptr, nullptr, ws.stream);  // the kernel the pipeline runs for this c
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_digits, ws.digits.ptr, (size_t)plan.nwin_total * n * 4, hipMemcpyDeviceToHost, ws.stream));
     HIP_TRY(hipStreamSynchronize(ws.stream));

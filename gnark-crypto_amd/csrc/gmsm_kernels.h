@@ -105,6 +105,54 @@ __global__ void __launch_bounds__(256) k_decompose(const uint32_t *__restrict__ 
     }
 }
 
+// The same with the window width as a template parameter: the loop over the windows unrolls, every limb index and shift
+// is a constant and the scalar stays in registers (the generic kernel indexes its limbs with a run-time value, which the
+// compiler serves from a 12 KB LDS array: 44 us for 2^20 scalars where the traffic needs 15). Instantiated for the widths
+// of the window table (preferred_c); forced or test widths take the generic kernel. Same digits, bit for bit.
+template <class FrP, class D, int C>
+__global__ void __launch_bounds__(256) k_decompose_c(const uint32_t *__restrict__ scalars, size_t n, WindowPlan plan,
+                                                     D *__restrict__ digits, const uint8_t *__restrict__ skip) {
+    constexpr int NR = FrP::N;
+    constexpr uint32_t NW = (FrP::BITS + C - 1) / C;  // computeNbChunks
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp<FrP> s;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(scalars + i * NR);
+        uint4 *dst = reinterpret_cast<uint4 *>(s.l);
+#pragma unroll
+        for (int k = 0; k < NR / 4; ++k) dst[k] = src[k];
+    }
+    const bool zero = s.is_zero() || (skip != nullptr && skip[i] != 0);
+    s = fp_from_mont(s);
+    constexpr uint32_t mask = (1u << C) - 1u;
+    constexpr int max = (1 << (C - 1)) - 1;
+    int carry = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < NW; ++w) {
+        const uint32_t bit = w * C, idx = bit >> 5, sh = bit & 31;
+        const uint64_t lo = s.l[idx];
+        const uint64_t hi = (idx + 1 < (uint32_t)NR) ? s.l[idx + 1 < (uint32_t)NR ? idx + 1 : idx] : 0u;
+        const uint64_t v = ((hi << 32) | lo) >> sh;
+        int digit = carry + (int)((uint32_t)v & mask);
+        uint32_t code;
+        if (w + 1 < NW) {
+            carry = 0;
+            if (digit > max) {
+                digit -= 1 << C;
+                carry = 1;
+            }
+            code = digit == 0 ? 0u : (digit > 0 ? ((uint32_t)digit << 1) : ((((uint32_t)(-digit) - 1u) << 1) | 1u));
+        } else {
+            code = (uint32_t)digit << 1;  // top window: no borrow (multiexp.go:788-800)
+        }
+        if (w >= plan.win_first && (w - plan.win_first) % plan.win_stride == 0) {
+            const uint32_t k = (w - plan.win_first) / plan.win_stride;
+            if (k < plan.nwin_local) digits[(size_t)k * n + i] = (D)(zero ? 0u : code);
+        }
+    }
+}
+
 __device__ __forceinline__ uint32_t code_bucket(uint32_t code) { return (code >> 1) - ((code & 1u) ^ 1u); }
 
 // ------------------------------------------------------------------ two-level grouping (coarse partition, fine sort)

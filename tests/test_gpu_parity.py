@@ -157,7 +157,7 @@ def test_decompose_matches_partition_scalars(gm, oracle_mod, curve, which):
     edge = scalars_from_ints(c_, [0, 1, 2, c_.r - 1, c_.r - 2, (1 << 16) - 1, 1 << 16, 1 << 15, (1 << 15) - 1, (1 << 64) - 1, 1 << 64,
                                   (1 << 128) + 12345, c_.r >> 1])
     sc[: len(edge)] = edge
-    for c in [2, 3, 4, 5, 8, 10, 11, 13, 15, 16]:
+    for c in [2, 3, 4, 5, 8, 9, 10, 11, 12, 13, 14, 15, 16]:  # 8, 9, 10, 12..16: the unrolled kernels of the window table; the rest generic
         nwin = o.nb_chunks(c)
         out = np.zeros((nwin, n), dtype=np.uint32)
         assert L.gmsm_debug_decompose(g.gid, P(sc), n, c, P(out)) == 0, gm._lib.last_error()
