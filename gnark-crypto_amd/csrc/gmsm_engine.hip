@@ -809,15 +809,49 @@ GMSM_EXPORT int gmsm_multiexp_bases_submit(uint64_t handle, const void *d_scalar
 // k MultiExp over the same registered bases, one scalar vector each (kzg.Commit over many polynomials with one SRS,
 // ecc/bn254/kzg/kzg.go:159-176, 246-300): a single blocking call that keeps two of them in flight. With host scalars
 // the copy of vector i+1 runs while vector i is being accumulated.
+static int multiexp_bases_batch_on(const BasesRef &rb, const uint64_t *scalars, const void *d_scalars, size_t n, size_t k,
+                                   void *hip_stream, uint64_t *out_jac);
+
 GMSM_EXPORT int gmsm_multiexp_bases_batch(uint64_t handle, const uint64_t *scalars, const void *d_scalars, size_t n,
                                           size_t k, void *hip_stream, uint64_t *out_jac) {
+    if (handle & SHARDED_TAG) {
+        // Bases registered on several devices: the k vectors are independent MultiExp calls, so they need no sharding of
+        // a single one - rank r (one host thread per logical rank) runs the contiguous block of vectors [r k/G, (r+1) k/G)
+        // on its device's copy of the bases; no exchange at all (the replica mode of sharding.py, inside the library).
+        std::shared_ptr<ShardedBases> sb = lookup_sharded(handle);
+        if (!sb) return fail(GMSM_ERR_ARG, "unknown bases handle");
+        if (n > sb->n) return fail(GMSM_ERR_LEN, "len(points) != len(scalars)");
+        if (k == 0) return GMSM_OK;
+        if (n && !scalars) return fail(GMSM_ERR_ARG, "gmsm_multiexp_bases_batch: a sharded handle takes host scalars");
+        const GroupVTable *vts = vtable(sb->group);
+        const size_t G = std::min<size_t>(sb->devices.size(), k), jl = vts->jac_bytes / 8, sl = vts->scalar_bytes / 8 * n;
+        std::vector<int> rcs(G, GMSM_OK);
+        std::vector<std::string> errs(G);
+        std::vector<std::thread> th;
+        for (size_t r = 0; r < G; ++r)
+            th.emplace_back([&, r] {
+                const size_t lo = r * k / G, hi = (r + 1) * k / G;
+                const BasesRef &rb = sb->replicas.at(sb->devices[r]);
+                rcs[r] = multiexp_bases_batch_on(rb, scalars ? scalars + lo * sl : nullptr, nullptr, n, hi - lo, nullptr, out_jac + lo * jl);
+                if (rcs[r]) errs[r] = gmsm_last_error();
+            });
+        for (auto &t : th) t.join();
+        for (size_t r = 0; r < G; ++r)
+            if (rcs[r]) return fail(rcs[r], "rank " + std::to_string(r) + " (device " + std::to_string(sb->devices[r]) + "): " + errs[r]);
+        return GMSM_OK;
+    }
     BasesRef rb = lookup_bases(handle);
     if (!rb) return fail(GMSM_ERR_ARG, "unknown bases handle");
-    const GroupVTable *vt = vtable(rb->group);
     if (n > rb->n) return fail(GMSM_ERR_LEN, "len(points) != len(scalars)");
     if (k == 0) return GMSM_OK;
     if (n && (scalars == nullptr) == (d_scalars == nullptr))
         return fail(GMSM_ERR_ARG, "gmsm_multiexp_bases_batch: give exactly one of scalars (host) / d_scalars (device)");
+    return multiexp_bases_batch_on(rb, scalars, d_scalars, n, k, hip_stream, out_jac);
+}
+
+static int multiexp_bases_batch_on(const BasesRef &rb, const uint64_t *scalars, const void *d_scalars, size_t n, size_t k,
+                                   void *hip_stream, uint64_t *out_jac) {
+    const GroupVTable *vt = vtable(rb->group);
     Context *ctx;
     int rc = get_context_for(rb->device, &ctx);
     if (rc) return rc;

@@ -106,8 +106,10 @@ int gmsm_multiexp_sharded(int group, const uint64_t *points, size_t n_points, co
 /* Resident bases on several devices: the n bases are uploaded (all devices at once, each over its own link) and
  * rewritten once on every distinct device of the list - full copies, so that any prefix can be cut evenly over the ranks.
  * The handle is accepted by gmsm_multiexp_bases (host scalars; sharded like gmsm_multiexp_sharded, mode auto),
- * gmsm_multiexp_bases_sharded (explicit mode) and gmsm_bases_release; the device-pointer entries take single-device
- * handles only. */
+ * gmsm_multiexp_bases_sharded (explicit mode), gmsm_multiexp_bases_batch (host scalars: the k vectors are independent
+ * MultiExp calls, rank r runs the block [r k/G, (r+1) k/G) of them on its device's copy - no sharding of a single call and
+ * no exchange; kzg.Commit per polynomial, ecc/bn254/kzg/kzg.go:159-176) and gmsm_bases_release; the device-pointer
+ * entries take single-device handles only. */
 int gmsm_bases_register_sharded(int group, const uint64_t *points, size_t n, const int *devices, int n_devices,
                                 uint64_t *out_handle);
 int gmsm_multiexp_bases_sharded(uint64_t handle, const uint64_t *scalars, size_t n_scalars, int nb_tasks, int mode,

@@ -95,6 +95,15 @@ def test_sharded_registered_bases(gm, oracle_mod, curve, which):
         assert err == "len(points) != len(scalars)"
         _, err = rb.MultiExp(sc, gm.MultiExpConfig(NbTasks=2000))
         assert err == "invalid config: config.NbTasks > 1024"
+        # k independent MultiExp over the sharded bases: block r of the vectors on rank r, no exchange (replica mode)
+        m = 5000
+        vecs = np.stack([random_scalars(rng_for(33, j), g.curve, m) for j in range(5)])
+        jacs, err = rb.MultiExpBatch(scalars=vecs)
+        assert err is None, err
+        for j in range(5):
+            assert (g.jac_to_affine(jacs[j]) == o.msm_affine(pts[:m], vecs[j], nthreads=8)).all(), j
+        jacs, err = rb.MultiExpBatch(scalars=vecs[:2])  # fewer vectors than ranks
+        assert err is None and (g.jac_to_affine(jacs[1]) == o.msm_affine(pts[:m], vecs[1], nthreads=8)).all()
     finally:
         rb.release()
 
