@@ -145,6 +145,65 @@ def median_ms(fn, reps=5):
     return sorted(ts)[len(ts) // 2]
 
 
+def tables_record(gm, g, d_pts, d_sc, sc, n, stream, jac, steps):
+    """MultiExp over registered bases with window tables: ms with the scalars resident / in host memory / two tickets in
+    flight, against the same handle without tables (GMSM_TABLES=0), result compared with the headline call's."""
+    import torch
+    rb = g.register_bases(d_points=d_pts.data_ptr(), n=n)
+    try:
+        t0 = time.perf_counter()
+        c = rb.precompute(0)
+        build_ms = (time.perf_counter() - t0) * 1e3
+        cfg = gm.MultiExpConfig()
+
+        def resident_ms():
+            rb.multiexp_device(d_sc.data_ptr(), n, stream)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                out = rb.multiexp_device(d_sc.data_ptr(), n, stream)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps * 1e3, out
+
+        def in_flight_ms():
+            def run(k):
+                prev = None
+                for _ in range(k):
+                    t = rb.submit(d_sc.data_ptr(), n)
+                    if prev is not None:
+                        rb.collect(prev)
+                    prev = t
+                return rb.collect(prev)
+            run(3)
+            t0 = time.perf_counter()
+            out = run(steps)
+            return (time.perf_counter() - t0) / steps * 1e3, out
+
+        runs0 = int(gm._lib.load().gmsm_debug_table_runs())
+        dev_ms, j1 = resident_ms()
+        used = int(gm._lib.load().gmsm_debug_table_runs()) > runs0
+        host_ms = median_ms(lambda: rb.MultiExp(sc, cfg))
+        fl_ms, j2 = in_flight_ms()
+        os.environ["GMSM_TABLES"] = "0"
+        try:
+            plain_ms, _ = resident_ms()
+            plain_host_ms = median_ms(lambda: rb.MultiExp(sc, cfg))
+        finally:
+            del os.environ["GMSM_TABLES"]
+        ref = g.jac_to_affine(jac)
+        return {"window_bits": c, "slabs": g.num_windows(c), "table_bytes": g.num_windows(c) * n * g.aff_limbs * 8,
+                "build_ms": round(build_ms, 1), "through_tables": used,
+                "device_scalars_ms": round(dev_ms, 4), "device_scalars_msm_per_s": round(1e3 / dev_ms, 2),
+                "host_scalars_ms": round(host_ms, 3), "host_scalars_msm_per_s": round(1e3 / host_ms, 2),
+                "two_in_flight_ms": round(fl_ms, 4), "two_in_flight_msm_per_s": round(1e3 / fl_ms, 2),
+                "same_handle_without_tables": {"device_scalars_ms": round(plain_ms, 4), "host_scalars_ms": round(plain_host_ms, 3)},
+                "equal_to_headline_result": bool((g.jac_to_affine(j1) == ref).all() and (g.jac_to_affine(j2) == ref).all()),
+                "note": "registered bases + gmsm_bases_precompute: 2^(c w) P_i for every window in HBM, all windows share one "
+                        "bucket set and one reduction; the reference has no counterpart (it takes the bases anew per call)"}
+    finally:
+        rb.release()
+
+
 def also_config(gm, lib, torch, curve, group, logn, steps, host_legs, with_cpu=True):
     """One of the other BASELINE.json configurations on this GPU: bases [a_i]G built ON the device (fixed-base batch,
     gmsm_batch_scalar_mul_device), uniform scalars b_i, K timed MultiExp calls over resident inputs, and the closed form
@@ -577,6 +636,13 @@ def main():
                       "note": "cold: bases+scalars copied from pageable host memory every call (gmsm_<curve>_g1_multiexp); "
                               "warm-bases: registered bases, scalars copied every call (gmsm_multiexp_bases); median of 5"}
 
+    # The same MultiExp over registered bases WITH window tables (gmsm_bases_precompute: 2^(c w) P_i in HBM, one bucket
+    # set): the resident-SRS path of kzg.Commit. Reported beside `value`, never instead of it - `value` is the entry that
+    # takes the bases anew on every call, like the reference's MultiExp.
+    tables = None
+    if not sharded and rank == 0 and not args.no_host_entry:
+        tables = tables_record(gm, g, d_pts, d_sc, sc, n, stream, jac, args.steps)
+
     # The same MultiExp through the drop-in C entry with the library spreading it over the devices (one process): all
     # `world` devices driven by rank 0 while the other ranks wait on the host; on one GPU two logical ranks on device 0
     # (a functional check of the path, not a speed-up: both ranks share one device and one PCIe link).
@@ -616,6 +682,8 @@ def main():
             "stage_ms": stages,
             "pipelined": pipelined,
             "host_entry": host_entry,
+            "value_tables": tables["device_scalars_msm_per_s"] if tables else None,
+            "tables": tables,
             "c_abi_sharded": c_abi,
             "replica_batch": replica,
             "roofline": roofline_record(g, n, my_pairs / (n * nwin), stages, acc_launches,

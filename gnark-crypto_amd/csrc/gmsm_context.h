@@ -2,6 +2,7 @@
 // translation units.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include <algorithm>
 #include <cstdio>
@@ -42,7 +43,14 @@ struct DeviceBuffer {
         cap = want;
         return GMSM_OK;
     }
+    void release() {  // caller has made sure nothing on the device still uses the buffer
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
 };
+
+extern std::atomic<unsigned long> g_table_runs;  // pipeline runs that went through window tables (gmsm_debug_table_runs)
 
 // Bases rewritten once into the lazy Montgomery domain and kept in HBM (gmsm_bases_register): the resident-SRS path.
 // Shared ownership (std::shared_ptr): the handle table holds one reference, every call and every outstanding ticket
@@ -53,17 +61,22 @@ struct ResidentBases {
     int device = -1;
     size_t n = 0;
     DeviceBuffer upoints, skip;
+    // window tables (gmsm_bases_precompute; Group::precompute_tables): slab w = 2^(tab_c w) P_i, same packed layout as
+    // upoints, tab_nw slabs of n points; tab_c == 0: none
+    unsigned tab_c = 0, tab_nw = 0;
+    DeviceBuffer tables;
     ResidentBases() = default;
     ResidentBases(const ResidentBases &) = delete;
     ResidentBases &operator=(const ResidentBases &) = delete;
     ~ResidentBases() {
-        if (!upoints.ptr && !skip.ptr) return;
+        if (!upoints.ptr && !skip.ptr && !tables.ptr) return;
         int prev = 0;
         (void)hipGetDevice(&prev);
         if (device >= 0) (void)hipSetDevice(device);
         (void)hipDeviceSynchronize();  // an enqueue-only call may still be reading the bases
         if (upoints.ptr) (void)hipFree(upoints.ptr);
         if (skip.ptr) (void)hipFree(skip.ptr);
+        if (tables.ptr) (void)hipFree(tables.ptr);
         (void)hipSetDevice(prev);
     }
 };
@@ -453,6 +466,8 @@ struct GroupVTable {
     int (*fft_run)(hipStream_t stream, FftDomain *d, void *d_a, bool inverse, bool dif, bool coset);
     int (*fft_bit_reverse)(hipStream_t stream, void *d_a, size_t n);
     // one rank's piece of a MultiExp that the library shards over several devices (Group::shard_piece)
+    int (*precompute_tables)(Context &ctx, Workspace &ws, ResidentBases *rb, unsigned c);  // window tables of registered bases
+    bool (*tables_serve)(size_t n_registered, size_t n_call);  // call sizes that run through the tables (Group::use_tables)
     int (*shard_piece)(Context &ctx, const uint64_t *points, const ResidentBases *resident, size_t resident_base,
                        const uint64_t *scalars, size_t n, unsigned c, unsigned win_first, unsigned win_stride,
                        uint64_t *out_xyzz);

@@ -22,6 +22,7 @@ static std::string g_any_error;
 // Entries that receive device pointers use the device that owns the pointer instead.
 static thread_local int g_device = -1;
 static std::atomic<int> g_default_device{0};
+std::atomic<unsigned long> g_table_runs{0};
 
 int fail(int code, const std::string &msg) {
     g_last_error = msg;
@@ -223,6 +224,15 @@ static int multiexp_sharded_run(int group, const uint64_t *points, const std::ma
         G = std::max<size_t>(1, std::min(G, n / SHARD_MIN_SLICE));
         const size_t slice = (n + G - 1) / G;  // the largest slice decides c: the ranks' totals must line up
         c = choose_c(vt->fr_bits, vt->aff_bytes, slice);
+        if (replicas && !replicas->empty()) {  // window tables on the replicas (gmsm_bases_precompute): their width
+            const ResidentBases *rb0 = replicas->begin()->second.get();
+            const unsigned forced = env_uint("GMSM_C", 0);
+            bool all = rb0->tab_c != 0;
+            for (const auto &kv : *replicas) all = all && kv.second->tab_c == rb0->tab_c;
+            if (all && !(forced >= 2 && forced <= 20 && forced != rb0->tab_c) && env_uint("GMSM_TABLES", 1) != 0 &&
+                vt->tables_serve(rb0->n, n / G) && vt->tables_serve(rb0->n, slice))
+                c = rb0->tab_c;
+        }
         nwin = num_windows(vt->fr_bits, c);
     } else {
         c = choose_c(vt->fr_bits, vt->aff_bytes, n);
@@ -691,6 +701,68 @@ GMSM_EXPORT int gmsm_bases_register_sharded(int group, const uint64_t *points, s
     g_sharded.push_back(sb);
     *out_handle = SHARDED_TAG | (uint64_t)g_sharded.size();
     return GMSM_OK;
+}
+
+// Window tables of registered bases: slab w = 2^(c w) P_i for every window of the c-bit decomposition, nwin copies of
+// the bases in HBM; MultiExp calls over the handle then fill ONE bucket set (Group::precompute_tables). c = 0: the
+// library's width for this many bases.
+static int precompute_on(const BasesRef &rb, unsigned c) {
+    const GroupVTable *vt = vtable(rb->group);
+    if (rb->tab_c != 0) {
+        if (c == 0 || c == rb->tab_c) return GMSM_OK;
+        return fail(GMSM_ERR_ARG, "gmsm_bases_precompute: the handle already has tables of another width");
+    }
+    Context *ctx;
+    int rc = get_context_for(rb->device, &ctx);
+    if (rc) return rc;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    HIP_TRY(hipSetDevice(ctx->device));
+    {
+        GMSM_LEASE_OR_FAIL(lease, *ctx);
+        rc = vt->precompute_tables(*ctx, *lease.w, rb.get(), c);
+    }
+    (void)hipSetDevice(prev);
+    return rc;
+}
+
+GMSM_EXPORT int gmsm_bases_precompute(uint64_t handle, unsigned c) {
+    if (handle & SHARDED_TAG) {
+        std::shared_ptr<ShardedBases> sb = lookup_sharded(handle);
+        if (!sb) return fail(GMSM_ERR_ARG, "unknown bases handle");
+        std::vector<std::thread> th;
+        std::vector<int> rcs(sb->replicas.size(), GMSM_OK);
+        std::vector<std::string> errs(sb->replicas.size());
+        size_t i = 0;
+        for (auto &kv : sb->replicas) {
+            BasesRef rb = kv.second;
+            th.emplace_back([&, rb, i] {
+                rcs[i] = precompute_on(rb, c);
+                if (rcs[i]) errs[i] = gmsm_last_error();
+            });
+            ++i;
+        }
+        for (auto &t : th) t.join();
+        for (size_t k = 0; k < rcs.size(); ++k)
+            if (rcs[k]) return fail(rcs[k], errs[k]);
+        return GMSM_OK;
+    }
+    BasesRef rb = lookup_bases(handle);
+    if (!rb) return fail(GMSM_ERR_ARG, "unknown bases handle");
+    return precompute_on(rb, c);
+}
+
+GMSM_EXPORT unsigned long gmsm_debug_table_runs(void) { return g_table_runs.load(); }
+
+// 0 = no tables; else the window width of the handle's tables
+GMSM_EXPORT unsigned gmsm_bases_table_bits(uint64_t handle) {
+    if (handle & SHARDED_TAG) {
+        std::shared_ptr<ShardedBases> sb = lookup_sharded(handle);
+        if (!sb || sb->replicas.empty()) return 0;
+        return sb->replicas.begin()->second->tab_c;
+    }
+    BasesRef rb = lookup_bases(handle);
+    return rb ? rb->tab_c : 0;
 }
 
 GMSM_EXPORT int gmsm_bases_release(uint64_t handle) {

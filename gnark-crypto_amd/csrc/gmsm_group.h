@@ -78,6 +78,7 @@ struct Group {
         p.win_first = win_first;
         p.win_stride = win_stride ? win_stride : 1;
         p.nwin_local = win_first < p.nwin_total ? (p.nwin_total - win_first + p.win_stride - 1) / p.win_stride : 0;
+        p.shared = 0;
         return p;
     }
 
@@ -125,39 +126,59 @@ struct Group {
     // Accumulation and reduction geometry of one pipeline run over nw windows of n points.
     struct Geometry {
         uint32_t seg, tpw;                     // accumulation: entries per thread, threads per window
-        uint32_t log2L, nblocks1, log2span;    // reduction
+        uint32_t log2L, nblocks1, log2span;    // reduction: buckets per serial thread, level-1 workgroups per window
+        uint32_t nblocks2;                     // 0: serial - combine - level 2; else a second combine of nblocks2 workgroups
     };
 
     static Geometry plan_geometry(const Context &ctx, uint32_t nw, size_t n, uint32_t NB) {
         Geometry q;
-        // reduction: buckets per level-1 thread, L = 2^log2L, and the number of level-1 workgroups per window (at most
-        // RED2_TPB of them: one quad of level 2 each).
-        constexpr size_t SPAN1 = COMBINE_N;  // threads' results one level-1 workgroup combines
+        // reduction: buckets per serial thread, L = 2^log2L; COMBINE_N of their (S, W) pairs per combine workgroup; the
+        // last level (k_reduce2_q) takes at most RED2_TPB blocks per window, one quad each. Few windows of many buckets
+        // (one rank's share of a window-sharded call, the single bucket set of the window tables) would need a long
+        // serial walk to get there: a second combine level in between keeps L short.
+        constexpr size_t SPAN1 = COMBINE_N;  // pairs one combine workgroup takes
         const auto blocks1 = [&](uint32_t l2) { return ((size_t)NB + (SPAN1 << l2) - 1) / (SPAN1 << l2); };
+        const auto blocks2 = [&](uint32_t l2) { return (blocks1(l2) + SPAN1 - 1) / SPAN1; };
         uint32_t log2L = tune_uint("GMSM_LOG2L", 0);
+        const uint32_t force_levels = tune_uint("GMSM_REDUCE_LEVELS", 0);  // 2 / 3; 0 = cost model
+        bool three = force_levels == 3;
         if (log2L == 0) {
             // serial kernel: 2L dependent one-lane additions on every SIMD, as many rounds as the threads need;
             // combine: 2 log2 N + log2 L + 1 quad steps (a quad step is about a third of a one-lane addition) per
             // round of workgroups, one per CU. Minimise the total in units of one-lane additions.
             size_t best = ~(size_t)0;
             for (uint32_t l2 = 1; l2 <= 8; ++l2) {
-                if (blocks1(l2) > (size_t)RED2_TPB) continue;
                 const size_t serial_threads = (size_t)nw * (((size_t)NB + ((size_t)1 << l2) - 1) >> l2);
                 // lanes of the serial kernel: one per thread, or a quad per thread at a third of the step time
                 const size_t serial_lanes = SERIAL_QUAD ? 4 * serial_threads : serial_threads;
                 const size_t serial_rounds = (serial_lanes + (size_t)ctx.num_cus * 256 - 1) / ((size_t)ctx.num_cus * 256);
                 const size_t rounds = ((size_t)nw * blocks1(l2) + ctx.num_cus - 1) / ctx.num_cus;
-                const size_t cost3 = (SERIAL_QUAD ? 1 : 3) * serial_rounds * ((size_t)2 << l2) + rounds * (2 * 6 + l2 + 1);
-                if (cost3 < best) {
-                    best = cost3;
+                const size_t cost_serial = (SERIAL_QUAD ? 1 : 3) * serial_rounds * ((size_t)2 << l2);
+                const size_t cost2 = cost_serial + rounds * (2 * 6 + l2 + 1);
+                if (blocks1(l2) <= (size_t)RED2_TPB && force_levels != 3 && cost2 < best) {
+                    best = cost2;
                     log2L = l2;
+                    three = false;
+                }
+                // second combine: its own rounds of 2 * 6 + 1 steps + the tail of the prescaling, and one more launch
+                const size_t rounds_b = ((size_t)nw * blocks2(l2) + ctx.num_cus - 1) / ctx.num_cus;
+                const size_t cost3 = cost2 + rounds_b * (2 * 6 + 8) + 4;
+                if (blocks1(l2) > 1 && blocks2(l2) <= (size_t)RED2_TPB && force_levels != 2 && cost3 + cost3 / 8 < best) {
+                    best = cost3 + cost3 / 8;  // a margin: the two-level form is the measured one
+                    log2L = l2;
+                    three = true;
                 }
             }
             if (log2L == 0) log2L = 8;
         }
-        while (blocks1(log2L) > (size_t)RED2_TPB) ++log2L;
+        if (three) {
+            while (blocks2(log2L) > (size_t)RED2_TPB) ++log2L;
+        } else {
+            while (blocks1(log2L) > (size_t)RED2_TPB) ++log2L;
+        }
         q.log2L = log2L;
         q.nblocks1 = (uint32_t)blocks1(log2L);
+        q.nblocks2 = three ? (uint32_t)blocks2(log2L) : 0u;
         q.log2span = log2L;
         for (size_t t = SPAN1; t > 1; t >>= 1) ++q.log2span;
         // entry-parallel segmented accumulation: seg entries per thread. Every thread does the same work, so the
@@ -208,7 +229,8 @@ struct Group {
         return;
         switch (plan.c) {
             GMSM_DECOMPOSE_C(8) GMSM_DECOMPOSE_C(9) GMSM_DECOMPOSE_C(10) GMSM_DECOMPOSE_C(12) GMSM_DECOMPOSE_C(13)
-            GMSM_DECOMPOSE_C(14) GMSM_DECOMPOSE_C(15) GMSM_DECOMPOSE_C(16) GMSM_DECOMPOSE_C(17)
+            GMSM_DECOMPOSE_C(14) GMSM_DECOMPOSE_C(15) GMSM_DECOMPOSE_C(16) GMSM_DECOMPOSE_C(17) GMSM_DECOMPOSE_C(18)
+            GMSM_DECOMPOSE_C(20)
             default: break;
         }
 #undef GMSM_DECOMPOSE_C
@@ -232,9 +254,14 @@ struct Group {
                                    const WindowPlan &plan, hipStream_t stream, const ResidentBases *resident,
                                    void *d_out = nullptr, size_t resident_offset = 0 /* first registered base used */,
                                    bool buckets_only = false) {
-        const uint32_t nw = plan.nwin_local;
+        const uint32_t nwd = plan.nwin_local;  // windows of the digit decomposition = totals handed out
         ws.pending_timed = false;
-        if (nw == 0) return GMSM_OK;
+        if (nwd == 0) return GMSM_OK;
+        // window tables: the (window, point) pairs of all windows form ONE set of entries over one bucket set
+        const bool shared = plan.shared != 0;
+        if (shared && !(resident && resident->tab_c == plan.c && plan.win_first == 0 && plan.win_stride == 1))
+            return fail(GMSM_ERR_ARG, "shared-bucket plan without matching window tables");
+        if (shared && n) g_table_runs.fetch_add(1, std::memory_order_relaxed);
         if (ws.uncollected) {  // stage events of an enqueue-only call (nobody waited for it): pick them up now
             if (ws.timed && hipEventQuery(ws.events[T_END]) == hipSuccess) StageTimer::collect(ws);
             ws.uncollected = false;
@@ -243,16 +270,19 @@ struct Group {
         int rc;
         if ((rc = begin_use(ws, stream))) return rc;
         if (n == 0) {
-            int rc0 = ws.ensure_pinned((size_t)nw * sizeof(Ext));
+            int rc0 = ws.ensure_pinned((size_t)nwd * sizeof(Ext));
             if (rc0) return rc0;
             if (d_out) HIP_TRY(hipStreamSynchronize(stream));  // an earlier copy out of ws.pinned may be in flight
-            for (uint32_t k = 0; k < nw; ++k) ((Ext *)ws.pinned)[k] = Ext::infinity();
+            for (uint32_t k = 0; k < nwd; ++k) ((Ext *)ws.pinned)[k] = Ext::infinity();
             if (d_out) {
-                HIP_TRY(hipMemcpyAsync(d_out, ws.pinned, (size_t)nw * sizeof(Ext), hipMemcpyHostToDevice, stream));
+                HIP_TRY(hipMemcpyAsync(d_out, ws.pinned, (size_t)nwd * sizeof(Ext), hipMemcpyHostToDevice, stream));
                 HIP_TRY(hipStreamSynchronize(stream));
             }
             return GMSM_OK;
         }
+        const size_t n_points = n;  // scalars / bases of this run
+        const uint32_t nw = shared ? 1u : nwd;  // bucket sets: what the sort, the accumulation and the reduction see as windows
+        if (shared) n *= nwd;                   // ... and their entries
         if (n >= ((size_t)1 << 31)) return fail(GMSM_ERR_ARG, "n must be < 2^31");
         const uint32_t NB = plan.nbuckets;
         constexpr size_t REC = sizeof(typename OpsSerial::Mem);  // bucket / partial record (lazy representation on the fast path)
@@ -277,7 +307,7 @@ struct Group {
         if (fb + lidx > 32) fb = 32 - lidx;
         const uint32_t fbits = (uint32_t)fb;
         const uint32_t nparts = NB >> fbits;
-        const bool big_chunk = n > ((size_t)1 << 25);
+        const bool big_chunk = n > ((size_t)1 << 25) && (size_t)nparts * 8 + PART_CHUNK_BIG * 6 <= 152 * 1024;
         const size_t pchunk_len = big_chunk ? PART_CHUNK_BIG : PART_CHUNK;  // chunk = one LDS staging buffer
         const uint32_t pchunks = (uint32_t)((n + pchunk_len - 1) / pchunk_len);
         const size_t scatter_lds = (size_t)nparts * 8 + pchunk_len * 6;
@@ -302,11 +332,11 @@ struct Group {
         if ((rc = ws.parted.ensure((size_t)nw * n * 4))) return rc;
         if ((rc = ws.starts.ensure((size_t)nw * (NB + 1) * 4))) return rc;
         if ((rc = ws.buckets.ensure((size_t)nw * NB * REC))) return rc;
-        if ((rc = ws.partials.ensure(tot_blk * 2 * REC))) return rc;
+        if ((rc = ws.partials.ensure((tot_blk + (size_t)nw * q.nblocks2) * 2 * REC))) return rc;
         const uint32_t T = (uint32_t)(((size_t)NB + ((size_t)1 << q.log2L) - 1) >> q.log2L);  // (S, W) pairs per window of k_reduce_serial
         if ((rc = ws.red_pre.ensure((size_t)nw * T * 2 * REC))) return rc;
-        if ((rc = ws.totals.ensure((size_t)nw * sizeof(Ext)))) return rc;
-        if ((rc = ws.ensure_pinned((size_t)nw * sizeof(Ext)))) return rc;
+        if ((rc = ws.totals.ensure((size_t)nwd * sizeof(Ext)))) return rc;
+        if ((rc = ws.ensure_pinned((size_t)nwd * sizeof(Ext)))) return rc;
         if ((rc = ws.blockhist.ensure((size_t)nw * pchunks * nparts * 4))) return rc;
         if ((rc = ws.counts.ensure((size_t)nw * (2 * nparts + 1) * 4))) return rc;
         if ((rc = ws.seg_partials.ensure(tot_thr * 2 * REC))) return rc;
@@ -344,19 +374,20 @@ struct Group {
         const uint8_t *skip = nullptr;
         const void *upoints = nullptr;
         if (resident) {
-            upoints = (const char *)resident->upoints.ptr + resident_offset * AFF_BYTES;
+            upoints = (const char *)(shared ? resident->tables.ptr : resident->upoints.ptr) + resident_offset * AFF_BYTES;
             skip = (const uint8_t *)resident->skip.ptr + resident_offset;
         } else {
-            if ((rc = ws.upoints.ensure(n * AFF_BYTES))) return rc;
-            if ((rc = ws.skip.ensure(n))) return rc;
-            hipLaunchKernelGGL((k_convert_points<U>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                               stream, d_points, n, ws.upoints.ptr, (uint8_t *)ws.skip.ptr);
+            if ((rc = ws.upoints.ensure(n_points * AFF_BYTES))) return rc;
+            if ((rc = ws.skip.ensure(n_points))) return rc;
+            hipLaunchKernelGGL((k_convert_points<U>), dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0,
+                               stream, d_points, n_points, ws.upoints.ptr, (uint8_t *)ws.skip.ptr);
             upoints = ws.upoints.ptr;
             skip = (const uint8_t *)ws.skip.ptr;
         }
         // (A decomposition fused with the coarse histogram was measured and dropped: one workgroup per 16 K-scalar chunk
         // leaves 3/4 of the CUs idle at 2^20, and at 2^24 it only breaks even.)
-        launch_decompose(d_scalars, n, plan, d16, ws.digits.ptr, skip, stream);
+        // (shared: digits[w][i] of the n_points scalars, read from here on as one window of nwd * n_points entries)
+        launch_decompose(d_scalars, n_points, plan, d16, ws.digits.ptr, skip, stream);
 
         const void *digits = ws.digits.ptr;
         uint32_t *sorted = (uint32_t *)ws.sorted.ptr, *parted = (uint32_t *)ws.parted.ptr, *starts = (uint32_t *)ws.starts.ptr;
@@ -372,7 +403,10 @@ struct Group {
             hipLaunchKernelGGL(k_part_hist<uint32_t>, dim3(pchunks, nw), dim3(1024), (size_t)nparts * 4, stream,
                                (const uint32_t *)digits, n, nparts, fbits, pchunk_len, bh);
         timer.mark(T_SCAN, stream);
-        hipLaunchKernelGGL(k_part_colscan, dim3((nparts + 31) / 32, nw), dim3(256), 0, stream, bh, pchunks, nparts, part_pop);
+        if ((size_t)((nparts + 31) / 32) * nw < (size_t)ctx.num_cus && pchunks >= 256)
+            hipLaunchKernelGGL(k_part_colscan<32>, dim3((nparts + 31) / 32, nw), dim3(1024), 0, stream, bh, pchunks, nparts, part_pop);
+        else
+            hipLaunchKernelGGL(k_part_colscan<8>, dim3((nparts + 31) / 32, nw), dim3(256), 0, stream, bh, pchunks, nparts, part_pop);
         hipLaunchKernelGGL(k_part_rowscan, dim3(nw), dim3(1024), 0, stream, part_pop, nparts, part_base, long_flag);
         timer.mark(T_SCATTER, stream);
         {
@@ -390,8 +424,13 @@ struct Group {
                            parted, n, NB, fbits, lidx, part_base, sorted, starts, stage_cap);
         // ---- 2. bucket accumulation
         timer.mark(T_ACCUMULATE, stream);
-        hipLaunchKernelGGL((k_accumulate_seg<U>), dim3((q.tpw + 255) / 256, nw), dim3(256), 0, stream, upoints, n, NB, q.seg,
-                           starts, sorted, buckets, seg_partials, seg_flags, seg_bucket, q.tpw);
+        if (shared)
+            hipLaunchKernelGGL((k_accumulate_seg<U, true>), dim3((q.tpw + 255) / 256, nw), dim3(256), 0, stream, upoints, n, NB,
+                               q.seg, starts, sorted, buckets, seg_partials, seg_flags, seg_bucket, q.tpw, (uint32_t)n_points,
+                               (uint32_t)resident->n);
+        else
+            hipLaunchKernelGGL((k_accumulate_seg<U, false>), dim3((q.tpw + 255) / 256, nw), dim3(256), 0, stream, upoints, n, NB,
+                               q.seg, starts, sorted, buckets, seg_partials, seg_flags, seg_bucket, q.tpw, 0u, 0u);
         timer.mark(T_FIXUP, stream);
         hipLaunchKernelGGL((k_fixup_seg<OpsSerial>), dim3((q.tpw + 255) / 256, nw), dim3(256), 0, stream, NB, seg_partials,
                            (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets, long_flag, long_list, FIX_MAXWALK);
@@ -400,14 +439,18 @@ struct Group {
                            (const uint32_t *)long_flag, (const LongChain *)long_list);
         // ---- 3. bucket reduction -> window totals (empty buckets are never written: the reduction consults starts[])
         timer.mark(T_REDUCE, stream);
-        if (!buckets_only) enqueue_reduce_kernels(ctx, ws, q, T, buckets, starts, nw, NB, stream);
+        if (!buckets_only) {
+            enqueue_reduce_kernels(ctx, ws, q, T, buckets, starts, nw, NB, stream);
+            if (nwd > nw)
+                hipLaunchKernelGGL((k_fill_infinity<Ext>), dim3((nwd - nw + 63) / 64), dim3(64), 0, stream, ws.totals.ptr, nw, nwd - nw);
+        }
         timer.mark(T_END, stream);
         HIP_TRY(hipGetLastError());
         if (!buckets_only) {
             if (d_out)
-                HIP_TRY(hipMemcpyAsync(d_out, ws.totals.ptr, (size_t)nw * sizeof(Ext), hipMemcpyDeviceToDevice, stream));
+                HIP_TRY(hipMemcpyAsync(d_out, ws.totals.ptr, (size_t)nwd * sizeof(Ext), hipMemcpyDeviceToDevice, stream));
             else
-                HIP_TRY(hipMemcpyAsync(ws.pinned, ws.totals.ptr, (size_t)nw * sizeof(Ext), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipMemcpyAsync(ws.pinned, ws.totals.ptr, (size_t)nwd * sizeof(Ext), hipMemcpyDeviceToHost, stream));
         }
         if ((rc = end_use(ws, stream))) return rc;
         ws.pending_timed = timer.on;
@@ -427,38 +470,53 @@ struct Group {
         else
             hipLaunchKernelGGL((k_reduce_serial<OpsSerial>), dim3((T + 255) / 256, nw), dim3(256), 0, stream, buckets, NB,
                                q.log2L, T, starts, ws.red_pre.ptr);
-        bool we = false;
-        if constexpr (COMBINE_WE) {
-            if (use_combine_we(ctx, q.nblocks1 * nw)) {
-                hipLaunchKernelGGL((k_combine_we<U, true>), dim3(q.nblocks1, nw), dim3(4 * COMBINE_N),
-                                   (2 * COMBINE_N + 1) * sizeof(QRec<U>), stream, q.log2L, ws.partials.ptr, prescale,
-                                   (const void *)ws.red_pre.ptr, T);
-                we = true;
+        // one combine level: `pairs` (S, W) pairs per window, each the sum of 2^l2 buckets (S prescaled by the caller's
+        // factor when l2 == 0) -> `blocks` pairs per window
+        const auto combine = [&](const void *in, uint32_t pairs, void *out, uint32_t blocks, uint32_t l2, uint32_t pre) {
+            if constexpr (COMBINE_WE) {
+                if (use_combine_we(ctx, blocks * nw)) {
+                    hipLaunchKernelGGL((k_combine_we<U, true>), dim3(blocks, nw), dim3(4 * COMBINE_N),
+                                       (2 * COMBINE_N + 1) * sizeof(QRec<U>), stream, l2, out, pre, in, pairs);
+                    return;
+                }
             }
+            hipLaunchKernelGGL((k_combine_q<U, true, COMBINE_N>), dim3(blocks, nw), dim3(4 * COMBINE_N),
+                               (2 * COMBINE_N + 1) * sizeof(QRec<U>), stream, l2, out, pre, in, pairs);
+        };
+        combine(ws.red_pre.ptr, T, ws.partials.ptr, q.nblocks1, q.log2L, prescale);
+        const void *last = ws.partials.ptr;
+        uint32_t nlast = q.nblocks1, rest = q.log2span - prescale;
+        if (q.nblocks2) {
+            // second combine: its input pairs carry S already multiplied by their own span (the prescale above), so the
+            // pairs count as single buckets (L = 1); its S_blk is doubled log2 N more times for the last level
+            constexpr size_t REC = sizeof(typename OpsSerial::Mem);
+            void *out2 = (char *)ws.partials.ptr + (size_t)nw * q.nblocks1 * 2 * REC;
+            uint32_t lgN = 0;
+            for (size_t t = COMBINE_N; t > 1; t >>= 1) ++lgN;
+            combine(ws.partials.ptr, q.nblocks1, out2, q.nblocks2, 0, lgN);
+            last = out2;
+            nlast = q.nblocks2;
+            rest = 0;
         }
-        if (!we)
-            hipLaunchKernelGGL((k_combine_q<U, true, COMBINE_N>), dim3(q.nblocks1, nw), dim3(4 * COMBINE_N),
-                               (2 * COMBINE_N + 1) * sizeof(QRec<U>), stream, q.log2L, ws.partials.ptr, prescale,
-                               (const void *)ws.red_pre.ptr, T);
         uint32_t active = 2;
-        while (active < q.nblocks1) active <<= 1;
-        hipLaunchKernelGGL((k_reduce2_q<U, true>), dim3(nw), dim3(4 * active), 2 * active * sizeof(QRec<U>), stream,
-                           ws.partials.ptr, q.nblocks1, q.log2span - prescale, active, ws.totals.ptr);
+        while (active < nlast) active <<= 1;
+        hipLaunchKernelGGL((k_reduce2_q<U, true>), dim3(nw), dim3(4 * active), 2 * active * sizeof(QRec<U>), stream, last, nlast,
+                           rest, active, ws.totals.ptr);
         (void)ctx;
     }
 
     // The reduction alone, over bucket sums that a multi-range call has merged (every record stored): totals -> ws.pinned.
     static int enqueue_reduce(Context &ctx, Workspace &ws, const void *buckets, const WindowPlan &plan, size_t n_for_geometry,
                               hipStream_t stream) {
-        const uint32_t nw = plan.nwin_local, NB = plan.nbuckets;
+        const uint32_t nw = bucket_sets(plan), nwd = plan.nwin_local, NB = plan.nbuckets;
         constexpr size_t REC = sizeof(typename OpsSerial::Mem);
         const Geometry q = plan_geometry(ctx, nw, n_for_geometry, NB);
         const uint32_t T = (uint32_t)(((size_t)NB + ((size_t)1 << q.log2L) - 1) >> q.log2L);
         int rc;
-        if ((rc = ws.partials.ensure((size_t)nw * q.nblocks1 * 2 * REC))) return rc;
+        if ((rc = ws.partials.ensure((size_t)nw * (q.nblocks1 + q.nblocks2) * 2 * REC))) return rc;
         if ((rc = ws.red_pre.ensure((size_t)nw * T * 2 * REC))) return rc;
-        if ((rc = ws.totals.ensure((size_t)nw * sizeof(Ext)))) return rc;
-        if ((rc = ws.ensure_pinned((size_t)nw * sizeof(Ext)))) return rc;
+        if ((rc = ws.totals.ensure((size_t)nwd * sizeof(Ext)))) return rc;
+        if ((rc = ws.ensure_pinned((size_t)nwd * sizeof(Ext)))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_combine_q<U, true, COMBINE_N>, (int)((2 * COMBINE_N + 1) * sizeof(QRec<U>))))) return rc;
         if constexpr (COMBINE_WE)
             if ((rc = ctx.allow_lds((const void *)k_combine_we<U, true>, (int)((2 * COMBINE_N + 1) * sizeof(QRec<U>))))) return rc;
@@ -466,8 +524,10 @@ struct Group {
             if ((rc = ctx.allow_lds((const void *)k_reduce_serial_q<U>, (int)(192 * sizeof(QRec<U>))))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_reduce2_q<U, true>, (int)(2 * RED2_TPB * sizeof(QRec<U>))))) return rc;
         enqueue_reduce_kernels(ctx, ws, q, T, buckets, nullptr, nw, NB, stream);
+        if (nwd > nw)
+            hipLaunchKernelGGL((k_fill_infinity<Ext>), dim3((nwd - nw + 63) / 64), dim3(64), 0, stream, ws.totals.ptr, nw, nwd - nw);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(ws.pinned, ws.totals.ptr, (size_t)nw * sizeof(Ext), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(ws.pinned, ws.totals.ptr, (size_t)nwd * sizeof(Ext), hipMemcpyDeviceToHost, stream));
         return GMSM_OK;
     }
 
@@ -714,17 +774,117 @@ struct Group {
     // Most points one pipeline run takes: the coarse partition pass keeps two 32-bit words per partition in LDS, which
     // caps it at 2^27 references per window. Larger inputs run as consecutive point ranges whose window totals are added
     // (the point decomposition of sharding.py, on one device). GMSM_MAX_RUN lowers the cap (tests).
-    static size_t max_run_points() {
-        const size_t cap = (size_t)1 << 27;
+    // A shared-bucket plan (window tables) sorts nwin * n entries as one window: a sort entry is 32 bits - the low
+    // bucket bits of the coarse pass next to (index, sign) - and the coarse pass takes at most 2^13 partitions.
+    static size_t max_run_points(const WindowPlan &plan = WindowPlan{0, 0, 0, 0, 1, 0, 0}) {
+        size_t cap = (size_t)1 << 27;
+        if (plan.shared) {
+            uint32_t log2NB = 0;
+            while ((1u << log2NB) < plan.nbuckets) ++log2NB;
+            const uint32_t fb_min = log2NB > 13 ? log2NB - 13 : 0;
+            cap = std::min(cap, (((size_t)1 << (31 - fb_min)) - 1) / plan.nwin_total);
+        }
         const size_t forced = env_uint("GMSM_MAX_RUN", 0);
         return forced ? std::min(cap, forced) : cap;
+    }
+
+    // ---- window tables of registered bases (gmsm_bases_precompute): table slab w = 2^(c w) P_i for every window w of the
+    // c-bit decomposition, so that the digits of ALL windows index one bucket set - one reduction of 2^(c-1) buckets
+    // instead of nwin of them, which in turn lets c grow (fewer windows = fewer additions). 288 GB of HBM pay for it:
+    // nwin copies of the bases (BN254 G1, 2^20 points, c = 19: 14 x 64 MiB).
+    static uint32_t bucket_sets(const WindowPlan &plan) { return plan.shared ? 1u : plan.nwin_local; }
+    // GMSM_TABLES: 0 = never, 1 (default) = the measured range of call sizes, 2 = whenever the handle has tables (tests)
+    static bool tables_serve(size_t n_registered, size_t n_call) {
+        const unsigned mode = env_uint("GMSM_TABLES", 1);
+        if (mode == 0 || n_call == 0) return false;
+        if (mode >= 2) return true;
+        if (n_call < table_min_points() || n_call > table_max_points()) return false;
+        return n_call * 16 >= n_registered;  // a short prefix of the bases: the tables' window is too wide for it
+    }
+    static bool use_tables(const ResidentBases *rb, size_t n) {
+        if (!rb || rb->tab_c == 0) return false;
+        const unsigned forced = env_uint("GMSM_C", 0);
+        if (forced >= 2 && forced <= 20 && forced != rb->tab_c) return false;
+        return tables_serve(rb->n, n);
+    }
+    // The plan of a MultiExp over n points: the measured window table, or the registered bases' tables when they exist
+    static WindowPlan plan_for(const ResidentBases *rb, size_t n) {
+        if (use_tables(rb, n)) {
+            WindowPlan plan = make_plan(rb->tab_c, 0, 1);
+            plan.shared = 1;
+            return plan;
+        }
+        return make_plan(choose_c(FR_BITS, AFF_BYTES, n), 0, 1);
+    }
+    // Default table width for n registered points, from sweeps of every group over 2^13..2^21 with the width forced
+    // (tools/tables_sweep.py, profiles/r03_tables.log). What moves it away from the plain path's width: the shared set
+    // holds nwin * n entries, so (a) a wider window pays twice - fewer slabs to add AND shorter chains of partial sums
+    // per bucket (nwin n / 2^(c-1) entries per bucket; BW6-761 2^18: fix-up 1.83 ms at c = 14, 0.10 ms at c = 18) -,
+    // (b) one reduction of 2^(c-1) buckets is cheap next to nwin of them, and (c) the TOP window must not be narrow: a
+    // top window of t bits drops its n entries into 2^t buckets of the one set (BN254 at c = 19: 7 bits, a million
+    // entries in 128 buckets, i.e. in one coarse partition - 0.9 ms of fine sort), which rules out 18, 19 for BN254,
+    // 17, 18 for BLS12-381 (17 also fills the top window: the carry doubles the buckets) and 15..17 for BW6-761.
+    static unsigned table_c(size_t n) {
+        unsigned lg = 0;
+        while (((size_t)2 << lg) <= n) ++lg;
+        if (FR_BITS > 300) return 18;                                        // BW6-761
+        if (AFF_BYTES == 64) return lg <= 14 ? 15 : lg <= 18 ? 16 : 17;      // BN254 G1
+        if (FR_BITS == 254) return lg <= 16 ? 15 : lg <= 19 ? 16 : 20;       // BN254 G2
+        return lg < 20 ? 16 : 20;                                            // BLS12-381 G1, G2
+    }
+    // Call sizes the tables serve (measured against the plain path, same sweeps): below, a call is all latency and the
+    // plain path's narrow windows win; above, the one window of nwin * n entries costs more in the sort and in the chains
+    // of partial sums than one reduction saves (BN254 G1 2^22: 6.02 against 5.90 ms), and wider tables would need sort
+    // entries of more than 32 bits.
+    static size_t table_min_points() { return (size_t)1 << (AFF_BYTES == 64 ? 13 : 15); }
+    static size_t table_max_points() { return (size_t)3 << (FR_BITS == 255 && AFF_BYTES == 96 ? 19 : 20); }
+    static int precompute_tables(Context &ctx, Workspace &ws, ResidentBases *rb, unsigned c) {
+        if (c == 0) c = table_c(rb->n);
+        if (c < 2 || c > 20) return fail(GMSM_ERR_ARG, "table window width must be 2..20");
+        if (rb->n == 0 || rb->n >= ((size_t)1 << 31)) return fail(GMSM_ERR_ARG, "window tables need 1 <= n < 2^31 bases");
+        const WindowPlan plan = make_plan(c, 0, 1);
+        const uint32_t nw = plan.nwin_total;
+        const size_t n = rb->n, slab = n * AFF_BYTES;
+        int rc;
+        rb->tab_c = 0;
+        if ((rc = rb->tables.ensure((size_t)nw * slab))) return rc;
+        if ((rc = order_after(ws, nullptr))) return rc;
+        if ((rc = ws.buckets.ensure(n * sizeof(XYZZL<U>)))) return rc;
+        if ((rc = ws.h2d_points.ensure(slab))) return rc;
+        if ((rc = ws.skip.ensure(n))) return rc;
+        if ((rc = ws.flagword.ensure(8))) return rc;
+        HIP_TRY(hipMemsetAsync(ws.flagword.ptr, 0, 8, ws.stream));
+        HIP_TRY(hipMemcpyAsync(rb->tables.ptr, rb->upoints.ptr, slab, hipMemcpyDeviceToDevice, ws.stream));
+        const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+        for (uint32_t w = 1; w < nw; ++w) {
+            char *prev = (char *)rb->tables.ptr + (size_t)(w - 1) * slab;
+            hipLaunchKernelGGL((k_table_double<U, INLINE_OPS>), grid, block, 0, ws.stream, (const void *)prev,
+                               (const uint8_t *)rb->skip.ptr, n, c, ws.buckets.ptr);
+            if ((rc = normalize_records(ws, n, ws.h2d_points.ptr))) return rc;
+            hipLaunchKernelGGL((k_convert_points<U>), grid, block, 0, ws.stream, (const void *)ws.h2d_points.ptr, n,
+                               (void *)(prev + slab), (uint8_t *)ws.skip.ptr);
+            hipLaunchKernelGGL(k_skip_mismatch, grid, block, 0, ws.stream, (const uint8_t *)rb->skip.ptr,
+                               (const uint8_t *)ws.skip.ptr, n, (uint32_t *)ws.flagword.ptr);
+        }
+        HIP_TRY(hipGetLastError());
+        uint32_t bad = 0;
+        HIP_TRY(hipMemcpyAsync(&bad, ws.flagword.ptr, 4, hipMemcpyDeviceToHost, ws.stream));
+        HIP_TRY(hipStreamSynchronize(ws.stream));
+        if (bad) {  // a base of even order (not a subgroup point): its multiples reach the identity - no tables, plain path
+            rb->tables.release();
+            return fail(GMSM_ERR_ARG, "window tables: a multiple 2^k P of a base is the identity (bases outside the prime-order subgroup)");
+        }
+        rb->tab_c = c;
+        rb->tab_nw = nw;
+        (void)ctx;
+        return GMSM_OK;
     }
 
     // Point ranges of a MultiExp over device-resident inputs. More than one range (a) beyond the cap of one pipeline run
     // and (b) - experiment, GMSM_DEVICE_RANGES - to keep the bases of a range inside the 256 MiB Infinity Cache while
     // all windows gather from them.
-    static unsigned device_ranges(size_t n) {
-        const size_t run = max_run_points();
+    static unsigned device_ranges(size_t n, const WindowPlan &plan) {
+        const size_t run = max_run_points(plan);
         unsigned nr = (unsigned)((n + run - 1) / run);
         const unsigned forced = tune_uint("GMSM_DEVICE_RANGES", 0);
         if (forced > nr) nr = (unsigned)std::min<size_t>(forced, n);
@@ -733,9 +893,9 @@ struct Group {
 
     static int multiexp_device(Context &ctx, Workspace &ws, const void *d_points, const void *d_scalars, size_t n,
                                hipStream_t caller_stream, J *out, const ResidentBases *resident = nullptr) {
-        const unsigned nr = device_ranges(n);
-        const unsigned c = choose_c(FR_BITS, AFF_BYTES, n);
-        WindowPlan plan = make_plan(c, 0, 1);
+        const WindowPlan plan = plan_for(resident, n);
+        const unsigned c = plan.c;
+        const unsigned nr = device_ranges(n, plan);
         std::vector<Ext> totals(plan.nwin_total);
         if (nr <= 1) {
             int rc = window_sums(ctx, ws, d_points, d_scalars, n, plan, caller_stream, totals.data(), resident);
@@ -749,14 +909,14 @@ struct Group {
         const size_t per = (n + nr - 1) / nr;
         int rc = order_after(ws, caller_stream);
         if (rc) return rc;
-        if ((rc = ws.carry.ensure((size_t)plan.nwin_local * plan.nbuckets * REC))) return rc;
+        if ((rc = ws.carry.ensure((size_t)bucket_sets(plan) * plan.nbuckets * REC))) return rc;
         for (unsigned r = 0; r * per < n; ++r) {
             const size_t lo = (size_t)r * per, len = std::min(per, n - lo);
             const void *dp = d_points ? (const char *)d_points + lo * AFF_BYTES : nullptr;
             if ((rc = enqueue_window_sums(ctx, ws, dp, (const char *)d_scalars + lo * SCALAR_BYTES, len, plan, ws.stream, resident,
                                           nullptr, lo, /*buckets_only=*/true)))
                 return rc;
-            hipLaunchKernelGGL((k_merge_buckets<OpsSerial>), dim3((plan.nbuckets + 255) / 256, plan.nwin_local), dim3(256), 0, ws.stream,
+            hipLaunchKernelGGL((k_merge_buckets<OpsSerial>), dim3((plan.nbuckets + 255) / 256, bucket_sets(plan)), dim3(256), 0, ws.stream,
                                ws.carry.ptr, (const void *)ws.buckets.ptr, (const uint32_t *)ws.starts.ptr, plan.nbuckets, r == 0 ? 1 : 0);
         }
         if ((rc = enqueue_reduce(ctx, ws, ws.carry.ptr, plan, per, ws.stream))) return rc;
@@ -770,8 +930,9 @@ struct Group {
     static int multiexp_submit(Context &ctx, Workspace &ws, const void *d_scalars, size_t n, const ResidentBases *resident) {
         if (n > max_run_points())
             return fail(GMSM_ERR_ARG, "submit/collect takes at most 2^27 points per ticket: use the blocking entry, which splits larger inputs");
-        const unsigned c = choose_c(FR_BITS, AFF_BYTES, n);
-        WindowPlan plan = make_plan(c, 0, 1);
+        WindowPlan plan = plan_for(resident, n);
+        if (n > max_run_points(plan)) plan = make_plan(choose_c(FR_BITS, AFF_BYTES, n), 0, 1);  // one run per ticket: plain path
+        const unsigned c = plan.c;
         int rc = enqueue_window_sums(ctx, ws, nullptr, d_scalars, n, plan, ws.stream, resident);
         if (rc) return rc;
         ws.pending_c = c;
@@ -829,7 +990,7 @@ struct Group {
     static int window_sums_from_host(Context &ctx, Workspace &first, const uint64_t *points, const ResidentBases *resident,
                                      size_t resident_base, const uint64_t *scalars, size_t n, const WindowPlan &plan,
                                      unsigned nr, Ext *out_totals) {
-        const uint32_t nw = plan.nwin_local;
+        const uint32_t nw = plan.nwin_local, nsets = bucket_sets(plan);
         if (nw == 0) return GMSM_OK;
         const size_t per = (n + nr - 1) / nr;
         Workspace *w[2] = {&first, nr > 1 ? ctx.acquire(false) : nullptr};
@@ -841,7 +1002,7 @@ struct Group {
         hipStream_t ms = nws == 2 ? first.mstream : first.stream;
         constexpr size_t REC = sizeof(typename OpsSerial::Mem);
         int rc = GMSM_OK;
-        if (nr > 1 && (rc = first.carry.ensure((size_t)nw * plan.nbuckets * REC))) {
+        if (nr > 1 && (rc = first.carry.ensure((size_t)nsets * plan.nbuckets * REC))) {
             if (w[1]) ctx.release(w[1]);
             return rc;
         }
@@ -884,7 +1045,7 @@ struct Group {
                 he = hipEventRecord(ws.ev_buckets, ws.stream);
                 if (he == hipSuccess) he = hipStreamWaitEvent(ms, ws.ev_buckets, 0);
             }
-            hipLaunchKernelGGL((k_merge_buckets<OpsSerial>), dim3((plan.nbuckets + 255) / 256, nw), dim3(256), 0, ms, first.carry.ptr,
+            hipLaunchKernelGGL((k_merge_buckets<OpsSerial>), dim3((plan.nbuckets + 255) / 256, nsets), dim3(256), 0, ms, first.carry.ptr,
                                (const void *)ws.buckets.ptr, (const uint32_t *)ws.starts.ptr, plan.nbuckets, r == 0 ? 1 : 0);
             if (he == hipSuccess && nws == 2) he = hipEventRecord(ws.ev_merged, ms);
             if (he == hipSuccess) he = hipGetLastError();
@@ -904,9 +1065,9 @@ struct Group {
     }
 
     // Point ranges of a host-buffer call over n points: host_ranges(), more if one of them would exceed a pipeline run.
-    static unsigned host_range_count(size_t n, bool with_points) {
+    static unsigned host_range_count(size_t n, bool with_points, const WindowPlan &plan) {
         unsigned nr = host_ranges(n, with_points);
-        const size_t run = max_run_points();
+        const size_t run = max_run_points(plan);
         if ((n + nr - 1) / nr > run) nr = (unsigned)((n + run - 1) / run);
         const size_t per = (n + nr - 1) / nr;
         return (unsigned)((n + per - 1) / per);
@@ -915,9 +1076,9 @@ struct Group {
     // MultiExp with the scalars (and, unless `resident`, the points) in host memory.
     static int multiexp_from_host(Context &ctx, Workspace &first, const uint64_t *points, const ResidentBases *resident,
                                   const uint64_t *scalars, size_t n, J *out) {
-        const unsigned nr = host_range_count(n, points != nullptr);
-        const unsigned c = choose_c(FR_BITS, AFF_BYTES, n);  // the ranges share one bucket set and one reduction
-        WindowPlan plan = make_plan(c, 0, 1);
+        const WindowPlan plan = plan_for(resident, n);  // the ranges share one bucket set and one reduction
+        const unsigned c = plan.c;
+        const unsigned nr = host_range_count(n, points != nullptr, plan);
         std::vector<Ext> totals(plan.nwin_total);
         int rc = window_sums_from_host(ctx, first, points, resident, 0, scalars, n, plan, nr, totals.data());
         if (rc) return rc;
@@ -933,13 +1094,16 @@ struct Group {
                            const uint64_t *scalars, size_t n, unsigned c, unsigned win_first, unsigned win_stride,
                            Ext *out_xyzz) {
         WindowPlan plan = make_plan(c, win_first, win_stride);
+        // a point slice over bases with window tables of this width: one bucket set (the engine asks for the tables' c)
+        if (resident && resident->tab_c == c && win_first == 0 && plan.win_stride == 1 && env_uint("GMSM_TABLES", 1) != 0)
+            plan.shared = 1;
         if (n == 0) {
             for (uint32_t k = 0; k < plan.nwin_local; ++k) out_xyzz[k] = Ext::infinity();
             return GMSM_OK;
         }
         GMSM_LEASE_OR_FAIL(lease, ctx);
         return window_sums_from_host(ctx, *lease.w, points, resident, resident_base, scalars, n, plan,
-                                     host_range_count(n, points != nullptr), out_xyzz);
+                                     host_range_count(n, points != nullptr, plan), out_xyzz);
     }
 
     static int multiexp_host(const uint64_t *points, size_t n_points, const uint64_t *scalars, size_t n_scalars,
@@ -1183,7 +1347,11 @@ struct VTableOf {
         return G::shard_piece(ctx, points, resident, resident_base, scalars, n, c, win_first, win_stride,
                               reinterpret_cast<typename G::Ext *>(out_xyzz));
     }
-    static unsigned host_piece_ranges(size_t n, bool with_points) { return G::host_range_count(n, with_points); }
+    static unsigned host_piece_ranges(size_t n, bool with_points) { return G::host_range_count(n, with_points, G::plan_for(nullptr, n)); }
+    static int precompute_tables(Context &ctx, Workspace &ws, ResidentBases *rb, unsigned c) {
+        return G::precompute_tables(ctx, ws, rb, c);
+    }
+    static bool tables_serve(size_t n_registered, size_t n_call) { return G::tables_serve(n_registered, n_call); }
     static int window_sums(Context &ctx, const void *d_points, const void *d_scalars, size_t n, unsigned c,
                            unsigned win_first, unsigned win_stride, hipStream_t stream, uint64_t *out_xyzz,
                            const ResidentBases *resident) {
@@ -1334,7 +1502,7 @@ struct VTableOf {
         static const GroupVTable vt = {G::FR_BITS,      G::AFF_BYTES,   G::SCALAR_BYTES, sizeof(typename G::J),
                                        sizeof(typename G::Ext), &multiexp_host, &multiexp_device, &window_sums,
                                        &fold,           &jac_to_affine, &debug_decompose, &debug_field_op,
-                                       &debug_group_op, &generate_points, &register_bases, &submit, &collect, &window_sums_enqueue, &fold_sets, &fold_powers, &multiexp_bases_host, &batch_scalar_mul, &batch_jac_to_affine, &decode_raw, &validate_points, &fft_domain_new, &fft_run, &fft_bit_reverse, &shard_piece, &host_piece_ranges};
+                                       &debug_group_op, &generate_points, &register_bases, &submit, &collect, &window_sums_enqueue, &fold_sets, &fold_powers, &multiexp_bases_host, &batch_scalar_mul, &batch_jac_to_affine, &decode_raw, &validate_points, &fft_domain_new, &fft_run, &fft_bit_reverse, &precompute_tables, &tables_serve, &shard_piece, &host_piece_ranges};
         return &vt;
     }
 };

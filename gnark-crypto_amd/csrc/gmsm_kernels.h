@@ -33,6 +33,8 @@ struct WindowPlan {
     uint32_t win_first;  // this launch handles windows win_first + k*win_stride, k < nwin_local (window sharding)
     uint32_t win_stride;
     uint32_t nwin_local;
+    uint32_t shared;     // 1: window tables (Group::precompute_tables) - the digits of all windows index ONE bucket set,
+                         // entry (w, i) gathers 2^(c w) P_i; the launch reports the total as window 0 and infinity above
 };
 
 template <class T>
@@ -216,16 +218,19 @@ __global__ void __launch_bounds__(1024) k_part_hist(const D *__restrict__ digits
     for (uint32_t p = threadIdx.x; p < nparts; p += blockDim.x) out[p] = lds_cnt[p];
 }
 
-// grid = (ceil(nparts/32), nwin), block = 256 = 32 partitions x 8 chunk segments: turns the per-chunk counts of every
+// grid = (ceil(nparts/32), nwin), block = 32 partitions x SEGS chunk segments: turns the per-chunk counts of every
 // (window, partition) into exclusive prefixes over the chunks (in place) and emits the partition population. Each
-// thread sums its segment of the chunks, the 8 segment sums of a partition are combined through LDS, then the segment
+// thread sums its segment of the chunks, the SEGS segment sums of a partition are combined through LDS, then the segment
 // is rewritten with running prefixes. Adjacent lanes work on adjacent partitions (128-byte rows of blockhist).
-static __global__ void __launch_bounds__(256) k_part_colscan(uint32_t *__restrict__ blockhist, uint32_t nchunks, uint32_t nparts,
-                                                             uint32_t *__restrict__ part_pop) {
-    __shared__ uint32_t seg_sum[8][32];
+// SEGS = 8 when the grid fills the chip; 32 for the few wide columns of a shared bucket set (one window of nwin * n
+// entries: thousands of chunks, 16-64 workgroups - a thread's walk over its chunks is what the kernel takes).
+template <uint32_t SEGS>
+__global__ void __launch_bounds__(32 * SEGS) k_part_colscan(uint32_t *__restrict__ blockhist, uint32_t nchunks, uint32_t nparts,
+                                                            uint32_t *__restrict__ part_pop) {
+    __shared__ uint32_t seg_sum[SEGS][32];
     const uint32_t lane = threadIdx.x & 31u, s = threadIdx.x >> 5, k = blockIdx.y;
     const uint32_t p = blockIdx.x * 32u + lane;
-    const uint32_t per = (nchunks + 7u) / 8u;
+    const uint32_t per = (nchunks + SEGS - 1u) / SEGS;
     const uint32_t c0 = s * per < nchunks ? s * per : nchunks;
     const uint32_t c1 = c0 + per < nchunks ? c0 + per : nchunks;
     uint32_t *bh = blockhist + (size_t)k * nchunks * nparts + p;
@@ -242,7 +247,7 @@ static __global__ void __launch_bounds__(256) k_part_colscan(uint32_t *__restric
         bh[(size_t)ch * nparts] = run;
         run += v;
     }
-    if (s == 7u) part_pop[(size_t)k * nparts + p] = run;
+    if (s == SEGS - 1u) part_pop[(size_t)k * nparts + p] = run;
 }
 
 // grid = nwin, block = 1024: exclusive scan of the partition populations -> part_base[k][0..nparts]
@@ -474,12 +479,26 @@ template <class P> struct AccWaves<Fp2U<P>> { static constexpr int value = P::UL
 // limbs, 90 KB of loop body, and 28 limbs, 130 KB, both beyond the 64 KB instruction cache: calling one shared copy of
 // the product instead is SLOWER, BW6-761 2^20 43.7 against 32.9 ms, BLS12-381 G2 2^22 55.1 against 47.0 ms - the calls
 // spill 0.5-1 KB per lane. What those kernels were missing is instruction-level parallelism, see GMSM_MUL_NACC.)
-template <class U>
+// TAB (window tables of registered bases, Group::precompute_tables): the launch sees ONE window whose entry e = w * tab_m + i
+// stands for 2^(c w) P_i, stored at slot w * tab_stride + i of `upoints` (tab_stride = registered points, tab_m = points
+// of this call); a separate instantiation, so the loop of the ordinary path is untouched.
+template <bool TAB>
+__device__ __forceinline__ size_t point_slot(uint32_t index, uint32_t tab_m, uint32_t tab_stride) {
+    if constexpr (TAB) {
+        const uint32_t w = index / tab_m;
+        return (size_t)w * tab_stride + (index - w * tab_m);
+    } else {
+        return index;
+    }
+}
+
+template <class U, bool TAB = false>
 __global__ void __launch_bounds__(256, AccWaves<U>::value) k_accumulate_seg(const void *__restrict__ upoints, size_t n, uint32_t nbuckets,
                                                            uint32_t seg, const uint32_t *__restrict__ starts,
                                                            const uint32_t *__restrict__ sorted, void *__restrict__ buckets,
                                                            void *__restrict__ partials, uint32_t *__restrict__ pflags,
-                                                           uint32_t *__restrict__ pbucket, uint32_t threads_per_win) {
+                                                           uint32_t *__restrict__ pbucket, uint32_t threads_per_win,
+                                                           uint32_t tab_m = 0, uint32_t tab_stride = 0) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
     const uint32_t *st = starts + (size_t)k * (nbuckets + 1);
     const uint32_t total = st[nbuckets];
@@ -518,7 +537,7 @@ __global__ void __launch_bounds__(256, AccWaves<U>::value) k_accumulate_seg(cons
     bool inf = true;
     uint32_t v = ent[e0];
     uint32_t vn = e0 + 1 < e1 ? ent[e0 + 1] : 0u;
-    UAffine<U> p = load_struct<UAffine<U>>(upoints, v >> 1);
+    UAffine<U> p = load_struct<UAffine<U>>(upoints, point_slot<TAB>(v >> 1, tab_m, tab_stride));
     for (uint32_t e = e0; e < e1; ++e) {
         if (e == bend) {  // the current run is complete on the right
             lz_acc_finish(acc, inf);
@@ -541,7 +560,7 @@ __global__ void __launch_bounds__(256, AccWaves<U>::value) k_accumulate_seg(cons
         const uint32_t vc = v;
         const UAffine<U> pc = p;
         const uint32_t vnn = e + 2 < e1 ? ent[e + 2] : 0u;
-        if (e + 1 < e1) p = load_struct<UAffine<U>>(upoints, vn >> 1);
+        if (e + 1 < e1) p = load_struct<UAffine<U>>(upoints, point_slot<TAB>(vn >> 1, tab_m, tab_stride));
         v = vn;
         vn = vnn;
         lz_madd_acc<true>(acc, inf, T::unpack(pc.x), T::unpack(pc.y), (vc & 1u) != 0);
@@ -793,6 +812,48 @@ __global__ void __launch_bounds__(256) k_merge_buckets(void *__restrict__ carry,
         A::add(c, v);
         A::store(carry, idx, c);
     }
+}
+
+// ------------------------------------------------------------------ window tables of registered bases
+// Group::precompute_tables: slab w of the table holds 2^(c w) P_i in the packed lazy-domain layout of the bases. One step
+// slab w-1 -> slab w: c doublings per point (this kernel, lazy XYZZ record out), k_batch_normalize, k_convert_points.
+// A point whose multiple is the identity (zz = 0: an even-order point, which no subgroup base is) leaves an infinity
+// record; the host then finds the slab's infinity flags different from the bases' and gives the tables up.
+template <class U, bool INL>
+__global__ void __launch_bounds__(256) k_table_double(const void *__restrict__ slab, const uint8_t *__restrict__ skip, size_t n,
+                                                      uint32_t c, void *__restrict__ recs) {
+    using T = LzTraits<U>;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    XYZZL<U> p;
+    bool inf = skip[i] != 0;
+    if (!inf) {
+        const UAffine<U> a = load_struct<UAffine<U>>(slab, i);
+        p.x = T::unpack(a.x);
+        p.y = T::unpack(a.y);
+        p.zz = p.zzz = lz_one((const U *)nullptr);
+#pragma nounroll
+        for (uint32_t l = 0; l < c; ++l) {
+            p = lz_pdbl<INL>(p);
+            lz_acc_finish(p, false);
+        }
+        inf = T::template to_sat<INL>(p.zz).is_zero();
+    }
+    lazy_store<U>(recs, i, p, inf);
+}
+
+// flag[0] |= 1 when the infinity flags of a table slab differ from the bases'
+static __global__ void __launch_bounds__(256) k_skip_mismatch(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, size_t n,
+                                                       uint32_t *__restrict__ flag) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (a[i] != 0) != (b[i] != 0)) atomicOr(flag, 1u);
+}
+
+// rows [first, first + count) of the window totals <- infinity (a shared-bucket launch has one total, in row 0)
+template <class Final>
+__global__ void k_fill_infinity(void *__restrict__ totals, uint32_t first, uint32_t count) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < count) policy_store<Final>(totals, first + r, Final::infinity());
 }
 
 }  // namespace gmsm

@@ -355,6 +355,19 @@ class ResidentBases:
     def __init__(self, group, handle, n):
         self.group, self.handle, self.n = group, handle, n
 
+    def precompute(self, c=0):
+        """gmsm_bases_precompute: window tables 2^(c w) P_i in HBM (c = 0: the library's width); every later MultiExp over
+        these bases fills one bucket set.  Returns the tables' window width."""
+        L = _lib.load()
+        rc = L.gmsm_bases_precompute(self.handle, int(c))
+        if rc:
+            raise RuntimeError(self.group._error(rc))
+        return int(L.gmsm_bases_table_bits(self.handle))
+
+    @property
+    def table_bits(self):
+        return int(_lib.load().gmsm_bases_table_bits(self.handle))
+
     def MultiExp(self, scalars, config=MultiExpConfig()):
         """MultiExp(bases[:len(scalars)], scalars): returns (jacobian_limbs, None) or (None, error)."""
         L = _lib.load()

@@ -114,6 +114,23 @@ int gmsm_bases_register_sharded(int group, const uint64_t *points, size_t n, con
                                 uint64_t *out_handle);
 int gmsm_multiexp_bases_sharded(uint64_t handle, const uint64_t *scalars, size_t n_scalars, int nb_tasks, int mode,
                                 uint64_t *out_jac);
+/* Window tables for registered bases (any handle of gmsm_bases_register* / _sharded): the multiples 2^(c w) P_i of every
+ * base for every window w of the c-bit decomposition are computed once and kept in HBM (nwin copies of the bases: BN254 G1,
+ * 2^20 bases, c = 19: 14 x 64 MiB - sized for 288 GB).  Every later MultiExp over the handle (all gmsm_multiexp_bases*
+ * entries, tickets, batches, point-sharded calls) then drops the digits of ALL windows into ONE set of 2^(c-1) buckets:
+ * one bucket reduction instead of nwin, and a wider window (fewer additions) than the plain path can afford.  Same
+ * group element, hence the same affine result, as without tables (the reference has no counterpart: its MultiExp takes
+ * the bases anew on every call, ecc/bn254/multiexp.go:61; this is what kzg.Commit over a fixed SRS can use,
+ * ecc/bn254/kzg/kzg.go:159-176).  c = 0: the library's width for this many bases; 2..20 otherwise.  Calls over a prefix
+ * shorter than n/16, call sizes outside the range where the tables were measured to win (about 2^13..2^21 points, by
+ * group) and calls with GMSM_C set to another width use the plain path; GMSM_TABLES=0 switches the tables off, =2 uses
+ * them for every call size (tests).
+ * Call it before the handle is used from several threads.  Bases outside the prime-order subgroup whose multiples reach
+ * the identity are refused (GMSM_ERR_ARG; the handle keeps working without tables).
+ * gmsm_bases_table_bits: the width of the handle's tables, 0 = none. */
+int gmsm_bases_precompute(uint64_t handle, unsigned c);
+unsigned gmsm_bases_table_bits(uint64_t handle);
+unsigned long gmsm_debug_table_runs(void); /* pipeline runs that went through window tables so far (tests) */
 /* The devices the drop-in entries shard over (one entry per logical rank); count = 0 restores the default (every
  * visible device).  gmsm_get_devices returns the number of configured ranks and writes up to max_devices of them. */
 int gmsm_set_devices(const int *devices, int count);
