@@ -1,5 +1,6 @@
 """Randomised parity sweep (not part of the pytest suites): many sizes, scalar distributions and entry points against the
-oracle. usage: python tools/fuzz_parity.py [seconds] [curve] [g1|g2]"""
+oracle; the registered-bases entries draw from three handles - plain, window tables of the library's width, tables of width 11.
+usage: python tools/fuzz_parity.py [seconds] [curve] [g1|g2]"""
 import importlib
 import sys
 import time
@@ -25,6 +26,12 @@ def main():
     nmax = 1 << 17
     pts_all = o.gen_points(nmax, 99, 5, nthreads=8)
     rb = g.register_bases(points=pts_all)
+    # the same bases with window tables (gmsm_bases_precompute), the library's width and a narrow one; GMSM_TABLES=2: every
+    # call size runs through them (the default policy would send most of these sizes down the plain path)
+    os.environ["GMSM_TABLES"] = "2"
+    handles = [rb, g.register_bases(points=pts_all), g.register_bases(points=pts_all)]
+    handles[1].precompute(0)
+    handles[2].precompute(11)
     t0 = time.time()
     cases = bad = 0
     while time.time() - t0 < budget:
@@ -70,14 +77,17 @@ def main():
             assert err is None, err
             got = g.jac_to_affine(jac)
         elif entry == 1:
+            rb = handles[int(rng.integers(0, 3))]
             jac, err = rb.MultiExp(sc)
             assert err is None
             got = g.jac_to_affine(jac)
         elif entry == 2:
             d = torch.from_numpy(sc.view(np.int64)).cuda()
             torch.cuda.synchronize()
+            rb = handles[int(rng.integers(0, 3))]
             got = g.jac_to_affine(rb.collect(rb.submit(d.data_ptr(), n)))
         else:
+            rb = handles[int(rng.integers(0, 3))]
             jacs, err = rb.MultiExpBatch(scalars=np.stack([sc, sc]))
             assert err is None
             got = g.jac_to_affine(jacs[1])
@@ -85,7 +95,8 @@ def main():
         if not (got == want).all():
             bad += 1
             print("MISMATCH", dict(n=n, kind=kind, entry=entry), flush=True)
-    rb.release()
+    for h in handles:
+        h.release()
     print(f"{curve} {which}: {cases} cases, {bad} mismatches", flush=True)
     sys.exit(1 if bad else 0)
 
