@@ -131,6 +131,7 @@ struct Workspace {
     hipEvent_t ev_buckets = nullptr, ev_merged = nullptr;  // a range's buckets are complete / have been merged
     hipEvent_t events[12] = {nullptr};  // stage boundaries of the call in flight when profiling is on
     bool timed = false;                 // events[] were recorded by the last enqueue
+    int timed_level = 0;                // ... at this profiling level (1: every stage, 2: the accumulation kernel only)
     void *pinned = nullptr;             // pinned host buffer for the window totals
     size_t pinned_cap = 0;
     DeviceBuffer h2d_points, h2d_scalars;  // staging of the host-pointer entries
@@ -299,24 +300,27 @@ enum TimedEvent { T_DECOMPOSE = 0, T_HIST, T_SCAN, T_SCATTER, T_ACCUMULATE, T_FI
 static constexpr int T_TO_STAGE[T_END] = {STAGE_DECOMPOSE, STAGE_HIST, STAGE_SCAN, STAGE_SCATTER,
                                           STAGE_ACCUMULATE, STAGE_FIXUP, STAGE_REDUCE};
 
-bool profiling_enabled();
+int profiling_level();  // 0 off, 1 every stage, 2 the accumulation kernel only (two events per pipeline run)
 // adds one call's stage durations (and the number of kernel instances behind each) to the process-wide accumulators
 void record_stage_times(const float *ms, const unsigned *launches);
 
 struct StageTimer {
     Workspace &ws;
+    int level;
     bool on;
-    explicit StageTimer(Workspace &w) : ws(w), on(profiling_enabled()) {
+    explicit StageTimer(Workspace &w) : ws(w), level(profiling_level()), on(level != 0) {
         if (on && !ws.events[0])
             for (int i = 0; i <= T_END; ++i) (void)hipEventCreate(&ws.events[i]);
+        ws.timed_level = level;
     }
     void mark(int ev, hipStream_t stream) {
-        if (on) (void)hipEventRecord(ws.events[ev], stream);
+        if (level == 1 || (level == 2 && (ev == T_ACCUMULATE || ev == T_FIXUP))) (void)hipEventRecord(ws.events[ev], stream);
     }
     static void collect(Workspace &ws) {  // call after the stream has been synchronised
         float ms[STAGE_COUNT] = {0};
         unsigned launches[STAGE_COUNT] = {0};
         for (int i = T_DECOMPOSE; i < T_END; ++i) {
+            if (ws.timed_level == 2 && i != T_ACCUMULATE) continue;
             float t = 0.f;
             if (hipEventElapsedTime(&t, ws.events[i], ws.events[i + 1]) != hipSuccess) continue;
             ms[T_TO_STAGE[i]] += t;

@@ -34,12 +34,12 @@ int fail(int code, const std::string &msg) {
 }
 
 static std::mutex g_prof_mu;
-static std::atomic<bool> g_profiling{false};
+static std::atomic<int> g_profiling{0};
 static double g_stage_ms[STAGE_COUNT] = {0};
 static unsigned long g_stage_launches[STAGE_COUNT] = {0};
 static unsigned long g_stage_calls = 0;
 
-bool profiling_enabled() { return g_profiling.load(std::memory_order_relaxed); }
+int profiling_level() { return g_profiling.load(std::memory_order_relaxed); }
 void record_stage_times(const float *ms, const unsigned *launches) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (int i = 0; i < STAGE_COUNT; ++i) {
@@ -1253,7 +1253,7 @@ GMSM_EXPORT int gmsm_generate_points(int group, const uint64_t *base_affine, con
 
 GMSM_EXPORT void gmsm_set_profiling(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_profiling.store(on != 0);
+    g_profiling.store(on == 2 ? 2 : on != 0 ? 1 : 0);
     for (int i = 0; i < STAGE_COUNT; ++i) {
         g_stage_ms[i] = 0;
         g_stage_launches[i] = 0;

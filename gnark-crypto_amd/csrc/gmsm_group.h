@@ -263,7 +263,7 @@ struct Group {
             return fail(GMSM_ERR_ARG, "shared-bucket plan without matching window tables");
         if (shared && n) g_table_runs.fetch_add(1, std::memory_order_relaxed);
         if (ws.uncollected) {  // stage events of an enqueue-only call (nobody waited for it): pick them up now
-            if (ws.timed && hipEventQuery(ws.events[T_END]) == hipSuccess) StageTimer::collect(ws);
+            if (ws.timed && hipEventQuery(ws.events[ws.timed_level == 2 ? T_FIXUP : T_END]) == hipSuccess) StageTimer::collect(ws);
             ws.uncollected = false;
         }
         // The workspace may still be in use by work enqueued earlier on another stream: order behind it.
