@@ -432,8 +432,13 @@ struct Group {
             hipLaunchKernelGGL((k_accumulate_seg<U, false>), dim3((q.tpw + 255) / 256, nw), dim3(256), 0, stream, upoints, n, NB,
                                q.seg, starts, sorted, buckets, seg_partials, seg_flags, seg_bucket, q.tpw, 0u, 0u);
         timer.mark(T_FIXUP, stream);
-        hipLaunchKernelGGL((k_fixup_seg<OpsSerial>), dim3((q.tpw + 255) / 256, nw), dim3(256), 0, stream, NB, seg_partials,
-                           (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets, long_flag, long_list, FIX_MAXWALK);
+        if (shared && n / NB >= 2 * (size_t)q.seg)  // buckets of several threads' worth of entries (dense chains): one thread per bucket
+            hipLaunchKernelGGL((k_fixup_bucket<OpsSerial>), dim3((NB + 255) / 256, nw), dim3(256), 0, stream, NB,
+                               (const uint32_t *)starts, q.seg, (const void *)seg_partials, q.tpw, (void *)buckets, long_flag, long_list,
+                               FIX_MAXWALK);
+        else
+            hipLaunchKernelGGL((k_fixup_seg<OpsSerial>), dim3((q.tpw + 255) / 256, nw), dim3(256), 0, stream, NB, seg_partials,
+                               (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets, long_flag, long_list, FIX_MAXWALK);
         hipLaunchKernelGGL((k_fixup_long<U>), dim3(2 * ctx.num_cus), dim3(256), 128 * sizeof(QRec<U>), stream, NB, seg_partials,
                            (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets,
                            (const uint32_t *)long_flag, (const LongChain *)long_list);

@@ -642,6 +642,37 @@ __global__ void __launch_bounds__(256) k_fixup_seg(uint32_t nbuckets, const void
     A::store(buckets, (size_t)k * nbuckets + dest, acc);
 }
 
+// The same fix-up with one thread per BUCKET, for a shared bucket set (window tables): there a bucket holds nwin times
+// the entries (BN254 G1, 2^20 points, c = 17: 240 against a thread's 80), so nearly every bucket is a chain of 3-4 partial
+// sums and k_fixup_seg's heads - one lane in three - walk them with the other lanes of their wave idle (0.100 ms). The
+// chain of bucket b follows from starts[] alone: its entries [lo, hi) lie in the accumulation threads lo / seg .. (hi -
+// 1) / seg, the first holds P1, the others P0. Chains longer than maxwalk go to the same list as before.
+template <class A>
+__global__ void __launch_bounds__(256) k_fixup_bucket(uint32_t nbuckets, const uint32_t *__restrict__ starts, uint32_t seg,
+                                                      const void *__restrict__ partials, uint32_t threads_per_win,
+                                                      void *__restrict__ buckets, uint32_t *__restrict__ long_count,
+                                                      LongChain *__restrict__ long_list, uint32_t maxwalk) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (b >= nbuckets) return;
+    const uint32_t *st = starts + (size_t)k * (nbuckets + 1);
+    const uint32_t lo = st[b], hi = st[b + 1];
+    if (hi <= lo) return;
+    const uint32_t t0 = lo / seg, t1 = (hi - 1) / seg;
+    if (t0 == t1) return;  // the bucket lies inside one thread's range: stored by the accumulation itself
+    const size_t base = (size_t)k * threads_per_win;
+    if (t1 - t0 > maxwalk) {
+        const uint32_t slot = atomicAdd(long_count, 1u);
+        long_list[slot] = LongChain{k, t0};
+        return;
+    }
+    typename A::Elem acc = A::load(partials, (base + t0) * 2 + 1);
+    for (uint32_t u = t0 + 1; u <= t1; ++u) {
+        const typename A::Elem q = A::load(partials, (base + u) * 2 + 0);
+        A::add(acc, q);
+    }
+    A::store(buckets, (size_t)k * nbuckets + b, acc);
+}
+
 // grid = any (grid-stride over the list), block = 256 = 64 quads, dynamic LDS = 128 * sizeof(QRec<U>).
 // Additions on lane quads with the operands in LDS (gmsm_quad.h): quad j first adds up the partial sums j, j + 64, ... of
 // the chain (each fetched into the quad's staging record, one coordinate per lane), then a tree over the 64 quads - for a
