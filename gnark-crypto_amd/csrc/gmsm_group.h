@@ -68,6 +68,7 @@ struct Group {
     // (BW6-761 fixup 0.75 ms either way - it is 322 K two-link chains in five rounds of 512-register workgroups), and 2^16
     // got slower (0.68 -> 2.6 ms: thousands of short chains, one workgroup each).
     static constexpr uint32_t FIX_MAXWALK = FIXUP_MAXWALK;
+    static constexpr bool SKEWED_HOST_RANGES = AFF_BYTES <= 96;  // host_ranges / window_sums_from_host
 
     static WindowPlan make_plan(unsigned c, unsigned win_first, unsigned win_stride) {
         WindowPlan p;
@@ -993,6 +994,10 @@ struct Group {
             return 16;
         }
         if (n < ((size_t)1 << 20)) return 1;  // scalars only (32 B per point)
+        // the two G1 groups of 64 / 96-byte points: three to eight ranges, the first (and, from four, the last) half as long
+        // (window_sums_from_host); the wider groups compute 3-10 times longer per point - the copy hardly shows, every
+        // range costs its launches: few, uniform ranges (BN254 G2 2^20: 6.19 ms with two, 6.43 with three skewed)
+        if (SKEWED_HOST_RANGES) return (unsigned)std::min<size_t>(8, std::max<size_t>(3, n >> 21));
         return (unsigned)std::min<size_t>(16, std::max<size_t>(2, n >> 20));
     }
 
@@ -1007,6 +1012,31 @@ struct Group {
         const uint32_t nw = plan.nwin_local, nsets = bucket_sets(plan);
         if (nw == 0) return GMSM_OK;
         const size_t per = (n + nr - 1) / nr;
+        // Range boundaries. With registered bases only the scalars cross PCIe and the device is the slower side: what the
+        // call exposes of its copies is the copy of the FIRST range (nothing to compute yet), so that one is half as long
+        // as the others - and so is the last one once there are many (its pipeline is the tail after the last copy).
+        // Measured (profiles/r03_host_skew.log, BN254 G1 warm-bases, uniform -> skewed): 2^20 2.27 -> 2.15 ms, 2^22 6.92 -> 6.67,
+        // 2^24 23.4 -> 22.5; with the bases crossing too (cold) the link is as slow as the device and uniform ranges are as
+        // good as any. A forced count (GMSM_HOST_RANGES) keeps uniform ranges.
+        std::vector<size_t> cut(nr + 1, 0);
+        {
+            const bool skew = SKEWED_HOST_RANGES && points == nullptr && nr >= 3 && env_uint("GMSM_HOST_RANGES", 0) == 0;
+            std::vector<double> wgt(nr, 1.0);
+            if (skew) {
+                wgt[0] = 0.5;
+                if (nr >= 4) wgt[nr - 1] = 0.5;
+            }
+            double tot = 0, run = 0;
+            for (double v : wgt) tot += v;
+            bool ok = true;
+            for (unsigned r = 0; r < nr; ++r) {
+                run += wgt[r];
+                cut[r + 1] = r + 1 == nr ? n : (size_t)((double)n * run / tot);
+                if (cut[r + 1] <= cut[r] || cut[r + 1] - cut[r] > max_run_points(plan)) ok = false;
+            }
+            if (!ok)
+                for (unsigned r = 0; r <= nr; ++r) cut[r] = std::min(n, (size_t)r * per);
+        }
         Workspace *w[2] = {&first, nr > 1 ? ctx.acquire(false) : nullptr};
         const unsigned nws = w[1] ? 2 : 1;
         // More than one range: every range stops after its fix-up, its bucket sums are added to the call's running buckets
@@ -1022,7 +1052,7 @@ struct Group {
         }
         for (unsigned r = 0; r < nr && rc == GMSM_OK; ++r) {
             Workspace &ws = *w[r % nws];
-            const size_t lo = (size_t)r * per, len = std::min(per, n - lo);
+            const size_t lo = cut[r], len = cut[r + 1] - lo;
             const void *dp = nullptr;
             // hipMemcpyAsync from pageable memory returns when the caller's buffer has been consumed; the kernels
             // queued behind it do not wait for the host, so range k computes while range k+1 is being copied
