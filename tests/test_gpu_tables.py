@@ -199,3 +199,47 @@ def test_tables_default_call_sizes(gm, oracle_mod, monkeypatch):
             assert (table_runs(gm) > before) == through, m
     finally:
         rb.release()
+
+
+def test_tables_concurrent_callers(gm, oracle_mod):
+    """Several threads over one handle with tables at once (two workspaces per device, the callers queue for them): blocking
+    calls with host scalars, device scalars and tickets interleaved; every result equals the oracle's."""
+    import threading
+    import torch
+    g = gm.G1Jac("bn254")
+    o = oracle_mod.Oracle("bn254", "g1")
+    n = (1 << 15) + 7
+    pts, sc = _inputs(o, g, n, 6)
+    expected = o.msm_affine(pts, sc, nthreads=16)
+    half = o.msm_affine(pts[: n // 2], sc[: n // 2], nthreads=16)
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    rb = g.register_bases(points=pts)
+    try:
+        rb.precompute(0)
+        before = table_runs(gm)
+        bad = []
+
+        def host_caller(i):
+            for k in range(4):
+                m = n if (i + k) % 2 == 0 else n // 2
+                jac, err = rb.MultiExp(sc[:m])
+                if err is not None or not (g.jac_to_affine(jac) == (expected if m == n else half)).all():
+                    bad.append(("host", i, k, err))
+
+        def device_caller(i):
+            for k in range(4):
+                jac = rb.multiexp_device(d_sc.data_ptr(), n, 0)
+                if not (g.jac_to_affine(jac) == expected).all():
+                    bad.append(("device", i, k))
+
+        th = [threading.Thread(target=host_caller, args=(i,)) for i in range(3)]
+        th += [threading.Thread(target=device_caller, args=(i,)) for i in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not bad, bad
+        assert table_runs(gm) - before == 20
+    finally:
+        rb.release()
