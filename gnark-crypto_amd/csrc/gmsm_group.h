@@ -69,6 +69,9 @@ struct Group {
     // got slower (0.68 -> 2.6 ms: thousands of short chains, one workgroup each).
     static constexpr uint32_t FIX_MAXWALK = FIXUP_MAXWALK;
     static constexpr bool SKEWED_HOST_RANGES = AFF_BYTES <= 96;  // host_ranges / window_sums_from_host
+    // plan_geometry: combine workgroups resident on a CU (measured on the pieces of a window-sharded call and on single
+    // bucket sets, profiles/r03_reduce_levels.log: with one per CU the model kept few windows on the two-level form)
+    static constexpr size_t COMBINE_RESIDENT = sizeof(U) <= 36 ? 4 : sizeof(U) <= 56 ? 3 : sizeof(U) <= 72 ? 2 : 1;
 
     static WindowPlan make_plan(unsigned c, unsigned win_first, unsigned win_stride) {
         WindowPlan p;
@@ -146,31 +149,51 @@ struct Group {
         if (log2L == 0) {
             // serial kernel: 2L dependent one-lane additions on every SIMD, as many rounds as the threads need;
             // combine: 2 log2 N + log2 L + 1 quad steps (a quad step is about a third of a one-lane addition) per
-            // round of workgroups, one per CU. Minimise the total in units of one-lane additions.
-            size_t best = ~(size_t)0;
-            for (uint32_t l2 = 1; l2 <= 8; ++l2) {
+            // round of workgroups. Minimise the total in units of one-lane additions.
+            // The width of the TWO-level form is chosen with one combine workgroup per CU and round - the model all
+            // full-call configurations were measured with. Whether a second combine level pays is then decided with
+            // the workgroups a CU really holds at once (COMBINE_RESIDENT; their steps interleave): with one per CU the
+            // model kept few windows on a long serial walk (2^20 piece of 8: reduce 0.221 ms, 0.176 with three levels;
+            // 2^24 piece of 4: 0.358 / 0.271 - profiles/r03_reduce_levels.log).
+            const auto costs = [&](uint32_t l2, size_t resident, size_t *c3) {
                 const size_t serial_threads = (size_t)nw * (((size_t)NB + ((size_t)1 << l2) - 1) >> l2);
                 // lanes of the serial kernel: one per thread, or a quad per thread at a third of the step time
                 const size_t serial_lanes = SERIAL_QUAD ? 4 * serial_threads : serial_threads;
                 const size_t serial_rounds = (serial_lanes + (size_t)ctx.num_cus * 256 - 1) / ((size_t)ctx.num_cus * 256);
-                const size_t rounds = ((size_t)nw * blocks1(l2) + ctx.num_cus - 1) / ctx.num_cus;
+                const size_t per_round = (size_t)ctx.num_cus * resident;
+                const size_t rounds = ((size_t)nw * blocks1(l2) + per_round - 1) / per_round;
                 const size_t cost_serial = (SERIAL_QUAD ? 1 : 3) * serial_rounds * ((size_t)2 << l2);
-                const size_t cost2 = cost_serial + rounds * (2 * 6 + l2 + 1);
-                if (blocks1(l2) <= (size_t)RED2_TPB && force_levels != 3 && cost2 < best) {
-                    best = cost2;
-                    log2L = l2;
-                    three = false;
-                }
+                const size_t c2 = cost_serial + rounds * (2 * 6 + l2 + 1);
                 // second combine: its own rounds of 2 * 6 + 1 steps + the tail of the prescaling, and one more launch
-                const size_t rounds_b = ((size_t)nw * blocks2(l2) + ctx.num_cus - 1) / ctx.num_cus;
-                const size_t cost3 = cost2 + rounds_b * (2 * 6 + 8) + 4;
-                if (blocks1(l2) > 1 && blocks2(l2) <= (size_t)RED2_TPB && force_levels != 2 && cost3 + cost3 / 8 < best) {
-                    best = cost3 + cost3 / 8;  // a margin: the two-level form is the measured one
-                    log2L = l2;
-                    three = true;
+                const size_t rounds_b = ((size_t)nw * blocks2(l2) + per_round - 1) / per_round;
+                *c3 = c2 + rounds_b * (2 * 6 + 8) + 4;
+                return c2;
+            };
+            size_t best2 = ~(size_t)0, best3 = ~(size_t)0, unused = 0;
+            uint32_t l2_two = 0, l2_three = 0;
+            for (uint32_t l2 = 1; l2 <= 8; ++l2) {
+                const size_t c2 = costs(l2, 1, &unused);
+                if (blocks1(l2) <= (size_t)RED2_TPB && c2 < best2) {
+                    best2 = c2;
+                    l2_two = l2;
+                }
+                size_t c3 = 0;
+                (void)costs(l2, COMBINE_RESIDENT, &c3);
+                if (blocks1(l2) > 1 && blocks2(l2) <= (size_t)RED2_TPB && c3 < best3) {
+                    best3 = c3;
+                    l2_three = l2;
                 }
             }
-            if (log2L == 0) log2L = 8;
+            const size_t two_resident = l2_two ? costs(l2_two, COMBINE_RESIDENT, &unused) : ~(size_t)0;
+            if (force_levels == 3 ? l2_three != 0 : (force_levels != 2 && l2_three != 0 && best3 < two_resident)) {
+                log2L = l2_three;
+                three = true;
+            } else if (l2_two) {
+                log2L = l2_two;
+                three = false;
+            } else {
+                log2L = 8;
+            }
         }
         if (three) {
             while (blocks2(log2L) > (size_t)RED2_TPB) ++log2L;
