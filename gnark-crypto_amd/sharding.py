@@ -4,8 +4,8 @@ over xGMI on ROCm, "gloo" in the CPU tests).  Two decompositions, both ending in
 * windows: window w is owned by rank w % world, every rank holds all bases (below);
 * points:  rank r owns points [r*n/world, (r+1)*n/world) and computes all windows of its slice; window w of the whole
   MultiExp is the sum of the ranks' totals for w (gmsm_fold_window_sets).  No replication of the bases, perfect balance;
-  measured per-rank cost on MI355X (tools/shard_model.py, BN254 G1, profiles/r03_shard_model.log): 2^24 on 8 ranks 3.40 ms
-  against 4.29 ms for the window decomposition; at 2^20 the window decomposition is ahead (0.61 / 0.65 ms) - see
+  measured per-rank cost on MI355X (tools/shard_model.py, BN254 G1, profiles/r03_shard_model.log): 2^24 on 8 ranks 3.27 ms
+  against 3.93 ms for the window decomposition; at 2^20 the window decomposition is ahead (0.53 / 0.60 ms) - see
   `choose_mode`.  (The same two decompositions exist INSIDE libgmsm.so for a single process that drives all devices:
   gmsm_multiexp_sharded, include/gmsm.h.)
 
@@ -79,8 +79,8 @@ def point_slice(n, rank, world):
 
 def choose_mode(n, world):
     """Measured per-rank cost (tools/shard_model.py, BN254 G1, ms; windows / points; round 3):
-         2^20:  N=2 1.20 / 1.19   N=4 0.79 / 0.80   N=8 0.61 / 0.65     (a rank with few windows runs a shorter
-         2^24:  N=2 13.1 / 11.8   N=4 7.34 / 6.38   N=8 4.29 / 3.40      reduction; its fold needs no per-rank sums)
+         2^20:  N=2 1.10 / 1.11   N=4 0.72 / 0.76   N=8 0.53 / 0.60     (a rank with few windows runs a shorter
+         2^24:  N=2 12.5 / 11.5   N=4 6.93 / 6.02   N=8 3.93 / 3.27      reduction; its fold needs no per-rank sums)
     points once a rank's slice reaches 2^20 points (no replicated base rewrite / decomposition), windows below."""
     return "points" if n // max(1, world) >= (1 << 20) else "windows"
 
