@@ -216,12 +216,22 @@ struct Group {
         if (seg == 0) {
             const size_t cap_blocks = (size_t)ctx.num_cus * AccWaves<U>::value;
             const size_t SEG_MAX = tune_uint("GMSM_SEGMAX", 512);  // measured: 512 best at 2^24, 256 at 2^22
+            // Shortest segment. A launch that does not fill the chip is a latency chain of `seg` additions per thread:
+            // with sparse buckets (<= 8 entries each: few chains of partial sums to close) shorter segments on more
+            // threads win - BN254 G1 2^14 0.605 -> 0.476 ms, 2^16 0.637 -> 0.585, BLS12-381 G1 2^16 1.17 -> 0.98; crowded
+            // buckets (the 8-bit windows of small inputs) would pay it back in the fix-up (BLS12-381 G1 2^14: 0.13 -> 0.49 ms).
+            // Measured for the three narrow element types (profiles/r03_short_segments.log).
+            size_t seg_floor = 32;
+            if (sizeof(U) <= 72 && n / NB <= 8) {
+                const size_t entries = (size_t)nw * n, cap_threads = cap_blocks * 256;
+                seg_floor = entries / 8 <= cap_threads ? 8 : entries / 16 <= cap_threads ? 16 : 32;
+            }
             size_t best_seg = 0, first_r = 0;
             double best_fill = -1.0;
             for (size_t r = 1; r < 100000; ++r) {
                 const size_t bpw = r * cap_blocks / nw;  // whole blocks per window in r rounds
                 if (bpw == 0) continue;
-                const size_t sg = std::max<size_t>((n + bpw * 256 - 1) / (bpw * 256), 32);
+                const size_t sg = std::max<size_t>((n + bpw * 256 - 1) / (bpw * 256), seg_floor);
                 if (sg > SEG_MAX) continue;
                 if (!first_r) first_r = r;
                 const size_t blocks = (size_t)nw * (((n + sg - 1) / sg + 255) / 256);
@@ -230,9 +240,9 @@ struct Group {
                     best_fill = fill;
                     best_seg = sg;
                 }
-                if (fill > 0.985 || r >= first_r + 5 || sg == 32) break;
+                if (fill > 0.985 || r >= first_r + 5 || sg == seg_floor) break;
             }
-            seg = (uint32_t)(best_seg ? best_seg : 32);
+            seg = (uint32_t)(best_seg ? best_seg : seg_floor);
         }
         q.seg = seg;
         q.tpw = (uint32_t)((n + seg - 1) / seg);  // threads per window (upper bound: <= n entries)
