@@ -134,7 +134,7 @@ struct Group {
         uint32_t nblocks2;                     // 0: serial - combine - level 2; else a second combine of nblocks2 workgroups
     };
 
-    static Geometry plan_geometry(const Context &ctx, uint32_t nw, size_t n, uint32_t NB) {
+    static Geometry plan_geometry(const Context &ctx, uint32_t nw, size_t n, uint32_t NB, bool shared_set = false) {
         Geometry q;
         // reduction: buckets per serial thread, L = 2^log2L; COMBINE_N of their (S, W) pairs per combine workgroup; the
         // last level (k_reduce2_q) takes at most RED2_TPB blocks per window, one quad each. Few windows of many buckets
@@ -225,6 +225,12 @@ struct Group {
             if (sizeof(U) <= 72 && n / NB <= 8) {
                 const size_t entries = (size_t)nw * n, cap_threads = cap_blocks * 256;
                 seg_floor = entries / 8 <= cap_threads ? 8 : entries / 16 <= cap_threads ? 16 : 32;
+            } else if (sizeof(U) <= 36 && shared_set) {
+                // the shared bucket set of the window tables is crowded by construction, but its chains are closed one
+                // thread per bucket (k_fixup_bucket): BN254 G1 2^14 0.456 -> 0.365 ms at 8, 2^16 0.472 -> 0.400 at 16
+                // (0.428 at 8), 2^17 and up best at 32
+                const size_t entries = (size_t)nw * n;
+                seg_floor = entries <= ((size_t)1 << 19) ? 8 : entries <= ((size_t)3 << 19) ? 16 : 32;
             }
             size_t best_seg = 0, first_r = 0;
             double best_fill = -1.0;
@@ -321,7 +327,7 @@ struct Group {
         const uint32_t NB = plan.nbuckets;
         constexpr size_t REC = sizeof(typename OpsSerial::Mem);  // bucket / partial record (lazy representation on the fast path)
 
-        const Geometry q = plan_geometry(ctx, nw, n, NB);
+        const Geometry q = plan_geometry(ctx, nw, n, NB, shared);
         const size_t tot_thr = (size_t)nw * q.tpw;
         const size_t tot_blk = (size_t)nw * q.nblocks1;
 
