@@ -387,6 +387,7 @@ static inline unsigned usable_cpus() {
 //   GMSM_MAX_RUN      lower the 2^27-point cap of one pipeline run  (tests of the point-range split)
 //   GMSM_HOST_RANGES  force the number of point ranges of a host-buffer call (tests)
 //   GMSM_DEVICES      devices the drop-in entries shard over, e.g. "0,1,2,3" (gmsm_set_devices overrides)
+//   GMSM_TABLES       window tables of registered bases: 0 never, 1 (default) the measured call sizes, 2 every size (tests)
 // Everything else that was a knob while the engine was being tuned is a compile-time constant now: tune_uint() returns
 // its default unless the library is built with -DGMSM_EXPERIMENTS (A/B builds, tools/build_ab.sh).
 static inline unsigned env_uint(const char *name, unsigned dflt) {
