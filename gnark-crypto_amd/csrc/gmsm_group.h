@@ -225,12 +225,14 @@ struct Group {
             if (sizeof(U) <= 72 && n / NB <= 8) {
                 const size_t entries = (size_t)nw * n, cap_threads = cap_blocks * 256;
                 seg_floor = entries / 8 <= cap_threads ? 8 : entries / 16 <= cap_threads ? 16 : 32;
-            } else if (sizeof(U) <= 36 && shared_set) {
+            } else if (sizeof(U) <= 72 && shared_set) {
                 // the shared bucket set of the window tables is crowded by construction, but its chains are closed one
                 // thread per bucket (k_fixup_bucket): BN254 G1 2^14 0.456 -> 0.365 ms at 8, 2^16 0.472 -> 0.400 at 16
-                // (0.428 at 8), 2^17 and up best at 32
+                // (0.428 at 8), 2^17 and up best at 32; BLS12-381 G1 2^15 0.775 -> 0.601 at 8, 2^16 0.817 -> 0.657 at 16;
+                // BN254 G2 (its one-lane additions cost three times as much) 2^15 1.088 -> 0.824 at 16, 2^16 best at 32
                 const size_t entries = (size_t)nw * n;
-                seg_floor = entries <= ((size_t)1 << 19) ? 8 : entries <= ((size_t)3 << 19) ? 16 : 32;
+                if (sizeof(U) <= 56) seg_floor = entries <= ((size_t)1 << 19) ? 8 : entries <= ((size_t)3 << 19) ? 16 : 32;
+                else seg_floor = entries <= ((size_t)3 << 18) ? 16 : 32;
             }
             size_t best_seg = 0, first_r = 0;
             double best_fill = -1.0;
