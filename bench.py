@@ -25,6 +25,14 @@ Rank 0 prints one JSON line.  Besides the contract fields it carries
   c_abi_sharded the same MultiExp through the drop-in C entry with the library itself spreading it over the devices
                 (gmsm_multiexp_sharded / gmsm_bases_register_sharded: one process, one host thread per device)
   replica_batch (--batch K) K MultiExp over the same registered bases spread over the ranks, one all-gather of results
+  fft           fr/fft beside the MSM (BN254 2^20 / 2^24, BLS12-381 and BW6-761 fr 2^24, one coset + inverse timing)
+  next_rows     SURVEY.md §8(f) N3 / N4-ingest: fixed-base batch 2^20 / 2^24, raw decode + validation 2^22, SRS dump 2^24
+  n24, tail     LAST keys of the line (the driver keeps the last 2000 characters): the 2^24 half of the metric in compact
+                form, and the headline's value_cold / value_warm_bases / bit_exact
+N > 1 adds backend / rccl_ranks / devices_seen (what the process group really was).  --oversubscribe (or
+GMSM_BENCH_SHARE_DEVICE=1): the rehearsal of the N > 1 path on fewer devices than ranks - rank r runs on device
+r % device_count, the process group is gloo (RCCL refuses two ranks on one device), everything else - shard_plan,
+Exchange, sharded_also, host_side_wait, c_abi_sharded, the JSON assembly - is the code the 8-GPU run executes.
 """
 import argparse
 import importlib
@@ -42,8 +50,9 @@ STAGES = ["decompose", "histogram", "scans", "scatter", "accumulate", "fixup", "
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md
 
 # BASELINE.json configs beyond the headline one: (curve, group, logn, steps, host-entry legs too)
-ALSO = [("bn254", "g1", 24, 5, True), ("bn254", "g1", 22, 5, True), ("bn254", "g1", 26, 3, False),
-        ("bls12_381", "g1", 22, 5, False), ("bls12_381", "g2", 22, 3, False), ("bw6_761", "g1", 20, 3, False)]
+# (BN254 G1 2^24 - the other half of BASELINE.json's metric - comes LAST: the driver keeps the tail of the line)
+ALSO = [("bn254", "g1", 22, 5, True), ("bn254", "g1", 26, 3, False), ("bls12_381", "g1", 22, 5, False),
+        ("bls12_381", "g2", 22, 3, False), ("bw6_761", "g1", 20, 3, False), ("bn254", "g1", 24, 5, True)]
 
 
 def uniform_scalars(rng, g, n):
@@ -154,7 +163,7 @@ def median_ms(fn, reps=5):
 
 def tables_record(gm, g, d_pts, d_sc, sc, n, stream, jac, steps):
     """MultiExp over registered bases with window tables: ms with the scalars resident / in host memory / two tickets in
-    flight, against the same handle without tables (GMSM_TABLES=0), result compared with the headline call's."""
+    flight, against the same handle without tables (GMSM_OPT_TABLES = 0), result compared with the headline call's."""
     import torch
     rb = g.register_bases(d_points=d_pts.data_ptr(), n=n)
     try:
@@ -191,12 +200,9 @@ def tables_record(gm, g, d_pts, d_sc, sc, n, stream, jac, steps):
         used = int(gm._lib.load().gmsm_debug_table_runs()) > runs0
         host_ms = median_ms(lambda: rb.MultiExp(sc, cfg))
         fl_ms, j2 = in_flight_ms()
-        os.environ["GMSM_TABLES"] = "0"
-        try:
+        with gm.options(tables=0):
             plain_ms, _ = resident_ms()
             plain_host_ms = median_ms(lambda: rb.MultiExp(sc, cfg))
-        finally:
-            del os.environ["GMSM_TABLES"]
         ref = g.jac_to_affine(jac)
         return {"window_bits": c, "slabs": g.num_windows(c), "table_bytes": g.num_windows(c) * n * g.aff_limbs * 8,
                 "build_ms": round(build_ms, 1), "through_tables": used,
@@ -315,7 +321,14 @@ def c_abi_sharded(gm, g, pts, sc, devices, reference_affine, reps=5):
                                                                and (g.jac_to_affine(jw) == reference_affine).all())}
 
 
-def sharded_also(gm, torch, dist, sharding, rank, world, local_rank, mode, logn=24, steps=5):
+def dist_max(torch, dist, seconds):
+    """max over the ranks of a host-side duration (the tensor lives where the process group's backend wants it)."""
+    t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sharded_also(gm, torch, dist, sharding, rank, world, dev_index, mode, rank_devices, logn=24, steps=5):
     """BASELINE.json configs[2]: BN254 G1 2^logn as ONE MultiExp over all ranks, timed like the headline loop (barrier +
     synchronize on both sides, max over ranks). Every rank builds the same bases [a_i]G on its device from the same
     seed; the result is checked against the closed form [sum a_i b_i]G on rank 0."""
@@ -332,7 +345,7 @@ def sharded_also(gm, torch, dist, sharding, rank, world, local_rank, mode, logn=
     d_pts = torch.empty((hi - lo, g.aff_limbs), dtype=torch.int64, device="cuda")
     g.batch_scalar_mul_device(g.generator, d_a.data_ptr(), hi - lo, d_pts.data_ptr(), stream)
     del d_a
-    exchange = sharding.Exchange(dist, torch.device("cuda", local_rank), plan["rows"], g.xyzz_limbs)
+    exchange = sharding.Exchange(dist, torch.device("cuda", dev_index), plan["rows"], g.xyzz_limbs)
 
     def enqueue(plan_, local):
         g.window_sums_enqueue(d_pts.data_ptr(), d_b.data_ptr(), hi - lo, plan_["c"], plan_["win_first"], plan_["win_stride"],
@@ -352,10 +365,8 @@ def sharded_also(gm, torch, dist, sharding, rank, world, local_rank, mode, logn=
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    out = {"workload": f"BN254 G1 MultiExp 2^{logn} points, {plan['mode']}-sharded x{world} + one RCCL all-gather",
+        dt = dist_max(torch, dist, dt)
+    out = {"workload": f"BN254 G1 MultiExp 2^{logn} points, {plan['mode']}-sharded x{world} + one all-gather ({dist.get_backend()})",
            "value": steps / dt, "unit": "MSM/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "n_gpus": world,
            "scaling": "strong"}
     expected = None
@@ -374,7 +385,7 @@ def sharded_also(gm, torch, dist, sharding, rank, world, local_rank, mode, logn=
         pts_host = d_p0.cpu().numpy().view(np.uint64)
         del d_a0, d_p0
         torch.cuda.empty_cache()
-        return c_abi_sharded(gm, g, pts_host, b, list(range(world)), expected, reps=3)
+        return c_abi_sharded(gm, g, pts_host, b, rank_devices, expected, reps=3)
     if world > 1:
         rec = host_side_wait(dist, rank, f"c_abi_{logn}", through_the_c_abi)
         if rank == 0:
@@ -413,6 +424,141 @@ def fft_config(gm, torch, curve="bn254", logn=24, reps=5):
             "round_trip_exact": ok}
 
 
+def fft_extra(gm, torch, curve, logn=24, reps=3):
+    """One coset transform and its inverse (FFT(DIF, OnCoset) then FFTInverse(DIT, OnCoset), fft.go:31-196) on 2^logn resident
+    elements: both timings and the exact round trip."""
+    c = gm.CURVES[curve]
+    n = 1 << logn
+    rng = np.random.default_rng([0x666674, logn, 1])
+    a = rng.integers(0, 2**64, size=(n, c.fr_limbs), dtype=np.uint64)
+    a[:, -1] &= np.uint64((1 << (c.fr_bits - 64 * (c.fr_limbs - 1) - 1)) - 1)
+    t = torch.from_numpy(a.view(np.int64)).cuda()
+    d = gm.fft.NewDomain(curve, n)
+    stream = torch.cuda.current_stream().cuda_stream
+    coset = gm.fft.OnCoset()
+    d.fft_device(t.data_ptr(), gm.fft.DIF, coset, stream=stream)  # first use builds the coset tables
+    d.fft_device(t.data_ptr(), gm.fft.DIT, coset, inverse=True, stream=stream)
+    ok = bool((t.cpu().numpy().view(np.uint64) == a).all())
+    fwd = inv = 0.0
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        d.fft_device(t.data_ptr(), gm.fft.DIF, coset, stream=stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        d.fft_device(t.data_ptr(), gm.fft.DIT, coset, inverse=True, stream=stream)
+        torch.cuda.synchronize()
+        fwd += (t1 - t0) * 1e3 / reps
+        inv += (time.perf_counter() - t1) * 1e3 / reps
+    d.release()
+    return {"workload": f"{curve.upper()} fr coset FFT (DIF) + coset FFTInverse (DIT), 2^{logn} elements resident in HBM",
+            "coset_fft_ms": fwd, "coset_inverse_ms": inv, "round_trip_exact": ok}
+
+
+MEASURED_MULMOD_PER_S = 174e9  # bare 9x29-bit lazy product on this chip (tools/ubench_fpmul.hip, profiles/peaks_r02.json)
+
+
+def next_rows(gm, lib, torch):
+    """SURVEY.md §8(f) N3 / N4-ingest next to the MSM, BN254 G1: the fixed-base batch that builds an SRS
+    (BatchScalarMultiplicationG1, ecc/bn254/g1.go:1039-1118), the raw wire format -> validated limbs
+    (marshal.go:826, Decoder checks :69-350) and an SRS dump streamed into HBM (kzg/marshal.go:98-113)."""
+    g = gm.G1Jac("bn254")
+    out = {}
+    stream = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng([0x6E6578, 1])
+    # ---- N3: out[i] = a_i * G on the device, 2^20 and 2^24 scalars
+    keep = None
+    for logn in (20, 24):
+        n = 1 << logn
+        a = uniform_scalars(rng, g, n)
+        d_a = torch.from_numpy(a.view(np.int64)).cuda()
+        d_p = torch.empty((n, g.aff_limbs), dtype=torch.int64, device="cuda")
+        g.batch_scalar_mul_device(g.generator, d_a.data_ptr(), n, d_p.data_ptr(), stream)
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            g.batch_scalar_mul_device(g.generator, d_a.data_ptr(), n, d_p.data_ptr(), stream)  # returns when complete
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        c = 8 if logn < 21 else 11  # Group::batch_scalar_mul: table width by batch size
+        nwin = (g.curve.fr_bits + c - 1) // c
+        prods = n * (nwin * 10 + 9)  # nwin mixed additions (8M + 2S) + the shared-inversion normalisation (~9 products a point)
+        # closed form: sum_i a_i G = (sum a_i) G, checked through a MultiExp with all-ones scalars against the oracle
+        out[f"batch_scalar_mul_device_2p{logn}"] = {
+            "ms": ms, "points_per_s": n / (ms * 1e-3), "window_bits": c, "mixed_adds_per_point": nwin,
+            "mulmod_per_s": prods / (ms * 1e-3), "frac_of_measured_multiplier_rate": prods / (ms * 1e-3) / MEASURED_MULMOD_PER_S,
+            "includes": "host build of the 2^(c-1) x nwin table + its upload, k_fixed_base, batch normalisation"}
+        if logn == 24:
+            keep = d_p
+        del d_a
+    # ---- N4: raw decode + checks at 2^22 (wire bytes built from the device-made points above)
+    n = 1 << 22
+    pts = keep[:n].cpu().numpy().view(np.uint64)  # Montgomery limbs, X | Y
+    reg = np.zeros_like(pts).reshape(-1, g.curve.fp_limbs)
+    rc = lib.gmsm_debug_field_op(g.gid, 0, 6, pts.ctypes.data, None, reg.shape[0], reg.ctypes.data)  # fromMont
+    assert rc == 0, gm._lib.last_error()
+    raw = np.ascontiguousarray(reg[:, ::-1]).byteswap().view(np.uint8).reshape(-1)  # big-endian, most significant limb first
+    d_out = torch.empty((n, g.aff_limbs), dtype=torch.int64, device="cuda")
+    bad = _ct.c_int64(-1)
+    raw_bytes = raw.size
+    for level, name in ((0, "decode_only"), (2, "decode_curve_subgroup")):
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rc = lib.gmsm_points_from_raw(g.gid, raw.ctypes.data, n, level, None, d_out.data_ptr(), _ct.byref(bad))
+            ts.append((time.perf_counter() - t0) * 1e3)
+            assert rc == 0, gm._lib.last_error()
+        ms = sorted(ts)[1]
+        out[f"points_from_raw_2p22_{name}"] = {"ms": ms, "GB_per_s_in": raw_bytes / (ms * 1e-3) / 1e9, "points_per_s": n / (ms * 1e-3),
+                                              "source": "pageable host memory (PCIe-inclusive)"}
+    same = bool((d_out.cpu().numpy().view(np.uint64) == pts).all())
+    out["points_from_raw_2p22_decode_curve_subgroup"]["equal_to_source_points"] = same
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        rc = lib.gmsm_points_validate(g.gid, None, keep.data_ptr(), n, 2, _ct.byref(bad))
+        ts.append((time.perf_counter() - t0) * 1e3)
+        assert rc == 0, gm._lib.last_error()
+    ms = sorted(ts)[1]
+    # [r]P by double-and-add: 254 doublings (9 products, dbl-2008-s-1) + ~127 mixed additions (10) per point, and the curve equation
+    prods = n * (254 * 9 + 127 * 10 + 3)
+    out["points_validate_2p22_level2_resident"] = {
+        "ms": ms, "points_per_s": n / (ms * 1e-3), "GB_per_s": n * 64 / (ms * 1e-3) / 1e9, "frac_of_hbm": n * 64 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        "mulmod_per_s": prods / (ms * 1e-3), "frac_of_measured_multiplier_rate": prods / (ms * 1e-3) / MEASURED_MULMOD_PER_S,
+        "note": "[r]P = infinity by double-and-add on saturated limbs: compute-bound by construction, the HBM fraction is reported for the contract"}
+    del d_out, raw, reg
+    # ---- N4: SRS dump (marker | length | raw []G1Affine memory) of 2^24 points, from the page cache into HBM
+    import tempfile
+    n = 1 << 24
+    host = keep.cpu().numpy().view(np.uint64)
+    del keep
+    torch.cuda.empty_cache()
+    with tempfile.NamedTemporaryFile(prefix="gmsm_srs_", suffix=".dump", delete=False) as f:
+        f.write(np.array([0xDEADBEEF, n], dtype=np.uint64).tobytes())
+        f.write(memoryview(host).cast("B"))
+        path = f.name
+    try:
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rb, err = g.register_bases_dump(path, 0, True, 0, 0)
+            ts.append((time.perf_counter() - t0) * 1e3)
+            assert err is None, err
+            if len(ts) < 3:
+                rb.release()
+        ms = sorted(ts)[1]
+        ones = np.zeros((4096, g.fr_limbs), dtype=np.uint64)
+        ones[:] = np.array([(g.curve.fr_R % g.curve.r >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(g.fr_limbs)], dtype=np.uint64)
+        j_dump, _ = rb.MultiExp(ones)
+        j_host, _ = g.MultiExp(host[:4096], ones)
+        rb.release()
+        out["bases_register_dump_2p24"] = {"ms": ms, "GB_per_s": (16 + n * 64) / (ms * 1e-3) / 1e9, "bytes": 16 + n * 64,
+                                          "source": "file in the page cache -> two pinned 32 MiB buffers -> HBM -> lazy-domain rewrite",
+                                          "prefix_multiexp_equal_to_host_points": bool((g.jac_to_affine(j_dump) == g.jac_to_affine(j_host)).all())}
+    finally:
+        os.unlink(path)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -431,6 +577,10 @@ def main():
                     help="register the bases once (gmsm_bases_register) and time MultiExp over the resident form")
     ap.add_argument("--batch", type=int, default=0,
                     help="also time K MultiExp over the same registered bases spread over the ranks (replica mode)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="N>1 rehearsal on fewer devices than ranks: rank r on device r %% device_count, gloo process group")
+    ap.add_argument("--also-logn", type=int, default=24, help="N>1: size of the second sharded MultiExp (the 2^24 half of the metric)")
+    ap.add_argument("--no-next-rows", action="store_true", help="skip the N3 / N4-ingest rows")
     ap.add_argument("--curve", default="bn254", help="exploration only: bn254 | bls12_381 | bw6_761")
     ap.add_argument("--group", default="g1", help="exploration only: g1 | g2")
     args = ap.parse_args()
@@ -446,12 +596,14 @@ def main():
     import torch
     import torch.distributed as dist
 
+    share = args.oversubscribe or os.environ.get("GMSM_BENCH_SHARE_DEVICE") == "1"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher (one rank per GPU, RCCL over xGMI); rank 0 of the
         # relaunched job prints the JSON line on this process's stdout
         have = torch.cuda.device_count()
-        if have < args.gpus:
-            raise SystemExit(f"bench.py --gpus {args.gpus}: needs {args.gpus} devices, this machine exposes {have}")
+        if have < args.gpus and not (share and have >= 1):
+            raise SystemExit(f"bench.py --gpus {args.gpus}: needs {args.gpus} devices, this machine exposes {have} "
+                             "(--oversubscribe rehearses the N > 1 path on fewer)")
         import socket
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
@@ -464,17 +616,28 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: the two must agree")
-    if torch.cuda.device_count() <= local_rank:
-        raise SystemExit(f"bench.py: rank {rank} needs device {local_rank}, this machine exposes {torch.cuda.device_count()}")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    if ndev < 1 or (ndev <= local_rank and not share):
+        raise SystemExit(f"bench.py: rank {rank} needs device {local_rank}, this machine exposes {ndev}")
+    dev_index = local_rank % ndev if share else local_rank
+    # RCCL refuses two ranks on one device: a rehearsal with more ranks than devices runs its collectives over gloo
+    backend = "gloo" if (share and world > ndev) else "nccl"
+    torch.cuda.set_device(dev_index)
+    rank_devices = [dev_index]
     if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        seen = [None] * world
+        dist.all_gather_object(seen, (dev_index, ndev))
+        rank_devices = [d for d, _ in seen]
 
     gm = importlib.import_module("gnark-crypto_amd")
     lib = gm._lib.load()
-    assert lib.gmsm_set_device(local_rank) == 0, gm._lib.last_error()
+    assert lib.gmsm_set_device(dev_index) == 0, gm._lib.last_error()
     g = (gm.G1Jac if args.group == "g1" else gm.G2Jac)(args.curve)
     n = 1 << args.logn
 
@@ -498,7 +661,7 @@ def main():
         # the device until ONE RCCL all-gather; every rank folds.
         plan = sharding.shard_plan(g, n, rank, world, args.shard)
         c, nwin = plan["c"], plan["nwin"]
-        exchange = sharding.Exchange(dist, torch.device("cuda", local_rank), plan["rows"], g.xyzz_limbs)
+        exchange = sharding.Exchange(dist, torch.device("cuda", dev_index), plan["rows"], g.xyzz_limbs)
         d_pts_loc, d_sc_loc, n_loc = d_pts[plan["lo"]:plan["hi"]], d_sc[plan["lo"]:plan["hi"]], plan["hi"] - plan["lo"]
 
     resident = None
@@ -542,9 +705,7 @@ def main():
     stages, _ = prof.stop()
     stages["accumulate"] = acc_only["accumulate"]  # the roofline's kernel duration is the timed region's
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt = dist_max(torch, dist, dt)
 
     # Two MultiExp calls in flight over resident bases (gmsm_multiexp_bases_submit/_collect): reported beside the
     # headline number, never instead of it. Every one of the K calls is submitted and collected inside the timed region.
@@ -624,8 +785,8 @@ def main():
             res, err = rbk.MultiExpBatch(d_scalars=d_vecs.data_ptr(), n=n, k=len(mine), stream=stream)
             assert err is None, err
             return res
-        gather = (sharding.torch_all_gather(dist, torch.device("cuda", local_rank)) if dist.is_initialized()
-                  else (lambda buf: buf[None]))
+        gather = (sharding.torch_all_gather(dist, torch.device("cpu") if backend == "gloo" else torch.device("cuda", dev_index))
+                  if dist.is_initialized() else (lambda buf: buf[None]))
         sharding.replicated_batch(K, rank, world, g.jac_limbs, local_batch, gather)
         barrier()
         tr0 = time.perf_counter()
@@ -633,9 +794,7 @@ def main():
         barrier()
         dtr = time.perf_counter() - tr0
         if world > 1:
-            tmax = torch.tensor([dtr], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dtr = float(tmax.item())
+            dtr = dist_max(torch, dist, dtr)
         replica = {"k": K, "value": K / dtr, "unit": "MSM/s", "ms_per_msm": dtr / K * 1e3, "n_gpus": world,
                    "scaling": "weak over K (every vector is a whole MultiExp on one GPU; no data-path collective)",
                    "equal_to_serial_result": bool(all((g.jac_to_affine(r_) == g.jac_to_affine(jac)).all() for r_ in resk))}
@@ -670,7 +829,7 @@ def main():
     c_abi = None
     if not args.no_host_entry:
         def through_the_c_abi():
-            return c_abi_sharded(gm, g, pts, sc, list(range(world)) if world > 1 else [0, 0], g.jac_to_affine(jac))
+            return c_abi_sharded(gm, g, pts, sc, rank_devices if world > 1 else [dev_index, dev_index], g.jac_to_affine(jac))
         if world > 1:
             barrier()
             c_abi = host_side_wait(dist, rank, "c_abi_headline", through_the_c_abi)
@@ -681,7 +840,7 @@ def main():
     also_sharded = None
     if sharded and not args.no_also and (args.curve, args.group) == ("bn254", "g1"):
         del d_pts_loc, d_sc_loc
-        also_sharded = sharded_also(gm, torch, dist, sharding, rank, world, local_rank, args.shard)
+        also_sharded = sharded_also(gm, torch, dist, sharding, rank, world, dev_index, args.shard, rank_devices, logn=args.also_logn)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -696,7 +855,8 @@ def main():
             "config": {"workload": f"{args.curve.upper()} {args.group.upper()} MultiExp 2^{args.logn} points, bases+scalars resident in HBM",
                        "arithmetic": f"{g.curve.p.bit_length()}-bit Montgomery field on 32-bit words (lazy 28/29-bit limbs, v_mad_u64_u32)",
                        "points": n, "window_bits": c, "windows": nwin, "resident_bases": resident is not None,
-                       "parallelism": "single GPU" if not sharded else f"{plan['mode']}-sharded x{world} + one RCCL all-gather"},
+                       "parallelism": "single GPU" if not sharded else
+                                      f"{plan['mode']}-sharded x{world} + one {'RCCL' if backend == 'nccl' else backend} all-gather"},
             "value_cold": host_entry["cold_msm_per_s"] if host_entry else None,
             "value_warm_bases": host_entry["warm_bases_msm_per_s"] if host_entry else None,
             "points_per_s": value * n,
@@ -712,20 +872,55 @@ def main():
                                         measured_traffic(args.curve, args.group, args.logn, world, nwin)),
             "int_roofline": int_roofline_record(my_pairs, stages["accumulate"]),
         }
+        tail = {}
         if sharded:
+            # what the process group really was: the SCALE record shows that RCCL saw N ranks on N devices
+            out["backend"] = dist.get_backend()
+            out["rccl_ranks"] = dist.get_world_size() if dist.get_backend() == "nccl" else 0
+            out["devices_seen"] = rank_devices
+            out["device_count"] = ndev
+            out["oversubscribed"] = bool(world > ndev)
             # the sharded result against the same MultiExp computed by this rank alone (after the timed region)
             single = g.multiexp_device(d_pts.data_ptr(), d_sc.data_ptr(), n, stream)
             out["equal_to_single_gpu_result"] = bool((g.jac_to_affine(single) == g.jac_to_affine(jac)).all())
             if also_sharded is not None:
                 out["also"] = [also_sharded]
+                cab = also_sharded.get("c_abi_sharded") or {}
+                out["n24"] = {"workload": also_sharded["workload"], "ms_per_step": round(also_sharded["ms_per_step"], 4),
+                              "value": round(also_sharded["value"], 3), "bit_exact": also_sharded.get("bit_exact"),
+                              "c_abi_cold_ms": cab.get("cold_ms"), "c_abi_warm_bases_ms": cab.get("warm_bases_ms"),
+                              "c_abi_equal_to_reference_result": cab.get("equal_to_reference_result")}
+            tail = {"backend": out["backend"], "rccl_ranks": out["rccl_ranks"], "devices_seen": rank_devices,
+                    "equal_to_single_gpu_result": out["equal_to_single_gpu_result"],
+                    "c_abi_equal_to_reference_result": (c_abi or {}).get("equal_to_reference_result")}
         if world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline(g, pts, sc, jac, args.curve, args.group))
         if world == 1 and not sharded and not args.no_also:
             del d_pts, d_sc, pts
             torch.cuda.empty_cache()
+            out["fft"] = [fft_config(gm, torch, "bn254", 20), fft_config(gm, torch, "bn254", 24),
+                          fft_config(gm, torch, "bls12_381", 24, reps=3), fft_config(gm, torch, "bw6_761", 24, reps=3),
+                          fft_extra(gm, torch, "bn254", 24)]
+            if not args.no_next_rows:
+                out["next_rows"] = next_rows(gm, lib, torch)
+                torch.cuda.empty_cache()
             out["also"] = [also_config(gm, lib, torch, *cfg_) for cfg_ in ALSO
                            if (cfg_[0], cfg_[1], cfg_[2]) != (args.curve, args.group, args.logn)]
-            out["fft"] = [fft_config(gm, torch, "bn254", 20), fft_config(gm, torch, "bn254", 24)]
+            r24 = next((r for r in out["also"] if r["workload"].startswith("BN254 G1 MultiExp 2^24")), None)
+            if r24 is not None:  # the 2^24 half of BASELINE.json's metric once more, compact, where the driver's tail keeps it
+                out["n24"] = {"ms_per_step": round(r24["ms_per_step"], 4), "value": round(r24["value"], 3),
+                              "value_warm_bases": round(r24.get("value_warm_bases", 0.0), 3), "value_cold": round(r24.get("value_cold", 0.0), 3),
+                              "roofline_frac": round(r24["roofline"]["frac"], 5), "roofline_traffic": r24["roofline"]["traffic"],
+                              "accumulate_ms": round(r24["roofline"]["avg_launch_ms"], 4), "window_bits": r24["window_bits"],
+                              "cpu_baseline_value": round(r24.get("cpu_baseline", {}).get("value", 0.0), 4),
+                              "cpu_cores": r24.get("cpu_baseline", {}).get("cores"), "bit_exact": r24["bit_exact"],
+                              "bit_exact_vs_cpu_port": r24.get("bit_exact_vs_cpu_port")}
+        # the headline's PCIe-inclusive rates and its parity verdict go last as well
+        for k in ("value_cold", "value_warm_bases", "bit_exact"):
+            if k in out:
+                tail[k] = out[k]
+        tail.update({"value": round(value, 3), "ms_per_step": round(ms_per_step, 4), "n_gpus": world})
+        out["tail"] = tail
         print(json.dumps(out), file=json_out, flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "gmsm_bases_register_dump", "gmsm_fft_domain_new", "gmsm_fft_domain_release", "gmsm_fft_domain_info", "gmsm_fft",
     "gmsm_fft_bit_reverse",
     "gmsm_bases_precompute", "gmsm_bases_table_bits", "gmsm_debug_table_runs", "gmsm_multiexp_sharded", "gmsm_bases_register_sharded", "gmsm_multiexp_bases_sharded", "gmsm_set_devices",
-    "gmsm_get_devices",
+    "gmsm_get_devices", "gmsm_set_option", "gmsm_get_option", "gmsm_trim", "gmsm_shutdown",
     "gmsm_device_count", "gmsm_set_device", "gmsm_last_error",
     "gmsm_version",
 ]
@@ -166,6 +166,14 @@ def load():
     L.gmsm_set_devices.argtypes = [ip, ctypes.c_int]
     L.gmsm_get_devices.restype = ctypes.c_int
     L.gmsm_get_devices.argtypes = [ip, ctypes.c_int]
+    L.gmsm_set_option.restype = ctypes.c_int
+    L.gmsm_set_option.argtypes = [ctypes.c_int, ctypes.c_uint]
+    L.gmsm_get_option.restype = ctypes.c_uint
+    L.gmsm_get_option.argtypes = [ctypes.c_int]
+    L.gmsm_trim.restype = ctypes.c_int
+    L.gmsm_trim.argtypes = [sz, ctypes.POINTER(sz)]
+    L.gmsm_shutdown.restype = ctypes.c_int
+    L.gmsm_shutdown.argtypes = []
     L.gmsm_device_count.restype = ctypes.c_int
     L.gmsm_set_device.restype = ctypes.c_int
     L.gmsm_set_device.argtypes = [ctypes.c_int]
@@ -189,3 +197,51 @@ def effective_cpus():
 
 def last_error():
     return load().gmsm_last_error().decode()
+
+
+# enum gmsm_option (include/gmsm.h)
+OPTIONS = {"window_bits": 0, "tables": 1, "max_run": 2, "host_ranges": 3, "fixed_base_bits": 4}
+
+
+def set_option(name, value):
+    rc = load().gmsm_set_option(OPTIONS[name], int(value))
+    if rc:
+        raise ValueError("gmsm: " + last_error())
+
+
+def get_option(name):
+    return int(load().gmsm_get_option(OPTIONS[name]))
+
+
+class options:
+    """with options(window_bits=11, max_run=4096): ...  - process-wide switches of the library (gmsm_set_option), restored
+    on exit.  The tests reach the point-range splits and the forced widths through this, not through the environment."""
+
+    def __init__(self, **kw):
+        self.kw, self.old = kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.old[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
+
+
+def trim(keep_bytes=0):
+    """gmsm_trim: scratch of the idle workspaces back to the device; returns the bytes released."""
+    freed = ctypes.c_size_t(0)
+    rc = load().gmsm_trim(keep_bytes, ctypes.byref(freed))
+    if rc:
+        raise RuntimeError("gmsm: " + last_error())
+    return int(freed.value)
+
+
+def shutdown():
+    rc = load().gmsm_shutdown()
+    if rc:
+        raise RuntimeError("gmsm: " + last_error())

@@ -43,12 +43,27 @@ struct DeviceBuffer {
         cap = want;
         return GMSM_OK;
     }
-    void release() {  // caller has made sure nothing on the device still uses the buffer
+    size_t release() {  // caller has made sure nothing on the device still uses the buffer; returns the bytes given back
+        const size_t had = cap;
         if (ptr) (void)hipFree(ptr);
         ptr = nullptr;
         cap = 0;
+        return had;
     }
 };
+
+// Process-wide switches (gmsm_set_option / gmsm_get_option, include/gmsm.h). The two a deployment may want - the window
+// width and the window-table policy - take their initial value from the environment ONCE, when the library is loaded
+// (GMSM_C, GMSM_TABLES); nothing on a call path reads the environment. The other two exist for the tests of the
+// point-range splits.
+struct Options {
+    std::atomic<unsigned> window_bits{0};  // GMSM_OPT_WINDOW_BITS: 0 = the measured table (preferred_c), 2..20 forced
+    std::atomic<unsigned> tables{1};       // GMSM_OPT_TABLES: 0 never, 1 the measured call sizes, 2 every size
+    std::atomic<unsigned> max_run{0};      // GMSM_OPT_MAX_RUN: lower the 2^27-point cap of one pipeline run (0 = off)
+    std::atomic<unsigned> host_ranges{0};  // GMSM_OPT_HOST_RANGES: force the point ranges of a host-buffer call (0 = off)
+    std::atomic<unsigned> fixed_base_bits{0};  // GMSM_OPT_FIXED_BASE_BITS: table width of the fixed-base batch (0 = by size)
+};
+Options &options();
 
 extern std::atomic<unsigned long> g_table_runs;  // pipeline runs that went through window tables (gmsm_debug_table_runs)
 
@@ -63,7 +78,12 @@ struct ResidentBases {
     DeviceBuffer upoints, skip;
     // window tables (gmsm_bases_precompute; Group::precompute_tables): slab w = 2^(tab_c w) P_i, same packed layout as
     // upoints, tab_nw slabs of n points; tab_c == 0: none
-    unsigned tab_c = 0, tab_nw = 0;
+    // tab_c is the publication point: written last (release) by precompute_tables, so a MultiExp running on another
+    // thread either sees 0 and takes the plain path or sees the width with complete tables behind it. tab_mu serialises
+    // concurrent gmsm_bases_precompute calls on one handle.
+    std::atomic<unsigned> tab_c{0};
+    unsigned tab_nw = 0;
+    std::mutex tab_mu;
     DeviceBuffer tables;
     ResidentBases() = default;
     ResidentBases(const ResidentBases &) = delete;
@@ -115,7 +135,7 @@ struct FftDomain {
 };
 
 // Everything one in-flight MultiExp needs on the device: scratch buffers, a pinned host buffer for the window totals, a
-// stream of its own (used when the caller gives none) and the stage events. A context owns two of them so that the
+// stream of its own (used when the caller gives none) and the stage events. A context owns three of them so that the
 // asynchronous entry points (gmsm_multiexp_bases_submit / _collect) can keep two MultiExp calls in flight: the sort and
 // accumulation of call i+1 overlap the latency-bound reduction, the copy-back and the host fold of call i.
 struct Workspace {
@@ -137,6 +157,7 @@ struct Workspace {
     DeviceBuffer h2d_points, h2d_scalars;  // staging of the host-pointer entries
     DeviceBuffer raw_bytes, flagword;      // point ingest: wire-format bytes, first-offender word
     bool busy = false;  // leased to a call (Context::acquire / release)
+    bool ticket = false;  // ... by gmsm_multiexp_bases_submit: only gmsm_multiexp_collect ends that lease
     // state of a submitted, not yet collected call
     bool pending = false;
     int pending_group = -1;
@@ -149,6 +170,39 @@ struct Workspace {
     hipEvent_t last_use = nullptr;     // recorded after the last call enqueued on this workspace ...
     hipStream_t last_stream = nullptr; // ... on this stream: a call on another stream waits for it first
     bool pending_timed = false;
+    // gmsm_trim / gmsm_shutdown: give back every scratch buffer larger than `keep` bytes (the caller holds the lease and
+    // has synchronised the workspace's streams). Returns the device bytes released.
+    size_t trim(size_t keep) {
+        DeviceBuffer *all[] = {&upoints, &skip, &seg_lvl, &seg_partials, &seg_flags, &seg_bucket, &parted, &digits, &sorted,
+                               &blockhist, &counts, &starts, &buckets, &partials, &totals, &red_pre, &carry, &h2d_points,
+                               &h2d_scalars, &raw_bytes, &flagword};
+        size_t freed = 0;
+        for (DeviceBuffer *b : all)
+            if (b->cap > keep) freed += b->release();
+        if (pinned && pinned_cap > keep) {
+            (void)hipHostFree(pinned);
+            pinned = nullptr;
+            pinned_cap = 0;
+        }
+        return freed;
+    }
+    void destroy() {  // gmsm_shutdown: streams and events too
+        (void)trim(0);
+        hipEvent_t *evs[] = {&ev_buckets, &ev_merged, &dep, &last_use};
+        for (hipEvent_t *e : evs) {
+            if (*e) (void)hipEventDestroy(*e);
+            *e = nullptr;
+        }
+        for (auto &e : events) {
+            if (e) (void)hipEventDestroy(e);
+            e = nullptr;
+        }
+        if (stream) (void)hipStreamDestroy(stream);
+        if (mstream) (void)hipStreamDestroy(mstream);
+        stream = mstream = nullptr;
+        last_stream = nullptr;
+        bases_ref.reset();
+    }
     int ensure_pinned(size_t bytes) {
         if (bytes <= pinned_cap) return GMSM_OK;
         if (pinned) HIP_TRY(hipHostFree(pinned));
@@ -159,14 +213,20 @@ struct Workspace {
     }
 };
 
-// One per device. Calls lease one of the two workspaces for their duration; the context lock protects nothing but the
+// One per device. Calls lease one of the workspaces for their duration; the context lock protects nothing but the
 // lease table, so two callers (two goroutines calling MultiExp, or the submit/collect pair) really overlap on the GPU:
 // each runs on its workspace's stream, and the host-side wait, copy-back and fold of one happen while the other computes.
+// THREE workspaces, of which submitted tickets may hold at most two (MAX_TICKETS): a blocking entry therefore always finds
+// a workspace that only blocking callers cycle through, and never has to wait for somebody's gmsm_multiexp_collect.
+// (Round 3 had two workspaces and a 2 s give-up timer for the case "both are uncollected tickets"; a slow collector then
+// turned into a spurious error for an unrelated caller.) Scratch is allocated on first use, so an unused third
+// workspace costs two streams and two events.
 struct Context {
+    static constexpr int NUM_WS = 3, MAX_TICKETS = 2;
     std::mutex mu;
     std::condition_variable cv;
     int device = -1;
-    Workspace ws[2];
+    Workspace ws[NUM_WS];
     int num_cus = 256;
     int init(int dev) {
         device = dev;
@@ -193,37 +253,32 @@ struct Context {
         lds_allowed.push_back(kernel);
         return GMSM_OK;
     }
-    // wait = false: nullptr when both workspaces are leased.
-    // wait = true: blocks until a workspace is free. The one case that cannot be waited out: both leases are submitted
-    // tickets (only gmsm_multiexp_collect ends those) and their holder is the caller itself - it would wait for its own
-    // collect. Callers are goroutines that migrate between OS threads, so the holder cannot be told from a thread id:
-    // instead the wait gives up (nullptr -> GMSM_ERR_ARG) once both workspaces have been uncollected tickets for
-    // TICKET_WAIT_MS without interruption; tickets of a caller that is about to collect them are waited for as usual.
-    static constexpr int TICKET_WAIT_MS = 2000;
-    Workspace *acquire(bool wait) {
+    // for_ticket (gmsm_multiexp_bases_submit; never waits): nullptr when MAX_TICKETS tickets are outstanding or no
+    // workspace is free right now. Otherwise wait = false: nullptr when every workspace is leased; wait = true: blocks
+    // until one is free - which always happens, because at least one workspace is never held by a ticket.
+    Workspace *acquire(bool wait, bool for_ticket = false) {
         std::unique_lock<std::mutex> lk(mu);
-        int stuck_ms = 0;
         for (;;) {
+            if (for_ticket) {
+                int out = 0;
+                for (auto &w : ws) out += (w.busy && w.ticket) ? 1 : 0;
+                if (out >= MAX_TICKETS) return nullptr;
+            }
             for (auto &w : ws)
                 if (!w.busy) {
                     w.busy = true;
+                    w.ticket = for_ticket;
                     return &w;
                 }
-            if (!wait) return nullptr;
-            if (ws[0].pending && ws[1].pending) {
-                if (stuck_ms >= TICKET_WAIT_MS) return nullptr;
-                cv.wait_for(lk, std::chrono::milliseconds(50));
-                stuck_ms += 50;
-            } else {
-                stuck_ms = 0;
-                cv.wait(lk);
-            }
+            if (!wait || for_ticket) return nullptr;
+            cv.wait(lk);
         }
     }
     void release(Workspace *w) {
         {
             std::lock_guard<std::mutex> lk(mu);
             w->busy = false;
+            w->ticket = false;
             w->pending = false;
         }
         cv.notify_all();
@@ -238,7 +293,7 @@ struct Lease {
     // work before touching any scratch buffer (entries that run on another stream do the same through begin_use).
     // A reference to registered bases that an enqueue-only call parked on the workspace is dropped here, outside the
     // context lock (the last owner's destructor synchronises the device before it frees the SRS).
-    Lease(Context &c, bool wait = true) : ctx(c), w(c.acquire(wait)) {
+    Lease(Context &c, bool wait = true, bool for_ticket = false) : ctx(c), w(c.acquire(wait, for_ticket)) {
         if (!w) return;
         if (w->last_use && w->last_stream != w->stream) (void)hipStreamWaitEvent(w->stream, w->last_use, 0);
         std::shared_ptr<ResidentBases> parked;
@@ -258,7 +313,7 @@ struct Lease {
 
 #define GMSM_LEASE_OR_FAIL(name, context)                                                                    \
     Lease name(context);                                                                                     \
-    if (!name.w) return fail(GMSM_ERR_ARG, "two submitted MultiExp calls are waiting for gmsm_multiexp_collect")
+    if (!name.w) return fail(GMSM_ERR_DEVICE, "no workspace could be leased (internal error)")
 
 // Orders the workspace's private stream after everything queued so far on the caller's stream (NULL = the device's
 // default stream): inputs produced there are complete before the pipeline reads them.
@@ -308,7 +363,7 @@ struct StageTimer {
     Workspace &ws;
     int level;
     bool on;
-    explicit StageTimer(Workspace &w) : ws(w), level(profiling_level()), on(level != 0) {
+    explicit StageTimer(Workspace &w, bool enabled = true) : ws(w), level(enabled ? profiling_level() : 0), on(level != 0) {
         if (on && !ws.events[0])
             for (int i = 0; i <= T_END; ++i) (void)hipEventCreate(&ws.events[i]);
         ws.timed_level = level;
@@ -382,14 +437,10 @@ static inline unsigned usable_cpus() {
     return n;
 }
 
-// Run-time switches of the shipped library, read from the environment at call time:
-//   GMSM_C            force the window width (2..20; cost only, the result does not depend on it)
-//   GMSM_MAX_RUN      lower the 2^27-point cap of one pipeline run  (tests of the point-range split)
-//   GMSM_HOST_RANGES  force the number of point ranges of a host-buffer call (tests)
-//   GMSM_DEVICES      devices the drop-in entries shard over, e.g. "0,1,2,3" (gmsm_set_devices overrides)
-//   GMSM_TABLES       window tables of registered bases: 0 never, 1 (default) the measured call sizes, 2 every size (tests)
-// Everything else that was a knob while the engine was being tuned is a compile-time constant now: tune_uint() returns
-// its default unless the library is built with -DGMSM_EXPERIMENTS (A/B builds, tools/build_ab.sh).
+// Run-time switches of the shipped library: `Options` above (gmsm_set_option) and the device list (gmsm_set_devices,
+// GMSM_DEVICES). env_uint is what the library's one-time initialisation and the -DGMSM_EXPERIMENTS builds read the
+// environment with; everything that was a knob while the engine was being tuned is a compile-time constant unless the
+// library is built with -DGMSM_EXPERIMENTS (A/B builds, tools/build_ab.sh): tune_uint() then reads GMSM_<NAME>.
 static inline unsigned env_uint(const char *name, unsigned dflt) {
     const char *v = getenv(name);
     if (!v || !*v) return dflt;
@@ -418,7 +469,7 @@ static inline constexpr unsigned tune_uint(const char *, unsigned dflt) { return
 //                  23.3 against 25.3; c = 10, 15 and 17 leave a top window of a few bits and are far slower)
 // Below ~2^17 points the pipeline is latency-bound (~0.6-1 ms for BN254 G1 whatever c). The entries were measured with
 // the width forced, so they include what a narrow top window costs (long chains of partial sums for k_fixup_long, one
-// crowded sort partition): widths whose top window holds only a few bits simply never won. GMSM_C overrides.
+// crowded sort partition): widths whose top window holds only a few bits simply never won. GMSM_OPT_WINDOW_BITS (GMSM_C) overrides.
 static inline unsigned preferred_c(unsigned fr_bits, size_t aff_bytes, size_t n) {
     unsigned lg = 0;
     while (lg < 63 && ((size_t)2 << lg) <= n) ++lg;  // floor(log2 n), n >= 1
@@ -429,7 +480,7 @@ static inline unsigned preferred_c(unsigned fr_bits, size_t aff_bytes, size_t n)
     return lg < 13 ? 8u : lg < 15 ? 13u : lg < 17 ? 15u : lg < 21 ? 16u : 17u;                       // BN254 G1
 }
 static inline unsigned choose_c(unsigned fr_bits, size_t aff_bytes, size_t n) {
-    unsigned forced = env_uint("GMSM_C", 0);
+    const unsigned forced = options().window_bits.load(std::memory_order_relaxed);
     if (forced >= 2 && forced <= 20) return forced;  // the range gmsm.h documents (gmsm_window_sums_*)
     return preferred_c(fr_bits, aff_bytes, n ? n : 1);
 }

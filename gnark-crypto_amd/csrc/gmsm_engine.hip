@@ -24,6 +24,18 @@ static thread_local int g_device = -1;
 static std::atomic<int> g_default_device{0};
 std::atomic<unsigned long> g_table_runs{0};
 
+// Process-wide switches; GMSM_C and GMSM_TABLES are read here ONCE (first use), never on a call path.
+Options &options() {
+    static Options *o = [] {
+        Options *x = new Options();
+        const unsigned c = env_uint("GMSM_C", 0);
+        x->window_bits.store(c >= 2 && c <= 20 ? c : 0);
+        x->tables.store(std::min(2u, env_uint("GMSM_TABLES", 1)));
+        return x;
+    }();
+    return *o;
+}
+
 int fail(int code, const std::string &msg) {
     g_last_error = msg;
     {
@@ -178,34 +190,71 @@ static ShardPool &shard_pool() {
 }
 
 // Devices the drop-in entries spread a MultiExp over, one entry per logical rank (a device may appear more than once).
-// Resolution: gmsm_set_devices; else a gmsm_set_device call pins the process to that one device; else GMSM_DEVICES
-// ("0,1,2,3"); else every visible device.
+// OPT-IN (round 4; the advisor's finding): a process that configured nothing runs every drop-in call on ONE device - the
+// calling thread's (gmsm_set_device) or device 0 - and creates no context, stream or worker thread anywhere else: the
+// usual deployment is one prover process per GPU, and a library that silently took all eight would compete with its
+// neighbours. Spreading is asked for with gmsm_set_devices(list) or GMSM_DEVICES ("0,1,2,3", or "all"), read once.
+// Resolution: gmsm_set_devices; else a gmsm_set_device call pins the process to that one device; else GMSM_DEVICES;
+// else no spreading. The explicit entries (gmsm_multiexp_sharded, gmsm_bases_register_sharded) with devices = NULL use the
+// configured list or, when there is none, every visible device - their caller asked for several devices by name.
 static std::mutex g_devices_mu;
 static std::vector<int> g_devices;
 static bool g_devices_explicit = false;
 static std::atomic<bool> g_pinned{false};  // gmsm_set_device was called
 
-static std::vector<int> shard_devices() {
-    {
-        std::lock_guard<std::mutex> lk(g_devices_mu);
-        if (g_devices_explicit) return g_devices;
-    }
-    if (g_pinned.load()) return {};
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return {};
-    std::vector<int> out;
-    if (const char *v = getenv("GMSM_DEVICES")) {
+// GMSM_DEVICES, parsed once. A malformed or out-of-range entry is an error the next drop-in call reports (it does not
+// silently shrink the list): err is non-empty then.
+struct EnvDevices {
+    std::vector<int> list;
+    std::string err;
+};
+static const EnvDevices &env_devices() {
+    static const EnvDevices *e = [] {
+        EnvDevices *x = new EnvDevices();
+        const char *v = getenv("GMSM_DEVICES");
+        if (!v || !*v) return x;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return x;
+        if (strcmp(v, "all") == 0) {
+            for (int d = 0; d < ndev; ++d) x->list.push_back(d);
+            return x;
+        }
         for (const char *p = v; *p;) {
             char *end = nullptr;
             const long d = strtol(p, &end, 10);
-            if (end == p) break;
-            if (d >= 0 && d < ndev) out.push_back((int)d);
+            if (end == p || (*end && *end != ',') || (*end == ',' && !end[1])) {
+                x->err = std::string("GMSM_DEVICES=\"") + v + "\": expected a comma-separated list of device indices or \"all\"";
+                break;
+            }
+            if (d < 0 || d >= ndev) {
+                x->err = std::string("GMSM_DEVICES=\"") + v + "\": device " + std::to_string(d) + " does not exist (" +
+                         std::to_string(ndev) + " visible)";
+                break;
+            }
+            x->list.push_back((int)d);
             p = *end ? end + 1 : end;
         }
-        return out;
+        if (!x->err.empty()) x->list.clear();
+        return x;
+    }();
+    return *e;
+}
+
+// The configured list; empty = nothing configured (or pinned). rc != 0: GMSM_DEVICES is malformed.
+static int shard_devices(std::vector<int> &out) {
+    out.clear();
+    {
+        std::lock_guard<std::mutex> lk(g_devices_mu);
+        if (g_devices_explicit) {
+            out = g_devices;
+            return GMSM_OK;
+        }
     }
-    for (int d = 0; d < ndev; ++d) out.push_back(d);
-    return out;
+    if (g_pinned.load()) return GMSM_OK;
+    const EnvDevices &e = env_devices();
+    if (!e.err.empty()) return fail(GMSM_ERR_ARG, e.err);
+    out = e.list;
+    return GMSM_OK;
 }
 
 constexpr size_t SHARD_MIN_SLICE = (size_t)1 << 16;  // fewer points per rank than this are not worth a second device
@@ -226,12 +275,12 @@ static int multiexp_sharded_run(int group, const uint64_t *points, const std::ma
         c = choose_c(vt->fr_bits, vt->aff_bytes, slice);
         if (replicas && !replicas->empty()) {  // window tables on the replicas (gmsm_bases_precompute): their width
             const ResidentBases *rb0 = replicas->begin()->second.get();
-            const unsigned forced = env_uint("GMSM_C", 0);
-            bool all = rb0->tab_c != 0;
-            for (const auto &kv : *replicas) all = all && kv.second->tab_c == rb0->tab_c;
-            if (all && !(forced >= 2 && forced <= 20 && forced != rb0->tab_c) && env_uint("GMSM_TABLES", 1) != 0 &&
+            const unsigned forced = options().window_bits.load();
+            bool all = rb0->tab_c.load() != 0;
+            for (const auto &kv : *replicas) all = all && kv.second->tab_c.load() == rb0->tab_c.load();
+            if (all && !(forced >= 2 && forced <= 20 && forced != rb0->tab_c.load()) && options().tables.load() != 0 &&
                 vt->tables_serve(rb0->n, n / G) && vt->tables_serve(rb0->n, slice))
-                c = rb0->tab_c;
+                c = rb0->tab_c.load();
         }
         nwin = num_windows(vt->fr_bits, c);
     } else {
@@ -250,12 +299,19 @@ static int multiexp_sharded_run(int group, const uint64_t *points, const std::ma
     std::mutex done_mu;
     std::condition_variable done_cv;
     size_t done = 0;
-    auto piece = [&](size_t r) {
+    auto piece_body = [&](size_t r) {
         Result &out = res[r];
         const int dev = devs[r];
         Context *ctx = nullptr;
         out.rc = get_context_for(dev, &ctx);
         if (out.rc == GMSM_OK && hipSetDevice(dev) != hipSuccess) out.rc = fail(GMSM_ERR_DEVICE, "hipSetDevice failed");
+        if (out.rc == GMSM_OK) {  // the piece must run where its context lives: say so loudly instead of computing on a neighbour
+            int cur = -1;
+            if (hipGetDevice(&cur) != hipSuccess || cur != dev || ctx->device != dev)
+                out.rc = fail(GMSM_ERR_DEVICE, "sharded MultiExp: rank " + std::to_string(r) + " expected device " + std::to_string(dev) +
+                                                   ", the worker thread is on device " + std::to_string(cur) + " (context of device " +
+                                                   std::to_string(ctx->device) + ")");
+        }
         if (out.rc == GMSM_OK) {
             const ResidentBases *rb = nullptr;
             if (replicas) {
@@ -272,21 +328,52 @@ static int multiexp_sharded_run(int group, const uint64_t *points, const std::ma
         }
         if (out.rc != GMSM_OK) out.err = gmsm_last_error();
     };
-    for (size_t r = 1; r < G; ++r)
-        shard_pool().post(devs[r], [&, r] {
-            piece(r);
-            std::lock_guard<std::mutex> lk(done_mu);  // the notify stays under the lock: the waiter owns these objects
-            ++done;
-            done_cv.notify_one();
-        });
+    // Nothing may leave a piece but a return code: the workers write into this frame (sets, res) and a C caller is above us.
+    auto piece = [&](size_t r) noexcept {
+        try {
+            piece_body(r);
+        } catch (const std::exception &e) {
+            res[r].rc = GMSM_ERR_DEVICE;
+            res[r].err = std::string("exception in a shard piece: ") + e.what();
+        } catch (...) {
+            res[r].rc = GMSM_ERR_DEVICE;
+            res[r].err = "unknown exception in a shard piece";
+        }
+    };
+    size_t posted = 0;
+    struct WaitAll {  // the frame outlives every worker that was handed a reference to it, whatever happens below
+        std::mutex &mu;
+        std::condition_variable &cv;
+        size_t &done;
+        const size_t &posted;
+        ~WaitAll() {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return done == posted; });
+        }
+    };
     int prev_dev = 0;
     (void)hipGetDevice(&prev_dev);
-    piece(0);
-    (void)hipSetDevice(prev_dev);
     {
-        std::unique_lock<std::mutex> lk(done_mu);
-        done_cv.wait(lk, [&] { return done == G - 1; });
+        WaitAll wait_all{done_mu, done_cv, done, posted};
+        try {
+            for (size_t r = 1; r < G; ++r) {
+                shard_pool().post(devs[r], [&, r] {
+                    piece(r);
+                    std::lock_guard<std::mutex> lk(done_mu);  // the notify stays under the lock: the waiter owns these objects
+                    ++done;
+                    done_cv.notify_one();
+                });
+                ++posted;
+            }
+        } catch (const std::exception &e) {  // std::bad_alloc / std::system_error out of the pool: the ranks not posted fail
+            for (size_t r = posted + 1; r < G; ++r) {
+                res[r].rc = GMSM_ERR_DEVICE;
+                res[r].err = std::string("cannot start the worker: ") + e.what();
+            }
+        }
+        piece(0);
     }
+    (void)hipSetDevice(prev_dev);
     for (size_t r = 0; r < G; ++r)
         if (res[r].rc != GMSM_OK) return fail(res[r].rc, "rank " + std::to_string(r) + " (device " + std::to_string(devs[r]) + "): " + res[r].err);
     if (mode == 1) {
@@ -321,8 +408,10 @@ GMSM_EXPORT int gmsm_multiexp_sharded(int group, const uint64_t *points, size_t 
     bool done;
     int rc = multiexp_precheck(vt, n_points, n_scalars, nb_tasks, out_jac, &done);
     if (rc || done) return rc;
-    std::vector<int> devs = (devices && n_devices > 0) ? std::vector<int>(devices, devices + n_devices) : shard_devices();
-    if (devs.empty()) {
+    std::vector<int> devs;
+    if (devices && n_devices > 0) devs.assign(devices, devices + n_devices);
+    else if ((rc = shard_devices(devs))) return rc;
+    if (devs.empty()) {  // nothing configured: the caller asked for a sharded call, so every visible device
         int ndev = gmsm_device_count();
         if (ndev <= 0) return fail(GMSM_ERR_DEVICE, "no usable HIP device; libgmsm has no CPU fallback");
         for (int d = 0; d < ndev; ++d) devs.push_back(d);
@@ -337,10 +426,12 @@ GMSM_EXPORT int gmsm_multiexp_sharded(int group, const uint64_t *points, size_t 
 GMSM_EXPORT int gmsm_multiexp(int group, const uint64_t *points, size_t n_points, const uint64_t *scalars,
                               size_t n_scalars, int nb_tasks, uint64_t *out_jac) {
     VT_OR_FAIL(group);
-    // more than one device configured (the default on a multi-GPU node unless gmsm_set_device pinned the process) and
-    // enough points for two slices: the call is spread over them
+    // more than one device CONFIGURED (gmsm_set_devices / GMSM_DEVICES - spreading is opt-in) and enough points for two
+    // slices: the call is spread over them
     if (n_points == n_scalars && nb_tasks <= 1024 && n_points >= 2 * SHARD_MIN_SLICE) {
-        const std::vector<int> devs = shard_devices();
+        std::vector<int> devs;
+        int rc = shard_devices(devs);
+        if (rc) return rc;
         if (devs.size() > 1) return multiexp_sharded_run(group, points, nullptr, scalars, n_points, devs, 0, out_jac);
     }
     return vt->multiexp_host(points, n_points, scalars, n_scalars, nb_tasks, out_jac);
@@ -372,7 +463,15 @@ GMSM_EXPORT int gmsm_fold(int group, const uint64_t *points, size_t n_points, co
                           int nb_tasks, uint64_t *out_jac) {
     VT_OR_FAIL(group);
     if (!combination_coeff) return fail(GMSM_ERR_ARG, "combination_coeff is null");
-    std::vector<uint64_t> powers(n_points * (vt->scalar_bytes / 8));  // 1, g, g^2, ... (multiexp.go:331-337)
+    if (!out_jac || (n_points && !points)) return fail(GMSM_ERR_ARG, "gmsm_fold: null argument");
+    if (nb_tasks > 1024) return fail(GMSM_ERR_CONFIG, "invalid config: config.NbTasks > 1024");
+    if (n_points >= ((size_t)1 << 31)) return fail(GMSM_ERR_ARG, "n must be < 2^31");
+    std::vector<uint64_t> powers;  // 1, g, g^2, ... (multiexp.go:331-337)
+    try {
+        powers.resize(n_points * (vt->scalar_bytes / 8));
+    } catch (const std::exception &) {
+        return fail(GMSM_ERR_DEVICE, "gmsm_fold: out of host memory for the powers of the coefficient");
+    }
     vt->fold_powers(combination_coeff, n_points, powers.data());
     return gmsm_multiexp(group, points, n_points, powers.data(), n_points, nb_tasks, out_jac);
 }
@@ -664,7 +763,8 @@ GMSM_EXPORT int gmsm_bases_register_sharded(int group, const uint64_t *points, s
     auto sb = std::make_shared<ShardedBases>();
     sb->group = group;
     sb->n = n;
-    sb->devices = (devices && n_devices > 0) ? std::vector<int>(devices, devices + n_devices) : shard_devices();
+    if (devices && n_devices > 0) sb->devices.assign(devices, devices + n_devices);
+    else if (int rc0 = shard_devices(sb->devices)) return rc0;
     const int ndev = gmsm_device_count();
     if (ndev <= 0) return fail(GMSM_ERR_DEVICE, "no usable HIP device; libgmsm has no CPU fallback");
     if (sb->devices.empty())
@@ -708,22 +808,22 @@ GMSM_EXPORT int gmsm_bases_register_sharded(int group, const uint64_t *points, s
 // library's width for this many bases.
 static int precompute_on(const BasesRef &rb, unsigned c) {
     const GroupVTable *vt = vtable(rb->group);
-    if (rb->tab_c != 0) {
-        if (c == 0 || c == rb->tab_c) return GMSM_OK;
+    std::lock_guard<std::mutex> only_one(rb->tab_mu);
+    if (rb->tab_c.load() != 0) {
+        if (c == 0 || c == rb->tab_c.load()) return GMSM_OK;
         return fail(GMSM_ERR_ARG, "gmsm_bases_precompute: the handle already has tables of another width");
     }
     Context *ctx;
     int rc = get_context_for(rb->device, &ctx);
     if (rc) return rc;
-    int prev = 0;
-    (void)hipGetDevice(&prev);
+    struct RestoreDevice {  // every exit path leaves the calling thread on the device it came with
+        int prev = 0;
+        RestoreDevice() { (void)hipGetDevice(&prev); }
+        ~RestoreDevice() { (void)hipSetDevice(prev); }
+    } restore;
     HIP_TRY(hipSetDevice(ctx->device));
-    {
-        GMSM_LEASE_OR_FAIL(lease, *ctx);
-        rc = vt->precompute_tables(*ctx, *lease.w, rb.get(), c);
-    }
-    (void)hipSetDevice(prev);
-    return rc;
+    GMSM_LEASE_OR_FAIL(lease, *ctx);
+    return vt->precompute_tables(*ctx, *lease.w, rb.get(), c);
 }
 
 GMSM_EXPORT int gmsm_bases_precompute(uint64_t handle, unsigned c) {
@@ -759,10 +859,10 @@ GMSM_EXPORT unsigned gmsm_bases_table_bits(uint64_t handle) {
     if (handle & SHARDED_TAG) {
         std::shared_ptr<ShardedBases> sb = lookup_sharded(handle);
         if (!sb || sb->replicas.empty()) return 0;
-        return sb->replicas.begin()->second->tab_c;
+        return sb->replicas.begin()->second->tab_c.load();
     }
     BasesRef rb = lookup_bases(handle);
-    return rb ? rb->tab_c : 0;
+    return rb ? rb->tab_c.load() : 0;
 }
 
 GMSM_EXPORT int gmsm_bases_release(uint64_t handle) {
@@ -789,10 +889,10 @@ GMSM_EXPORT int gmsm_bases_release(uint64_t handle) {
     }
     for (Context *c : ctxs) {
         if (!c) continue;
-        BasesRef parked[2];
+        BasesRef parked[Context::NUM_WS];
         {
             std::lock_guard<std::mutex> lk(c->mu);
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < Context::NUM_WS; ++i) {
                 Workspace &w = c->ws[i];
                 if (w.busy || !w.bases_ref) continue;
                 const bool mine = w.bases_ref == rb || (sb && sb->replicas.count(c->device) && sb->replicas[c->device] == w.bases_ref);
@@ -860,7 +960,7 @@ GMSM_EXPORT int gmsm_multiexp_bases_submit(uint64_t handle, const void *d_scalar
     int rc = get_context_for(rb->device, &ctx);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
-    Lease lease(*ctx, /*wait=*/false);
+    Lease lease(*ctx, /*wait=*/false, /*for_ticket=*/true);
     Workspace *ws = lease.w;
     if (!ws) return fail(GMSM_ERR_ARG, "two MultiExp calls are already in flight: collect one first");
     // the scalars are produced on the caller's stream (NULL = the default stream): order our stream behind it
@@ -935,7 +1035,7 @@ static int multiexp_bases_batch_on(const BasesRef &rb, const uint64_t *scalars, 
         return GMSM_OK;
     }
     Workspace *w[2] = {ctx->acquire(true), nullptr};
-    if (!w[0]) return fail(GMSM_ERR_ARG, "two submitted MultiExp calls are waiting for gmsm_multiexp_collect");
+    if (!w[0]) return fail(GMSM_ERR_DEVICE, "no workspace could be leased (internal error)");
     w[1] = ctx->acquire(false);  // a concurrent caller may hold it: then this batch runs one call at a time
     const size_t nws = w[1] ? 2 : 1;
     size_t submitted = 0, collected = 0;
@@ -979,7 +1079,7 @@ GMSM_EXPORT int gmsm_multiexp_collect(uint64_t ticket, uint64_t *out_jac) {
         std::lock_guard<std::mutex> lk(g_ctx_mu);
         if (dev < g_ctx.size()) ctx = g_ctx[dev];
     }
-    if (!ctx || slot < 1 || slot > 2) return fail(GMSM_ERR_ARG, "unknown MultiExp ticket");
+    if (!ctx || slot < 1 || slot > (unsigned)Context::NUM_WS) return fail(GMSM_ERR_ARG, "unknown MultiExp ticket");
     Workspace &ws = ctx->ws[slot - 1];
     const GroupVTable *vt;
     {
@@ -1307,18 +1407,140 @@ GMSM_EXPORT int gmsm_set_devices(const int *devices, int count) {
     g_devices = list;
     g_devices_explicit = count > 0;
     if (count > 0) g_default_device.store(list[0]);  // the single-device entries follow the first of them
-    else g_pinned.store(false);                      // count = 0: back to "every visible device"
+    else g_pinned.store(false);                      // count = 0: back to the default (GMSM_DEVICES, else no spreading)
     return GMSM_OK;
 }
 
 GMSM_EXPORT int gmsm_get_devices(int *out_devices, int max_devices) {
-    const std::vector<int> list = shard_devices();
-    if (list.empty()) {  // pinned: the calling thread's device
+    std::vector<int> list;
+    if (shard_devices(list) != GMSM_OK) return -1;  // malformed GMSM_DEVICES: gmsm_last_error() has the text
+    if (list.empty()) {  // nothing configured (or pinned): the calling thread's device
         if (out_devices && max_devices > 0) out_devices[0] = g_device >= 0 ? g_device : g_default_device.load();
         return 1;
     }
-    for (int i = 0; i < (int)list.size() && i < max_devices; ++i) out_devices[i] = list[i];
+    if (out_devices)
+        for (int i = 0; i < (int)list.size() && i < max_devices; ++i) out_devices[i] = list[i];
     return (int)list.size();
+}
+
+// ------------------------------------------------------------------ switches and lifecycle
+GMSM_EXPORT int gmsm_set_option(int key, unsigned value) {
+    Options &o = options();
+    switch (key) {
+        case GMSM_OPT_WINDOW_BITS:
+            if (value != 0 && (value < 2 || value > 20)) return fail(GMSM_ERR_ARG, "GMSM_OPT_WINDOW_BITS: 0 (the measured table) or 2..20");
+            o.window_bits.store(value);
+            return GMSM_OK;
+        case GMSM_OPT_TABLES:
+            if (value > 2) return fail(GMSM_ERR_ARG, "GMSM_OPT_TABLES: 0 never, 1 the measured call sizes, 2 every call size");
+            o.tables.store(value);
+            return GMSM_OK;
+        case GMSM_OPT_MAX_RUN: o.max_run.store(value); return GMSM_OK;
+        case GMSM_OPT_HOST_RANGES: o.host_ranges.store(value); return GMSM_OK;
+        case GMSM_OPT_FIXED_BASE_BITS:
+            if (value != 0 && (value < 2 || value > 14)) return fail(GMSM_ERR_ARG, "GMSM_OPT_FIXED_BASE_BITS: 0 (by batch size) or 2..14");
+            o.fixed_base_bits.store(value);
+            return GMSM_OK;
+        default: return fail(GMSM_ERR_ARG, "gmsm_set_option: unknown key");
+    }
+}
+
+GMSM_EXPORT unsigned gmsm_get_option(int key) {
+    Options &o = options();
+    switch (key) {
+        case GMSM_OPT_WINDOW_BITS: return o.window_bits.load();
+        case GMSM_OPT_TABLES: return o.tables.load();
+        case GMSM_OPT_MAX_RUN: return o.max_run.load();
+        case GMSM_OPT_HOST_RANGES: return o.host_ranges.load();
+        case GMSM_OPT_FIXED_BASE_BITS: return o.fixed_base_bits.load();
+        default: return 0;
+    }
+}
+
+// Scratch of the idle workspaces back to the device (the reference's buffers are per call and garbage-collected,
+// ecc/bn254/multiexp.go:148-176; ours are grow-only so that a steady stream of calls never allocates - one 2^26 call
+// would otherwise pin tens of GB for the life of the process). Workspaces that are leased right now are left alone.
+GMSM_EXPORT int gmsm_trim(size_t keep_bytes, size_t *out_freed) {
+    if (out_freed) *out_freed = 0;
+    std::vector<Context *> ctxs;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        ctxs = g_ctx;
+    }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    size_t freed = 0;
+    for (Context *c : ctxs) {
+        if (!c) continue;
+        (void)hipSetDevice(c->device);
+        std::vector<Workspace *> mine;
+        while (Workspace *w = c->acquire(false)) mine.push_back(w);
+        for (Workspace *w : mine) {
+            // an enqueue-only call (gmsm_window_sums_enqueue) may have left work on the caller's stream
+            if (w->last_use) (void)hipEventSynchronize(w->last_use);
+            (void)hipStreamSynchronize(w->stream);
+            (void)hipStreamSynchronize(w->mstream);
+            std::shared_ptr<ResidentBases> parked;
+            parked.swap(w->bases_ref);
+            freed += w->trim(keep_bytes);
+        }
+        for (Workspace *w : mine) c->release(w);
+    }
+    (void)hipSetDevice(prev);
+    if (out_freed) *out_freed = freed;
+    return GMSM_OK;
+}
+
+// Everything back: registered bases, FFT domains, workspaces, streams, events, contexts. The library is usable again
+// afterwards (contexts reappear on first use). No other call may be running or start while this one runs; outstanding
+// tickets are refused (collect them first).
+GMSM_EXPORT int gmsm_shutdown(void) {
+    std::vector<Context *> ctxs;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        ctxs = g_ctx;
+    }
+    for (Context *c : ctxs) {
+        if (!c) continue;
+        std::lock_guard<std::mutex> lk(c->mu);
+        for (auto &w : c->ws)
+            if (w.busy && w.ticket) return fail(GMSM_ERR_ARG, "gmsm_shutdown: a submitted MultiExp has not been collected");
+    }
+    {
+        // The handle tables keep their length (a handle is index + 1: an old handle must stay unknown, not come to name
+        // a later registration); the memory goes with the last reference, at the end of this block.
+        std::vector<BasesRef> bases;
+        std::vector<std::shared_ptr<ShardedBases>> sharded;
+        {
+            std::lock_guard<std::mutex> lk(g_bases_mu);
+            for (auto &b : g_bases) bases.push_back(std::move(b)), b = nullptr;
+            for (auto &b : g_sharded) sharded.push_back(std::move(b)), b = nullptr;
+        }
+        std::vector<FftRef> ffts;
+        {
+            std::lock_guard<std::mutex> lk(g_fft_mu);
+            for (auto &d : g_fft) ffts.push_back(std::move(d)), d = nullptr;
+        }
+    }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (Context *c : ctxs) {
+        if (!c) continue;
+        (void)hipSetDevice(c->device);
+        Workspace *all[Context::NUM_WS];
+        for (int i = 0; i < Context::NUM_WS; ++i) all[i] = c->acquire(true);  // blocking callers still inside finish first
+        (void)hipDeviceSynchronize();
+        for (Workspace *w : all) w->destroy();
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        for (Context *&c : g_ctx) {
+            delete c;
+            c = nullptr;
+        }
+    }
+    (void)hipSetDevice(prev);
+    return GMSM_OK;
 }
 
 GMSM_EXPORT const char *gmsm_last_error(void) {
@@ -1328,6 +1550,6 @@ GMSM_EXPORT const char *gmsm_last_error(void) {
     }
     return g_last_error.c_str();
 }
-GMSM_EXPORT const char *gmsm_version(void) { return "gmsm 0.3 (gfx950)"; }
+GMSM_EXPORT const char *gmsm_version(void) { return "gmsm 0.4 (gfx950)"; }
 
 }  // extern "C"

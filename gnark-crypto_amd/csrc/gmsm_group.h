@@ -301,7 +301,7 @@ struct Group {
         if (nwd == 0) return GMSM_OK;
         // window tables: the (window, point) pairs of all windows form ONE set of entries over one bucket set
         const bool shared = plan.shared != 0;
-        if (shared && !(resident && resident->tab_c == plan.c && plan.win_first == 0 && plan.win_stride == 1))
+        if (shared && !(resident && resident->tab_c.load() == plan.c && plan.win_first == 0 && plan.win_stride == 1))
             return fail(GMSM_ERR_ARG, "shared-bucket plan without matching window tables");
         if (shared && n) g_table_runs.fetch_add(1, std::memory_order_relaxed);
         if (ws.uncollected) {  // stage events of an enqueue-only call (nobody waited for it): pick them up now
@@ -408,7 +408,10 @@ struct Group {
             if ((rc = ctx.allow_lds((const void *)k_reduce_serial_q<U>, (int)(192 * sizeof(QRec<U>))))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_reduce2_q<U, true>, (int)(2 * RED2_TPB * sizeof(QRec<U>))))) return rc;
 
-        StageTimer timer(ws);
+        // Stage times cover single-run calls: the ranges of a multi-range call (buckets_only) reuse a workspace's events
+        // before anybody could read them, and their merges and the one reduction run on another stream - such calls are
+        // left out of the profile instead of being reported with two of their ranges and no reduction.
+        StageTimer timer(ws, /*enabled=*/!buckets_only);
         ws.timed = timer.on;
         // ---- 0. inputs: rewrite the bases into the lazy Montgomery domain + infinity flags (unless registered earlier),
         // signed-digit decomposition of every scalar
@@ -737,8 +740,8 @@ struct Group {
             return GMSM_OK;
         }
         // table size against additions per scalar: 2^7 x 32 windows up to 2^21 scalars, 2^10 x 24 beyond (BN254)
-        const unsigned c = tune_uint("GMSM_FB_C", n < ((size_t)1 << 21) ? 8 : 11);
-        if (c < 2 || c > 14) return fail(GMSM_ERR_ARG, "GMSM_FB_C out of range (2..14)");
+        const unsigned forced_c = options().fixed_base_bits.load(std::memory_order_relaxed);
+        const unsigned c = forced_c ? forced_c : n < ((size_t)1 << 21) ? 8 : 11;
         const WindowPlan plan = make_plan(c, 0, 1);
         std::vector<Aff> table;
         build_fixed_base_table(base, plan, (int)std::min<unsigned>(16, usable_cpus()), table);
@@ -829,7 +832,7 @@ struct Group {
 
     // Most points one pipeline run takes: the coarse partition pass keeps two 32-bit words per partition in LDS, which
     // caps it at 2^27 references per window. Larger inputs run as consecutive point ranges whose window totals are added
-    // (the point decomposition of sharding.py, on one device). GMSM_MAX_RUN lowers the cap (tests).
+    // (the point decomposition of sharding.py, on one device). GMSM_OPT_MAX_RUN lowers the cap (tests).
     // A shared-bucket plan (window tables) sorts nwin * n entries as one window: a sort entry is 32 bits - the low
     // bucket bits of the coarse pass next to (index, sign) - and the coarse pass takes at most 2^13 partitions.
     static size_t max_run_points(const WindowPlan &plan = WindowPlan{0, 0, 0, 0, 1, 0, 0}) {
@@ -840,7 +843,7 @@ struct Group {
             const uint32_t fb_min = log2NB > 13 ? log2NB - 13 : 0;
             cap = std::min(cap, (((size_t)1 << (31 - fb_min)) - 1) / plan.nwin_total);
         }
-        const size_t forced = env_uint("GMSM_MAX_RUN", 0);
+        const size_t forced = options().max_run.load(std::memory_order_relaxed);
         return forced ? std::min(cap, forced) : cap;
     }
 
@@ -849,24 +852,24 @@ struct Group {
     // instead of nwin of them, which in turn lets c grow (fewer windows = fewer additions). 288 GB of HBM pay for it:
     // nwin copies of the bases (BN254 G1, 2^20 points, c = 19: 14 x 64 MiB).
     static uint32_t bucket_sets(const WindowPlan &plan) { return plan.shared ? 1u : plan.nwin_local; }
-    // GMSM_TABLES: 0 = never, 1 (default) = the measured range of call sizes, 2 = whenever the handle has tables (tests)
+    // GMSM_OPT_TABLES: 0 = never, 1 (default) = the measured range of call sizes, 2 = whenever the handle has tables (tests)
     static bool tables_serve(size_t n_registered, size_t n_call) {
-        const unsigned mode = env_uint("GMSM_TABLES", 1);
+        const unsigned mode = options().tables.load(std::memory_order_relaxed);
         if (mode == 0 || n_call == 0) return false;
         if (mode >= 2) return true;
         if (n_call < table_min_points() || n_call > table_max_points()) return false;
         return n_call * 16 >= n_registered;  // a short prefix of the bases: the tables' window is too wide for it
     }
     static bool use_tables(const ResidentBases *rb, size_t n) {
-        if (!rb || rb->tab_c == 0) return false;
-        const unsigned forced = env_uint("GMSM_C", 0);
-        if (forced >= 2 && forced <= 20 && forced != rb->tab_c) return false;
+        if (!rb || rb->tab_c.load() == 0) return false;
+        const unsigned forced = options().window_bits.load(std::memory_order_relaxed);
+        if (forced >= 2 && forced <= 20 && forced != rb->tab_c.load()) return false;
         return tables_serve(rb->n, n);
     }
     // The plan of a MultiExp over n points: the measured window table, or the registered bases' tables when they exist
     static WindowPlan plan_for(const ResidentBases *rb, size_t n) {
         if (use_tables(rb, n)) {
-            WindowPlan plan = make_plan(rb->tab_c, 0, 1);
+            WindowPlan plan = make_plan(rb->tab_c.load(), 0, 1);
             plan.shared = 1;
             return plan;
         }
@@ -902,7 +905,6 @@ struct Group {
         const uint32_t nw = plan.nwin_total;
         const size_t n = rb->n, slab = n * AFF_BYTES;
         int rc;
-        rb->tab_c = 0;
         if ((rc = rb->tables.ensure((size_t)nw * slab))) return rc;
         if ((rc = order_after(ws, nullptr))) return rc;
         if ((rc = ws.buckets.ensure(n * sizeof(XYZZL<U>)))) return rc;
@@ -930,8 +932,8 @@ struct Group {
             rb->tables.release();
             return fail(GMSM_ERR_ARG, "window tables: a multiple 2^k P of a base is the identity (bases outside the prime-order subgroup)");
         }
-        rb->tab_c = c;
         rb->tab_nw = nw;
+        rb->tab_c.store(c, std::memory_order_release);  // publication: everything above is complete (stream synchronised)
         (void)ctx;
         return GMSM_OK;
     }
@@ -1022,9 +1024,9 @@ struct Group {
     // as 2 ranges (cold 3.99 / 3.31 / 3.94 ms with 1 / 2 / 4 ranges, profiles/r02_host_ranges.log). Now the ranges share one
     // bucket set and ONE reduction (k_merge_buckets), a range costs its share of the accumulation plus ~0.1 ms, and the
     // call is cut finer: what is exposed is the copy of the first range and the tail after the last.
-    // GMSM_HOST_RANGES overrides.
+    // GMSM_OPT_HOST_RANGES overrides.
     static unsigned host_ranges(size_t n, bool with_points) {
-        const unsigned forced = env_uint("GMSM_HOST_RANGES", 0);
+        const unsigned forced = options().host_ranges.load(std::memory_order_relaxed);
         if (forced) return (unsigned)std::min<size_t>(forced, std::max<size_t>(1, n));
         // Measured (profiles/r03_host_ranges.log, BN254 G1, cold / warm-bases ms): 2^20 1 range 3.73 / 2.51, 2: 3.19 / 2.23,
         // 4: 2.95 / 2.31, 8: 3.38 / 2.70; 2^22 4: 9.47 / 6.97, 8: 8.87 / 7.11, 16: 9.69 / 8.26; 2^24 8: 32.5 / 23.5, 16: 31.5 / 23.3,
@@ -1058,10 +1060,10 @@ struct Group {
         // as the others - and so is the last one once there are many (its pipeline is the tail after the last copy).
         // Measured (profiles/r03_host_skew.log, BN254 G1 warm-bases, uniform -> skewed): 2^20 2.27 -> 2.15 ms, 2^22 6.92 -> 6.67,
         // 2^24 23.4 -> 22.5; with the bases crossing too (cold) the link is as slow as the device and uniform ranges are as
-        // good as any. A forced count (GMSM_HOST_RANGES) keeps uniform ranges.
+        // good as any. A forced count (GMSM_OPT_HOST_RANGES) keeps uniform ranges.
         std::vector<size_t> cut(nr + 1, 0);
         {
-            const bool skew = SKEWED_HOST_RANGES && points == nullptr && nr >= 3 && env_uint("GMSM_HOST_RANGES", 0) == 0;
+            const bool skew = SKEWED_HOST_RANGES && points == nullptr && nr >= 3 && options().host_ranges.load(std::memory_order_relaxed) == 0;
             std::vector<double> wgt(nr, 1.0);
             if (skew) {
                 wgt[0] = 0.5;
@@ -1180,7 +1182,7 @@ struct Group {
                            Ext *out_xyzz) {
         WindowPlan plan = make_plan(c, win_first, win_stride);
         // a point slice over bases with window tables of this width: one bucket set (the engine asks for the tables' c)
-        if (resident && resident->tab_c == c && win_first == 0 && plan.win_stride == 1 && env_uint("GMSM_TABLES", 1) != 0)
+        if (resident && resident->tab_c.load() == c && win_first == 0 && plan.win_stride == 1 && options().tables.load(std::memory_order_relaxed) != 0)
             plan.shared = 1;
         if (n == 0) {
             for (uint32_t k = 0; k < plan.nwin_local; ++k) out_xyzz[k] = Ext::infinity();

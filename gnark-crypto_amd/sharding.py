@@ -113,10 +113,16 @@ class Exchange:
         self.dist, self.world = dist, dist.get_world_size()
         self.rows, self.limbs = rows, xyzz_limbs
         self.local = torch.zeros((rows, xyzz_limbs), dtype=torch.int64, device=device)
-        self.gathered = torch.zeros((self.world * rows, xyzz_limbs), dtype=torch.int64, device=device)
+        # A gloo process group (the CPU tests; bench.py --oversubscribe, where several ranks share one GPU and RCCL refuses
+        # duplicate devices) gathers on the host: the totals cross to the host for the fold anyway.
+        self.via_host = device.type != "cpu" and dist.get_backend() == "gloo"
+        self.gathered = torch.zeros((self.world * rows, xyzz_limbs), dtype=torch.int64, device="cpu" if self.via_host else device)
 
     def gather(self):
         """-> (world, rows, xyzz_limbs) uint64 on the host, identical on every rank."""
+        if self.via_host:
+            self.dist.all_gather_into_tensor(self.gathered, self.local.cpu())  # .cpu() waits for the producer (current stream)
+            return self.gathered.numpy().view(np.uint64).reshape(self.world, self.rows, self.limbs)
         self.dist.all_gather_into_tensor(self.gathered, self.local)  # ordered after the producer on the current stream
         return self.gathered.cpu().numpy().view(np.uint64).reshape(self.world, self.rows, self.limbs)
 

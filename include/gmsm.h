@@ -23,10 +23,14 @@
  *                fallback inside this library: without a usable gfx950 device every compute entry fails loudly.
  *
  * Threading: every entry point is re-entrant and may be called concurrently from any OS thread (goroutines
- * migrate); per device two calls run at a time, further callers wait their turn.
- * Several GPUs: on a node with more than one visible device the drop-in entries spread every MultiExp of 2^17 points or
- * more over all of them (point slices, one host thread per device, one fold; see gmsm_multiexp_sharded) unless
- * gmsm_set_device pinned the process to one device or gmsm_set_devices / GMSM_DEVICES chose a subset.
+ * migrate); per device up to three calls run at a time (three workspaces, of which submitted tickets hold at most two, so a
+ * blocking entry never waits for somebody else's gmsm_multiexp_collect), further callers wait their turn.
+ * Several GPUs: OPT-IN. A process that configures nothing runs every drop-in call on one device (gmsm_set_device, else
+ * device 0) and touches no other - the usual deployment is one prover per GPU. After gmsm_set_devices(list) or with
+ * GMSM_DEVICES="0,1,2,3" / "all" in the environment (read once) the drop-in entries spread every MultiExp of 2^17 points
+ * or more over the listed devices (point slices, one host thread per device, one fold; see gmsm_multiexp_sharded); the
+ * footprint is then one context per listed device: six streams, pinned result buffers, scratch that grows with the
+ * largest call (gmsm_trim gives it back) and two pooled host threads.
  * Limits: n < 2^31. One pipeline run takes up to 2^27 points; the MultiExp entries split larger inputs into point
  * ranges themselves, gmsm_window_sums_* and gmsm_multiexp_bases_submit refuse them (GMSM_ERR_ARG).
  * Ownership: the caller owns all buffers; host pointers are not retained after return.
@@ -94,13 +98,14 @@ int gmsm_fold(int group, const uint64_t *points, size_t n_points, const uint64_t
  *      the workers are the devices: one host thread per logical rank runs its piece on its device, the ranks' window totals
  *      (<= 64 extended-Jacobian points each) come back through each device's pinned result buffer and the calling thread
  *      runs the one fold (multiexp.go:302-315).  Same arguments, layouts, return codes and result as gmsm_multiexp.
- *      devices / n_devices: one entry per logical rank, a device may appear more than once (two ranks on one device use
- *      both of its workspaces); NULL / 0 = the configured list (gmsm_set_devices, else GMSM_DEVICES, else every visible
- *      device).  mode: 0 auto (= 1), 1 points - rank r takes points [r n/G, (r+1) n/G) and all windows; every device
+ *      devices / n_devices: one entry per logical rank, a device may appear more than once (ranks on one device share
+ *      its workspaces); NULL / 0 = the configured list (gmsm_set_devices, else GMSM_DEVICES), and every visible device
+ *      when nothing is configured - this entry is an explicit request for several devices.  mode: 0 auto (= 1), 1 points - rank r takes points [r n/G, (r+1) n/G) and all windows; every device
  *      copies only its slice over its own PCIe link -, 2 windows - rank r takes windows r, r+G, ... of all points (the
  *      reference's per-window workers; every rank needs all bases).  Ranks whose slice would fall below 2^16 points are
  *      left out.  gmsm_<curve>_g{1,2}_multiexp, gmsm_multiexp, gmsm_multiexp_affine and gmsm_fold call this themselves
- *      when more than one device is configured. ---- */
+ *      when more than one device has been configured (opt-in, see "Several GPUs" above).  Every worker checks that it runs
+ *      on the device of its context; a failure names the rank and the device. ---- */
 int gmsm_multiexp_sharded(int group, const uint64_t *points, size_t n_points, const uint64_t *scalars, size_t n_scalars,
                           int nb_tasks, const int *devices, int n_devices, int mode, uint64_t *out_jac);
 /* Resident bases on several devices: the n bases are uploaded (all devices at once, each over its own link) and
@@ -123,16 +128,19 @@ int gmsm_multiexp_bases_sharded(uint64_t handle, const uint64_t *scalars, size_t
  * the bases anew on every call, ecc/bn254/multiexp.go:61; this is what kzg.Commit over a fixed SRS can use,
  * ecc/bn254/kzg/kzg.go:159-176).  c = 0: the library's width for this many bases; 2..20 otherwise.  Calls over a prefix
  * shorter than n/16, call sizes outside the range where the tables were measured to win (about 2^13..2^21 points, by
- * group) and calls with GMSM_C set to another width use the plain path; GMSM_TABLES=0 switches the tables off, =2 uses
- * them for every call size (tests).
- * Call it before the handle is used from several threads.  Bases outside the prime-order subgroup whose multiples reach
+ * group) and calls with GMSM_OPT_WINDOW_BITS forced to another width use the plain path; GMSM_OPT_TABLES = 0 switches the
+ * tables off, 2 uses them for every call size (tests).
+ * Safe while other threads use the handle: the tables are published (release store of their width) only when complete,
+ * calls that started earlier keep the plain path; concurrent precompute calls on one handle are serialised.  Bases outside the prime-order subgroup whose multiples reach
  * the identity are refused (GMSM_ERR_ARG; the handle keeps working without tables).
  * gmsm_bases_table_bits: the width of the handle's tables, 0 = none. */
 int gmsm_bases_precompute(uint64_t handle, unsigned c);
 unsigned gmsm_bases_table_bits(uint64_t handle);
 unsigned long gmsm_debug_table_runs(void); /* pipeline runs that went through window tables so far (tests) */
-/* The devices the drop-in entries shard over (one entry per logical rank); count = 0 restores the default (every
- * visible device).  gmsm_get_devices returns the number of configured ranks and writes up to max_devices of them. */
+/* The devices the drop-in entries shard over (one entry per logical rank); count = 0 restores the default (GMSM_DEVICES
+ * if set, else no spreading: one device).  gmsm_get_devices returns the number of configured ranks (1 and the calling
+ * thread's device when nothing is configured; -1 when GMSM_DEVICES is malformed) and writes up to max_devices of them
+ * (out_devices may be NULL). */
 int gmsm_set_devices(const int *devices, int count);
 int gmsm_get_devices(int *out_devices, int max_devices);
 
@@ -162,7 +170,7 @@ int gmsm_multiexp_bases_device(uint64_t handle, const void *d_scalars, size_t n_
  *      MultiExp at once, BenchmarkManyMultiExpG1Reference, ecc/bn254/multiexp_test.go:385-415).
  *      submit launches the whole device pipeline for device-resident scalars over registered bases and returns without
  *      waiting; collect waits, folds the windows and writes the Jacobian result. At most two tickets may be outstanding
- *      per device (a third submit returns GMSM_ERR_ARG); d_scalars must stay valid until its ticket is collected.
+ *      per device (a third submit returns GMSM_ERR_ARG; so does a submit while all three workspaces are busy); d_scalars must stay valid until its ticket is collected.
  *      hip_stream: the stream the scalars were produced on (NULL = the default stream); the pipeline is ordered
  *      after the work already queued there. The sort/accumulate of one call overlaps the latency-bound bucket reduction, copy-back and
  *      host fold of the other. ---- */
@@ -293,12 +301,36 @@ void gmsm_set_profiling(int on);
 int gmsm_get_stage_times(double *out_ms, int max_stages, unsigned long *out_calls);
 int gmsm_get_stage_launches(unsigned long *out_launches, int max_stages);
 
+/* ---- switches (process-wide).  GMSM_OPT_WINDOW_BITS and GMSM_OPT_TABLES take their initial value from the environment
+ *      variables GMSM_C / GMSM_TABLES once, when the library is first used; nothing reads the environment per call.
+ *      GMSM_OPT_MAX_RUN / GMSM_OPT_HOST_RANGES exist for the tests of the point-range splits (0 = off). ---- */
+enum gmsm_option {
+    GMSM_OPT_WINDOW_BITS = 0, /* 0 = the library's measured table per group and size, 2..20 = forced (cost only: the
+                                 affine result does not depend on c, multiexp_test.go:95-126) */
+    GMSM_OPT_TABLES = 1,      /* window tables of registered bases: 0 never, 1 (default) the measured call sizes, 2 always */
+    GMSM_OPT_MAX_RUN = 2,     /* lower the 2^27-point cap of one pipeline run: larger calls split into point ranges */
+    GMSM_OPT_HOST_RANGES = 3, /* force the number of point ranges a host-buffer call is cut into */
+    GMSM_OPT_FIXED_BASE_BITS = 4 /* table width of gmsm_batch_scalar_mul*: 0 = by batch size (8, and 11 from 2^21 scalars), 2..14 */
+};
+int gmsm_set_option(int key, unsigned value);
+unsigned gmsm_get_option(int key);
+
+/* ---- lifecycle.  Scratch buffers are grow-only per workspace (a steady stream of calls never allocates); the reference's
+ *      per-call buffers are garbage-collected (ecc/bn254/multiexp.go:148-176), so a long-lived process needs the
+ *      equivalent:  gmsm_trim releases every scratch / staging buffer larger than keep_bytes of every workspace that is
+ *      idle right now, on every device (*out_freed = device bytes given back; registered bases, window tables and FFT
+ *      domains stay).  gmsm_shutdown releases everything - handles become unknown, contexts, streams and events are
+ *      destroyed - and leaves the library usable (state reappears on first use); no other call may run or start meanwhile,
+ *      and it refuses (GMSM_ERR_ARG) while a submitted ticket is uncollected. ---- */
+int gmsm_trim(size_t keep_bytes, size_t *out_freed);
+int gmsm_shutdown(void);
+
 int gmsm_device_count(void);
 /* Device used by later calls of this thread AND process-wide default for threads that never called it (a goroutine
  * that is moved to another OS thread keeps its device as long as the process uses one device; a process that drives
  * several devices from several threads must pin them, runtime.LockOSThread). Entries that take device pointers or a
  * bases handle do not depend on it: they run on the device that owns the pointer / the registered bases.
- * Calling it also pins the drop-in entries to ONE device: they no longer spread a MultiExp over the node's GPUs
+ * Calling it also pins the drop-in entries to ONE device even when GMSM_DEVICES lists several
  * (gmsm_set_devices(NULL, 0) undoes that). */
 int gmsm_set_device(int device);
 /* text of the calling thread's last failure; a thread that never failed gets the most recent failure of the process

@@ -21,6 +21,20 @@ def gm():
     return importlib.import_module("gnark-crypto_amd")
 
 
+@pytest.fixture
+def forced_options(gm):
+    """forced_options(max_run=4096, ...): library switches (gmsm_set_option) for the rest of the test, restored after it."""
+    old = {}
+
+    def force(**kw):
+        for k, v in kw.items():
+            old.setdefault(k, gm.get_option(k))
+            gm.set_option(k, v)
+    yield force
+    for k, v in old.items():
+        gm.set_option(k, v)
+
+
 @pytest.fixture(scope="session")
 def oracle_mod():
     import oracle  # noqa: E402  (oracle/oracle.py, test infrastructure)

@@ -40,12 +40,12 @@ def test_layout_sizes(gm, curve, which):
 
 
 @pytest.mark.parametrize("curve,which", ALL_GROUPS)
-def test_default_window_table(gm, curve, which, monkeypatch):
+def test_default_window_table(gm, curve, which):
     """gmsm_default_window_bits: the measured per-group table (gmsm_context.h, profiles/r02_window_sweeps.log). It is a
     pure cost choice, but the sharded paths rely on every rank getting the same answer for the same n, on the width
     staying inside what gmsm_window_sums_* accept, and on the top window never being the few-bit kind that serialises
     the sort."""
-    monkeypatch.delenv("GMSM_C", raising=False)
+    gm.set_option("window_bits", 0)
     g = (gm.G1Jac if which == "g1" else gm.G2Jac)(curve)
     fr_bits = g.curve.fr_bits
     prev = None
@@ -66,8 +66,9 @@ def test_default_window_table(gm, curve, which, monkeypatch):
              ("bw6_761", "g1"): {13: 9, 20: 14, 22: 16}, ("bw6_761", "g2"): {13: 9, 20: 14, 22: 16}}[(curve, which)]
     for lg, c in table.items():
         assert g.default_window_bits(1 << lg) == c, (lg, c)
-    monkeypatch.setenv("GMSM_C", "11")
-    assert g.default_window_bits(1 << 20) == 11
+    with gm.options(window_bits=11):  # gmsm_set_option(GMSM_OPT_WINDOW_BITS): the switch the tests and sweeps use
+        assert g.default_window_bits(1 << 20) == 11
+    assert g.default_window_bits(1 << 20) == table.get(20, g.default_window_bits(1 << 20))
 
 
 def test_dump_header_errors_need_no_device(gm, tmp_path):

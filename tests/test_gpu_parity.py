@@ -488,8 +488,8 @@ def test_sharded_exchange_pieces_on_one_gpu(gm, oracle_mod, curve, which, mode):
 def test_two_multiexp_in_flight(gm, oracle_mod, curve, which):
     """gmsm_multiexp_bases_submit / gmsm_multiexp_collect: two MultiExp calls over the same resident bases in flight on
     two workspaces (the GPU-side counterpart of BenchmarkManyMultiExpG1Reference, ecc/bn254/multiexp_test.go:385-415).
-    Every result equals the oracle whatever the collection order; a third submit, a repeated ticket and a synchronous
-    call with both slots taken are refused; a synchronous call with one slot taken uses the other one."""
+    Every result equals the oracle whatever the collection order; a third submit and a repeated ticket are refused;
+    synchronous calls go through whether one or two tickets are outstanding (three workspaces, tickets hold at most two)."""
     import torch
     g = _group(gm, curve, which)
     o = oracle_mod.Oracle(curve, which)
@@ -520,8 +520,12 @@ def test_two_multiexp_in_flight(gm, oracle_mod, curve, which):
         t1 = rb.submit(d_sc[1].data_ptr(), sets[1][1], stream=torch.cuda.current_stream().cuda_stream)
         with pytest.raises(RuntimeError, match="already in flight"):
             rb.submit(d_sc[2].data_ptr(), sets[2][1])
-        with pytest.raises(RuntimeError, match="waiting for gmsm_multiexp_collect"):
-            rb.multiexp_device(d_sc[2].data_ptr(), sets[2][1])
+        # two tickets outstanding: a blocking call still goes through at once (the third workspace, which tickets can
+        # never hold) - round 3 gave up here after two seconds, whoever held the tickets
+        jac_sync = rb.multiexp_device(d_sc[2].data_ptr(), sets[2][1])
+        assert (g.jac_to_affine(jac_sync) == expect[2]).all()
+        jac, err = rb.MultiExp(sets[3][0])
+        assert err is None and (g.jac_to_affine(jac) == expect[3]).all()
         assert (g.jac_to_affine(rb.collect(t1)) == expect[1]).all()
         with pytest.raises(RuntimeError, match="ticket"):
             rb.collect(t1)
@@ -734,9 +738,9 @@ def test_batch_scalar_multiplication(gm, oracle_mod, curve, which):
     assert g.BatchScalarMultiplication(base, sc[:0]).shape == (0, g.aff_limbs)
 
 
-def test_batch_scalar_multiplication_large_table(gm, oracle_mod, monkeypatch):
+def test_batch_scalar_multiplication_large_table(gm, oracle_mod, forced_options):
     """The larger table (c = 11, chosen from 2^21 scalars on) on a size the oracle checks in seconds."""
-    monkeypatch.setenv("GMSM_FB_C", "11")
+    forced_options(fixed_base_bits=11)
     g = _group(gm, "bn254", "g1")
     o = oracle_mod.Oracle("bn254", "g1")
     n = 20000

@@ -152,13 +152,13 @@ def test_dropin_entries_shard_over_configured_devices(gm, oracle_mod):
             assert err is None and (g.jac_to_affine(jac) == expected).all()
     finally:
         gm.set_devices(None)
-    assert gm.get_devices() == list(range(L.gmsm_device_count()))
+    assert len(gm.get_devices()) == 1  # nothing configured: no spreading (opt-in), the calling thread's device
 
 
 # ------------------------------------------------------------------ point-range splits of the single-device entries
 @pytest.mark.parametrize("curve,which", [("bn254", "g1"), ("bls12_381", "g2")])
-def test_pipeline_run_cap_splits_every_entry(gm, oracle_mod, curve, which, monkeypatch):
-    """Inputs beyond one pipeline run (2^27 points; GMSM_MAX_RUN lowers the cap) are cut into point ranges whose window
+def test_pipeline_run_cap_splits_every_entry(gm, oracle_mod, curve, which, forced_options):
+    """Inputs beyond one pipeline run (2^27 points; GMSM_OPT_MAX_RUN lowers the cap) are cut into point ranges whose window
     totals are added - the reference's split + AddAssign (multiexp.go:98-140): device entry, registered bases (device and
     host scalars) and the host entry, n not a multiple of the run."""
     import torch
@@ -167,7 +167,7 @@ def test_pipeline_run_cap_splits_every_entry(gm, oracle_mod, curve, which, monke
     n = 3 * 4096 + 77
     pts, sc = _inputs(o, g, n, 5)
     expected = o.msm_affine(pts, sc, nthreads=8)
-    monkeypatch.setenv("GMSM_MAX_RUN", "4096")
+    forced_options(max_run=4096)
     d_pts = torch.from_numpy(pts.view(np.int64)).cuda()
     d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
     stream = torch.cuda.current_stream().cuda_stream
@@ -191,14 +191,14 @@ def test_pipeline_run_cap_splits_every_entry(gm, oracle_mod, curve, which, monke
 
 
 @pytest.mark.parametrize("ranges", [1, 3, 7])
-def test_host_ranges_forced(gm, oracle_mod, monkeypatch, ranges):
-    """The host entries cut a call into point ranges so that PCIe runs under compute; GMSM_HOST_RANGES forces the count."""
+def test_host_ranges_forced(gm, oracle_mod, forced_options, ranges):
+    """The host entries cut a call into point ranges so that PCIe runs under compute; GMSM_OPT_HOST_RANGES forces the count."""
     g = gm.G1Jac("bn254")
     o = oracle_mod.Oracle("bn254", "g1")
     n = 10007
     pts, sc = _inputs(o, g, n, 6)
     expected = o.msm_affine(pts, sc, nthreads=8)
-    monkeypatch.setenv("GMSM_HOST_RANGES", str(ranges))
+    forced_options(host_ranges=ranges)
     jac, err = g.MultiExp(pts, sc)
     assert err is None and (g.jac_to_affine(jac) == expected).all()
     rb = g.register_bases(points=pts)
@@ -210,10 +210,11 @@ def test_host_ranges_forced(gm, oracle_mod, monkeypatch, ranges):
         rb.release()
 
 
-def test_forced_window_width_is_clamped(gm, monkeypatch):
-    """GMSM_C outside the documented 2..20 is ignored (it used to be accepted up to 24 and then failed in hipMalloc)."""
+def test_forced_window_width_is_clamped(gm, forced_options):
+    """A forced width outside the documented 2..20 is refused (it used to be accepted up to 24 and then failed in hipMalloc)."""
     g = gm.G1Jac("bn254")
-    monkeypatch.setenv("GMSM_C", "23")
+    with pytest.raises(ValueError, match="2..20"):
+        gm.set_option("window_bits", 23)
     assert g.default_window_bits(1 << 20) == 16
-    monkeypatch.setenv("GMSM_C", "12")
+    forced_options(window_bits=12)
     assert g.default_window_bits(1 << 20) == 12

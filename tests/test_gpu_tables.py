@@ -13,10 +13,11 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True)
-def tables_for_every_size(monkeypatch):
+def tables_for_every_size(gm):
     """The library sends only the call sizes through the tables for which they were measured to win (2^13..2^21 points,
-    by group); the parity tests are smaller: GMSM_TABLES=2 = whenever the handle has tables."""
-    monkeypatch.setenv("GMSM_TABLES", "2")
+    by group); the parity tests are smaller: GMSM_OPT_TABLES = 2 = whenever the handle has tables."""
+    with gm.options(tables=2):
+        yield
 
 
 def table_runs(gm):
@@ -115,9 +116,9 @@ def test_tables_crowded_buckets(gm, oracle_mod):
 
 
 @pytest.mark.parametrize("curve,which", [("bn254", "g1"), ("bls12_381", "g2")])
-def test_tables_point_ranges_and_switches(gm, oracle_mod, curve, which, monkeypatch):
+def test_tables_point_ranges_and_switches(gm, oracle_mod, curve, which):
     """The shared bucket set under the splits of the entries: pipeline-run cap (device ranges + k_merge_buckets), forced
-    host ranges; GMSM_TABLES=0 and a foreign GMSM_C fall back to the plain path over the same handle."""
+    host ranges; GMSM_OPT_TABLES = 0 and a foreign forced width fall back to the plain path over the same handle."""
     import torch
     g = _jac_group(gm, curve, which)
     o = oracle_mod.Oracle(curve, which)
@@ -130,23 +131,19 @@ def test_tables_point_ranges_and_switches(gm, oracle_mod, curve, which, monkeypa
     try:
         c = rb.precompute(9)
         assert c == 9
-        for env in ({"GMSM_MAX_RUN": "4096"}, {"GMSM_HOST_RANGES": "5"}, {"GMSM_TABLES": "0"}, {"GMSM_C": "11"},
-                    {"GMSM_C": "9", "GMSM_MAX_RUN": "5000"}):
-            for k, v in env.items():
-                monkeypatch.setenv(k, v)
-            before = table_runs(gm)
-            assert (g.jac_to_affine(rb.multiexp_device(d_sc.data_ptr(), n, stream)) == expected).all(), env
-            plain = env.get("GMSM_TABLES") == "0" or env.get("GMSM_C") == "11"
-            ranges = 4 if "GMSM_MAX_RUN" in env and env["GMSM_MAX_RUN"] == "4096" else 3 if "GMSM_MAX_RUN" in env else 1
-            assert table_runs(gm) - before == (0 if plain else ranges), env
-            jac, err = rb.MultiExp(sc)
-            assert err is None and (g.jac_to_affine(jac) == expected).all(), env
-            m = 2 * 4096 + 1
-            jac, err = rb.MultiExp(sc[:m])
-            assert err is None and (g.jac_to_affine(jac) == o.msm_affine(pts[:m], sc[:m], nthreads=8)).all(), env
-            for k in env:
-                monkeypatch.delenv(k)
-            monkeypatch.setenv("GMSM_TABLES", "2")
+        for env in ({"max_run": 4096}, {"host_ranges": 5}, {"tables": 0}, {"window_bits": 11},
+                    {"window_bits": 9, "max_run": 5000}):
+            with gm.options(**env):
+                before = table_runs(gm)
+                assert (g.jac_to_affine(rb.multiexp_device(d_sc.data_ptr(), n, stream)) == expected).all(), env
+                plain = env.get("tables") == 0 or env.get("window_bits") == 11
+                ranges = 4 if env.get("max_run") == 4096 else 3 if "max_run" in env else 1
+                assert table_runs(gm) - before == (0 if plain else ranges), env
+                jac, err = rb.MultiExp(sc)
+                assert err is None and (g.jac_to_affine(jac) == expected).all(), env
+                m = 2 * 4096 + 1
+                jac, err = rb.MultiExp(sc[:m])
+                assert err is None and (g.jac_to_affine(jac) == o.msm_affine(pts[:m], sc[:m], nthreads=8)).all(), env
     finally:
         rb.release()
 
@@ -181,10 +178,10 @@ def test_tables_on_sharded_handle(gm, oracle_mod):
         rb.release()
 
 
-def test_tables_default_call_sizes(gm, oracle_mod, monkeypatch):
+def test_tables_default_call_sizes(gm, oracle_mod, forced_options):
     """Without the test switch the tables serve the measured range only: a 2^13-point call over BN254 G1 runs through
     them, a prefix below n/16 and a call below 2^13 points take the plain path; results agree either way."""
-    monkeypatch.setenv("GMSM_TABLES", "1")
+    forced_options(tables=1)
     g = gm.G1Jac("bn254")
     o = oracle_mod.Oracle("bn254", "g1")
     n = (1 << 16) + 3

@@ -26,9 +26,9 @@ def main():
     nmax = 1 << 17
     pts_all = o.gen_points(nmax, 99, 5, nthreads=8)
     rb = g.register_bases(points=pts_all)
-    # the same bases with window tables (gmsm_bases_precompute), the library's width and a narrow one; GMSM_TABLES=2: every
+    # the same bases with window tables (gmsm_bases_precompute), the library's width and a narrow one; GMSM_OPT_TABLES = 2: every
     # call size runs through them (the default policy would send most of these sizes down the plain path)
-    os.environ["GMSM_TABLES"] = "2"
+    gm.set_option("tables", 2)
     handles = [rb, g.register_bases(points=pts_all), g.register_bases(points=pts_all)]
     handles[1].precompute(0)
     handles[2].precompute(11)

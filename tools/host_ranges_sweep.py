@@ -1,4 +1,4 @@
-"""Cold / warm-bases time of the host-pointer entries for a list of GMSM_HOST_RANGES settings (0 = the library's choice).
+"""Cold / warm-bases time of the host-pointer entries for a list of GMSM_OPT_HOST_RANGES settings (0 = the library's choice).
 usage: python tools/host_ranges_sweep.py curve group logn ranges,ranges,...   e.g.  bn254 g1 20 0,1,2,4,8"""
 import importlib
 import os
@@ -43,10 +43,7 @@ def main():
     reps = 5 if logn <= 22 else 3
     print(f"{curve} {group} 2^{logn}: resident {resident:.3f} ms", flush=True)
     for v in variants:
-        if v:
-            os.environ["GMSM_HOST_RANGES"] = str(v)
-        else:
-            os.environ.pop("GMSM_HOST_RANGES", None)
+        gm.set_option("host_ranges", v or 0)
         jc, err = g.MultiExp(pts, sc)
         assert err is None, err
         jw, err = rb.MultiExp(sc)

@@ -1,5 +1,5 @@
 """Calls over registered bases with host scalars: the shipped point ranges (unequal for the two narrow G1 groups) against
-uniform ranges of the old count (GMSM_HOST_RANGES forces a count and uniform ranges), plain and with window tables, two rounds
+uniform ranges of the old count (GMSM_OPT_HOST_RANGES forces a count and uniform ranges), plain and with window tables, two rounds
 in one session -> profiles/r03_host_skew.log.  usage: python tools/host_skew_ab.py"""
 import importlib, os, sys, time
 import numpy as np, torch
@@ -28,12 +28,12 @@ for curve, which, logn, old in (("bn254","g1",20,2), ("bn254","g1",21,2), ("bn25
     reps = 9 if logn <= 22 else 5
     res = []
     for rnd in range(2):
-        os.environ.pop("GMSM_HOST_RANGES", None)
+        gm.set_option("host_ranges", 0)
         new = med(lambda: rb.MultiExp(sc), reps); newt = med(lambda: rbt.MultiExp(sc), reps) if rbt else 0
-        os.environ["GMSM_HOST_RANGES"] = str(old)
+        gm.set_option("host_ranges", old)
         o = med(lambda: rb.MultiExp(sc), reps); ot = med(lambda: rbt.MultiExp(sc), reps) if rbt else 0
         res.append(f"new {new:.3f} old({old} uniform) {o:.3f}" + (f" | tables new {newt:.3f} old {ot:.3f}" if rbt else ""))
-    os.environ.pop("GMSM_HOST_RANGES", None)
+    gm.set_option("host_ranges", 0)
     print(f"{curve} {which} 2^{logn} warm-bases: " + " ; ".join(res), flush=True)
     rb.release()
     if rbt: rbt.release()

@@ -2,7 +2,7 @@
 (point, scalar) pairs = 2^27 + 2^22 points, so gmsm_multiexp_device cuts the call into two point ranges by itself
 (Group::device_ranges, the reference's split + AddAssign, ecc/bn254/multiexp.go:98-140).  Checked through the closed form
 of tests/test_gpu_parity.py::test_bn254_g1_2_pow_26_closed_form: bases [a_i]G, result must be [33 * sum a_i b_i]G.
-Needs ~25 GB of device memory; not part of the suite (the suite covers the same path with GMSM_MAX_RUN lowered).
+Needs ~25 GB of device memory; not part of the suite (the suite covers the same path with GMSM_OPT_MAX_RUN lowered).
 Usage: python tools/natural_cap_check.py        (GPU box; the oracle is the checker)"""
 import os
 import sys
@@ -21,7 +21,7 @@ def main():
     import oracle as oracle_mod
     from conftest import random_scalars, rng_for
     gm = importlib.import_module("gnark-crypto_amd")
-    assert "GMSM_MAX_RUN" not in os.environ
+    assert gm.get_option("max_run") == 0
     g = gm.G1Jac("bn254")
     o = oracle_mod.Oracle("bn254", "g1")
     m, reps = 1 << 22, 33

@@ -1,5 +1,5 @@
 """Window-size sweep: ms per MultiExp for every c in a range, sizes 2^lo..2^hi (BN254 G1 unless told otherwise).
-usage: python tools/sweep_c.py [lo hi [curve group [cmin cmax]]]   (GMSM_C is read by the library on every call)"""
+usage: python tools/sweep_c.py [lo hi [curve group [cmin cmax]]]   (the width is forced with gmsm_set_option(GMSM_OPT_WINDOW_BITS))"""
 import importlib
 import os
 import sys
@@ -28,11 +28,11 @@ def main():
     d_sc = torch.from_numpy(np.roll(a, 1, axis=0).view(np.int64)).cuda()
     for logn in range(lo, hi + 1):
         n = 1 << logn
-        os.environ.pop("GMSM_C", None)
+        gm.set_option("window_bits", 0)
         default_c = g.default_window_bits(n)
         row = {}
         for c in range(cmin, cmax + 1):
-            os.environ["GMSM_C"] = str(c)
+            gm.set_option("window_bits", c)
             g.multiexp_device(d_pts.data_ptr(), d_sc.data_ptr(), n, stream)
             torch.cuda.synchronize()
             reps = 8 if logn <= 18 else 4
@@ -44,7 +44,7 @@ def main():
         best = min(row, key=row.get)
         print(f"{curve} {group} 2^{logn}: default c={default_c} {row.get(default_c, float('nan')):.3f} ms | best c={best} {row[best]:.3f} ms | " +
               " ".join(f"{c}:{v:.3f}" for c, v in row.items()), flush=True)
-    os.environ.pop("GMSM_C", None)
+    gm.set_option("window_bits", 0)
 
 
 if __name__ == "__main__":

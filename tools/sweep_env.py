@@ -1,7 +1,8 @@
 """Environment-switch sweep in ONE process: ms per MultiExp and per-stage times for a list of GMSM_* settings.
 usage: python tools/sweep_env.py curve group logn [reps] -- "GMSM_C=20" "GMSM_C=17,GMSM_LOG2L=5,GMSM_PART_LOG2=14" ...
-An empty string "" is the default configuration. The library reads its GMSM_* switches on every call (GMSM_C always; the
-tuning knobs only in a -DGMSM_EXPERIMENTS build, tools/build_ab.sh + GMSM_LIB), so one set of device-resident inputs
+An empty string "" is the default configuration. GMSM_C / GMSM_TABLES / GMSM_MAX_RUN / GMSM_HOST_RANGES are applied with
+gmsm_set_option (the library reads the environment once, at load); the tuning knobs exist only in a -DGMSM_EXPERIMENTS
+build (tools/build_ab.sh + GMSM_LIB), which reads them from the environment per call. One set of device-resident inputs
 serves every variant. Every variant's affine result is compared with the default's."""
 import ctypes
 import importlib
@@ -14,6 +15,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 gm = importlib.import_module("gnark-crypto_amd")
+OPTION_OF = {"GMSM_C": "window_bits", "GMSM_TABLES": "tables", "GMSM_MAX_RUN": "max_run", "GMSM_HOST_RANGES": "host_ranges"}
 STAGES = ["decompose", "histogram", "scans", "scatter", "accumulate", "fixup", "reduce", "reserved"]
 
 
@@ -39,7 +41,10 @@ def main():
         keys = []
         for kv in filter(None, var.split(",")):
             k, v = kv.split("=")
-            os.environ[k] = v
+            if k in OPTION_OF:
+                gm.set_option(OPTION_OF[k], int(v))
+            else:
+                os.environ[k] = v
             keys.append(k)
         try:
             out = g.multiexp_device(d_pts.data_ptr(), d_sc.data_ptr(), n, stream)
@@ -64,7 +69,10 @@ def main():
         except Exception as e:  # a variant the library refuses (geometry limits) must not end the sweep
             print(f"{curve} {group} 2^{logn} [{var}] FAILED: {e}", flush=True)
         for k in keys:
-            os.environ.pop(k, None)
+            if k in OPTION_OF:
+                gm.set_option(OPTION_OF[k], 1 if k == "GMSM_TABLES" else 0)
+            else:
+                os.environ.pop(k, None)
 
 
 if __name__ == "__main__":
