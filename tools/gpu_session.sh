@@ -13,3 +13,5 @@ tail -c 600 $O/bench.json; echo
 ( timeout 1200 python bench.py --gpus 8 --oversubscribe > $O/rehearsal_8.json 2> $O/rehearsal_8.err; echo "rc=$?" >> $O/rehearsal_8.err )
 tail -c 700 $O/rehearsal_8.json; echo; tail -2 $O/rehearsal_8.err
 tools/profile_fft.sh $S/fft_prof bn254 20 24
+( timeout 300 tools/ubench_batch_affine 20 23; timeout 300 tools/ubench_batch_affine 24 23 ) > $O/batch_affine.log 2>&1
+cat $O/batch_affine.log
