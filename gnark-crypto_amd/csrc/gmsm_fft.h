@@ -46,6 +46,34 @@ __device__ __forceinline__ void fft_store(T *a, size_t i, const T &v) {
     for (int k = 0; k < (int)(sizeof(T) / 16); ++k) dst[k] = src[k];
 }
 
+// Table entries that are only 4-byte aligned (pre-cut twiddles: 9 / 14 words each): dword-aligned vector loads
+template <class T>
+__device__ __forceinline__ T fft_load_words(const T *a, size_t i) {
+    static_assert(sizeof(T) % 4 == 0, "element size");
+    struct __attribute__((packed, aligned(4))) Raw { uint32_t w[sizeof(T) / 4]; };
+    const Raw raw = *reinterpret_cast<const Raw *>(a + i);
+    T r;
+    __builtin_memcpy(&r, &raw, sizeof(T));
+    return r;
+}
+template <class FrP> __device__ __forceinline__ Fp<FrP> fft_load_tw(const Fp<FrP> *t, size_t i) { return fft_load(t, i); }
+template <class FrP> __device__ __forceinline__ FpU<FrP> fft_load_tw(const FpU<FrP> *t, size_t i) { return fft_load_words(t, i); }
+
+// out[i] = scale * base^i, i < count, already cut into lazy limbs (what the butterflies multiply by: no re-cut per use)
+template <class FrP>
+__global__ void __launch_bounds__(256) k_fft_pow_table_cut(FftPowers<FrP> pw, Fp<FrP> scale, size_t count, FpU<FrP> *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Fp<FrP> acc = scale;
+#pragma nounroll
+    for (int b = 0; b < 40; ++b)
+        if ((i >> b) & 1) acc = fp_mul(acc, pw.p[b]);
+    const FpU<FrP> u = fpu_unpack<FrP>(acc.l);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(out + i);
+#pragma unroll
+    for (int k = 0; k < FrP::UL; ++k) dst[k] = u.l[k];
+}
+
 // out[i] = scale * base^i, i < count (BuildExpTable, fft/domain.go; here one thread per entry)
 template <class FrP>
 __global__ void __launch_bounds__(256) k_fft_pow_table(FftPowers<FrP> pw, Fp<FrP> scale, size_t count, Fp<FrP> *__restrict__ out) {
@@ -105,10 +133,31 @@ __global__ void __launch_bounds__(256) k_fft_scale_const_lz(Fp<FrP> *__restrict_
 #ifndef GMSM_FFT_LOWB
 #define GMSM_FFT_LOWB 10
 #endif
+// Round 4: the twiddle table holds the entries already cut into lazy limbs (FftTw = FpU: 36 instead of 32 bytes per BN254
+// entry, no shifts and masks per butterfly), and the stage of bit 0 - every twiddle is w^0 - skips its product.
+// -DGMSM_FFT_PRECUT=0 / -DGMSM_FFT_SKIP_ONE=0 build the round-3 forms (A/B).
+#ifndef GMSM_FFT_PRECUT
+#define GMSM_FFT_PRECUT 1
+#endif
+#ifndef GMSM_FFT_SKIP_ONE
+#define GMSM_FFT_SKIP_ONE 1
+#endif
+// DIT passes without conditional subtractions (FftLz::dit_free) and, for every pass that is not the transform's last,
+// stores of a lazy representative (< 2q) instead of the canonical element. -DGMSM_FFT_DIT_FREE=0 / -DGMSM_FFT_LAZY_STORE=0: A/B.
+#ifndef GMSM_FFT_DIT_FREE
+#define GMSM_FFT_DIT_FREE 1
+#endif
+#ifndef GMSM_FFT_LAZY_STORE
+#define GMSM_FFT_LAZY_STORE 1
+#endif
+template <class FrP> struct FftTwOf { using type = typename std::conditional<GMSM_FFT_PRECUT != 0, FpU<FrP>, Fp<FrP>>::type; };
+template <class FrP> using FftTw = typename FftTwOf<FrP>::type;
+
 template <class FrP, bool DIF>
 __global__ void __launch_bounds__(512) k_fft_pass_lz(Fp<FrP> *__restrict__ a, unsigned log2n, unsigned bl, unsigned B, unsigned log2C,
-                                                     const Fp<FrP> *__restrict__ twz, const Fp<FrP> *__restrict__ pre, int pre_rev,
-                                                     const Fp<FrP> *__restrict__ post, int post_mode, Fp<FrP> post_c) {
+                                                     const FftTw<FrP> *__restrict__ twz, const Fp<FrP> *__restrict__ pre, int pre_rev,
+                                                     const Fp<FrP> *__restrict__ post, int post_mode, Fp<FrP> post_c, int final_pass) {
+    constexpr bool FREE = !DIF && GMSM_FFT_DIT_FREE != 0;  // reduction-free Cooley-Tukey butterflies (values < 40q in the tile)
     extern __shared__ __align__(16) unsigned char lds_raw[];
     using Z = FftLz<FrP>;
     using U = FpU<FrP>;
@@ -136,9 +185,26 @@ __global__ void __launch_bounds__(512) k_fft_pass_lz(Fp<FrP> *__restrict__ a, un
             const size_t i = base + ((size_t)mid0 << bl) + c;
             const size_t j = i & (((size_t)1 << b) - 1);
             U x = tile[(mid0 << log2C) + c], y = tile[(mid1 << log2C) + c];
-            const Fp<FrP> w = fft_load(twz, j << (log2n - 1 - b));  // entry 0 is the domain's one: no special case
-            if (DIF) Z::dif(x, y, w);
-            else Z::dit(x, y, w);
+            if (FREE && GMSM_FFT_SKIP_ONE && b == 0) {
+                Z::dit_one(x, y);
+            } else if (FREE) {
+                const FftTw<FrP> w = fft_load_tw(twz, j << (log2n - 1 - b));
+                Z::dit_free(x, y, w);
+            } else if (GMSM_FFT_SKIP_ONE && !Z::TIGHT && b == 0) {
+                // bit 0: j = 0 for every butterfly of the stage, the twiddle is one - DIF and DIT both reduce to
+                // (x, y) <- (x + y, x - y). The difference x - y + 4q < 6q + D comes back into A2 with two top-limb
+                // steps (each takes 2q off a value whose top limb proves it is above 2q): < 2q + D, no product.
+                const U s = fpu_add_a2<FrP, false>(x, y);
+                U d = fpu_sub<FrP, 4>(x, y);
+                fpu_csub2q_carry(d);
+                fpu_csub2q_carry(d);
+                x = s;
+                y = d;
+            } else {
+                const FftTw<FrP> w = fft_load_tw(twz, j << (log2n - 1 - b));  // entry 0 is the domain's one
+                if (DIF) Z::dif(x, y, w);
+                else Z::dit(x, y, w);
+            }
             tile[(mid0 << log2C) + c] = x;
             tile[(mid1 << log2C) + c] = y;
         }
@@ -148,9 +214,12 @@ __global__ void __launch_bounds__(512) k_fft_pass_lz(Fp<FrP> *__restrict__ a, un
         const unsigned mid = e >> log2C, c = e & (C - 1);
         const size_t g = base + ((size_t)mid << bl) + c;
         U x = tile[e];
+        // a product takes any of the tile's classes (A2, or < 40q after a reduction-free pass) to below 1.3q
         if (post_mode == 3) x = Z::mul(x, post_c);
         else if (post_mode != 0) x = Z::mul(x, fft_load(post, post_mode == 2 ? fft_bitrev(g, log2n) : g));
-        fft_store(a, g, Z::store(x));
+        const bool lazy = GMSM_FFT_LAZY_STORE != 0 && !final_pass;  // the next pass re-cuts whatever fits the element
+        if (FREE && post_mode == 0) fft_store(a, g, lazy ? Z::store_lazy_big(x) : Z::store_big(x));
+        else fft_store(a, g, lazy ? Z::store_lazy_a2(x) : Z::store(x));
     }
 }
 
@@ -236,13 +305,20 @@ struct FftField {
         const size_t half = n / 2;
         int rc;
         if (half) {
-            if ((rc = d->twiddles_lz.ensure(half * sizeof(Fr)))) return rc;
-            if ((rc = d->twiddles_inv_lz.ensure(half * sizeof(Fr)))) return rc;
+            if ((rc = d->twiddles_lz.ensure(half * sizeof(FftTw<FrP>)))) return rc;
+            if ((rc = d->twiddles_inv_lz.ensure(half * sizeof(FftTw<FrP>)))) return rc;
             const unsigned blocks = (unsigned)((half + 255) / 256);
-            hipLaunchKernelGGL((k_fft_pow_table<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(gen), lazy_shift(), half,
-                               (Fr *)d->twiddles_lz.ptr);
-            hipLaunchKernelGGL((k_fft_pow_table<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(gen_inv), lazy_shift(), half,
-                               (Fr *)d->twiddles_inv_lz.ptr);
+            if constexpr (GMSM_FFT_PRECUT != 0) {
+                hipLaunchKernelGGL((k_fft_pow_table_cut<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(gen), lazy_shift(), half,
+                                   (FpU<FrP> *)d->twiddles_lz.ptr);
+                hipLaunchKernelGGL((k_fft_pow_table_cut<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(gen_inv), lazy_shift(), half,
+                                   (FpU<FrP> *)d->twiddles_inv_lz.ptr);
+            } else {
+                hipLaunchKernelGGL((k_fft_pow_table<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(gen), lazy_shift(), half,
+                                   (Fr *)d->twiddles_lz.ptr);
+                hipLaunchKernelGGL((k_fft_pow_table<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(gen_inv), lazy_shift(), half,
+                                   (Fr *)d->twiddles_inv_lz.ptr);
+            }
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
@@ -306,6 +382,7 @@ struct FftField {
             constexpr unsigned LOWB = sizeof(Fr) <= 32 ? GMSM_FFT_LOWB : GMSM_FFT_LOWB - 1;  // 2^10 x 36 B = 36 KiB of LDS
             const unsigned tpb = log2n >= 22 ? 512u : 256u;
             static_assert(LOWB <= FFT_MAX_CHAIN, "additions between two reductions to canonical form");
+            static_assert(LOWB <= FftLz<FrP>::DIT_FREE_STAGES - 1 && 8 <= FftLz<FrP>::DIT_FREE_STAGES - 1, "stages of a reduction-free pass");
             struct Pass { unsigned bl, B, log2C; } passes[16];
             int np = 0;
             const unsigned low = std::min(log2n, LOWB);
@@ -319,7 +396,7 @@ struct FftField {
                 rest -= Bk;
             }
             {
-                const Fr *twz = (const Fr *)(inverse ? d->twiddles_inv_lz.ptr : d->twiddles_lz.ptr);
+                const FftTw<FrP> *twz = (const FftTw<FrP> *)(inverse ? d->twiddles_inv_lz.ptr : d->twiddles_lz.ptr);
                 for (int k = 0; k < np; ++k) {
                     const Pass &ps = passes[dif ? np - 1 - k : k];
                     const size_t lds = ((size_t)sizeof(FpU<FrP>) << ps.B) << ps.log2C;
@@ -329,11 +406,11 @@ struct FftField {
                     if (dif) {
                         if ((rc = ctx_allow_lds((const void *)k_fft_pass_lz<FrP, true>, 128 * 1024))) return rc;
                         hipLaunchKernelGGL((k_fft_pass_lz<FrP, true>), dim3((unsigned)tiles), dim3(tpb), lds, stream, a, log2n, ps.bl,
-                                           ps.B, ps.log2C, twz, pre_k, pre_rev, post, post_k, card_inv_lz);
+                                           ps.B, ps.log2C, twz, pre_k, pre_rev, post, post_k, card_inv_lz, k == np - 1 ? 1 : 0);
                     } else {
                         if ((rc = ctx_allow_lds((const void *)k_fft_pass_lz<FrP, false>, 128 * 1024))) return rc;
                         hipLaunchKernelGGL((k_fft_pass_lz<FrP, false>), dim3((unsigned)tiles), dim3(tpb), lds, stream, a, log2n, ps.bl,
-                                           ps.B, ps.log2C, twz, pre_k, pre_rev, post, post_k, card_inv_lz);
+                                           ps.B, ps.log2C, twz, pre_k, pre_rev, post, post_k, card_inv_lz, k == np - 1 ? 1 : 0);
                     }
                 }
             }

@@ -86,6 +86,54 @@ static int check(const char *name) {
                 if (memcmp(&o, &s[i], sizeof o) != 0 && bad++ < 5) printf("%s: pattern %d dif %d: element %zu differs\n", name, pattern, dif, i);
             }
         }
+        // Round 4: the reduction-free DIT pass (dit_one for bit 0, dit_free above it) started from the WORST input the
+        // device ever loads - a lazy representative just below 2^(32N), i.e. the canonical value plus as many q as fit -
+        // and ended by store_big / store_lazy_big; the value must stay below 40q all the way (limbs nearly normalised).
+        {
+            std::vector<Fr> s = a;
+            std::vector<FpU<P>> z(N);
+            for (size_t i = 0; i < N; ++i) {
+                z[i] = Z::load(a[i]);
+                for (int rep = 0; rep < 8; ++rep) {  // + q while the sum still fits 32N bits
+                    FpU<P> t;
+                    for (int k = 0; k < P::UL; ++k) t.l[k] = z[i].l[k] + P::UQ1[k];
+                    fpu_normalize(t);
+                    if ((uint64_t)t.l[P::UL - 1] >> (32 * P::N - P::UW * (P::UL - 1)) != 0) break;
+                    z[i] = t;
+                }
+            }
+            for (unsigned st = 0; st < LOG; ++st) {
+                const unsigned b = st;
+                for (size_t q = 0; q < N / 2; ++q) {
+                    const size_t i0 = ((q >> b) << (b + 1)) | (q & (((size_t)1 << b) - 1)), i1 = i0 | ((size_t)1 << b);
+                    const size_t j = i0 & (((size_t)1 << b) - 1), t = j << (LOG - 1 - b);
+                    const Fr tt = fp_mul(s[i1], tw[t]);
+                    s[i1] = fp_sub(s[i0], tt);
+                    s[i0] = fp_add(s[i0], tt);
+                    if (b == 0) Z::dit_one(z[i0], z[i1]);
+                    else Z::dit_free(z[i0], z[i1], twz[t]);
+                    for (const FpU<P> *v : {&z[i0], &z[i1]}) {
+                        for (int k = 0; k < P::UL - 1; ++k)
+                            if (v->l[k] > (1u << P::UW) + (1u << (32 - P::UW))) ++cls;
+                        // below 40q: top limb below 40 * (top(q) + 1)
+                        if ((uint64_t)v->l[P::UL - 1] >= 40ull * (P::UQ1[P::UL - 1] + 1ull)) ++cls;
+                    }
+                }
+            }
+            for (size_t i = 0; i < N; ++i) {
+                const Fr o = Z::store_big(z[i]);
+                if (memcmp(&o, &s[i], sizeof o) != 0 && bad++ < 5) printf("%s: pattern %d free DIT: element %zu differs\n", name, pattern, i);
+                // the lazy store followed by a canonicalising reload must name the same element, and fit below 2q + q/512
+                const Fr lz = Z::store_lazy_big(z[i]);
+                const Fr back = Z::store(Z::load(lz));
+                if (memcmp(&back, &s[i], sizeof back) != 0 && bad++ < 5) printf("%s: pattern %d lazy store: element %zu differs\n", name, pattern, i);
+                FpU<P> a2 = Z::load(o);  // class A2 lazy store of a canonical value plus q: below 2q exactly
+                for (int k = 0; k < P::UL; ++k) a2.l[k] += P::UQ1[k];
+                const Fr la = Z::store_lazy_a2(a2);
+                const Fr back2 = Z::store(Z::load(la));
+                if (memcmp(&back2, &s[i], sizeof back2) != 0 && bad++ < 5) printf("%s: pattern %d a2 lazy store: element %zu differs\n", name, pattern, i);
+            }
+        }
     }
     printf("%s: tight=%d shift=%u: %d mismatches, %d class violations\n", name, (int)Z::TIGHT, Z::DOMAIN_SHIFT, bad, cls);
     return bad + cls;
