@@ -149,6 +149,8 @@ struct Workspace {
     DeviceBuffer carry;          // running bucket sums of a multi-range host call (k_merge_buckets)
     hipStream_t mstream = nullptr;                         // merges + the one reduction of a multi-range call
     hipEvent_t ev_buckets = nullptr, ev_merged = nullptr;  // a range's buckets are complete / have been merged
+    hipStream_t cstream = nullptr;                         // the base rewrite of an unregistered call, beside its scalar pipeline
+    hipEvent_t ev_fork = nullptr, ev_conv = nullptr;       // inputs are ready on the call's stream / the rewrite is complete
     hipEvent_t events[12] = {nullptr};  // stage boundaries of the call in flight when profiling is on
     bool timed = false;                 // events[] were recorded by the last enqueue
     int timed_level = 0;                // ... at this profiling level (1: every stage, 2: the accumulation kernel only)
@@ -188,7 +190,7 @@ struct Workspace {
     }
     void destroy() {  // gmsm_shutdown: streams and events too
         (void)trim(0);
-        hipEvent_t *evs[] = {&ev_buckets, &ev_merged, &dep, &last_use};
+        hipEvent_t *evs[] = {&ev_buckets, &ev_merged, &dep, &last_use, &ev_fork, &ev_conv};
         for (hipEvent_t *e : evs) {
             if (*e) (void)hipEventDestroy(*e);
             *e = nullptr;
@@ -199,7 +201,8 @@ struct Workspace {
         }
         if (stream) (void)hipStreamDestroy(stream);
         if (mstream) (void)hipStreamDestroy(mstream);
-        stream = mstream = nullptr;
+        if (cstream) (void)hipStreamDestroy(cstream);
+        stream = mstream = cstream = nullptr;
         last_stream = nullptr;
         bases_ref.reset();
     }
@@ -237,8 +240,11 @@ struct Context {
         for (auto &w : ws) {
             HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
             HIP_TRY(hipStreamCreateWithFlags(&w.mstream, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&w.cstream, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&w.ev_buckets, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&w.ev_merged, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&w.ev_conv, hipEventDisableTiming));
         }
         return GMSM_OK;
     }

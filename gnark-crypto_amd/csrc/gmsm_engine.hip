@@ -1480,6 +1480,7 @@ GMSM_EXPORT int gmsm_trim(size_t keep_bytes, size_t *out_freed) {
             if (w->last_use) (void)hipEventSynchronize(w->last_use);
             (void)hipStreamSynchronize(w->stream);
             (void)hipStreamSynchronize(w->mstream);
+            (void)hipStreamSynchronize(w->cstream);
             std::shared_ptr<ResidentBases> parked;
             parked.swap(w->bases_ref);
             freed += w->trim(keep_bytes);

@@ -45,6 +45,7 @@ struct Group {
     using OpsElem = typename OpsSerial::Elem;
     // Level 1 of the bucket reduction = k_reduce_serial (one thread per L buckets, no LDS) + k_combine_q (COMBINE_N
     // (S, W) pairs per workgroup of 4 * COMBINE_N threads); level 2 = k_reduce2_q, at most RED2_TPB level-1 results per window.
+    static constexpr size_t FORK_CONVERT_MIN = (size_t)1 << 18;  // unregistered calls from here on rewrite their bases on a side stream
     static constexpr int COMBINE_N = 64;
     static constexpr int RED2_TPB = 64;
     // The serial part itself runs on quads (k_reduce_serial_q) for every element type but the 9-limb prime field.
@@ -418,16 +419,28 @@ struct Group {
         timer.mark(T_DECOMPOSE, stream);
         const uint8_t *skip = nullptr;
         const void *upoints = nullptr;
+        bool forked = false;
         if (resident) {
             upoints = (const char *)(shared ? resident->tables.ptr : resident->upoints.ptr) + resident_offset * AFF_BYTES;
             skip = (const uint8_t *)resident->skip.ptr + resident_offset;
         } else {
+            // Round 4: the rewrite of the bases runs on a stream of its own BESIDE the scalar pipeline (decomposition and
+            // the two sort passes touch only the scalars; those kernels are bound by LDS atomics and latency, the rewrite
+            // by HBM) and joins before the accumulation. Infinity points are recognised by the accumulation from the
+            // rewritten record (uaffine_is_infinity), so the decomposition needs no flags from here. 2^20: 36 us off the
+            // critical path, 2^24: 0.44 ms. Small calls keep the single stream (two events cost more than they hide).
             if ((rc = ws.upoints.ensure(n_points * AFF_BYTES))) return rc;
-            if ((rc = ws.skip.ensure(n_points))) return rc;
+            forked = n_points >= FORK_CONVERT_MIN;
+            hipStream_t cs = forked ? ws.cstream : stream;
+            if (forked) {
+                HIP_TRY(hipEventRecord(ws.ev_fork, stream));
+                HIP_TRY(hipStreamWaitEvent(cs, ws.ev_fork, 0));
+            }
             hipLaunchKernelGGL((k_convert_points<U>), dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0,
-                               stream, d_points, n_points, ws.upoints.ptr, (uint8_t *)ws.skip.ptr);
+                               cs, d_points, n_points, ws.upoints.ptr, (uint8_t *)nullptr);
+            if (forked) HIP_TRY(hipEventRecord(ws.ev_conv, cs));
             upoints = ws.upoints.ptr;
-            skip = (const uint8_t *)ws.skip.ptr;
+            skip = nullptr;
         }
         // (A decomposition fused with the coarse histogram was measured and dropped: one workgroup per 16 K-scalar chunk
         // leaves 3/4 of the CUs idle at 2^20, and at 2^24 it only breaks even.)
@@ -468,6 +481,7 @@ struct Group {
         hipLaunchKernelGGL(k_fine_sort, dim3(nparts, nw), dim3(1024), ((size_t)4 << fbits) + (size_t)stage_cap * 4, stream,
                            parted, n, NB, fbits, lidx, part_base, sorted, starts, stage_cap);
         // ---- 2. bucket accumulation
+        if (forked) HIP_TRY(hipStreamWaitEvent(stream, ws.ev_conv, 0));  // the rewritten bases are complete
         timer.mark(T_ACCUMULATE, stream);
         if (shared)
             hipLaunchKernelGGL((k_accumulate_seg<U, true>), dim3((q.tpw + 255) / 256, nw), dim3(256), 0, stream, upoints, n, NB,

@@ -437,6 +437,19 @@ struct UAffine {  // packed lazy-domain coordinates (values < 2q): same size as 
     uint32_t x[LzTraits<U>::PACKED_WORDS], y[LzTraits<U>::PACKED_WORDS];
 };
 
+// The point at infinity, affine (0, 0) (g1.go:41-47), stays all-zero words through the rewrite (the Montgomery product of
+// zero is zero, and no finite point has both coordinates divisible by q): the accumulation recognises it from the
+// gathered record itself - one OR of the two low words for every entry, the full test only when that is zero - so the
+// scalar pipeline of an unregistered call does not have to wait for the rewrite to learn which points to skip.
+template <class U>
+__device__ __forceinline__ bool uaffine_is_infinity(const UAffine<U> &p) {
+    if ((p.x[0] | p.y[0]) != 0u) return false;
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < (int)LzTraits<U>::PACKED_WORDS; ++i) any |= p.x[i] | p.y[i];
+    return any == 0u;
+}
+
 template <class U>
 __global__ void __launch_bounds__(256) k_convert_points(const void *__restrict__ points, size_t n, void *__restrict__ upoints,
                                                         uint8_t *__restrict__ skip) {
@@ -444,7 +457,7 @@ __global__ void __launch_bounds__(256) k_convert_points(const void *__restrict__
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Affine<typename T::Sat> a = load_struct<Affine<typename T::Sat>>(points, i);
-    skip[i] = a.is_infinity() ? 1 : 0;
+    if (skip != nullptr) skip[i] = a.is_infinity() ? 1 : 0;
     const U ux = T::template from_sat<true>(a.x), uy = T::template from_sat<true>(a.y);
     UAffine<U> u;
     T::pack(ux, u.x);
@@ -563,7 +576,8 @@ __global__ void __launch_bounds__(256, AccWaves<U>::value) k_accumulate_seg(cons
         if (e + 1 < e1) p = load_struct<UAffine<U>>(upoints, point_slot<TAB>(vn >> 1, tab_m, tab_stride));
         v = vn;
         vn = vnn;
-        lz_madd_acc<true>(acc, inf, T::unpack(pc.x), T::unpack(pc.y), (vc & 1u) != 0);
+        if (!uaffine_is_infinity<U>(pc))  // affine (0, 0) contributes nothing (g1.go:825)
+            lz_madd_acc<true>(acc, inf, T::unpack(pc.x), T::unpack(pc.y), (vc & 1u) != 0);
     }
     {
         const bool open_right = bend > e1;
