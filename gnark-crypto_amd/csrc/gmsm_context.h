@@ -112,6 +112,8 @@ struct FftDomain {
     // Device tables. "Lazy domain" = the canonical element 2^(L*W-32N) * factor (gmsm_fft_lazy.h): what the lazy-limb
     // butterflies multiply by.
     DeviceBuffer twiddles_lz, twiddles_inv_lz;  // w^t, w^-t for t < n/2, lazy domain
+    DeviceBuffer twiddles_rev_lz, twiddles_inv_rev_lz;  // the same in bit-reversed order (top-down passes), on first use
+    bool rev_ready = false;
     DeviceBuffer coset, coset_inv_scaled;       // u^i and u^-i / n for i < n (lazy domain), built by the first coset transform
     std::vector<uint64_t> cardinality_inv_lz;   // 1/n, lazy domain
     bool coset_ready = false;
@@ -120,7 +122,7 @@ struct FftDomain {
     FftDomain(const FftDomain &) = delete;
     FftDomain &operator=(const FftDomain &) = delete;
     ~FftDomain() {
-        DeviceBuffer *bufs[] = {&twiddles_lz, &twiddles_inv_lz, &coset, &coset_inv_scaled};
+        DeviceBuffer *bufs[] = {&twiddles_lz, &twiddles_inv_lz, &twiddles_rev_lz, &twiddles_inv_rev_lz, &coset, &coset_inv_scaled};
         bool any = false;
         for (auto *b : bufs) any = any || b->ptr;
         if (!any) return;

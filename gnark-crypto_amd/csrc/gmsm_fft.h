@@ -46,48 +46,23 @@ __device__ __forceinline__ void fft_store(T *a, size_t i, const T &v) {
     for (int k = 0; k < (int)(sizeof(T) / 16); ++k) dst[k] = src[k];
 }
 
-// Table entries that are only 4-byte aligned (pre-cut twiddles: 9 / 14 words each): dword-aligned vector loads
-template <class T>
-__device__ __forceinline__ T fft_load_words(const T *a, size_t i) {
-    static_assert(sizeof(T) % 4 == 0, "element size");
-    struct __attribute__((packed, aligned(4))) Raw { uint32_t w[sizeof(T) / 4]; };
-    const Raw raw = *reinterpret_cast<const Raw *>(a + i);
-    T r;
-    __builtin_memcpy(&r, &raw, sizeof(T));
-    return r;
-}
-template <class FrP> __device__ __forceinline__ Fp<FrP> fft_load_tw(const Fp<FrP> *t, size_t i) { return fft_load(t, i); }
-template <class FrP> __device__ __forceinline__ FpU<FrP> fft_load_tw(const FpU<FrP> *t, size_t i) { return fft_load_words(t, i); }
-
-// out[i] = scale * base^i, i < count, already cut into lazy limbs (what the butterflies multiply by: no re-cut per use)
-template <class FrP>
-__global__ void __launch_bounds__(256) k_fft_pow_table_cut(FftPowers<FrP> pw, Fp<FrP> scale, size_t count, FpU<FrP> *__restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    Fp<FrP> acc = scale;
-#pragma nounroll
-    for (int b = 0; b < 40; ++b)
-        if ((i >> b) & 1) acc = fp_mul(acc, pw.p[b]);
-    const FpU<FrP> u = fpu_unpack<FrP>(acc.l);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(out + i);
-#pragma unroll
-    for (int k = 0; k < FrP::UL; ++k) dst[k] = u.l[k];
-}
-
-// out[i] = scale * base^i, i < count (BuildExpTable, fft/domain.go; here one thread per entry)
-template <class FrP>
-__global__ void __launch_bounds__(256) k_fft_pow_table(FftPowers<FrP> pw, Fp<FrP> scale, size_t count, Fp<FrP> *__restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    Fp<FrP> acc = scale;
-#pragma nounroll
-    for (int b = 0; b < 40; ++b)
-        if ((i >> b) & 1) acc = fp_mul(acc, pw.p[b]);
-    fft_store(out, i, acc);
-}
-
 __device__ __forceinline__ size_t fft_bitrev(size_t i, unsigned log2n) {
     return log2n ? (size_t)(__brevll((unsigned long long)i) >> (64 - log2n)) : 0;
+}
+
+// out[i] = scale * base^e, i < count, e = i (BuildExpTable, fft/domain.go; here one thread per entry) or, rev_bits != 0,
+// e = i with its low rev_bits bits reversed: the twiddle table in the order the top-down passes read it.
+template <class FrP>
+__global__ void __launch_bounds__(256) k_fft_pow_table(FftPowers<FrP> pw, Fp<FrP> scale, size_t count, Fp<FrP> *__restrict__ out,
+                                                       unsigned rev_bits = 0) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const size_t e = rev_bits ? fft_bitrev(i, rev_bits) : i;
+    Fp<FrP> acc = scale;
+#pragma nounroll
+    for (int b = 0; b < 40; ++b)
+        if ((e >> b) & 1) acc = fp_mul(acc, pw.p[b]);
+    fft_store(out, i, acc);
 }
 
 // a[i] *= table[rev ? bitrev(i) : i] (coset scaling; the table may carry 1/n folded in) and a[i] *= c (CardinalityInv,
@@ -110,54 +85,41 @@ __global__ void __launch_bounds__(256) k_fft_scale_const_lz(Fp<FrP> *__restrict_
     fft_store(a, i, Z::store(Z::mul(Z::load(fft_load(a, i)), c)));
 }
 
-// Several consecutive radix-2 stages in one pass over HBM. A stage pairs elements whose indices differ in one bit b
-// (DIF walks b downwards from log2n-1, DIT upwards from 0): (a[i], a[i+2^b]) <- (a[i] + a[i+2^b], (a[i] - a[i+2^b]) w^(j <<
-// (log2n-1-b))) for DIF (difFFT, fft.go:198-262; j = i mod 2^b), t = a[i+2^b] w^(...); (a[i] + t, a[i] - t) for DIT (ditFFT,
-// fft.go:264-330). A pass takes the B stages of bits [bl, bl+B) and a workgroup owns a tile of 2^B x C elements - every
-// value of those B bits x C consecutive values of the low bits (C x 32 bytes contiguous per row, so the strided passes
-// still move whole 128-256-byte runs) - stages it in LDS, runs the B stages with a barrier in between and writes it back:
-// one read and one write of the vector per pass instead of per stage (2^24: 3 passes instead of 24 trips through HBM).
-// (Rounds 1-2 kept the first two versions - one launch per stage, and the tiled pass on the canonical saturated field -
-// as A/B baselines: 6.0 and 3.25-3.48 ms at 2^24 against 2.65; removed in round 3.)
+// Several consecutive radix-2 stages in one pass over HBM. A stage pairs elements whose indices differ in one bit b. A
+// pass takes the B stages of bits [bl, bl+B) and a workgroup owns a tile of 2^B x C elements - every value of those B
+// bits x C consecutive values of the low bits (C x 32 bytes contiguous per row, so the strided passes still move whole
+// 128-256-byte runs) - stages it in LDS, runs the B stages with a barrier in between and writes it back: one read and
+// one write of the vector per pass instead of per stage (2^24: 3 passes instead of 24 trips through HBM).
 //
-// k_fft_pass on lazy limbs. The tile holds FpU values of the class A2 (36 bytes per BN254 element: an odd number of
-// words, so consecutive elements fall into different LDS banks); `twz` and the scaling tables are in the lazy domain.
+// Round 4 - ONE butterfly for every transform. The kernel is bound by VALU issue (rocprofv3: SQ_ACTIVE_INST_VALU = 96 %
+// of the kernel's cycles, ~400 instructions per butterfly of which 190 are the product, profiles/r04_fft_stats.md), so
+// what counts is instructions per butterfly. The reference's DIF is Gentleman-Sande - (x, y) <- (x + y, (x - y) w) - whose
+// sums double the bound of a value at every stage, so every stage needs a conditional subtraction; its DIT is
+// Cooley-Tukey - t = y w, (x, y) <- (x + t, x - t) - where a bound grows by 2q per stage and a whole pass needs none
+// (FftLz::dit_free). The forward order "natural in, bit-reversed out" has a Cooley-Tukey form too: bit b from the top
+// down, the pair (i, i + 2^b) of block k = i >> (b + 1) takes the twiddle w^(bitrev_(log n - 1)(k)) - the SAME block
+// index in every stage, so one table in bit-reversed order (FftDomain::twiddles_rev_lz) serves all of them, and the top
+// passes, whose blocks are few, read a handful of entries where the Gentleman-Sande form streamed the whole table. Every
+// output is the same field element whichever flow graph computes it, so parity is untouched (the A/B and the bit-exact
+// suite: profiles/r04_fft_ab.log). BN254 2^24: DIF 2.59 -> 2.3x ms, DIT 2.58 -> 2.36.
+//   TOPDOWN = true : stages from bit bl + B - 1 down (FFT/FFTInverse with decimation DIF), twz = bit-reversed table
+//   TOPDOWN = false: stages from bit bl up (decimation DIT), twz = natural table, entry j << (log n - 1 - b)
+// The stage whose twiddles are all one (the first of the transform: bit log n - 1 top-down, bit 0 bottom-up) runs without
+// its product (dit_one). Values in the tile are below 40q (FftLz); they come back below 2q once per pass, on the store:
+// the canonical element from the transform's last pass, any representative that fits the element from the others.
 // Scalings of the transform fused into the pass that touches the vector first / last:
 //   pre  != null : every element is multiplied by pre[pre_rev ? bitrev(i) : i] as it is loaded (coset FFT, fft.go:43-82)
 //   post_mode 1/2: ... by post[i] / post[bitrev(i)] as it is stored (inverse coset FFT, fft.go:153-195)
 //   post_mode 3  : ... by the constant post_c (CardinalityInv, fft.go:144-150)
 // Tile of the contiguous low pass: 2^10 elements (36 KB of LDS for a 32-byte field: four workgroups per CU instead of the
-// two that 2^11 allowed) and 512 threads per tile from 2^22 elements on. Measured, BN254 fr DIF, 2^11 x 256 threads ->
-// 2^10 x 256 / 512: 2^16 0.080 -> 0.061 / 0.053 ms, 2^20 0.197 -> 0.187 / 0.192, 2^24 2.73 -> 2.60 / 2.53
-// (profiles/r03_fft_tiles.log; 2^9 tiles and 1024 threads lose).
+// two that 2^11 allowed) and 512 threads per tile from 2^22 elements on (profiles/r03_fft_tiles.log).
 #ifndef GMSM_FFT_LOWB
 #define GMSM_FFT_LOWB 10
 #endif
-// Round 4: the twiddle table holds the entries already cut into lazy limbs (FftTw = FpU: 36 instead of 32 bytes per BN254
-// entry, no shifts and masks per butterfly), and the stage of bit 0 - every twiddle is w^0 - skips its product.
-// -DGMSM_FFT_PRECUT=0 / -DGMSM_FFT_SKIP_ONE=0 build the round-3 forms (A/B).
-#ifndef GMSM_FFT_PRECUT
-#define GMSM_FFT_PRECUT 1
-#endif
-#ifndef GMSM_FFT_SKIP_ONE
-#define GMSM_FFT_SKIP_ONE 1
-#endif
-// DIT passes without conditional subtractions (FftLz::dit_free) and, for every pass that is not the transform's last,
-// stores of a lazy representative (< 2q) instead of the canonical element. -DGMSM_FFT_DIT_FREE=0 / -DGMSM_FFT_LAZY_STORE=0: A/B.
-#ifndef GMSM_FFT_DIT_FREE
-#define GMSM_FFT_DIT_FREE 1
-#endif
-#ifndef GMSM_FFT_LAZY_STORE
-#define GMSM_FFT_LAZY_STORE 1
-#endif
-template <class FrP> struct FftTwOf { using type = typename std::conditional<GMSM_FFT_PRECUT != 0, FpU<FrP>, Fp<FrP>>::type; };
-template <class FrP> using FftTw = typename FftTwOf<FrP>::type;
-
-template <class FrP, bool DIF>
+template <class FrP, bool TOPDOWN>
 __global__ void __launch_bounds__(512) k_fft_pass_lz(Fp<FrP> *__restrict__ a, unsigned log2n, unsigned bl, unsigned B, unsigned log2C,
-                                                     const FftTw<FrP> *__restrict__ twz, const Fp<FrP> *__restrict__ pre, int pre_rev,
+                                                     const Fp<FrP> *__restrict__ twz, const Fp<FrP> *__restrict__ pre, int pre_rev,
                                                      const Fp<FrP> *__restrict__ post, int post_mode, Fp<FrP> post_c, int final_pass) {
-    constexpr bool FREE = !DIF && GMSM_FFT_DIT_FREE != 0;  // reduction-free Cooley-Tukey butterflies (values < 40q in the tile)
     extern __shared__ __align__(16) unsigned char lds_raw[];
     using Z = FftLz<FrP>;
     using U = FpU<FrP>;
@@ -176,34 +138,20 @@ __global__ void __launch_bounds__(512) k_fft_pass_lz(Fp<FrP> *__restrict__ a, un
     }
     __syncthreads();
     const unsigned nbf = elems >> 1;
+    const unsigned one_bit = TOPDOWN ? log2n - 1 : 0u;  // the stage whose twiddles are all one
     for (unsigned st = 0; st < B; ++st) {
-        const unsigned bb = DIF ? B - 1 - st : st;
+        const unsigned bb = TOPDOWN ? B - 1 - st : st;
         const unsigned b = bl + bb;
         for (unsigned q = t; q < nbf; q += T) {
             const unsigned c = q & (C - 1), p = q >> log2C;
             const unsigned mid0 = ((p >> bb) << (bb + 1)) | (p & ((1u << bb) - 1)), mid1 = mid0 | (1u << bb);
             const size_t i = base + ((size_t)mid0 << bl) + c;
-            const size_t j = i & (((size_t)1 << b) - 1);
             U x = tile[(mid0 << log2C) + c], y = tile[(mid1 << log2C) + c];
-            if (FREE && GMSM_FFT_SKIP_ONE && b == 0) {
+            if (b == one_bit) {
                 Z::dit_one(x, y);
-            } else if (FREE) {
-                const FftTw<FrP> w = fft_load_tw(twz, j << (log2n - 1 - b));
-                Z::dit_free(x, y, w);
-            } else if (GMSM_FFT_SKIP_ONE && !Z::TIGHT && b == 0) {
-                // bit 0: j = 0 for every butterfly of the stage, the twiddle is one - DIF and DIT both reduce to
-                // (x, y) <- (x + y, x - y). The difference x - y + 4q < 6q + D comes back into A2 with two top-limb
-                // steps (each takes 2q off a value whose top limb proves it is above 2q): < 2q + D, no product.
-                const U s = fpu_add_a2<FrP, false>(x, y);
-                U d = fpu_sub<FrP, 4>(x, y);
-                fpu_csub2q_carry(d);
-                fpu_csub2q_carry(d);
-                x = s;
-                y = d;
             } else {
-                const FftTw<FrP> w = fft_load_tw(twz, j << (log2n - 1 - b));  // entry 0 is the domain's one
-                if (DIF) Z::dif(x, y, w);
-                else Z::dit(x, y, w);
+                const size_t tw = TOPDOWN ? (i >> (b + 1)) : ((i & (((size_t)1 << b) - 1)) << (log2n - 1 - b));
+                Z::dit_free(x, y, fft_load(twz, tw));
             }
             tile[(mid0 << log2C) + c] = x;
             tile[(mid1 << log2C) + c] = y;
@@ -214,12 +162,12 @@ __global__ void __launch_bounds__(512) k_fft_pass_lz(Fp<FrP> *__restrict__ a, un
         const unsigned mid = e >> log2C, c = e & (C - 1);
         const size_t g = base + ((size_t)mid << bl) + c;
         U x = tile[e];
-        // a product takes any of the tile's classes (A2, or < 40q after a reduction-free pass) to below 1.3q
-        if (post_mode == 3) x = Z::mul(x, post_c);
-        else if (post_mode != 0) x = Z::mul(x, fft_load(post, post_mode == 2 ? fft_bitrev(g, log2n) : g));
-        const bool lazy = GMSM_FFT_LAZY_STORE != 0 && !final_pass;  // the next pass re-cuts whatever fits the element
-        if (FREE && post_mode == 0) fft_store(a, g, lazy ? Z::store_lazy_big(x) : Z::store_big(x));
-        else fft_store(a, g, lazy ? Z::store_lazy_a2(x) : Z::store(x));
+        if (post_mode != 0) {  // the transform's last pass: a product takes the tile's class (< 40q) to below 1.3q
+            x = post_mode == 3 ? Z::mul(x, post_c) : Z::mul(x, fft_load(post, post_mode == 2 ? fft_bitrev(g, log2n) : g));
+            fft_store(a, g, Z::store(x));
+        } else {
+            fft_store(a, g, final_pass ? Z::store_big(x) : Z::store_lazy_big(x));  // the next pass re-cuts whatever fits the element
+        }
     }
 }
 
@@ -305,20 +253,13 @@ struct FftField {
         const size_t half = n / 2;
         int rc;
         if (half) {
-            if ((rc = d->twiddles_lz.ensure(half * sizeof(FftTw<FrP>)))) return rc;
-            if ((rc = d->twiddles_inv_lz.ensure(half * sizeof(FftTw<FrP>)))) return rc;
+            if ((rc = d->twiddles_lz.ensure(half * sizeof(Fr)))) return rc;
+            if ((rc = d->twiddles_inv_lz.ensure(half * sizeof(Fr)))) return rc;
             const unsigned blocks = (unsigned)((half + 255) / 256);
-            if constexpr (GMSM_FFT_PRECUT != 0) {
-                hipLaunchKernelGGL((k_fft_pow_table_cut<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(gen), lazy_shift(), half,
-                                   (FpU<FrP> *)d->twiddles_lz.ptr);
-                hipLaunchKernelGGL((k_fft_pow_table_cut<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(gen_inv), lazy_shift(), half,
-                                   (FpU<FrP> *)d->twiddles_inv_lz.ptr);
-            } else {
-                hipLaunchKernelGGL((k_fft_pow_table<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(gen), lazy_shift(), half,
-                                   (Fr *)d->twiddles_lz.ptr);
-                hipLaunchKernelGGL((k_fft_pow_table<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(gen_inv), lazy_shift(), half,
-                                   (Fr *)d->twiddles_inv_lz.ptr);
-            }
+            hipLaunchKernelGGL((k_fft_pow_table<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(gen), lazy_shift(), half,
+                               (Fr *)d->twiddles_lz.ptr, 0u);
+            hipLaunchKernelGGL((k_fft_pow_table<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(gen_inv), lazy_shift(), half,
+                               (Fr *)d->twiddles_inv_lz.ptr, 0u);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
@@ -330,6 +271,30 @@ struct FftField {
         Fr s = Fr::one();
         for (unsigned i = 0; i < FftLz<FrP>::DOMAIN_SHIFT; ++i) s = fp_dbl(s);
         return s;
+    }
+
+    // The twiddle tables in bit-reversed order (entry k = w^(+-bitrev_(log n - 1)(k))): what the top-down passes (decimation
+    // DIF) index with the block number. Built by the first such transform, like the coset tables; the caller holds d->mu.
+    static int ensure_rev_tables(hipStream_t stream, FftDomain *d) {
+        if (d->rev_ready) return GMSM_OK;
+        const size_t half = ((size_t)1 << d->log2n) / 2;
+        if (half) {
+            int rc;
+            if ((rc = d->twiddles_rev_lz.ensure(half * sizeof(Fr)))) return rc;
+            if ((rc = d->twiddles_inv_rev_lz.ensure(half * sizeof(Fr)))) return rc;
+            Fr gen, gen_inv;
+            memcpy(&gen, d->generator.data(), sizeof(Fr));
+            memcpy(&gen_inv, d->generator_inv.data(), sizeof(Fr));
+            const unsigned blocks = (unsigned)((half + 255) / 256);
+            hipLaunchKernelGGL((k_fft_pow_table<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(gen), lazy_shift(), half,
+                               (Fr *)d->twiddles_rev_lz.ptr, d->log2n - 1);
+            hipLaunchKernelGGL((k_fft_pow_table<FrP>), dim3(blocks), dim3(256), 0, stream, powers_of(gen_inv), lazy_shift(), half,
+                               (Fr *)d->twiddles_inv_rev_lz.ptr, d->log2n - 1);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(stream));  // complete before the flag says so (any stream may read them next)
+        }
+        d->rev_ready = true;
+        return GMSM_OK;
     }
 
     // cosetTable = u^i and cosetTableInv (with 1/n folded in) = u^-i / n, built on first use (domain.go:150-160); both in
@@ -364,6 +329,7 @@ struct FftField {
         const unsigned blocks_n = (unsigned)((n + 255) / 256);
         int rc;
         if (coset && (rc = ensure_coset_tables(stream, d))) return rc;
+        if (dif && n > 1 && (rc = ensure_rev_tables(stream, d))) return rc;
         const bool fused = n > 1;  // the scalings ride on the first / last pass
         Fr card_inv_lz;
         memcpy(&card_inv_lz, d->cardinality_inv_lz.data(), sizeof(Fr));
@@ -381,7 +347,6 @@ struct FftField {
             // from the top bits down, DIT from the bottom up.
             constexpr unsigned LOWB = sizeof(Fr) <= 32 ? GMSM_FFT_LOWB : GMSM_FFT_LOWB - 1;  // 2^10 x 36 B = 36 KiB of LDS
             const unsigned tpb = log2n >= 22 ? 512u : 256u;
-            static_assert(LOWB <= FFT_MAX_CHAIN, "additions between two reductions to canonical form");
             static_assert(LOWB <= FftLz<FrP>::DIT_FREE_STAGES - 1 && 8 <= FftLz<FrP>::DIT_FREE_STAGES - 1, "stages of a reduction-free pass");
             struct Pass { unsigned bl, B, log2C; } passes[16];
             int np = 0;
@@ -396,7 +361,8 @@ struct FftField {
                 rest -= Bk;
             }
             {
-                const FftTw<FrP> *twz = (const FftTw<FrP> *)(inverse ? d->twiddles_inv_lz.ptr : d->twiddles_lz.ptr);
+                const Fr *twz = dif ? (const Fr *)(inverse ? d->twiddles_inv_rev_lz.ptr : d->twiddles_rev_lz.ptr)
+                                    : (const Fr *)(inverse ? d->twiddles_inv_lz.ptr : d->twiddles_lz.ptr);
                 for (int k = 0; k < np; ++k) {
                     const Pass &ps = passes[dif ? np - 1 - k : k];
                     const size_t lds = ((size_t)sizeof(FpU<FrP>) << ps.B) << ps.log2C;

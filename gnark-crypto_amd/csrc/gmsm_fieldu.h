@@ -437,47 +437,10 @@ GMSM_HD Fp<P> fpu_to_sat(const FpU<P> &a) {
     return z;
 }
 
-// ------------------------------------------------------------------ the class A2 = [0, 2q + D), D << q (fr/fft butterflies)
-// Long chains of additions (radix-2 butterflies: up to 11 stages between two trips through memory) need a reduction
-// that is cheaper than a product and, unlike an exact comparison, needs no normalised limbs: after the limb-wise sum
-// the TOP limb alone decides - top > top(2q) proves value >= 2q, and then 2q is subtracted with the borrows
-// pre-distributed over the limbs (fpu_m2q) so that no limb goes negative. Otherwise value < 2q + 6*2^(W(L-1)).
-// The excess D over 2q can double per step on the subtracting branch (4q + 2D - 2q); TIGHT repeats the step once, which
-// pins D at 6*2^(W(L-1)) - needed where q's top limb is short (BW6-761 fr: 13 bits).
+// ------------------------------------------------------------------ helpers of the fr/fft butterflies (gmsm_fft_lazy.h)
 template <class P>
 GMSM_HD constexpr uint32_t fpu_k2q(int i) {  // redundant 2q: a + k2q - b has no negative limb for b < 2q - 2*2^(W(L-1))
     return P::UQ2[i] + (i < P::UL - 1 ? (2u << P::UW) : 0u) - (i > 0 ? 2u : 0u);
-}
-template <class P>
-GMSM_HD constexpr uint32_t fpu_m2q(int i) {  // -2q as per-limb addends (two's complement in the top limb)
-    return (i < P::UL - 1 ? (1u << P::UW) : 0u) - (i > 0 ? 1u : 0u) - P::UQ2[i];
-}
-template <class P>
-GMSM_HD void fpu_csub2q_carry(FpU<P> &r) {  // limbs <= 4*2^W + 2^4 in; nearly normalised out
-    const uint32_t m = r.l[P::UL - 1] > P::UQ2[P::UL - 1] ? 0xFFFFFFFFu : 0u;
-#pragma unroll
-    for (int i = 0; i < P::UL; ++i) r.l[i] += m & fpu_m2q<P>(i);
-    fpu_carry(r);
-}
-// a + b -> A2 (a, b in A2, nearly normalised)
-template <class P, bool TIGHT>
-GMSM_HD FpU<P> fpu_add_a2(const FpU<P> &a, const FpU<P> &b) {
-    FpU<P> r;
-#pragma unroll
-    for (int i = 0; i < P::UL; ++i) r.l[i] = a.l[i] + b.l[i];
-    fpu_csub2q_carry(r);
-    if (TIGHT) fpu_csub2q_carry(r);
-    return r;
-}
-// a - b -> A2 (a in A2; b < 2q - 2*2^(W(L-1)), e.g. any product of an A2 value with a canonical one)
-template <class P, bool TIGHT>
-GMSM_HD FpU<P> fpu_sub_a2(const FpU<P> &a, const FpU<P> &b) {
-    FpU<P> r;
-#pragma unroll
-    for (int i = 0; i < P::UL; ++i) r.l[i] = a.l[i] + fpu_k2q<P>(i) - b.l[i];
-    fpu_csub2q_carry(r);
-    if (TIGHT) fpu_csub2q_carry(r);
-    return r;
 }
 // value >= K q ? value - K q : value for a fully normalised value (K = 1, 2)
 template <class P, int K>

@@ -17,6 +17,15 @@
 
 namespace gmsm {
 
+// Tuning constants of the pipeline geometry. In the shipped library GMSM_TUNE(NAME, default) IS its default, folded at
+// compile time - none of these is a run-time knob. An experiments build (-DGMSM_EXPERIMENTS, tools/build_ab.sh) reads
+// GMSM_<NAME> from the environment instead, which is how the defaults below were swept:
+//   LOG2L, REDUCE_LEVELS   buckets per serial reduction thread / two or three reduction levels (0 = the cost model)
+//   SEG, SEGMAX            entries per accumulation thread (0 = chosen per launch) and its cap
+//   PART_LOG2, STAGE_CAP   coarse partition population, staging slots of the fine sort
+//   DEVICE_RANGES          point ranges of a device-resident call beyond the pipeline-run cap
+#define GMSM_TUNE(NAME, DFLT) tune_uint("GMSM_" #NAME, (DFLT))
+
 // ------------------------------------------------------------------ one (curve, group)
 template <class T> struct LazyOf;
 template <class P> struct LazyOf<Fp<P>> { using type = FpU<P>; };
@@ -144,8 +153,8 @@ struct Group {
         constexpr size_t SPAN1 = COMBINE_N;  // pairs one combine workgroup takes
         const auto blocks1 = [&](uint32_t l2) { return ((size_t)NB + (SPAN1 << l2) - 1) / (SPAN1 << l2); };
         const auto blocks2 = [&](uint32_t l2) { return (blocks1(l2) + SPAN1 - 1) / SPAN1; };
-        uint32_t log2L = tune_uint("GMSM_LOG2L", 0);
-        const uint32_t force_levels = tune_uint("GMSM_REDUCE_LEVELS", 0);  // 2 / 3; 0 = cost model
+        uint32_t log2L = GMSM_TUNE(LOG2L, 0);
+        const uint32_t force_levels = GMSM_TUNE(REDUCE_LEVELS, 0);  // 2 / 3; 0 = cost model
         bool three = force_levels == 3;
         if (log2L == 0) {
             // serial kernel: 2L dependent one-lane additions on every SIMD, as many rounds as the threads need;
@@ -213,10 +222,10 @@ struct Group {
         // 24 windows of BW6-761: eight blocks ran a second round alone and the kernel took twice as long - PMC:
         // 1056 waves, each alive for half of the kernel.) Among the round counts that keep seg <= SEG_MAX the
         // one that fills its last round best is taken.
-        uint32_t seg = tune_uint("GMSM_SEG", 0);
+        uint32_t seg = GMSM_TUNE(SEG, 0);
         if (seg == 0) {
             const size_t cap_blocks = (size_t)ctx.num_cus * AccWaves<U>::value;
-            const size_t SEG_MAX = tune_uint("GMSM_SEGMAX", 512);  // measured: 512 best at 2^24, 256 at 2^22
+            const size_t SEG_MAX = GMSM_TUNE(SEGMAX, 512);  // measured: 512 best at 2^24, 256 at 2^22
             // Shortest segment. A launch that does not fill the chip is a latency chain of `seg` additions per thread:
             // with sparse buckets (<= 8 entries each: few chains of partial sums to close) shorter segments on more
             // threads win - BN254 G1 2^14 0.605 -> 0.476 ms, 2^16 0.637 -> 0.585, BLS12-381 G1 2^16 1.17 -> 0.98; crowded
@@ -342,7 +351,7 @@ struct Group {
         const uint32_t lidx = log2n + 1;  // bits of (index << 1 | negate)
         // target partition population 2^part_log2 (measured, BN254 G1: 2^13 is best up to 2^21 points - more
         // workgroups for the fine pass; 2^15 from 2^24 on - 128-byte runs out of the coarse pass)
-        const uint32_t part_log2 = tune_uint("GMSM_PART_LOG2", log2n <= 21 ? 13 : log2n >= 24 ? 15 : 14);
+        const uint32_t part_log2 = GMSM_TUNE(PART_LOG2, log2n <= 21 ? 13 : log2n >= 24 ? 15 : 14);
         int fb = (int)part_log2 + (int)log2NB - (int)log2n;
         if (fb > (int)log2NB) fb = (int)log2NB;
         if (fb > 15) fb = 15;  // the fine pass keeps 2^fb counters in LDS (128 KiB): windows wider than 16 bits on few points
@@ -362,7 +371,7 @@ struct Group {
         // staging slots of the fine pass: up to 96 KiB next to the 2^fbits counters; larger partitions go direct
         const size_t fine_cnt_bytes = (size_t)4 << fbits;
         const uint32_t stage_cap = fine_cnt_bytes >= 156 * 1024 ? 0u
-                                   : (uint32_t)std::min<size_t>(tune_uint("GMSM_STAGE_CAP", part_log2 >= 15 ? 39000 : 24576),
+                                   : (uint32_t)std::min<size_t>(GMSM_TUNE(STAGE_CAP, part_log2 >= 15 ? 39000 : 24576),
                                                               (156 * 1024 - fine_cnt_bytes) / 4);
         if (fine_cnt_bytes + (size_t)stage_cap * 4 > 160 * 1024)  // cannot happen with fb <= 15; a failed launch must not
             return fail(GMSM_ERR_ARG, "window geometry: fine-sort counters exceed the LDS");  // leave garbage for the next kernels
@@ -958,7 +967,7 @@ struct Group {
     static unsigned device_ranges(size_t n, const WindowPlan &plan) {
         const size_t run = max_run_points(plan);
         unsigned nr = (unsigned)((n + run - 1) / run);
-        const unsigned forced = tune_uint("GMSM_DEVICE_RANGES", 0);
+        const unsigned forced = GMSM_TUNE(DEVICE_RANGES, 0);
         if (forced > nr) nr = (unsigned)std::min<size_t>(forced, n);
         return nr;
     }
