@@ -170,3 +170,42 @@ def test_c_client_links_and_fails_loudly_without_a_gpu(gm, tmp_path):
     r = subprocess.run([exe, "0", fin, str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1, (r.returncode, r.stderr)
     assert "no CPU fallback" in r.stderr
+
+
+def test_options_and_lifecycle_entries_need_no_device(gm):
+    """gmsm_set_option / gmsm_get_option validate and round-trip without touching a device; gmsm_trim and gmsm_shutdown on a
+    process that never created a context are no-ops; gmsm_get_devices reports one rank (nothing configured: no spreading)."""
+    lib = gm._lib.load()
+    assert gm.get_option("window_bits") in range(0, 21) and gm.get_option("tables") in (0, 1, 2)
+    with gm.options(window_bits=13, tables=0, max_run=4096, host_ranges=3, fixed_base_bits=11):
+        assert [gm.get_option(k) for k in ("window_bits", "tables", "max_run", "host_ranges", "fixed_base_bits")] == [13, 0, 4096, 3, 11]
+        assert gm.G1Jac("bn254").default_window_bits(1 << 20) == 13
+    assert gm.get_option("max_run") == 0 and gm.get_option("host_ranges") == 0
+    for name, bad in (("window_bits", 1), ("window_bits", 21), ("tables", 3), ("fixed_base_bits", 15)):
+        with pytest.raises(ValueError):
+            gm.set_option(name, bad)
+    assert lib.gmsm_set_option(99, 1) == gm._lib.GMSM_ERR_ARG and lib.gmsm_get_option(99) == 0
+    if lib.gmsm_device_count() == 0:
+        assert gm.trim(0) == 0
+        gm.shutdown()
+        gm.shutdown()
+    assert lib.gmsm_get_devices(None, 0) == 1  # NULL output is allowed
+    assert len(gm.get_devices()) == 1
+
+
+def test_race_client_builds_as_c(tmp_path):
+    """tests/c/race_client.c (the sanitizer workload) is plain C99 + pthreads against include/gmsm.h and links to the shipped
+    library; without a device it says so and exits 77."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "gnark-crypto_amd", "csrc")
+    exe = str(tmp_path / "race_client")
+    subprocess.run(["gcc", "-std=gnu99", "-Wall", "-Werror", "-O1", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c", "race_client.c"), "-o", exe, "-L", libdir, "-lgmsm", "-lpthread",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: tests/test_gpu_sanitizers.py runs the client")
+    r = subprocess.run([exe, "1", "100"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 77 and "no device" in r.stderr
