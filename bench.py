@@ -135,13 +135,13 @@ def int_roofline_record(madds, acc_ms_total):
 
 def measured_traffic(curve, group, logn, world, nwin=None):
     """HBM/fabric bytes per k_accumulate_seg launch from the committed rocprofv3 PMC passes of THIS round's build
-    (FETCH_SIZE + WRITE_SIZE, separate passes; profiles/traffic_r03.json, keyed curve_group_logn).  Counters cannot be
+    (FETCH_SIZE + WRITE_SIZE, separate passes; profiles/traffic_r04.json, keyed curve_group_logn).  Counters cannot be
     read from inside the timed run, so this is the profiled value for the same workload - or None when that workload was
     not profiled."""
     if world != 1:
         return None
     try:
-        with open(os.path.join(ROOT, "profiles", "traffic_r03.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "traffic_r04.json")) as f:
             rec = json.load(f)
         key = f"{curve}_{group}_{logn}"
         if nwin is not None and rec.get("windows", {}).get(key, nwin) != nwin:
@@ -420,7 +420,8 @@ def fft_config(gm, torch, curve="bn254", logn=24, reps=5):
             "butterflies_per_s": n * logn / 2 / (ms * 1e-3), "hbm_passes": passes,
             "roofline": {"bound": "hbm", "achieved": traffic / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                         "note": "compulsory bytes of the passes / wall time; the butterflies (one saturated Montgomery product each) bind first"},
+                         "note": "compulsory bytes of the passes / wall time; the kernel is VALU-issue-bound (profiles/r04_fft_stats.md: "
+                                 "SQ_ACTIVE_INST_VALU 96 % of its cycles, ~370 instructions per butterfly, 190 of them the lazy-limb product)"},
             "round_trip_exact": ok}
 
 

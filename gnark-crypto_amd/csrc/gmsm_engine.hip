@@ -149,7 +149,7 @@ struct ShardPool {
         std::mutex mu;
         std::condition_variable cv;
         std::deque<std::function<void()>> q;
-        bool started = false;
+        int workers = 0;
     };
     std::mutex mu;
     std::map<int, Dev *> devs;  // never freed: the workers outlive every static destructor
@@ -163,9 +163,10 @@ struct ShardPool {
         }
         {
             std::lock_guard<std::mutex> lk(d->mu);
-            if (!d->started) {
-                d->started = true;
-                for (int i = 0; i < 2; ++i)
+            // two workers per device; a thread that cannot be created (std::system_error) leaves through the caller's
+            // handler with nothing queued - and nothing is ever queued for a device that has no worker at all
+            for (; d->workers < 2; ++d->workers) {
+                try {
                     std::thread([d] {
                         for (;;) {
                             std::function<void()> job;
@@ -178,6 +179,10 @@ struct ShardPool {
                             job();
                         }
                     }).detach();
+                } catch (...) {
+                    if (d->workers == 0) throw;
+                    break;  // one worker serves the device
+                }
             }
             d->q.push_back(std::move(fn));
         }

@@ -77,3 +77,42 @@ func (p *G2Jac) MultiExp(points []G2Affine, scalars []fr.Element, config ecc.Mul
 	}
 	return p, nil
 }
+
+// UseDevices asks the library to spread every MultiExp of 2^17 points or more over the listed GPUs of the node (one
+// entry per logical rank). Spreading is opt-in: a process that never calls this - and has no GMSM_DEVICES in its
+// environment - runs on one device and touches no other. UseDevices(nil) goes back to that.
+func UseDevices(devices []int) error {
+	if len(devices) == 0 {
+		if rc := C.gmsm_set_devices(nil, 0); rc != 0 {
+			return gmsmError(rc)
+		}
+		return nil
+	}
+	list := make([]C.int, len(devices))
+	for i, d := range devices {
+		list[i] = C.int(d)
+	}
+	if rc := C.gmsm_set_devices(&list[0], C.int(len(list))); rc != 0 {
+		return gmsmError(rc)
+	}
+	return nil
+}
+
+// TrimDeviceMemory gives the scratch the library grew for its largest call so far back to the devices (buffers of the
+// workspaces that are idle right now, above keepBytes each); registered bases and FFT domains stay. Returns the bytes freed.
+func TrimDeviceMemory(keepBytes uint64) (uint64, error) {
+	var freed C.size_t
+	if rc := C.gmsm_trim(C.size_t(keepBytes), &freed); rc != 0 {
+		return 0, gmsmError(rc)
+	}
+	return uint64(freed), nil
+}
+
+// Shutdown releases everything the library holds on every device (call it when no MultiExp is running; outstanding
+// tickets are refused). The library stays usable: its state reappears with the next call.
+func Shutdown() error {
+	if rc := C.gmsm_shutdown(); rc != 0 {
+		return gmsmError(rc)
+	}
+	return nil
+}

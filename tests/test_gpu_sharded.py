@@ -218,3 +218,41 @@ def test_forced_window_width_is_clamped(gm, forced_options):
     assert g.default_window_bits(1 << 20) == 16
     forced_options(window_bits=12)
     assert g.default_window_bits(1 << 20) == 12
+
+
+def test_spreading_is_opt_in_and_gmsm_devices_is_parsed_strictly():
+    """A process that configures nothing keeps every drop-in call on one device (no context anywhere else); GMSM_DEVICES
+    opts in ("0,0" = two logical ranks on this box, "all"); a malformed or out-of-range list is an error of the call, not
+    a silently shorter list.  Each case is its own process: the variable is read once."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = (
+        "import importlib, sys, numpy as np\n"
+        f"sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'oracle')!r})\n"
+        "gm = importlib.import_module('gnark-crypto_amd'); import oracle\n"
+        "g = gm.G1Jac('bn254'); o = oracle.Oracle('bn254', 'g1')\n"
+        "n = (1 << 17) + 5\n"
+        "pts = o.gen_points(n, 7, 3, nthreads=8)\n"
+        "sc = np.random.default_rng(3).integers(0, 2**62, size=(n, 4), dtype=np.uint64)\n"
+        "print('devices', gm.get_devices() if gm._lib.load().gmsm_get_devices(None, 0) >= 0 else 'error')\n"
+        "jac, err = g.MultiExp(pts, sc)\n"
+        "print('err', err)\n"
+        "print('ok', err is None and bool((g.jac_to_affine(jac) == o.msm_affine(pts, sc, nthreads=16)).all()))\n")
+    def run(value):
+        env = {k: v for k, v in os.environ.items() if k != "GMSM_DEVICES"}
+        if value is not None:
+            env["GMSM_DEVICES"] = value
+        r = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stdout
+    out = run(None)
+    assert "devices [0]" in out and "ok True" in out
+    out = run("0,0")
+    assert "devices [0, 0]" in out and "ok True" in out
+    out = run("all")
+    assert "ok True" in out
+    for bad in ("0,,1", "0,x", "0,", "7777"):
+        out = run(bad)
+        assert "devices error" in out and "GMSM_DEVICES" in out and "ok False" in out, (bad, out)

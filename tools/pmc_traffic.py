@@ -46,7 +46,7 @@ def main(args):
         except (OSError, ValueError, KeyError):
             pass
     print(json.dumps({"note": "HBM/fabric bytes per k_accumulate_seg launch: rocprofv3 PMC FETCH_SIZE + WRITE_SIZE (separate passes, "
-                              "KiB x 1024) on the round-3 build with the shipped window table, one bench.py configuration per "
+                              "KiB x 1024) on this round's build with the shipped window table, one bench.py configuration per "
                               "pass; FETCH_SIZE as reported - calibrated at factor 1.00 for this kernel's 64-byte-per-lane gather "
                               "(profiles/r03_fetch_calibration.md)",
                       "k_accumulate_seg": out, "windows": windows, "detail": detail}, indent=1))
