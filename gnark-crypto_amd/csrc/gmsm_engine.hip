@@ -1446,6 +1446,10 @@ GMSM_EXPORT int gmsm_set_option(int key, unsigned value) {
             if (value != 0 && (value < 2 || value > 14)) return fail(GMSM_ERR_ARG, "GMSM_OPT_FIXED_BASE_BITS: 0 (by batch size) or 2..14");
             o.fixed_base_bits.store(value);
             return GMSM_OK;
+        case GMSM_OPT_SPIN_WAIT_US:
+            if (value > 1000000) return fail(GMSM_ERR_ARG, "GMSM_OPT_SPIN_WAIT_US: at most 1000000");
+            o.spin_wait_us.store(value);
+            return GMSM_OK;
         default: return fail(GMSM_ERR_ARG, "gmsm_set_option: unknown key");
     }
 }
@@ -1458,6 +1462,7 @@ GMSM_EXPORT unsigned gmsm_get_option(int key) {
         case GMSM_OPT_MAX_RUN: return o.max_run.load();
         case GMSM_OPT_HOST_RANGES: return o.host_ranges.load();
         case GMSM_OPT_FIXED_BASE_BITS: return o.fixed_base_bits.load();
+        case GMSM_OPT_SPIN_WAIT_US: return o.spin_wait_us.load();
         default: return 0;
     }
 }

@@ -11,6 +11,7 @@
 
 #include "gmsm_context.h"
 #include "gmsm_kernels.h"
+#include "gmsm_fixup_q.h"
 #include "gmsm_fixedbase.h"
 #include "gmsm_ingest.h"
 #include "gmsm_fft.h"
@@ -78,6 +79,12 @@ struct Group {
     // (BW6-761 fixup 0.75 ms either way - it is 322 K two-link chains in five rounds of 512-register workgroups), and 2^16
     // got slower (0.68 -> 2.6 ms: thousands of short chains, one workgroup each).
     static constexpr uint32_t FIX_MAXWALK = FIXUP_MAXWALK;
+    // k_fixup_seg on lane quads (gmsm_fixup_q.h) for the element types whose one-lane addition spills: everything wider than
+    // the 14-limb prime field (BN254 G2, BLS12-381 G2, BW6-761). -DGMSM_FIXUP_QUAD_WORDS=1000 builds the one-lane form (A/B).
+#ifndef GMSM_FIXUP_QUAD_WORDS
+#define GMSM_FIXUP_QUAD_WORDS 15
+#endif
+    static constexpr bool FIXUP_QUAD = sizeof(U) >= GMSM_FIXUP_QUAD_WORDS * 4;
     static constexpr bool SKEWED_HOST_RANGES = AFF_BYTES <= 96;  // host_ranges / window_sums_from_host
     // plan_geometry: combine workgroups resident on a CU (measured on the pieces of a window-sharded call and on single
     // bucket sets, profiles/r03_reduce_levels.log: with one per CU the model kept few windows on the two-level form)
@@ -113,7 +120,7 @@ struct Group {
     // Waits for the pipeline enqueued on `stream` and hands out the window totals (pinned buffer -> host_xyzz).
     static int collect_window_sums(Workspace &ws, hipStream_t stream, uint32_t nw, Ext *host_xyzz) {
         if (nw == 0) return GMSM_OK;
-        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(wait_stream(stream));
         if (ws.pending_timed) StageTimer::collect(ws);
         ws.pending_timed = false;
         memcpy(host_xyzz, ws.pinned, (size_t)nw * sizeof(Ext));
@@ -411,6 +418,8 @@ struct Group {
         if ((rc = ctx.allow_lds((const void *)k_part_scatter<uint32_t, PART_CHUNK_BIG>, 152 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_fine_sort, 160 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_fixup_long<U>, (int)(128 * sizeof(QRec<U>))))) return rc;
+        if constexpr (FIXUP_QUAD)
+            if ((rc = ctx.allow_lds((const void *)k_fixup_seg_q<U>, (int)(128 * sizeof(QRec<U>))))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_combine_q<U, true, COMBINE_N>, (int)((2 * COMBINE_N + 1) * sizeof(QRec<U>))))) return rc;
         if constexpr (COMBINE_WE)
             if ((rc = ctx.allow_lds((const void *)k_combine_we<U, true>, (int)((2 * COMBINE_N + 1) * sizeof(QRec<U>))))) return rc;
@@ -504,6 +513,10 @@ struct Group {
             hipLaunchKernelGGL((k_fixup_bucket<OpsSerial>), dim3((NB + 255) / 256, nw), dim3(256), 0, stream, NB,
                                (const uint32_t *)starts, q.seg, (const void *)seg_partials, q.tpw, (void *)buckets, long_flag, long_list,
                                FIX_MAXWALK);
+        else if constexpr (FIXUP_QUAD)
+            hipLaunchKernelGGL((k_fixup_seg_q<U>), dim3((q.tpw + 63) / 64, nw), dim3(256), 128 * sizeof(QRec<U>), stream, NB,
+                               (const void *)seg_partials, (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw,
+                               (void *)buckets, long_flag, long_list, FIX_MAXWALK);
         else
             hipLaunchKernelGGL((k_fixup_seg<OpsSerial>), dim3((q.tpw + 255) / 256, nw), dim3(256), 0, stream, NB, seg_partials,
                                (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets, long_flag, long_list, FIX_MAXWALK);
@@ -1162,7 +1175,7 @@ struct Group {
             if (he != hipSuccess) rc = fail(GMSM_ERR_DEVICE, std::string("multi-range merge: ") + hipGetErrorString(he));
         }
         if (rc == GMSM_OK && nr > 1) rc = enqueue_reduce(ctx, first, first.carry.ptr, plan, per, ms);
-        if (rc == GMSM_OK && hipStreamSynchronize(ms) != hipSuccess) rc = fail(GMSM_ERR_DEVICE, "hipStreamSynchronize failed");
+        if (rc == GMSM_OK && wait_stream(ms) != hipSuccess) rc = fail(GMSM_ERR_DEVICE, "hipStreamSynchronize failed");
         for (unsigned i = 0; i < nws; ++i) {  // nothing of this call is left running on either workspace
             (void)hipStreamSynchronize(w[i]->stream);
             if (rc == GMSM_OK && w[i]->pending_timed) StageTimer::collect(*w[i]);

@@ -3,7 +3,7 @@
 out=/root/repo/gpurun_out/${1:-prof}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-Q="--no-cpu-baseline --no-host-entry --no-pipeline --no-also"
+Q="--no-cpu-baseline --no-host-entry --no-pipeline --no-also --no-next-rows"
 run() {  # label, bench args...
   label=$1; shift
   rocprofv3 --kernel-trace --stats -d $out/$label/trace -o t --output-format csv -- python /root/repo/bench.py $Q "$@" > $out/$label/bench.json 2> $out/$label/trace.log
