@@ -62,7 +62,7 @@ struct Options {
     std::atomic<unsigned> max_run{0};      // GMSM_OPT_MAX_RUN: lower the 2^27-point cap of one pipeline run (0 = off)
     std::atomic<unsigned> host_ranges{0};  // GMSM_OPT_HOST_RANGES: force the point ranges of a host-buffer call (0 = off)
     std::atomic<unsigned> fixed_base_bits{0};  // GMSM_OPT_FIXED_BASE_BITS: table width of the fixed-base batch (0 = by size)
-    std::atomic<unsigned> spin_wait_us{4000};  // GMSM_OPT_SPIN_WAIT_US: poll a call's stream this long before blocking on it
+    std::atomic<unsigned> spin_wait_us{0};     // GMSM_OPT_SPIN_WAIT_US: poll a call's stream this long before blocking on it (0 = park at once)
 };
 Options &options();
 
@@ -324,10 +324,10 @@ struct Lease {
     Lease name(context);                                                                                     \
     if (!name.w) return fail(GMSM_ERR_DEVICE, "no workspace could be leased (internal error)")
 
-// Waits for a call's stream. hipStreamSynchronize parks the thread on an interrupt and the wake-up costs 10-30 us - 1 % of a
-// 2 ms MultiExp, after the GPU has already finished. Calls that end within GMSM_OPT_SPIN_WAIT_US (default 4 ms: every
-// BN254 G1 call up to 2^21 points) are polled instead; a longer call falls back to the blocking wait after that, so the
-// core is never spun for more than the option says.
+// Waits for a call's stream. hipStreamSynchronize parks the thread and wakes it when the stream has drained; with
+// GMSM_OPT_SPIN_WAIT_US = t the stream is polled for up to t microseconds first. Measured (profiles/r04_spin_wait.log, same
+// process, alternating): 2^16 0.548 -> 0.542 ms, 2^20 1.787 -> 1.781 ms per call - the runtime's own wait already spins
+// briefly, so the gain is 5-6 us for a core kept busy for the whole call: OFF by default, there for callers who want it.
 static inline hipError_t wait_stream(hipStream_t s) {
     const unsigned spin_us = options().spin_wait_us.load(std::memory_order_relaxed);
     if (spin_us) {

@@ -55,7 +55,10 @@ struct Group {
     using OpsElem = typename OpsSerial::Elem;
     // Level 1 of the bucket reduction = k_reduce_serial (one thread per L buckets, no LDS) + k_combine_q (COMBINE_N
     // (S, W) pairs per workgroup of 4 * COMBINE_N threads); level 2 = k_reduce2_q, at most RED2_TPB level-1 results per window.
-    static constexpr size_t FORK_CONVERT_MIN = (size_t)1 << 18;  // unregistered calls from here on rewrite their bases on a side stream
+#ifndef GMSM_FORK_CONVERT_LOG2
+#define GMSM_FORK_CONVERT_LOG2 18
+#endif
+    static constexpr size_t FORK_CONVERT_MIN = (size_t)1 << GMSM_FORK_CONVERT_LOG2;  // unregistered calls from here on rewrite their bases on a side stream
     static constexpr int COMBINE_N = 64;
     static constexpr int RED2_TPB = 64;
     // The serial part itself runs on quads (k_reduce_serial_q) for every element type but the 9-limb prime field.
