@@ -142,6 +142,7 @@ __global__ void __launch_bounds__(512) k_fft_pass_lz(Fp<FrP> *__restrict__ a, un
     for (unsigned st = 0; st < B; ++st) {
         const unsigned bb = TOPDOWN ? B - 1 - st : st;
         const unsigned b = bl + bb;
+        const bool carry = ((B - 1 - st) & 1u) != 0;  // every second stage, never the last of the pass (FftLz: LIMBS)
         for (unsigned q = t; q < nbf; q += T) {
             const unsigned c = q & (C - 1), p = q >> log2C;
             const unsigned mid0 = ((p >> bb) << (bb + 1)) | (p & ((1u << bb) - 1)), mid1 = mid0 | (1u << bb);
@@ -151,7 +152,8 @@ __global__ void __launch_bounds__(512) k_fft_pass_lz(Fp<FrP> *__restrict__ a, un
                 Z::dit_one(x, y);
             } else {
                 const size_t tw = TOPDOWN ? (i >> (b + 1)) : ((i & (((size_t)1 << b) - 1)) << (log2n - 1 - b));
-                Z::dit_free(x, y, fft_load(twz, tw));
+                if (carry) Z::template dit_free<true>(x, y, fft_load(twz, tw));
+                else Z::template dit_free<false>(x, y, fft_load(twz, tw));
             }
             tile[(mid0 << log2C) + c] = x;
             tile[(mid1 << log2C) + c] = y;

@@ -35,15 +35,29 @@ struct FftLz {
     // no conditional subtraction at all; the elements come back below 2q once per pass, on the store, by an estimated
     // quotient (reduce_big). Bounds: loaded value < 5.3q (anything that fits 2^(32N)); the stage without its product
     // (dit_one, the first of a transform): +8q; every other stage +2q: 5.3 + 8 + 2 * 10 < 34q.
+    // LIMBS. The carry passes of the two outputs are a seventh of a butterfly's instructions, and only every SECOND stage
+    // needs them: with carried inputs (limbs <= 2^W + 8) a stage leaves x + t <= 2 * 2^W + 8 and x + 2q' - t <= 4 * 2^W + 8
+    // (the redundant 2q carries 2 * 2^W per limb besides its own < 2^W); the next stage can still multiply such a y - one
+    // operand up to 4 * 2^W + 8 against an exactly normalised table entry keeps a column below L * 5 * 2^(2W) < 2^64 -
+    // and its own sums stay below 8 * 2^W <= 2^32 until they are carried at its end. CARRY = false therefore alternates
+    // with CARRY = true, the last stage of a pass being a CARRY = false one: the store's reduction (reduce_big, or the
+    // final product) takes un-carried limbs.
+    static_assert(W <= 29 && (unsigned long long)L * 5 < (1ull << (64 - 2 * W)), "column accumulator with an un-carried operand");
     static constexpr unsigned DIT_FREE_STAGES = 11;
-    template <class TW>
+    template <bool CARRY, class TW>
     GMSM_HD static void dit_free(U &x, U &y, const TW &w) {
-        const U t = mul(y, w);  // < 1.2 q < 2q - 2 units: what the redundant 2q below admits
-        U r;
+        const U t = mul(y, w);  // < 1.2 q < 2q - 2 units: what the redundant 2q below admits; limbs exactly normalised
+        U r, s;
 #pragma unroll
-        for (int i = 0; i < L; ++i) r.l[i] = x.l[i] + fpu_k2q<P>(i) - t.l[i];
-        fpu_carry(r);
-        x = fpu_add(x, t);
+        for (int i = 0; i < L; ++i) {
+            r.l[i] = x.l[i] + fpu_k2q<P>(i) - t.l[i];
+            s.l[i] = x.l[i] + t.l[i];
+        }
+        if (CARRY) {
+            fpu_carry(r);
+            fpu_carry(s);
+        }
+        x = s;
         y = r;
     }
     // the stage of bit 0, whose twiddles are all one: (x, y) <- (x + y, x - y + 8q), y < 8q (the first stage of a DIT pass)
@@ -52,8 +66,9 @@ struct FftLz {
         x = fpu_add(x, y);
         y = d;
     }
-    // v < 40q (nearly normalised limbs) -> the same residue below 2q + 2^-10 q, limbs fully normalised: k q is taken
-    // off, k = floor(top(v) * floor(2^32 / (top(q) + 1)) / 2^32) <= floor(v / q), short of it by at most one.
+    // v < 40q (limbs below 2^32, carried or not) -> the same residue below 2q + 2^-10 q, limbs fully normalised: k q is
+    // taken off, k = floor(top(v) * floor(2^32 / (top(q) + 1)) / 2^32) <= floor(v / q), short of it by at most one (the
+    // carries an un-carried value still owes its top limb are a few units of 2^(W(L-1)), far below q).
     GMSM_HD static U reduce_big(const U &v) {
         constexpr uint32_t QT1 = P::UQ1[L - 1] + 1u;
         constexpr uint32_t M = (uint32_t)(0x100000000ull / QT1);

@@ -85,12 +85,20 @@ static int check(const char *name) {
                         s[i1] = fp_sub(s[i0], tt);
                         s[i0] = fp_add(s[i0], tt);
                     }
-                    if (b == (topdown ? LOG - 1 : 0u)) Z::dit_one(z[i0], z[i1]);
-                    else Z::dit_free(z[i0], z[i1], topdown ? twr[i0 >> (b + 1)] : twz[t]);
-                    for (const FpU<P> *v : {&z[i0], &z[i1]}) {
+                    const bool carry = ((LOG - 1 - st) & 1u) != 0;  // as the kernel: every second stage, never the last
+                    for (const FpU<P> *v : {&z[i0], &z[i1]})    // what a stage may be handed: limbs <= 4 * 2^W + 8
                         for (int k = 0; k < P::UL - 1; ++k)
-                            if (v->l[k] > (1u << P::UW) + (1u << (32 - P::UW))) ++cls;
-                        if ((uint64_t)v->l[P::UL - 1] >= 40ull * (P::UQ1[P::UL - 1] + 1ull)) ++cls;  // below 40q
+                            if (v->l[k] > (4u << P::UW) + 8u) ++cls;
+                    if (b == (topdown ? LOG - 1 : 0u)) Z::dit_one(z[i0], z[i1]);
+                    else if (carry) Z::template dit_free<true>(z[i0], z[i1], topdown ? twr[i0 >> (b + 1)] : twz[t]);
+                    else Z::template dit_free<false>(z[i0], z[i1], topdown ? twr[i0 >> (b + 1)] : twz[t]);
+                    for (const FpU<P> *v : {&z[i0], &z[i1]}) {
+                        if (carry || b == (topdown ? LOG - 1 : 0u))
+                            for (int k = 0; k < P::UL - 1; ++k)
+                                if (v->l[k] > (1u << P::UW) + (1u << (32 - P::UW))) ++cls;
+                        FpU<P> nv = *v;
+                        fpu_normalize(nv);
+                        if ((uint64_t)nv.l[P::UL - 1] >= 40ull * (P::UQ1[P::UL - 1] + 1ull)) ++cls;  // below 40q
                     }
                 }
             }

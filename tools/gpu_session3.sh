@@ -6,7 +6,7 @@ cd /root/repo
 O=gpurun_out/$S
 mkdir -p $O
 ( timeout 900 python -m pytest tests/test_gpu_fft.py -x -q > $O/fft_tests.log 2>&1; echo "pytest rc=$?" >> $O/fft_tests.log ); tail -3 $O/fft_tests.log
-for v in default fft0 default fft0; do
+for v in default nofork fft0 default nofork fft0; do
   if [ $v = default ]; then unset GMSM_LIB; else export GMSM_LIB=/root/repo/gnark-crypto_amd/csrc/build_ab_$v/libgmsm_ab.so; fi
   echo "== $v"; timeout 300 python tools/bench_fft.py bn254 16 20 22 24
 done > $O/fft_ab.log 2>&1
