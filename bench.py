@@ -542,7 +542,7 @@ def next_rows(gm, lib, torch):
     prods = m * (255 * 9 + 127 * 10 + 3)  # dbl-2008-s-1: 9 products, madd-2008-s: 10, the curve equation 3
     out["points_validate_bls12_381_g1_2p20_level2_resident"] = {
         "ms": ms, "points_per_s": m / (ms * 1e-3), "mulmod_per_s": prods / (ms * 1e-3),
-        "note": "on the curve and [r]P = infinity (saturated 12 x 32-bit limbs, one lane per point): compute-bound"}
+        "note": "on the curve and [r]P = infinity by double-and-add on the pipeline's lazy limbs, one lane per point: compute-bound"}
     del d_a2, d_p2
     del d_out, raw, reg
     # ---- N4: SRS dump (marker | length | raw []G1Affine memory) of 2^24 points, from the page cache into HBM

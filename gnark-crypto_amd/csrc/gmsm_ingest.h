@@ -15,12 +15,13 @@
 //
 // Subgroup membership is decided as the definition says - on the curve and [r]P = infinity - instead of through the
 // reference's endomorphism shortcuts (x^2 phi(P) + P etc.): the same predicate for every point ON the curve, one
-// generic routine for all six groups, and an ingest is a one-off (a 2^20-point BN254 G2 SRS validates in ~0.1 s).
+// generic routine for all six groups, and an ingest is a one-off (a 2^20-point BLS12-381 G1 SRS validates in ~0.06 s).
 // Points that are not on the curve are always rejected, whatever the subgroup flag says for the rest.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gmsm_context.h"
 #include "gmsm_curve.h"
+#include "gmsm_curveu.h"
 
 namespace gmsm {
 
@@ -62,17 +63,35 @@ GMSM_HD bool point_on_curve(const Affine<F> &a) {
     return limbs_equal(lhs, rhs);
 }
 
-// [r]P == infinity by double-and-add over the bits of the scalar-field modulus
+// [r]P == infinity by double-and-add over the bits of the scalar-field modulus - on the lazy limbs of the MSM pipeline
+// (gmsm_curveu.h) since round 4: the saturated group law (gmsm_curve.h: a carry chain per partial product) ran this loop
+// at 31 G products/s for BLS12-381 G1, the lazy one runs the accumulation kernel at twice that. Same special cases: the
+// doubling of a 2-torsion point (zz becomes 0 mod q: tested after every doubling, exactly) and P + (-P) (inside the
+// mixed addition) both lead to the infinity flag.
+template <class F> struct IngestLazy;
+template <class P> struct IngestLazy<Fp<P>> { using type = FpU<P>; };
+template <class P> struct IngestLazy<Fp2<P>> { using type = Fp2U<P>; };
+template <class P> __device__ __forceinline__ bool ingest_zz_is_zero(const FpU<P> &zz) { return fpu_prod_is_zero(zz); }   // a product: < 3q
+template <class P> __device__ __forceinline__ bool ingest_zz_is_zero(const Fp2U<P> &zz) { return lz_is_zero(zz); }       // class R
+
 template <class F, class FrP>
 __device__ bool point_in_r_torsion(const Affine<F> &a) {
+    using U = typename IngestLazy<F>::type;
+    using T = LzTraits<U>;
+    constexpr bool INL = sizeof(U) <= 14 * 4;  // wider elements call their products (code size, as in gmsm_fixedbase.h)
     if (a.is_infinity()) return true;
-    XYZZ<F> acc = XYZZ<F>::infinity();
+    const U px = T::template from_sat<INL>(a.x), py = T::template from_sat<INL>(a.y);
+    XYZZL<U> acc;
+    bool inf = true;
 #pragma nounroll
     for (int bit = FrP::BITS - 1; bit >= 0; --bit) {
-        acc = xyzz_double(acc);
-        if ((FrP::Q[bit >> 5] >> (bit & 31)) & 1u) xyzz_add_mixed(acc, a, false);
+        if (!inf) {
+            acc = lz_pdbl<INL>(acc);
+            if (ingest_zz_is_zero(acc.zz)) inf = true;
+        }
+        if ((FrP::Q[bit >> 5] >> (bit & 31)) & 1u) lz_madd<INL>(acc, inf, px, py, false);
     }
-    return acc.is_infinity();
+    return inf;
 }
 
 // level 0: nothing, 1: on the curve, 2: on the curve and in the r-torsion (NEEDS_TORSION false: prime-order curve, the
