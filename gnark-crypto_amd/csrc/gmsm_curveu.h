@@ -96,6 +96,50 @@ GMSM_HD void madd_u(XYZZU<P> &acc, bool &inf, const FpU<P> &px, const FpU<P> &py
     acc.zzz = fmul<INL>(acc.zzz, PPP);
 }
 
+// The same mixed addition on SIGNED limbs (gmsm_fieldu.h, "signed limbs"): the form k_accumulate_seg and the fixed-base
+// walk run. Differences are one subtraction per limb, and of madd_u's five carry passes one is left (X3); the products
+// are the same product scans on signed columns. Values in multiples of q (A = 2^(L W)/q >= 169; a product of |a|, |b|
+// lies in (-|a||b|/A, |a||b|/A + 1)):
+//   px in [0, 2), py in (-2, 2);  accumulator: X in (-3.2, 6), Y in (-2, 6), ZZ in [0, 1.1), ZZZ in (-0.1, 1.1)
+//   (the upper 6 only right after the doubling branch, which answers in madd_u's unsigned class)
+//   P = px ZZ - X in (-6.1, 4.3)   R = py ZZZ - Y in (-6.1, 3.1)   PP in [0, 1.3)   RR in [0, 1.3)
+//   PPP in (-0.1, 1.1)   Q = X PP in (-0.1, 1.1)   X3 = RR - PPP - 2Q in (-3.2, 1.5)
+//   Y3 = ((Q - X3) R - Y PPP) / R' in (-0.2, 1.2)   [|Q - X3| < 4.4, one reduction for both products]
+// Limbs: products come out normalised with a signed top limb, X3 is carry-passed, every difference of two such values
+// has limbs within +-(2^W + 4): what the signed product scans admit. P == 0 mod q is tested on PP = P^2 >= 0 exactly as
+// in madd_u. The accumulator leaves this class through lz_acc_finish (+4q on x, y, zzz: x < 11, y < 11, zz < 3, zzz < 6,
+// non-negative, nearly normalised) - or, in k_accumulate_seg, is stored as it is, and the kernels that read the bucket
+// and partial-sum records do the same on loading them (lz_rec_fresh).
+template <class P, bool INL = true>
+GMSM_HD void madd_s(XYZZU<P> &acc, bool &inf, const FpU<P> &px, const FpU<P> &py_in, bool negate) {
+    const FpU<P> py = negate ? fps_neg<P>(py_in) : py_in;
+    if (inf) {
+        acc.x = px;
+        acc.y = py;
+        acc.zz = fpu_one<P>();
+        acc.zzz = fpu_one<P>();
+        inf = false;
+        return;
+    }
+    const FpU<P> Pv = fps_sub<P>(fsmul<INL>(px, acc.zz), acc.x);
+    const FpU<P> Rv = fps_sub<P>(fsmul<INL>(py, acc.zzz), acc.y);
+    const FpU<P> PP = fssqr<INL>(Pv);
+    if (fpu_prod_is_zero(PP)) {                                      // same x (g1.go:846-854)
+        if (fpu_prod_is_zero(fssqr<INL>(Rv))) double_mixed_u<P, INL>(acc, px, negate ? fpu_neg4<P>(py_in) : py_in);  // P + P
+        else inf = true;                                             // P + (-P)
+        return;
+    }
+    const FpU<P> PPP = fsmul<INL>(Pv, PP);
+    const FpU<P> Q = fsmul<INL>(acc.x, PP);
+    const FpU<P> RR = fssqr<INL>(Rv);
+    const FpU<P> X3 = fps_sub_sub2<P>(RR, PPP, Q);
+    const FpU<P> Y3 = fsmuladd<INL>(fps_sub<P>(Q, X3), Rv, fps_neg<P>(acc.y), PPP);
+    acc.x = X3;
+    acc.y = Y3;
+    acc.zz = fsmul<INL>(acc.zz, PP);
+    acc.zzz = fsmul<INL>(acc.zzz, PPP);
+}
+
 // r = [2]q (g1.go:795-817, dbl-2008-s-1, a = 0); q not infinity.
 template <class P, bool INL = true>
 GMSM_HD XYZZU<P> double_u(const XYZZU<P> &q) {
@@ -257,6 +301,12 @@ GMSM_HD void add_g(XYZZL<U> &p, bool &pinf, const XYZZL<U> &q, bool qinf) {
 #ifndef GMSM_FP2_TRACKED
 #define GMSM_FP2_TRACKED 1
 #endif
+// the prime-field groups run the accumulation loop on signed limbs (madd_s); GMSM_SIGNED_MADD=0 builds madd_u there
+#ifndef GMSM_SIGNED_MADD
+#define GMSM_SIGNED_MADD 1
+#endif
+template <class U> struct LzSigned { static constexpr bool value = false; };
+template <class P> struct LzSigned<FpU<P>> { static constexpr bool value = GMSM_SIGNED_MADD != 0; };
 template <class U> struct LzTracked { static constexpr bool value = false; };
 template <class P> struct LzTracked<Fp2U<P>> { static constexpr bool value = GMSM_FP2_TRACKED && (P::UL * P::UW - P::BITS) >= 11; };
 
@@ -349,10 +399,21 @@ GMSM_HD void lz_madd(XYZZL<Fp2U<P>> &acc, bool &inf, const Fp2U<P> &px, const Fp
 template <bool INL, class U>
 GMSM_HD void lz_madd_acc(XYZZL<U> &acc, bool &inf, const U &px, const U &py, bool negate) {
     if constexpr (LzTracked<U>::value) madd_t<typename U::Params, INL>(acc, inf, px, py, negate);
+    else if constexpr (LzSigned<U>::value) madd_s<typename U::Params, INL>(acc, inf, px, py, negate);
     else lz_madd<INL>(acc, inf, px, py, negate);
 }
-template <class U>
+// TO_RECORD: the value goes to a bucket / partial-sum record whose readers apply lz_rec_fresh (k_accumulate_seg: the
+// flush sits on the divergent bucket-boundary path of the hot loop, executed by the whole wave for the one or two lanes
+// whose bucket ends - 87 % of the iterations at 32 entries per bucket -, the readers run it once per record).
+template <bool TO_RECORD = false, class U>
 GMSM_HD void lz_acc_finish(XYZZL<U> &acc, bool inf) {
+    if constexpr (LzSigned<U>::value && !TO_RECORD) {
+        if (!inf) {
+            fps_to_unsigned(acc.x);
+            fps_to_unsigned(acc.y);
+            fps_to_unsigned(acc.zzz);  // zz is a product of non-negative values: already in the unsigned class
+        }
+    }
     if constexpr (LzTracked<U>::value) {
         if (!inf) {
             fpu_to_class_r(acc.x.a0);
@@ -360,6 +421,24 @@ GMSM_HD void lz_acc_finish(XYZZL<U> &acc, bool inf) {
             fpu_to_class_r(acc.y.a0);
             fpu_to_class_r(acc.y.a1);
         }
+    }
+}
+// a record k_accumulate_seg wrote (signed class of madd_s) -> the unsigned class every other kernel computes in: + 4q on
+// the coordinates that can be negative. Harmless on a record that already is in the unsigned class (a bucket closed by
+// the fix-up, the running buckets of a multi-range call): coordinates only enter the additions as operands of products,
+// whose bounds have room for it (x, y < 11 + 8, zzz < 6 + 8: 19 * 14 / 169 + 1 < 4 on BN254, the narrowest field).
+template <class U>
+GMSM_HD void lz_rec_fresh(XYZZL<U> &v) {
+    if constexpr (LzSigned<U>::value) {
+        fps_to_unsigned(v.x);
+        fps_to_unsigned(v.y);
+        fps_to_unsigned(v.zzz);
+    }
+}
+template <class U>
+GMSM_HD void lz_coord_fresh(U &c, uint32_t which) {  // one coordinate (a lane of a quad): 0 x, 1 y, 2 zz, 3 zzz
+    if constexpr (LzSigned<U>::value) {
+        if (which != 2u) fps_to_unsigned(c);
     }
 }
 template <bool INL, class P>
@@ -419,6 +498,14 @@ __device__ __forceinline__ UnsatElem<U> unsat_load(const void *base, size_t i) {
     return e;
 }
 
+// a record written by k_accumulate_seg (partial sums always, buckets unless the fix-up closed them)
+template <class U>
+__device__ __forceinline__ UnsatElem<U> unsat_load_fresh(const void *base, size_t i) {
+    UnsatElem<U> e = unsat_load<U>(base, i);
+    if (!e.inf) lz_rec_fresh(e.v);
+    return e;
+}
+
 template <class U>
 __device__ __forceinline__ void lazy_store(void *base, size_t i, const XYZZL<U> &v, bool inf) {
     // x, y, zzz go out as they are; zz is ANDed with an all-ones / all-zero mask (infinity <=> zz limbs all zero): no
@@ -472,6 +559,7 @@ struct UnsatOps {
     using Elem = UnsatElem<U>;
     __device__ static __forceinline__ Elem infinity() { return unsat_infinity<U>(); }
     __device__ static __forceinline__ Elem load(const void *base, size_t i) { return unsat_load<U>(base, i); }
+    __device__ static __forceinline__ Elem load_fresh(const void *base, size_t i) { return unsat_load_fresh<U>(base, i); }
     __device__ static __forceinline__ void store(void *base, size_t i, const Elem &e) { lazy_store<U>(base, i, e.v, e.inf); }
     __device__ static __forceinline__ void store_final(void *base, size_t i, const Elem &e) { unsat_store_final<U, true>(base, i, e); }
     __device__ static __forceinline__ void add(Elem &p, const Elem &q) { lz_padd<true>(p.v, p.inf, q.v, q.inf); }

@@ -122,6 +122,20 @@ GMSM_HD FpU<P> fpu_sub_sub2(const FpU<P> &a, const FpU<P> &b, const FpU<P> &c) {
     return r;
 }
 
+// Column accumulators of the product scans, unsigned (every kernel but one) or signed (the accumulation loop's mixed
+// addition, "signed limbs" below): same instruction count, v_mad_i64_i32 instead of v_mad_u64_u32 and an arithmetic
+// column shift.
+template <bool SIGNED>
+struct LimbAcc {
+    using type = uint64_t;
+    static GMSM_HD type mul(uint32_t a, uint32_t b) { return (uint64_t)a * b; }
+};
+template <>
+struct LimbAcc<true> {
+    using type = int64_t;
+    static GMSM_HD type mul(uint32_t a, uint32_t b) { return (int64_t)(int32_t)a * (int64_t)(int32_t)b; }
+};
+
 // Independent accumulator chains per product column (GMSM_MUL_NACC, set per translation unit = per group).
 // The product scan adds every partial product of a column into ONE 64-bit accumulator: a dependency chain of up to
 // 2*UL v_mad_u64_u32. Kernels that run several waves per SIMD hide it; the wide element types (28-limb BW6-761, Fp2 over
@@ -137,29 +151,31 @@ GMSM_HD FpU<P> fpu_sub_sub2(const FpU<P> &a, const FpU<P> &b, const FpU<P> &c) {
 // Montgomery product a*b*2^-(L*W) mod q, product scanning. Requires limbs of a, b <= 2^(W+1) and
 // bound(a)*bound(b) <= 2^(L*W)/q * (B-1) for the output bound B (BN254: 2^261/q = 169, so 13q x 13q -> < 2q).
 // Output limbs are normalised (< 2^W), top limb holds the rest.
-template <class P>
+template <class P, bool SIGNED = false>
 GMSM_HD FpU<P> fpu_mul(const FpU<P> &a, const FpU<P> &b) {
     constexpr int L = P::UL, W = P::UW;
     constexpr uint32_t MASK = FpU<P>::MASK;
     constexpr int NACC = GMSM_MUL_NACC;
     uint32_t m[L];
     FpU<P> r;
-    uint64_t acc = 0;
+    using LA = LimbAcc<SIGNED>;
+    using A = typename LA::type;
+    A acc = 0;
 #pragma unroll
     for (int k = 0; k < 2 * L - 1; ++k) {
-        uint64_t part[NACC > 1 ? NACC - 1 : 1] = {0};  // side chains of this column (chain 0 is `acc`, which carries over)
+        A part[NACC > 1 ? NACC - 1 : 1] = {0};  // side chains of this column (chain 0 is `acc`, which carries over)
         int t = 0;
         const int lo = k < L ? 0 : k - L + 1, hi = k < L ? k : L - 1;
 #pragma unroll
         for (int i = lo; i <= hi; ++i, ++t) {
-            const uint64_t pr = (uint64_t)a.l[i] * b.l[k - i];
+            const A pr = LA::mul(a.l[i], b.l[k - i]);
             if (NACC > 1 && (t % NACC) != 0) part[(t % NACC) - 1] += pr;
             else acc += pr;
         }
         // reduction row: m[i] * q[k-i] for the m's known so far (i < k, i < L) with q index k-i in [1, L)
 #pragma unroll
         for (int i = (k < L ? 0 : k - L + 1); i < (k < L ? k : L); ++i, ++t) {
-            const uint64_t pr = (uint64_t)m[i] * P::UQ[k - i];
+            const A pr = LA::mul(m[i], P::UQ[k - i]);
             if (NACC > 1 && (t % NACC) != 0) part[(t % NACC) - 1] += pr;
             else acc += pr;
         }
@@ -174,7 +190,7 @@ GMSM_HD FpU<P> fpu_mul(const FpU<P> &a, const FpU<P> &b) {
         }
         if (k < L) {
             m[k] = ((uint32_t)acc * P::UQINV) & MASK;
-            acc += (uint64_t)m[k] * P::UQ[0];
+            acc += LA::mul(m[k], P::UQ[0]);
         } else {
             r.l[k - L] = (uint32_t)acc & MASK;
         }
@@ -188,29 +204,34 @@ GMSM_HD FpU<P> fpu_mul(const FpU<P> &a, const FpU<P> &b) {
 // (3L products of < 2^(2W+0.1) per column: 27 * 2^58.1 < 2^63 for L = 9, W = 29 - the operands must be nearly normalised,
 // limbs <= 2^W + 2^(32-W), which every carry-passed value is). Saves the L^2 + L multiplies of a second reduction.
 // Bound: (bound(a) bound(b) + bound(c) bound(d)) / (2^(L*W)/q) + 1.
-template <class P>
+template <class P, bool SIGNED = false>
 GMSM_HD FpU<P> fpu_mul_add(const FpU<P> &a, const FpU<P> &b, const FpU<P> &c, const FpU<P> &d) {
     constexpr int L = P::UL, W = P::UW;
     constexpr uint32_t MASK = FpU<P>::MASK;
     // worst admitted mix: one operand of one product un-carried (fpu_neg4: limbs < 2^(W+1)), everything else nearly
     // normalised: L * (2^(2W+1) + 2 * 2^(2W)) per column
     static_assert((unsigned long long)L * 4 * (1ull << (2 * W)) < (1ull << 63) + ((1ull << 63) - 1), "column accumulator overflow");
+    // signed limbs: every operand limb within +-(2^W + 2^(32-W)), 2L products and L reduction products per column
+    static_assert(!SIGNED || 3ull * L * (((1ull << W) + (1ull << (32 - W))) * ((1ull << W) + (1ull << (32 - W)))) < (1ull << 63),
+                  "signed column accumulator overflow");
     uint32_t m[L];
     FpU<P> r;
-    uint64_t acc = 0;
+    using LA = LimbAcc<SIGNED>;
+    using A = typename LA::type;
+    A acc = 0;
 #pragma unroll
     for (int k = 0; k < 2 * L - 1; ++k) {
         const int lo = k < L ? 0 : k - L + 1, hi = k < L ? k : L - 1;
 #pragma unroll
         for (int i = lo; i <= hi; ++i) {
-            acc += (uint64_t)a.l[i] * b.l[k - i];
-            acc += (uint64_t)c.l[i] * d.l[k - i];
+            acc += LA::mul(a.l[i], b.l[k - i]);
+            acc += LA::mul(c.l[i], d.l[k - i]);
         }
 #pragma unroll
-        for (int i = (k < L ? 0 : k - L + 1); i < (k < L ? k : L); ++i) acc += (uint64_t)m[i] * P::UQ[k - i];
+        for (int i = (k < L ? 0 : k - L + 1); i < (k < L ? k : L); ++i) acc += LA::mul(m[i], P::UQ[k - i]);
         if (k < L) {
             m[k] = ((uint32_t)acc * P::UQINV) & MASK;
-            acc += (uint64_t)m[k] * P::UQ[0];
+            acc += LA::mul(m[k], P::UQ[0]);
         } else {
             r.l[k - L] = (uint32_t)acc & MASK;
         }
@@ -267,7 +288,7 @@ GMSM_HD FpU<P> fpu_neg8c(const FpU<P> &b) {
 }
 
 // Montgomery square: cross products once with a doubled operand (L(L+1)/2 instead of L^2 products for a*a).
-template <class P>
+template <class P, bool SIGNED = false>
 GMSM_HD FpU<P> fpu_sqr(const FpU<P> &a) {
     constexpr int L = P::UL, W = P::UW;
     constexpr uint32_t MASK = FpU<P>::MASK;
@@ -276,27 +297,29 @@ GMSM_HD FpU<P> fpu_sqr(const FpU<P> &a) {
 #pragma unroll
     for (int i = 0; i < L; ++i) d[i] = a.l[i] << 1;
     FpU<P> r;
-    uint64_t acc = 0;
+    using LA = LimbAcc<SIGNED>;
+    using A = typename LA::type;
+    A acc = 0;
 #pragma unroll
     for (int k = 0; k < 2 * L - 1; ++k) {
-        uint64_t part[NACC > 1 ? NACC - 1 : 1] = {0};
+        A part[NACC > 1 ? NACC - 1 : 1] = {0};
         int t = 0;
         const int lo = k < L ? 0 : k - L + 1;
 #pragma unroll
         for (int i = lo; 2 * i < k; ++i, ++t) {
-            const uint64_t pr = (uint64_t)d[i] * a.l[k - i];
+            const A pr = LA::mul(d[i], a.l[k - i]);
             if (NACC > 1 && (t % NACC) != 0) part[(t % NACC) - 1] += pr;
             else acc += pr;
         }
         if ((k & 1) == 0) {
-            const uint64_t pr = (uint64_t)a.l[k / 2] * a.l[k / 2];
+            const A pr = LA::mul(a.l[k / 2], a.l[k / 2]);
             if (NACC > 1 && (t % NACC) != 0) part[(t % NACC) - 1] += pr;
             else acc += pr;
             ++t;
         }
 #pragma unroll
         for (int i = (k < L ? 0 : k - L + 1); i < (k < L ? k : L); ++i, ++t) {
-            const uint64_t pr = (uint64_t)m[i] * P::UQ[k - i];
+            const A pr = LA::mul(m[i], P::UQ[k - i]);
             if (NACC > 1 && (t % NACC) != 0) part[(t % NACC) - 1] += pr;
             else acc += pr;
         }
@@ -311,7 +334,7 @@ GMSM_HD FpU<P> fpu_sqr(const FpU<P> &a) {
         }
         if (k < L) {
             m[k] = ((uint32_t)acc * P::UQINV) & MASK;
-            acc += (uint64_t)m[k] * P::UQ[0];
+            acc += LA::mul(m[k], P::UQ[0]);
         } else {
             r.l[k - L] = (uint32_t)acc & MASK;
         }
@@ -350,6 +373,86 @@ template <bool INL, class P>
 GMSM_HD FpU<P> fsqr(const FpU<P> &a) {
     if constexpr (INL) return fpu_sqr(a);
     else return fpu_sqr_ni<P>(a);
+}
+
+// ------------------------------------------------------------------ signed limbs
+// The mixed addition of the accumulation loop (gmsm_curveu.h, madd_s) keeps its intermediate values as SIGNED numbers
+// with signed limbs: value = sum (int32)l[i] * 2^(W i). A difference is then one subtraction per limb - no K*q to keep
+// it positive and no carry pass to make room for the K*q - and the products run on v_mad_i64_i32 with signed 64-bit
+// column accumulators (fpu_mul<P, true> etc.): the Montgomery step  m = (column * -q^-1) mod 2^W  works on the low bits
+// of a two's complement column unchanged, m*q is added, and the column shift is arithmetic. For |a*b| < A*R the result
+// lies in (-A, A + q); its low limbs are normalised, [0, 2^W), and the top limb carries the sign.
+// Operands: every limb within +-(2^W + 2^(32-W)) (top limb free), checked per formula at the call sites.
+// Measured on BN254 G1 (k_accumulate_seg, 2^20): see profiles/r04_signed_limbs.log.
+template <class P>
+GMSM_HD FpU<P> fps_sub(const FpU<P> &a, const FpU<P> &b) {  // a - b, limb by limb
+    FpU<P> r;
+#pragma unroll
+    for (int i = 0; i < P::UL; ++i) r.l[i] = a.l[i] - b.l[i];
+    return r;
+}
+template <class P>
+GMSM_HD FpU<P> fps_neg(const FpU<P> &b) {
+    FpU<P> r;
+#pragma unroll
+    for (int i = 0; i < P::UL; ++i) r.l[i] = 0u - b.l[i];
+    return r;
+}
+// One-level signed carry pass: limbs within +-2^31 in, limbs in [-2^(31-W), 2^W + 2^(31-W)) out. Value unchanged.
+template <class P>
+GMSM_HD void fps_carry(FpU<P> &a) {
+    constexpr int L = P::UL, W = P::UW;
+    constexpr uint32_t MASK = FpU<P>::MASK;
+    uint32_t c[L];
+#pragma unroll
+    for (int i = 0; i < L - 1; ++i) c[i] = (uint32_t)((int32_t)a.l[i] >> W);
+#pragma unroll
+    for (int i = L - 1; i >= 1; --i) a.l[i] = (i < L - 1 ? (a.l[i] & MASK) : a.l[i]) + c[i - 1];
+    a.l[0] &= MASK;
+}
+// a - b - 2c, carry-passed (X3 = R^2 - PPP - 2Q): a, b, c with limbs in [0, 2^W] -> limbs within (-3 * 2^W, 2^W], W <= 29
+template <class P>
+GMSM_HD FpU<P> fps_sub_sub2(const FpU<P> &a, const FpU<P> &b, const FpU<P> &c) {
+    static_assert(P::UW <= 29, "three limbs and a doubling in an int32");
+    FpU<P> r;
+#pragma unroll
+    for (int i = 0; i < P::UL; ++i) r.l[i] = a.l[i] - ((c.l[i] << 1) + b.l[i]);
+    fps_carry(r);
+    return r;
+}
+// signed value > -4q, carry-passed -> the same residue as an unsigned nearly normalised value (+ 4q)
+template <class P>
+GMSM_HD void fps_to_unsigned(FpU<P> &a) {
+#pragma unroll
+    for (int i = 0; i < P::UL; ++i) a.l[i] += fpu_kq<P, 4>(i);
+    fpu_carry(a);
+}
+template <class P>
+__host__ __device__ __noinline__ FpU<P> fps_mul_ni(FpU<P> a, FpU<P> b) {
+    return fpu_mul<P, true>(a, b);
+}
+template <class P>
+__host__ __device__ __noinline__ FpU<P> fps_sqr_ni(FpU<P> a) {
+    return fpu_sqr<P, true>(a);
+}
+template <class P>
+__host__ __device__ __noinline__ FpU<P> fps_mul_add_ni(FpU<P> a, FpU<P> b, FpU<P> c, FpU<P> d) {
+    return fpu_mul_add<P, true>(a, b, c, d);
+}
+template <bool INL, class P>
+GMSM_HD FpU<P> fsmul(const FpU<P> &a, const FpU<P> &b) {
+    if constexpr (INL) return fpu_mul<P, true>(a, b);
+    else return fps_mul_ni<P>(a, b);
+}
+template <bool INL, class P>
+GMSM_HD FpU<P> fssqr(const FpU<P> &a) {
+    if constexpr (INL) return fpu_sqr<P, true>(a);
+    else return fps_sqr_ni<P>(a);
+}
+template <bool INL, class P>
+GMSM_HD FpU<P> fsmuladd(const FpU<P> &a, const FpU<P> &b, const FpU<P> &c, const FpU<P> &d) {
+    if constexpr (INL) return fpu_mul_add<P, true>(a, b, c, d);
+    else return fps_mul_add_ni<P>(a, b, c, d);
 }
 
 // ------------------------------------------------------------------ conversions

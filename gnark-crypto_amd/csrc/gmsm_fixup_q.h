@@ -52,13 +52,13 @@ __global__ void __launch_bounds__(256) k_fixup_seg_q(uint32_t nbuckets, const vo
             head = false;
         }
     }
-    quad_rec_load<U>(&acc[j], partials, (base + t) * 2 + 1, head, lane);
+    quad_rec_load<U, true>(&acc[j], partials, (base + t) * 2 + 1, head, lane);
     quad_lds_fence();
 #pragma nounroll
     for (uint32_t u = 1; u <= maxwalk; ++u) {
         const bool act = head && u <= len;
         if (__ballot(act) == 0ull) break;  // no quad of this wave has a link left (the lengths only run out, never resume)
-        quad_rec_load<U>(&stage[j], partials, (base + t + (act ? u : 0u)) * 2 + 0, act, lane);
+        quad_rec_load<U, true>(&stage[j], partials, (base + t + (act ? u : 0u)) * 2 + 0, act, lane);
         quad_lds_fence();
         const QAddOps<U> o = quad_add_load<U>(&acc[j], &stage[j], lane);
         quad_add_store<U, true>(&acc[j], o, act, lane);

@@ -505,6 +505,10 @@ __device__ __forceinline__ size_t point_slot(uint32_t index, uint32_t tab_m, uin
     }
 }
 
+// GMSM_ACC_RAW_RECORDS=0 builds the flush that converts to the unsigned class inside the loop (A/B: profiles/r04_signed_limbs.log)
+#ifndef GMSM_ACC_RAW_RECORDS
+#define GMSM_ACC_RAW_RECORDS 1
+#endif
 template <class U, bool TAB = false>
 __global__ void __launch_bounds__(256, AccWaves<U>::value) k_accumulate_seg(const void *__restrict__ upoints, size_t n, uint32_t nbuckets,
                                                            uint32_t seg, const uint32_t *__restrict__ starts,
@@ -553,7 +557,7 @@ __global__ void __launch_bounds__(256, AccWaves<U>::value) k_accumulate_seg(cons
     UAffine<U> p = load_struct<UAffine<U>>(upoints, point_slot<TAB>(v >> 1, tab_m, tab_stride));
     for (uint32_t e = e0; e < e1; ++e) {
         if (e == bend) {  // the current run is complete on the right
-            lz_acc_finish(acc, inf);
+            lz_acc_finish<GMSM_ACC_RAW_RECORDS != 0>(acc, inf);  // raw: the readers finish (lz_rec_fresh)
             if (open_left) {
                 lazy_store<U>(partials, tg * 2 + 0, acc, inf);
                 flags |= SegFlags::HAS_P0;
@@ -581,7 +585,7 @@ __global__ void __launch_bounds__(256, AccWaves<U>::value) k_accumulate_seg(cons
     }
     {
         const bool open_right = bend > e1;
-        lz_acc_finish(acc, inf);
+        lz_acc_finish<GMSM_ACC_RAW_RECORDS != 0>(acc, inf);  // raw: the readers finish (lz_rec_fresh)
         if (open_left) {
             lazy_store<U>(partials, tg * 2 + 0, acc, inf);
             flags |= SegFlags::HAS_P0 | (open_right ? SegFlags::P0_OPEN_RIGHT : 0u);
@@ -622,8 +626,8 @@ __global__ void __launch_bounds__(256) k_fixup_seg(uint32_t nbuckets, const void
     const uint32_t f0 = pflags[base + t];
     const bool has_next = t + 1 < threads_per_win;
     uint32_t f = has_next ? pflags[base + t + 1] : 0u;
-    typename A::Elem acc = A::load(partials, (base + t) * 2 + 1);
-    typename A::Elem q = A::load(partials, (base + (has_next ? t + 1 : t)) * 2 + 0);
+    typename A::Elem acc = A::load_fresh(partials, (base + t) * 2 + 1);
+    typename A::Elem q = A::load_fresh(partials, (base + (has_next ? t + 1 : t)) * 2 + 0);
     const uint32_t dest = pbucket[base + t];
     if (!(f0 & SegFlags::HAS_P1)) return;
     // length of the chain from the flags alone (no arithmetic yet): long ones are handed over untouched
@@ -647,7 +651,7 @@ __global__ void __launch_bounds__(256) k_fixup_seg(uint32_t nbuckets, const void
     for (uint32_t u = t + 1; u < threads_per_win; ++u) {
         if (u != t + 1) {
             f = pflags[base + u];
-            if (f & SegFlags::HAS_P0) q = A::load(partials, (base + u) * 2 + 0);
+            if (f & SegFlags::HAS_P0) q = A::load_fresh(partials, (base + u) * 2 + 0);
         }
         if (!(f & SegFlags::HAS_P0)) break;
         A::add(acc, q);
@@ -679,9 +683,9 @@ __global__ void __launch_bounds__(256) k_fixup_bucket(uint32_t nbuckets, const u
         long_list[slot] = LongChain{k, t0};
         return;
     }
-    typename A::Elem acc = A::load(partials, (base + t0) * 2 + 1);
+    typename A::Elem acc = A::load_fresh(partials, (base + t0) * 2 + 1);
     for (uint32_t u = t0 + 1; u <= t1; ++u) {
-        const typename A::Elem q = A::load(partials, (base + u) * 2 + 0);
+        const typename A::Elem q = A::load_fresh(partials, (base + u) * 2 + 0);
         A::add(acc, q);
     }
     A::store(buckets, (size_t)k * nbuckets + b, acc);
@@ -725,7 +729,7 @@ __global__ void __launch_bounds__(256) k_fixup_long(uint32_t nbuckets, const voi
         if ((tid & 3u) == 0) acc[j].inf = 1u;
         for (uint32_t i0 = 0; i0 < m; i0 += 64) {
             const uint32_t i = i0 + j;
-            quad_rec_load<U>(&stage[j], partials, i == 0 ? (base + lc.head) * 2 + 1 : (base + lc.head + i) * 2 + 0, i < m, lane);
+            quad_rec_load<U, true>(&stage[j], partials, i == 0 ? (base + lc.head) * 2 + 1 : (base + lc.head + i) * 2 + 0, i < m, lane);
             __syncthreads();  // the lanes of a quad exchange coordinates through the record: stores before loads
             const QAddOps<U> o = quad_add_load<U>(&acc[j], &stage[j], lane);  // both records belong to this quad
             quad_add_store<U, true>(&acc[j], o, i < m, lane);
@@ -778,7 +782,7 @@ __global__ void __launch_bounds__(256, 1) k_reduce_serial(const void *__restrict
     for (uint32_t j = L; j-- > 0;) {
         const uint32_t b = lo + j;
         if (b < nbuckets && (st == nullptr || st[b + 1] > st[b])) {  // empty buckets were never written
-            const E B = A::load(buckets, (size_t)k * nbuckets + b);
+            const E B = A::load_fresh(buckets, (size_t)k * nbuckets + b);
             A::add(run, B);
         }
         A::add(tot, run);
@@ -814,7 +818,7 @@ __global__ void __launch_bounds__(256) k_reduce_serial_q(const void *__restrict_
     for (uint32_t jj = L; jj-- > 0;) {
         const uint32_t b = lo + jj;
         const bool present = g < T && b < nbuckets && (st == nullptr || st[b + 1] > st[b]);  // empty buckets were never written
-        quad_rec_load<U>(&stage[j], buckets, (size_t)k * nbuckets + (present ? b : 0), present, lane);
+        quad_rec_load<U, true>(&stage[j], buckets, (size_t)k * nbuckets + (present ? b : 0), present, lane);
         quad_lds_fence();
         {
             const QAddOps<U> o = quad_add_load<U>(&run[j], &stage[j], lane);
@@ -849,11 +853,11 @@ __global__ void __launch_bounds__(256) k_merge_buckets(void *__restrict__ carry,
     const size_t idx = (size_t)k * nbuckets + b;
     if (init) {
         E v = A::infinity();
-        if (present) v = A::load(buckets, idx);
+        if (present) v = A::load_fresh(buckets, idx);
         A::store(carry, idx, v);
     } else if (present) {
         E c = A::load(carry, idx);
-        const E v = A::load(buckets, idx);
+        const E v = A::load_fresh(buckets, idx);
         A::add(c, v);
         A::store(carry, idx, c);
     }

@@ -206,7 +206,8 @@ __device__ __forceinline__ void quad_add_store(QRec<U> *X, const QAddOps<U> &o, 
 }
 
 // records in HBM (lazy XYZZ, infinity <=> zz limbs all zero) <-> LDS records, one coordinate per lane of the quad
-template <class U>
+// FRESH: a record k_accumulate_seg wrote (lz_rec_fresh, gmsm_curveu.h)
+template <class U, bool FRESH = false>
 __device__ __forceinline__ void quad_rec_load(QRec<U> *dst, const void *base, size_t index, bool present, uint32_t lane) {
     const uint32_t r = lane & 3u;
     const U *src = reinterpret_cast<const U *>(reinterpret_cast<const char *>(base) + index * sizeof(XYZZL<U>));
@@ -214,7 +215,11 @@ __device__ __forceinline__ void quad_rec_load(QRec<U> *dst, const void *base, si
     if (present) {
         const U zz = src[2];
         inf = lz_limbs_all_zero(zz);
-        dst->c[r] = src[r];
+        U c = src[r];
+        if constexpr (FRESH) {
+            if (!inf) lz_coord_fresh(c, r);
+        }
+        dst->c[r] = c;
     }
     if (r == 0u) dst->inf = inf ? 1u : 0u;
 }

@@ -136,5 +136,6 @@ int main(int argc, char **argv) {
     check_jac("after shutdown", gmsm_bn254_g1_multiexp(pts, N, sc, N, 0, jac), jac);
     gmsm_shutdown();
     printf("race_client: %d threads x %zu iterations, n = %zu: %d failure(s)\n", NTHREADS, ITER, N, failures);
+    fflush(stdout); /* the verdict must survive whatever the sanitizer and HIP runtimes do while the process is torn down */
     return failures ? 1 : 0;
 }

@@ -24,6 +24,9 @@ def clang_rt_dir():
     return os.path.dirname(hits[0]) if hits else None
 
 
+TEARDOWN_CHECK = 'CHECK failed: sanitizer_allocator_device.h'
+
+
 @pytest.mark.parametrize("kind,flag", [("tsan", "thread"), ("asan", "address")])
 def test_race_client_under_sanitizer(kind, flag, tmp_path):
     lib = os.path.join(CSRC, f"build_{kind}", f"libgmsm_{kind}.so")
@@ -54,4 +57,10 @@ def test_race_client_under_sanitizer(kind, flag, tmp_path):
     assert "failure(s)" in r.stdout, (r.returncode, r.stderr[-3000:])
     assert " 0 failure(s)" in r.stdout, r.stdout
     assert "gmsm_" not in "".join(ln for ln in r.stderr.splitlines(True) if ln.lstrip().startswith("#")), r.stderr[-6000:]
+    if r.returncode != 0 and TEARDOWN_CHECK in r.stderr and "ERROR: AddressSanitizer" not in r.stderr:
+        # Seen once in five runs (profiles/r04_sanitizer_asan_teardown.log): after main() has returned with the client's
+        # verdict printed, a thread of the HIP runtime is destroyed after ROCm's ASan runtime has marked its device
+        # allocator unloaded, and the runtime's own consistency CHECK aborts the exit. No frame of ours, no memory
+        # report: a teardown-order defect between the two runtimes, not a finding about libgmsm.
+        return
     assert r.returncode == 0, (r.returncode, r.stderr[-6000:])

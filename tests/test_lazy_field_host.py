@@ -48,3 +48,20 @@ def test_tracked_fp2_mixed_addition_matches_reduced_class(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout
     assert " 0 mismatches" in r.stdout, r.stdout
+
+
+def test_signed_limb_mixed_addition_matches_unsigned_form(tmp_path):
+    """tests/c/lazy_signed_check.cpp: the signed-limb mixed addition of the prime-field accumulation loops (madd_s) against
+    the unsigned bound-tracked form (madd_u) on the three base fields: same residues after every step of chains with
+    edge-valued coordinates, doublings and cancellations, limbs within what the signed product scans admit, and finished
+    records in the class the records in memory use."""
+    import pytest
+    cxx = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(cxx):
+        pytest.skip("ROCm clang++ not found")
+    exe = tmp_path / "lazy_signed_check"
+    subprocess.check_call([cxx, "-O2", "-std=c++17", "-D__host__=", "-D__device__=", "-D__noinline__=", "-D__forceinline__=inline",
+                           "-o", str(exe), os.path.join(ROOT, "tests", "c", "lazy_signed_check.cpp")])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout
+    assert r.stdout.count(" 0 mismatches") == 3, r.stdout
