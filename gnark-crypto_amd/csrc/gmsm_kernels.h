@@ -288,6 +288,9 @@ static __global__ void __launch_bounds__(1024) k_part_rowscan(const uint32_t *__
 // session, profiles/r03_part_chunk.log). Beyond 2^25 points the coarse pass has 2048 partitions and the longer chunk's
 // longer runs win again (2^26: 9.5 against 10.3 ms): PART_CHUNK_BIG.
 constexpr uint32_t PART_CHUNK = 12288, PART_CHUNK_BIG = 16384;
+#ifndef GMSM_SCATTER_COUNT
+#define GMSM_SCATTER_COUNT 0
+#endif
 template <class D, uint32_t CHUNK>
 __global__ void __launch_bounds__(1024) k_part_scatter(const D *__restrict__ digits, size_t n, uint32_t nparts,
                                                               uint32_t fbits, uint32_t lidx, size_t chunk_len,
@@ -303,14 +306,24 @@ __global__ void __launch_bounds__(1024) k_part_scatter(const D *__restrict__ dig
     const uint32_t chunk = blockIdx.x, k = blockIdx.y, nchunks = gridDim.x, t = threadIdx.x, T = blockDim.x;
     const uint32_t *goff = blockhist + ((size_t)k * nchunks + chunk) * nparts;  // prefix of (chunk, p) inside partition p
     const uint32_t *pbase = part_base + (size_t)k * (nparts + 1);
+    // The chunk's population of every partition is already known: k_part_hist counted it and k_part_colscan turned the
+    // counts into prefixes over the chunks, so it is the difference to the next chunk's prefix (the last chunk: to the
+    // partition's population) - no counting pass of LDS atomics over the entries (GMSM_SCATTER_COUNT=1 builds that pass).
+#if GMSM_SCATTER_COUNT
     for (uint32_t p = t; p < nparts; p += T) cnt[p] = 0;
     __syncthreads();
+#else
+    {
+        const bool last = chunk + 1 == nchunks;
+        for (uint32_t p = t; p < nparts; p += T) cnt[p] = (last ? pbase[p + 1] - pbase[p] : goff[nparts + p]) - goff[p];
+    }
+#endif
     const size_t lo = (size_t)chunk * chunk_len;
     const size_t hi = lo + chunk_len < n ? lo + chunk_len : n;
     const D *d = digits + (size_t)k * n;
     const uint32_t fmask = (1u << fbits) - 1u;
     static_assert(CHUNK % 1024 == 0, "a whole number of entries per thread");
-    constexpr int PER = CHUNK / 1024;  // entries per thread, kept in registers between the two passes
+    constexpr int PER = CHUNK / 1024;  // entries per thread, in registers while the cursors are prepared
     uint32_t ent[PER];
     uint32_t pid[PER];
 #pragma unroll
@@ -322,7 +335,9 @@ __global__ void __launch_bounds__(1024) k_part_scatter(const D *__restrict__ dig
             const uint32_t b = code_bucket(code);
             pid[j] = b >> fbits;
             ent[j] = ((b & fmask) << lidx) | ((uint32_t)i << 1) | (code & 1u);
+#if GMSM_SCATTER_COUNT
             atomicAdd(&cnt[pid[j]], 1u);
+#endif
         }
     }
     __syncthreads();
