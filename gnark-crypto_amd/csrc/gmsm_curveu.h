@@ -305,8 +305,12 @@ GMSM_HD void add_g(XYZZL<U> &p, bool &pinf, const XYZZL<U> &q, bool qinf) {
 #ifndef GMSM_SIGNED_MADD
 #define GMSM_SIGNED_MADD 1
 #endif
+#ifndef GMSM_SIGNED_MADD2
+#define GMSM_SIGNED_MADD2 1   // the same for the Fp2 groups (madd_ts; 0: madd_t for BLS12-381, madd_g for BN254)
+#endif
 template <class U> struct LzSigned { static constexpr bool value = false; };
 template <class P> struct LzSigned<FpU<P>> { static constexpr bool value = GMSM_SIGNED_MADD != 0; };
+template <class P> struct LzSigned<Fp2U<P>> { static constexpr bool value = GMSM_SIGNED_MADD2 != 0; };
 template <class U> struct LzTracked { static constexpr bool value = false; };
 template <class P> struct LzTracked<Fp2U<P>> { static constexpr bool value = GMSM_FP2_TRACKED && (P::UL * P::UW - P::BITS) >= 11; };
 
@@ -385,6 +389,121 @@ GMSM_HD void fpu_to_class_r(FpU<P> &a) {  // a < 12q, nearly normalised
     fpu_cond_sub_4q(a);
 }
 
+// ------------------------------------------------------------------ the Fp2 mixed addition on signed limbs
+// madd_s carried over to Fp2 = Fp[u]/(u^2 + 1): components are signed numbers on signed limbs, a difference is one
+// subtraction per limb, a product component is ONE signed two-product scan (c0 = a0 b0 + (-a1) b1, c1 = a0 b1 + a1 b0: a
+// negation is one instruction per limb, where the unsigned forms pay K q - a1 and a carry pass), and nothing is ever
+// compared with q inside the loop. Unlike madd_t's bound tracking this needs no spare bits beyond the 7 of BN254's radix:
+// without K q offsets the values stay within +-8q, so BN254 G2 leaves the reduced class R of madd_g - whose every
+// subtraction is two sequential borrow chains and a conditional +4q - as well.
+// Values in multiples of q, per component (A = 2^(L W)/q >= 169; m(.) = largest |component|; a product component lies in
+// (-(m m' + m m')/A, (m m' + m m')/A + 1)):
+//   px, py: m < 2;  accumulator: m(X) < 5.3, m(Y) < 2.5, m(ZZ), m(ZZZ) < 1.1  (or class R, < 4, after the doubling branch)
+//   P = px ZZ - X: m < 7.2    R = py ZZZ - Y: m < 5.1
+//   PP = P^2: a0 = (P0 + P1)(P0 - P1) in (-1.3, 2.3), a1 = 2 P0 P1 in (-0.7, 2.7);   RR likewise, smaller
+//   PPP = P PP, Q = X PP: m < 1.3      X3 = RR - PPP - 2Q: m < 5.3      D = Q - X3: m < 6.6
+//   Y3 = D R - Y PPP: one four-product scan per component where the columns hold 5L products (BLS12-381), else two
+//   two-product scans, summed and carried (BN254: 27 products of < 2^58.1 per column is what a signed 64-bit column holds)
+// Limbs: every operand of a scan is a scan result (normalised, signed top limb), carry-passed, or the difference of two
+// such values: within +-(2^W + 2^(32-W)). Of a square, the sum and the difference of the components and the doubled cross
+// product are carry-passed for that reason. P == 0 is tested on P^2 (a field: P^2 = 0 <=> P = 0), whose a0 can come out as
+// -q, 0, q or 2q (fps_prod_is_zero). The accumulator leaves the class through lz_acc_finish / lz_rec_fresh: + 8q, then
+// exactly into R.
+template <class P>
+GMSM_HD bool fps_prod_is_zero(const FpU<P> &a) {  // a == 0 mod q for a scan result in (-2q, 3q)
+    const uint32_t l0 = a.l[0];
+    if (l0 != 0u && l0 != P::UQ1[0] && l0 != P::UQ2[0] && l0 != ((0u - P::UQ1[0]) & FpU<P>::MASK)) return false;
+    FpU<P> n = a;
+#pragma unroll
+    for (int i = 0; i < P::UL; ++i) n.l[i] += P::UQ1[i];  // (-q, 4q)
+    fps_normalize(n);
+    return fpu_is_zero_r(n);
+}
+template <class P>
+GMSM_HD Fp2U<P> f2s_sub(const Fp2U<P> &a, const Fp2U<P> &b) { return Fp2U<P>{fps_sub<P>(a.a0, b.a0), fps_sub<P>(a.a1, b.a1)}; }
+template <class P>
+GMSM_HD Fp2U<P> f2s_neg(const Fp2U<P> &a) { return Fp2U<P>{fps_neg<P>(a.a0), fps_neg<P>(a.a1)}; }
+template <bool INL, class P>
+GMSM_HD Fp2U<P> f2s_mul(const Fp2U<P> &x, const Fp2U<P> &y) {
+    Fp2U<P> z;
+    z.a0 = fsmuladd<INL>(x.a0, y.a0, fps_neg<P>(x.a1), y.a1);
+    z.a1 = fsmuladd<INL>(x.a0, y.a1, x.a1, y.a0);
+    return z;
+}
+// x^2: a0 = (x0 + x1)(x0 - x1), a1 = 2 x0 x1 (e2_bn254.go:41-50); `half1` = x0 x1 (for the zero test)
+template <bool INL, class P>
+GMSM_HD Fp2U<P> f2s_sqr(const Fp2U<P> &x, FpU<P> &half1) {
+    FpU<P> sum = fps_add<P>(x.a0, x.a1), dif = fps_sub<P>(x.a0, x.a1);
+    fps_carry(sum);
+    fps_carry(dif);
+    Fp2U<P> z;
+    z.a0 = fsmul<INL>(sum, dif);
+    half1 = fsmul<INL>(x.a0, x.a1);
+    z.a1 = fps_add<P>(half1, half1);
+    fps_carry(z.a1);
+    return z;
+}
+
+template <class P, bool INL>
+GMSM_HD void madd_ts(XYZZL<Fp2U<P>> &acc, bool &inf, const Fp2U<P> &px, const Fp2U<P> &py_in, bool negate) {
+    using U = Fp2U<P>;
+    const U py = negate ? f2s_neg<P>(py_in) : py_in;
+    if (inf) {
+        acc.x = px;
+        acc.y = py;
+        acc.zz = lz_one((const U *)nullptr);
+        acc.zzz = lz_one((const U *)nullptr);
+        inf = false;
+        return;
+    }
+    const U Pv = f2s_sub<P>(f2s_mul<INL>(px, acc.zz), acc.x);
+    const U Rv = f2s_sub<P>(f2s_mul<INL>(py, acc.zzz), acc.y);
+    FpU<P> hp, hr;
+    const U PP = f2s_sqr<INL>(Pv, hp);
+    if (fps_prod_is_zero(PP.a0) && fps_prod_is_zero(hp)) {            // same x (g2.go, as g1.go:846-854)
+        const U RR0 = f2s_sqr<INL>(Rv, hr);
+        if (fps_prod_is_zero(RR0.a0) && fps_prod_is_zero(hr))         // P + P: the reduced-class doubling (rare)
+            double_mixed_g<U, INL>(acc, px, negate ? lz_sub(lz_zero((const U *)nullptr), py_in) : py_in);
+        else inf = true;                                              // P + (-P)
+        return;
+    }
+    const U PPP = f2s_mul<INL>(Pv, PP);
+    const U Q = f2s_mul<INL>(acc.x, PP);
+    const U RR = f2s_sqr<INL>(Rv, hr);
+    const U X3{fps_sub_sub2<P>(RR.a0, PPP.a0, Q.a0), fps_sub_sub2<P>(RR.a1, PPP.a1, Q.a1)};
+    const U D = f2s_sub<P>(Q, X3);
+    // Y3 = D R - Y PPP:  a0 = D0 R0 - D1 R1 - Y0 PPP0 + Y1 PPP1,  a1 = D0 R1 + D1 R0 - Y0 PPP1 - Y1 PPP0
+    const FpU<P> nD1 = fps_neg<P>(D.a1), nY0 = fps_neg<P>(acc.y.a0), nY1 = fps_neg<P>(acc.y.a1);
+    U Y3;
+    if constexpr (INL && FpsFits4<P>::value) {
+        Y3.a0 = fpu_mul_add4<P, true>(D.a0, Rv.a0, nD1, Rv.a1, nY0, PPP.a0, acc.y.a1, PPP.a1);
+        Y3.a1 = fpu_mul_add4<P, true>(D.a0, Rv.a1, D.a1, Rv.a0, nY0, PPP.a1, nY1, PPP.a0);
+    } else {
+        Y3.a0 = fps_add<P>(fsmuladd<INL>(D.a0, Rv.a0, nD1, Rv.a1), fsmuladd<INL>(nY0, PPP.a0, acc.y.a1, PPP.a1));
+        Y3.a1 = fps_add<P>(fsmuladd<INL>(D.a0, Rv.a1, D.a1, Rv.a0), fsmuladd<INL>(nY0, PPP.a1, nY1, PPP.a0));
+        fps_carry(Y3.a0);
+        fps_carry(Y3.a1);
+    }
+    acc.x = X3;
+    acc.y = Y3;
+    acc.zz = f2s_mul<INL>(acc.zz, PP);
+    acc.zzz = f2s_mul<INL>(acc.zzz, PPP);
+}
+
+// a signed component > -8q (carry-passed or a scan result) -> R
+template <class P>
+GMSM_HD void fps_to_class_r(FpU<P> &a) {
+#pragma unroll
+    for (int i = 0; i < P::UL; ++i) a.l[i] += fpu_kq<P, 8>(i);
+    fpu_to_class_r(a);
+}
+template <class P>
+GMSM_HD void f2s_to_class_r(Fp2U<P> &a) {
+    fps_to_class_r(a.a0);
+    fps_to_class_r(a.a1);
+}
+
+
 // ---- dispatch: prime-field elements use the bound-tracked forms above, Fp2 elements the reduced-class forms ----
 template <bool INL, class P>
 GMSM_HD void lz_madd(XYZZL<FpU<P>> &acc, bool &inf, const FpU<P> &px, const FpU<P> &py, bool negate) {
@@ -394,51 +513,57 @@ template <bool INL, class P>
 GMSM_HD void lz_madd(XYZZL<Fp2U<P>> &acc, bool &inf, const Fp2U<P> &px, const Fp2U<P> &py, bool negate) {
     madd_g<Fp2U<P>, INL>(acc, inf, px, py, negate);
 }
+// a record k_accumulate_seg wrote (signed class of madd_s) -> the unsigned class every other kernel computes in: + 4q on
+// the coordinates that can be negative. Harmless on a record that already is in the unsigned class (a bucket closed by
+// the fix-up, the running buckets of a multi-range call): coordinates only enter the additions as operands of products,
+// whose bounds have room for it (x, y < 11 + 8, zzz < 6 + 8: 19 * 14 / 169 + 1 < 4 on BN254, the narrowest field).
+// (Fp2: + 8q and exactly into R = [0, 4q) on every component - R stays R.)
+template <class U>
+GMSM_HD void lz_coord_fresh(U &c, uint32_t which) {  // one coordinate (a lane of a quad): 0 x, 1 y, 2 zz, 3 zzz
+    if constexpr (LzSigned<U>::value) {
+        if constexpr (IsLazyPrimeField<U>::value) {
+            if (which != 2u) fps_to_unsigned(c);  // zz is a product of non-negative values: already unsigned
+        } else {
+            f2s_to_class_r(c);
+        }
+    }
+}
+template <class U>
+GMSM_HD void lz_rec_fresh(XYZZL<U> &v) {
+    lz_coord_fresh(v.x, 0u);
+    lz_coord_fresh(v.y, 1u);
+    lz_coord_fresh(v.zz, 2u);
+    lz_coord_fresh(v.zzz, 3u);
+}
 // the mixed addition of an accumulation LOOP (k_accumulate_seg, the fixed-base walk): may leave the coordinates in a
 // wider class than the records in memory use; lz_acc_finish brings them back before the store
 template <bool INL, class U>
 GMSM_HD void lz_madd_acc(XYZZL<U> &acc, bool &inf, const U &px, const U &py, bool negate) {
-    if constexpr (LzTracked<U>::value) madd_t<typename U::Params, INL>(acc, inf, px, py, negate);
-    else if constexpr (LzSigned<U>::value) madd_s<typename U::Params, INL>(acc, inf, px, py, negate);
-    else lz_madd<INL>(acc, inf, px, py, negate);
+    if constexpr (LzSigned<U>::value) {
+        if constexpr (IsLazyPrimeField<U>::value) madd_s<typename U::Params, INL>(acc, inf, px, py, negate);
+        else madd_ts<typename U::Params, INL>(acc, inf, px, py, negate);
+    } else if constexpr (LzTracked<U>::value) {
+        madd_t<typename U::Params, INL>(acc, inf, px, py, negate);
+    } else {
+        lz_madd<INL>(acc, inf, px, py, negate);
+    }
 }
 // TO_RECORD: the value goes to a bucket / partial-sum record whose readers apply lz_rec_fresh (k_accumulate_seg: the
 // flush sits on the divergent bucket-boundary path of the hot loop, executed by the whole wave for the one or two lanes
 // whose bucket ends - 87 % of the iterations at 32 entries per bucket -, the readers run it once per record).
 template <bool TO_RECORD = false, class U>
 GMSM_HD void lz_acc_finish(XYZZL<U> &acc, bool inf) {
-    if constexpr (LzSigned<U>::value && !TO_RECORD) {
-        if (!inf) {
-            fps_to_unsigned(acc.x);
-            fps_to_unsigned(acc.y);
-            fps_to_unsigned(acc.zzz);  // zz is a product of non-negative values: already in the unsigned class
+    if constexpr (LzSigned<U>::value) {
+        if constexpr (!TO_RECORD) {
+            if (!inf) lz_rec_fresh(acc);
         }
-    }
-    if constexpr (LzTracked<U>::value) {
+    } else if constexpr (LzTracked<U>::value) {
         if (!inf) {
             fpu_to_class_r(acc.x.a0);
             fpu_to_class_r(acc.x.a1);
             fpu_to_class_r(acc.y.a0);
             fpu_to_class_r(acc.y.a1);
         }
-    }
-}
-// a record k_accumulate_seg wrote (signed class of madd_s) -> the unsigned class every other kernel computes in: + 4q on
-// the coordinates that can be negative. Harmless on a record that already is in the unsigned class (a bucket closed by
-// the fix-up, the running buckets of a multi-range call): coordinates only enter the additions as operands of products,
-// whose bounds have room for it (x, y < 11 + 8, zzz < 6 + 8: 19 * 14 / 169 + 1 < 4 on BN254, the narrowest field).
-template <class U>
-GMSM_HD void lz_rec_fresh(XYZZL<U> &v) {
-    if constexpr (LzSigned<U>::value) {
-        fps_to_unsigned(v.x);
-        fps_to_unsigned(v.y);
-        fps_to_unsigned(v.zzz);
-    }
-}
-template <class U>
-GMSM_HD void lz_coord_fresh(U &c, uint32_t which) {  // one coordinate (a lane of a quad): 0 x, 1 y, 2 zz, 3 zzz
-    if constexpr (LzSigned<U>::value) {
-        if (which != 2u) fps_to_unsigned(c);
     }
 }
 template <bool INL, class P>

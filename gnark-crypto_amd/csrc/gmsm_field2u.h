@@ -5,8 +5,10 @@
 // only 7 spare bits in BN254's 2^261 radix, the bounds would run away. The G2 path therefore keeps every stored value
 // in the *reduced class* R = [0, 4q) with exactly normalised limbs: additions and subtractions end with one
 // conditional +-4q, products come out < 2q by themselves (operands up to 8q are fine: 64 q^2 / 2^261 < 0.4 q).
-// (BLS12-381 has 11 spare bits: its G2 accumulation LOOP tracks bounds like the prime-field path, gmsm_curveu.h madd_t,
-// and returns to R when a bucket is flushed; fixup, reduction and BN254 G2 work on R throughout.)
+// (The accumulation LOOP of both G2 groups left R in round 4: on signed limbs nothing needs a K q offset, the values stay
+// within +-8q, and 7 spare bits are enough - gmsm_curveu.h madd_ts; its records return to R when they are read. Fixup and
+// reduction work on R throughout. Before: madd_g on R for BN254, madd_t - bounds tracked as on the prime-field path, 11
+// spare bits - for BLS12-381; both still build with -DGMSM_SIGNED_MADD2=0.)
 //
 // Replaces: fptower.E2 Add/Sub/Double/Neg/Mul/Square (ecc/bn254/internal/fptower/e2_fallback.go:10-28,
 // e2_bn254.go:28-50; BLS12-381: e2_bls381.go:15-38). Exact arithmetic mod q: converting back with f2u_to_sat gives the

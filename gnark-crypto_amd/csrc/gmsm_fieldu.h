@@ -244,30 +244,34 @@ GMSM_HD FpU<P> fpu_mul_add(const FpU<P> &a, const FpU<P> &b, const FpU<P> &c, co
 // (a*b + c*d + e*f + g*h) * 2^-(L*W) mod q with ONE reduction: one component of the difference of two Fp2 products
 // (gmsm_curveu.h, madd_t). Every operand nearly normalised (limbs <= 2^W + 2^(32-W)): 5L products per column.
 // Bound: (sum of the four bound products) / (2^(L*W)/q) + 1.
-template <class P>
+template <class P, bool SIGNED = false>
 GMSM_HD FpU<P> fpu_mul_add4(const FpU<P> &a, const FpU<P> &b, const FpU<P> &c, const FpU<P> &d, const FpU<P> &e,
                             const FpU<P> &f, const FpU<P> &g, const FpU<P> &h) {
     constexpr int L = P::UL, W = P::UW;
     constexpr uint32_t MASK = FpU<P>::MASK;
     static_assert((unsigned long long)L * 5 * ((1ull << (2 * W)) + (1ull << (W + 6))) < (1ull << 63), "column accumulator overflow");
+    static_assert(!SIGNED || 5ull * L * (((1ull << W) + (1ull << (32 - W))) * ((1ull << W) + (1ull << (32 - W)))) < (1ull << 63),
+                  "signed column accumulator overflow");
     uint32_t m[L];
     FpU<P> r;
-    uint64_t acc = 0;
+    using LA = LimbAcc<SIGNED>;
+    using A = typename LA::type;
+    A acc = 0;
 #pragma unroll
     for (int k = 0; k < 2 * L - 1; ++k) {
         const int lo = k < L ? 0 : k - L + 1, hi = k < L ? k : L - 1;
 #pragma unroll
         for (int i = lo; i <= hi; ++i) {
-            acc += (uint64_t)a.l[i] * b.l[k - i];
-            acc += (uint64_t)c.l[i] * d.l[k - i];
-            acc += (uint64_t)e.l[i] * f.l[k - i];
-            acc += (uint64_t)g.l[i] * h.l[k - i];
+            acc += LA::mul(a.l[i], b.l[k - i]);
+            acc += LA::mul(c.l[i], d.l[k - i]);
+            acc += LA::mul(e.l[i], f.l[k - i]);
+            acc += LA::mul(g.l[i], h.l[k - i]);
         }
 #pragma unroll
-        for (int i = (k < L ? 0 : k - L + 1); i < (k < L ? k : L); ++i) acc += (uint64_t)m[i] * P::UQ[k - i];
+        for (int i = (k < L ? 0 : k - L + 1); i < (k < L ? k : L); ++i) acc += LA::mul(m[i], P::UQ[k - i]);
         if (k < L) {
             m[k] = ((uint32_t)acc * P::UQINV) & MASK;
-            acc += (uint64_t)m[k] * P::UQ[0];
+            acc += LA::mul(m[k], P::UQ[0]);
         } else {
             r.l[k - L] = (uint32_t)acc & MASK;
         }
@@ -410,6 +414,29 @@ GMSM_HD void fps_carry(FpU<P> &a) {
     for (int i = L - 1; i >= 1; --i) a.l[i] = (i < L - 1 ? (a.l[i] & MASK) : a.l[i]) + c[i - 1];
     a.l[0] &= MASK;
 }
+template <class P>
+GMSM_HD FpU<P> fps_add(const FpU<P> &a, const FpU<P> &b) {  // a + b, limb by limb (no carry)
+    FpU<P> r;
+#pragma unroll
+    for (int i = 0; i < P::UL; ++i) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+// exact sequential normalisation of a signed value: low limbs in [0, 2^W), the top limb carries the rest and the sign
+template <class P>
+GMSM_HD void fps_normalize(FpU<P> &a) {
+#pragma unroll
+    for (int i = 0; i < P::UL - 1; ++i) {
+        const uint32_t c = (uint32_t)((int32_t)a.l[i] >> P::UW);
+        a.l[i] &= FpU<P>::MASK;
+        a.l[i + 1] += c;
+    }
+}
+// can the column accumulators of a signed four-product scan (fpu_mul_add4<P, true>) hold 5L products?
+template <class P>
+struct FpsFits4 {
+    static constexpr unsigned long long LIM = (1ull << P::UW) + (1ull << (32 - P::UW));
+    static constexpr bool value = 5ull * P::UL * (LIM * LIM) < (1ull << 63);
+};
 // a - b - 2c, carry-passed (X3 = R^2 - PPP - 2Q): a, b, c with limbs in [0, 2^W] -> limbs within (-3 * 2^W, 2^W], W <= 29
 template <class P>
 GMSM_HD FpU<P> fps_sub_sub2(const FpU<P> &a, const FpU<P> &b, const FpU<P> &c) {

@@ -5,7 +5,9 @@
 // coordinates, both signs, the same point twice in a row (the doubling branch) and a point followed by its negation
 // (back to infinity); after every step both accumulators must hold the same residues, and the tracked one - after
 // lz_acc_finish - exactly normalised limbs below 4q. Exit code = number of mismatches (capped).
-// Build: clang++ -O2 -std=c++17 -D__host__= -D__device__= -D__noinline__= -D__forceinline__=inline tests/c/lazy_g2_check.cpp
+// (Since round 4 the shipped accumulation loop runs madd_ts on signed limbs - tests/c/lazy_signed_check.cpp; madd_t is
+// what -DGMSM_SIGNED_MADD2=0 builds, and this check is compiled that way.)
+// Build: clang++ -O2 -std=c++17 -DGMSM_SIGNED_MADD2=0 -D__host__= -D__device__= -D__noinline__= -D__forceinline__=inline tests/c/lazy_g2_check.cpp
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
