@@ -258,6 +258,29 @@ def test_msm_random_matches_oracle(gm, oracle_mod, curve, which, logn):
     assert (_msm_gpu_affine(g, pts, sc) == o.msm_affine(pts, sc, nthreads=8)).all()
 
 
+@pytest.mark.parametrize("curve,which,n", [("bn254", "g1", 64 * 157 + 37), ("bn254", "g1", 64), ("bn254", "g1", 63),
+                                           ("bls12_381", "g1", 4097), ("bls12_381", "g2", 1025), ("bw6_761", "g1", 777)])
+def test_msm_window_17_ragged_sizes(gm, oracle_mod, forced_options, curve, which, n):
+    """Window width 17 - what every call from 2^21 points runs, with 17-bit digit codes in uint32 arrays - at sizes that are
+    not a multiple of the 64-lane wave, one full wave and one short of it: random scalars (bit 16 of the code set in half of
+    the digits), every fifth scalar a single limb, infinities among the points; against the oracle, and against the same
+    call at c = 16 (uint16 codes)."""
+    g = _group(gm, curve, which)
+    o = oracle_mod.Oracle(curve, which)
+    rng = rng_for(17, g.gid, n)
+    pts = o.gen_points(n, int(rng.integers(1, 2**62)), int(rng.integers(1, 2**62)), nthreads=8)
+    sc = random_scalars(rng, g.curve, n)
+    pts[[1, n // 2, n - 1]] = 0
+    sc[::5, 1:] = 0
+    sc[7 % n] = 0
+    want = o.msm_affine(pts, sc, nthreads=8)
+    forced_options(window_bits=17)
+    got17 = _msm_gpu_affine(g, pts, sc)
+    forced_options(window_bits=16)
+    got16 = _msm_gpu_affine(g, pts, sc)
+    assert (got17 == want).all() and (got16 == want).all()
+
+
 def test_msm_bn254_g1_2p20_config(gm, oracle_mod):
     """BASELINE config C2: BN254 G1, n = 2^20, against the oracle on the same seeded input."""
     g = gm.G1Affine("bn254")
