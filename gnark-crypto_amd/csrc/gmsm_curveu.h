@@ -685,6 +685,9 @@ struct UnsatOps {
     __device__ static __forceinline__ Elem infinity() { return unsat_infinity<U>(); }
     __device__ static __forceinline__ Elem load(const void *base, size_t i) { return unsat_load<U>(base, i); }
     __device__ static __forceinline__ Elem load_fresh(const void *base, size_t i) { return unsat_load_fresh<U>(base, i); }
+    __device__ static __forceinline__ void fresh(Elem &e) {  // what load_fresh does, for a record that was loaded raw
+        if (!e.inf) lz_rec_fresh(e.v);
+    }
     __device__ static __forceinline__ void store(void *base, size_t i, const Elem &e) { lazy_store<U>(base, i, e.v, e.inf); }
     __device__ static __forceinline__ void store_final(void *base, size_t i, const Elem &e) { unsat_store_final<U, true>(base, i, e); }
     __device__ static __forceinline__ void add(Elem &p, const Elem &q) { lz_padd<true>(p.v, p.inf, q.v, q.inf); }

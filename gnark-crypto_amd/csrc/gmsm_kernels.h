@@ -209,10 +209,32 @@ __global__ void __launch_bounds__(1024) k_part_hist(const D *__restrict__ digits
     const size_t lo = (size_t)chunk * chunk_len;
     const size_t hi = lo + chunk_len < n ? lo + chunk_len : n;
     const D *d = digits + (size_t)k * n;
-    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const uint32_t code = d[i];
+    // 16-byte loads (4 or 8 codes per lane and request): with one 2- or 4-byte load per lane and iteration the pass ran at
+    // the latency of its loads, not at the rate of HBM or of the LDS atomics (2^24: 0.335 ms for 1 GB, the same with half
+    // the bytes - profiles/r04_dig17_ab.log). The order of the codes does not matter to a histogram.
+    constexpr size_t PERV = 16 / sizeof(D);
+    auto count = [&](uint32_t code) {
         if (code) atomicAdd(&lds_cnt[code_bucket(code) >> fbits], 1u);
+    };
+    size_t a0 = lo + ((16u - (uint32_t)(reinterpret_cast<uintptr_t>(d + lo) & 15u)) & 15u) / sizeof(D);  // first aligned code
+    if (a0 > hi) a0 = hi;
+    const size_t nvec = (hi - a0) / PERV, a1 = a0 + nvec * PERV;
+    for (size_t i = lo + threadIdx.x; i < a0; i += blockDim.x) count(d[i]);
+    const uint4 *dv = reinterpret_cast<const uint4 *>(d + a0);
+    for (size_t v = threadIdx.x; v < nvec; v += blockDim.x) {
+        const uint4 q = dv[v];
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (sizeof(D) == 4) {
+                count(w[j]);
+            } else {
+                count(w[j] & 0xffffu);
+                count(w[j] >> 16);
+            }
+        }
     }
+    for (size_t i = a1 + threadIdx.x; i < hi; i += blockDim.x) count(d[i]);
     __syncthreads();
     uint32_t *out = blockhist + ((size_t)k * nchunks + chunk) * nparts;
     for (uint32_t p = threadIdx.x; p < nparts; p += blockDim.x) out[p] = lds_cnt[p];
@@ -641,8 +663,8 @@ __global__ void __launch_bounds__(256) k_fixup_seg(uint32_t nbuckets, const void
     const uint32_t f0 = pflags[base + t];
     const bool has_next = t + 1 < threads_per_win;
     uint32_t f = has_next ? pflags[base + t + 1] : 0u;
-    typename A::Elem acc = A::load_fresh(partials, (base + t) * 2 + 1);
-    typename A::Elem q = A::load_fresh(partials, (base + (has_next ? t + 1 : t)) * 2 + 0);
+    typename A::Elem acc = A::load(partials, (base + t) * 2 + 1);  // raw: made fresh below, by the chain heads only
+    typename A::Elem q = A::load(partials, (base + (has_next ? t + 1 : t)) * 2 + 0);
     const uint32_t dest = pbucket[base + t];
     if (!(f0 & SegFlags::HAS_P1)) return;
     // length of the chain from the flags alone (no arithmetic yet): long ones are handed over untouched
@@ -663,12 +685,14 @@ __global__ void __launch_bounds__(256) k_fixup_seg(uint32_t nbuckets, const void
         long_list[slot] = LongChain{k, t};
         return;
     }
+    A::fresh(acc);
     for (uint32_t u = t + 1; u < threads_per_win; ++u) {
         if (u != t + 1) {
             f = pflags[base + u];
-            if (f & SegFlags::HAS_P0) q = A::load_fresh(partials, (base + u) * 2 + 0);
+            if (f & SegFlags::HAS_P0) q = A::load(partials, (base + u) * 2 + 0);
         }
         if (!(f & SegFlags::HAS_P0)) break;
+        A::fresh(q);
         A::add(acc, q);
         if (!(f & SegFlags::P0_OPEN_RIGHT)) break;
     }
