@@ -378,12 +378,12 @@ __global__ void __launch_bounds__(1024) k_part_scatter(const D *__restrict__ dig
             spid[slot] = (uint16_t)pid[j];
         }
     }
+    // lbase[p] becomes the displacement of partition p: staging slot -> address in `parted` (the placement above does not
+    // read lbase), so that the write-out below looks nothing up in global memory - it had two dependent loads per entry
+    for (uint32_t p = t; p < nparts; p += T) lbase[p] = pbase[p] + goff[p] - lbase[p];
     __syncthreads();
     uint32_t *out = parted + (size_t)k * n;
-    for (uint32_t slot = t; slot < total; slot += T) {
-        const uint32_t p = spid[slot];
-        out[pbase[p] + goff[p] + (slot - lbase[p])] = stage[slot];
-    }
+    for (uint32_t slot = t; slot < total; slot += T) out[lbase[spid[slot]] + slot] = stage[slot];
 }
 
 // grid = (nparts, nwin), block = 1024. Counting sort of one partition by fine bucket; also emits starts[] of its buckets.
@@ -817,11 +817,21 @@ __global__ void __launch_bounds__(256, 1) k_reduce_serial(const void *__restrict
     const uint32_t L = 1u << log2L, lo = g * L;
     const uint32_t *st = starts ? starts + (size_t)k * (nbuckets + 1) : nullptr;  // null: every record is stored
     E run = A::infinity(), tot = A::infinity();
+    // The bucket of the NEXT step is requested before the two additions of this one (the kernel runs one wave per SIMD, so
+    // nothing else would hide the round trip of a load issued where its value is needed). Measured: no difference at
+    // 2^16..2^20 (profiles/r04_reduce_prefetch.log) - the L round trips per thread are not what the 0.12 ms are made of.
+    auto present = [&](uint32_t b) { return b < nbuckets && (st == nullptr || st[b + 1] > st[b]); };  // empty buckets were never written
+    bool have_next = present(lo + L - 1);
+    E next = A::infinity();
+    if (have_next) next = A::load(buckets, (size_t)k * nbuckets + lo + L - 1);
 #pragma nounroll
     for (uint32_t j = L; j-- > 0;) {
-        const uint32_t b = lo + j;
-        if (b < nbuckets && (st == nullptr || st[b + 1] > st[b])) {  // empty buckets were never written
-            const E B = A::load_fresh(buckets, (size_t)k * nbuckets + b);
+        const bool have = have_next;
+        E B = next;
+        have_next = j > 0 && present(lo + j - 1);
+        if (have_next) next = A::load(buckets, (size_t)k * nbuckets + lo + j - 1);
+        if (have) {
+            A::fresh(B);  // a record the accumulation wrote
             A::add(run, B);
         }
         A::add(tot, run);
