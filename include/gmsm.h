@@ -148,9 +148,11 @@ int gmsm_get_devices(int *out_devices, int max_devices);
  *      d_points / d_scalars are device pointers with the layouts above; hip_stream is the hipStream_t the inputs were
  *      produced on (NULL = default stream): the engine runs on a private stream ordered after the work queued there;
  *      the call returns after the result has been copied back to out_jac (host memory).
- *      Concurrency (all blocking entries): any number of threads may call at once; per device two calls are in flight
- *      at a time on two workspaces/streams - the sort and accumulation of one overlap the latency-bound reduction,
- *      copy-back and host fold of the other - further callers wait their turn. ---- */
+ *      Concurrency (all blocking entries): any number of threads may call at once; per device up to three calls are in
+ *      flight at a time, each on its own workspace and streams - the sort and accumulation of one overlap the
+ *      latency-bound reduction, copy-back and host fold of another - and further callers wait their turn. At most two of
+ *      the three workspaces are ever held by uncollected tickets (gmsm_multiexp_submit), so a blocking call never waits
+ *      for somebody else's gmsm_multiexp_collect. ---- */
 int gmsm_multiexp_device(int group, const void *d_points, const void *d_scalars, size_t n, void *hip_stream,
                          uint64_t *out_jac);
 
