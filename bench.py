@@ -283,6 +283,144 @@ def also_config(gm, lib, torch, curve, group, logn, steps, host_legs, with_cpu=T
     return out
 
 
+# The reference's own benchmark matrix (BenchmarkMultiExpG1, ecc/bn254/multiexp_test.go:301-364) times every size under three
+# scalar distributions; provers add vectors full of 0 / 1 / repeated values. Stored (Montgomery) limbs, as the reference builds them.
+DISTRIBUTIONS = ["uniform", "smallvalues", "redundancy", "value_one", "all_equal"]
+
+
+def skewed_scalars(kind, base, g, rng):
+    """The scalar vector of one distribution, derived from the uniform vector `base` (n, fr_limbs):
+      smallvalues  every 5th scalar SetZero(); [0] = 1 (multiexp_test.go:319-325): the STORED limbs are 1, i.e. the value
+                   R^-1 mod r - the same full-width scalar n/5 times, one crowded bucket in EVERY window
+      redundancy   runs of 100 equal scalars (:327-334)
+      value_one    30 % of the scalars are the field element 1 (Montgomery R mod r): one crowded bucket in window 0 only
+      all_equal    every scalar the same"""
+    n = base.shape[0]
+    sc = base.copy()
+    if kind == "smallvalues":
+        sc[::5] = 0
+        sc[::5, 0] = 1
+    elif kind == "redundancy":
+        sc = np.ascontiguousarray(np.repeat(base[: (n + 99) // 100], 100, axis=0)[:n])
+    elif kind == "value_one":
+        one = (1 << (64 * g.fr_limbs)) % g.curve.r
+        sc[rng.random(n) < 0.3] = np.array([(one >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(g.fr_limbs)], dtype=np.uint64)
+    elif kind == "all_equal":
+        sc = np.ascontiguousarray(np.tile(base[:1], (n, 1)))
+    elif kind != "uniform":
+        raise ValueError(kind)
+    return sc
+
+
+def distributions_block(gm, lib, torch, configs=(("bn254", "g1", 20, 10), ("bn254", "g1", 24, 3)), kinds=None, cold=True):
+    """MultiExp under the reference's benchmark distributions: per (group, size) one row per distribution with the resident
+    ms (K timed calls), its ratio to the uniform row, the stage breakdown, the cold host-entry ms and a closed-form
+    bit_exact (bases [a_i]G built on the device, expected [sum a_i b_i]G from the oracle - valid for any b)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle  # test infrastructure: here only the checker
+    rows = []
+    for curve, group, logn, steps in configs:
+        g = (gm.G1Jac if group == "g1" else gm.G2Jac)(curve)
+        n = 1 << logn
+        rng = np.random.default_rng([0x646973, logn, len(curve), 1 if group == "g2" else 0])
+        a = uniform_scalars(rng, g, n)
+        base = uniform_scalars(rng, g, n)
+        d_a = torch.from_numpy(a.view(np.int64)).cuda()
+        d_pts = torch.empty((n, g.aff_limbs), dtype=torch.int64, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        g.batch_scalar_mul_device(g.generator, d_a.data_ptr(), n, d_pts.data_ptr(), stream)
+        del d_a
+        pts_host = d_pts.cpu().numpy().view(np.uint64) if cold else None
+        o = oracle.Oracle(curve, group)
+        uniform_ms = None
+        for kind in (kinds or DISTRIBUTIONS):
+            b = skewed_scalars(kind, base, g, rng)
+            d_b = torch.from_numpy(b.view(np.int64)).cuda()
+            jac = g.multiexp_device(d_pts.data_ptr(), d_b.data_ptr(), n, stream)  # warm-up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                jac = g.multiexp_device(d_pts.data_ptr(), d_b.data_ptr(), n, stream)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            prof = StageProfile(lib)
+            prof.start()
+            for _ in range(max(2, steps // 2)):
+                g.multiexp_device(d_pts.data_ptr(), d_b.data_ptr(), n, stream)
+            torch.cuda.synchronize()
+            stages, _ = prof.stop()
+            if kind == "uniform":
+                uniform_ms = ms
+            row = {"group": f"{curve}_{group}", "logn": logn, "distribution": kind, "ms": round(ms, 4),
+                   "vs_uniform": round(ms / uniform_ms, 3) if uniform_ms else None,
+                   "stage_ms": {k: round(v, 4) for k, v in stages.items() if k != "reserved"}}
+            if cold:
+                cfg = gm.MultiExpConfig()
+                row["cold_ms"] = round(median_ms(lambda: g.MultiExp(pts_host, b, cfg), reps=3), 3)
+            row["bit_exact"] = bool((g.jac_to_affine(jac) == o.fixed_base_msm_affine(a, b)).all())
+            rows.append(row)
+            del d_b
+        del d_pts, pts_host
+        torch.cuda.empty_cache()
+    return {"rows": rows, "worst_vs_uniform": max((r["vs_uniform"] or 0.0) for r in rows),
+            "all_bit_exact": all(r["bit_exact"] for r in rows),
+            "note": "the reference's BenchmarkMultiExpG1 distributions (multiexp_test.go:301-364) + value_one / all_equal; "
+                    "ms = resident inputs, cold_ms = host buffers through the drop-in entry (median of 3); bit_exact = closed form"}
+
+
+def small_n_block(gm, torch, curve="bn254", group="g1", logns=(5, 6, 8, 10, 12, 14, 16), reps=30, with_cpu=True):
+    """Sizes below 2^20 (the reference benches from 2^5, multiexp_test.go:344; Pedersen commits with NbTasks: 1,
+    fr/pedersen/pedersen.go:100-131): per size the resident ms, the cold drop-in entry (host buffers in, Jacobian out), and
+    the CPU port with one thread (NbTasks 1) and with all cores - the measured GPU/CPU crossover the Go stub routes by."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle  # test infrastructure: the reported CPU legs and the checker
+    g = (gm.G1Jac if group == "g1" else gm.G2Jac)(curve)
+    o = oracle.Oracle(curve, group)
+    nmax = 1 << max(logns)
+    rng = np.random.default_rng([0x736D6C, len(curve), 1 if group == "g2" else 0])
+    pts = g.generate_points(nmax, int(rng.integers(1, 2**62)), int(rng.integers(1, 2**62)))
+    sc = uniform_scalars(rng, g, nmax)
+    d_pts = torch.from_numpy(pts.view(np.int64)).cuda()
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    cfg = gm.MultiExpConfig()
+    cores = effective_cpus()
+    rows = []
+    for logn in logns:
+        n = 1 << logn
+        jac = g.multiexp_device(d_pts.data_ptr(), d_sc.data_ptr(), n, stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            jac = g.multiexp_device(d_pts.data_ptr(), d_sc.data_ptr(), n, stream)
+        torch.cuda.synchronize()
+        res_ms = (time.perf_counter() - t0) / reps * 1e3
+        p_, s_ = np.ascontiguousarray(pts[:n]), np.ascontiguousarray(sc[:n])
+        cold_ms = median_ms(lambda: g.MultiExp(p_, s_, cfg), reps=9)
+        jc, _ = g.MultiExp(p_, s_, cfg)
+        row = {"logn": logn, "resident_ms": round(res_ms, 4), "cold_ms": round(cold_ms, 4)}
+        expected = o.msm_affine(p_, s_, nthreads=2 * cores)
+        row["bit_exact"] = bool((g.jac_to_affine(jac) == expected).all() and (g.jac_to_affine(jc) == expected).all())
+        if with_cpu:
+            def cpu_ms(nb_tasks, threads):
+                k, t_tot = 0, 0.0
+                while k < 3 or (t_tot < 0.2 and k < 200):
+                    t1 = time.perf_counter()
+                    o.multiexp(p_, s_, nb_tasks=nb_tasks, num_cpu=cores if nb_tasks == 0 else 1, nthreads=threads)
+                    t_tot += time.perf_counter() - t1
+                    k += 1
+                return t_tot / k * 1e3
+            row["cpu_port_1thread_ms"] = round(cpu_ms(1, 1), 4)
+            row["cpu_port_allcores_ms"] = round(cpu_ms(0, min(2 * cores, len(os.sched_getaffinity(0)))), 4)
+            row["gpu_cold_over_cpu_allcores"] = round(cold_ms / row["cpu_port_allcores_ms"], 3)
+        rows.append(row)
+    cross = next((r["logn"] for r in rows if with_cpu and r["cold_ms"] < min(r["cpu_port_1thread_ms"], r["cpu_port_allcores_ms"])), None)
+    return {"group": f"{curve}_{group}", "rows": rows, "cpu_cores": cores, "cpu_kind": "port",
+            "crossover_logn_cold_vs_cpu_port": cross,
+            "note": "resident: bases+scalars in HBM; cold: gmsm_<curve>_<group>_multiexp with host buffers (median of 9); CPU: the "
+                    "oracle's restatement of the reference's MultiExp with NbTasks 1 / all cores on this box"}
+
+
 def host_side_wait(dist, rank, key, work):
     """Rank 0 runs work() while the other ranks wait on the HOST (a key in the rendezvous store): an RCCL barrier would
     keep their GPUs spinning in a collective kernel, and rank 0 is about to use those GPUs from its own process."""

@@ -147,6 +147,8 @@ struct Workspace {
     DeviceBuffer seg_lvl;        // hierarchical chain fixup: level partials, flags, long-chain flags
     DeviceBuffer seg_partials, seg_flags, seg_bucket;  // split-bucket partial sums of the segmented accumulation
     DeviceBuffer parted;         // coarse-partitioned references (two-level grouping)
+    DeviceBuffer heavy;          // oversized partitions of the fine sort: their list, the count per window, sub-run bucket counts
+    DeviceBuffer long_pieces;    // long chains of the fix-up: per-chain piece counters, the pieces' sums
     DeviceBuffer digits, sorted, blockhist, counts, starts, buckets, partials, totals;
     DeviceBuffer red_pre;        // per-thread (S, W) of the bucket reduction (k_reduce_serial -> k_combine_q)
     DeviceBuffer carry;          // running bucket sums of a multi-range host call (k_merge_buckets)
@@ -178,7 +180,7 @@ struct Workspace {
     // gmsm_trim / gmsm_shutdown: give back every scratch buffer larger than `keep` bytes (the caller holds the lease and
     // has synchronised the workspace's streams). Returns the device bytes released.
     size_t trim(size_t keep) {
-        DeviceBuffer *all[] = {&upoints, &skip, &seg_lvl, &seg_partials, &seg_flags, &seg_bucket, &parted, &digits, &sorted,
+        DeviceBuffer *all[] = {&upoints, &skip, &seg_lvl, &seg_partials, &seg_flags, &seg_bucket, &parted, &heavy, &long_pieces, &digits, &sorted,
                                &blockhist, &counts, &starts, &buckets, &partials, &totals, &red_pre, &carry, &h2d_points,
                                &h2d_scalars, &raw_bytes, &flagword};
         size_t freed = 0;

@@ -6,7 +6,7 @@
 //
 // Same contract as k_fixup_seg: the quad of accumulation thread t closes the chain  P1[t], P0[t+1], ..., P0[t+m]  of the
 // bucket that thread t left open to the right, when it has at most `maxwalk` followers; longer chains go to the list that
-// k_fixup_long consumes. Every record a quad touches is its own (acc[j], stage[j]): no workgroup barriers, only the
+// k_fixup_long consumes (as pieces, long_chain_append). Every record a quad touches is its own (acc[j], stage[j]): no workgroup barriers, only the
 // ordering of a wave's own LDS accesses.
 // grid = (ceil(threads_per_win / 64), nwin), block = 256, dynamic LDS = 128 * sizeof(QRec<U>).
 #pragma once
@@ -19,7 +19,8 @@ __global__ void __launch_bounds__(256) k_fixup_seg_q(uint32_t nbuckets, const vo
                                                      const uint32_t *__restrict__ pflags, const uint32_t *__restrict__ pbucket,
                                                      uint32_t threads_per_win, void *__restrict__ buckets,
                                                      uint32_t *__restrict__ long_count, LongChain *__restrict__ long_list,
-                                                     uint32_t maxwalk) {
+                                                     uint32_t *__restrict__ piece_done, uint32_t maxwalk,
+                                                     const uint32_t *__restrict__ starts, uint32_t seg) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     QRec<U> *acc = reinterpret_cast<QRec<U> *>(lds_raw), *stage = acc + 64;
     const uint32_t tid = threadIdx.x, j = tid >> 2, lane = tid & 63u, k = blockIdx.y;
@@ -27,28 +28,14 @@ __global__ void __launch_bounds__(256) k_fixup_seg_q(uint32_t nbuckets, const vo
     const size_t base = (size_t)k * threads_per_win;
     const uint32_t f0 = t < threads_per_win ? pflags[base + t] : 0u;
     bool head = (f0 & SegFlags::HAS_P1) != 0;
-    // followers of the chain, from the flags alone (the four lanes of a quad read the same words: uniform in the quad)
-    uint32_t len = 0;
+    // followers of the chain, from starts[] (the four lanes of a quad read the same words: uniform in the quad): the
+    // bucket's entries end in accumulation thread (hi - 1) / seg
+    uint32_t len = 0, dest = 0;
     if (head) {
-        bool closed = false;
-        for (uint32_t u = t + 1; u < threads_per_win && u <= t + maxwalk; ++u) {
-            const uint32_t fu = pflags[base + u];
-            if (!(fu & SegFlags::HAS_P0)) {
-                closed = true;
-                break;
-            }
-            ++len;
-            if (!(fu & SegFlags::P0_OPEN_RIGHT)) {
-                closed = true;
-                break;
-            }
-        }
-        if (!closed && t + maxwalk + 1 >= threads_per_win) closed = true;  // runs off the end of the window: short
-        if (!closed) {  // a long chain: handed over untouched
-            if ((tid & 3u) == 0) {
-                const uint32_t slot = atomicAdd(long_count, 1u);
-                long_list[slot] = LongChain{k, t};
-            }
+        dest = pbucket[base + t];
+        len = (starts[(size_t)k * (nbuckets + 1) + dest + 1] - 1u) / seg - t;
+        if (len > maxwalk) {  // a long chain: handed over untouched
+            if ((tid & 3u) == 0) long_chain_append(long_count, long_list, piece_done, k, t, len + 1u);
             head = false;
         }
     }
@@ -64,7 +51,7 @@ __global__ void __launch_bounds__(256) k_fixup_seg_q(uint32_t nbuckets, const vo
         quad_add_store<U, true>(&acc[j], o, act, lane);
         quad_lds_fence();
     }
-    if (head) quad_rec_store<U>(buckets, (size_t)k * nbuckets + pbucket[base + t], &acc[j], lane);
+    if (head) quad_rec_store<U>(buckets, (size_t)k * nbuckets + dest, &acc[j], lane);
 }
 
 }  // namespace gmsm

@@ -404,12 +404,28 @@ struct Group {
         if ((rc = ws.seg_partials.ensure(tot_thr * 2 * REC))) return rc;
         if ((rc = ws.seg_flags.ensure(tot_thr * 4))) return rc;
         if ((rc = ws.seg_bucket.ensure(tot_thr * 4))) return rc;
-        // long-chain list of the fixup (k_fixup_seg appends, k_fixup_long consumes): one counter (slot of the first window;
-        // k_part_rowscan zeroes it) + at most one entry per FIXUP_MAXWALK threads
-        const size_t list_cap = tot_thr / FIX_MAXWALK + nw + 1;
+        // long-chain list of the fixup (the fix-up kernels append pieces of LONG_PIECE links, k_fixup_long consumes): one counter
+        // (slot of the first window; k_part_rowscan zeroes it) + the items: chains have more than FIX_MAXWALK followers
+        const size_t list_cap = tot_thr / FIX_MAXWALK + tot_thr / LONG_PIECE + nw + 16;
         if ((rc = ws.seg_lvl.ensure((size_t)nw * 4 + 16 + list_cap * sizeof(LongChain)))) return rc;
         uint32_t *long_flag = (uint32_t *)ws.seg_lvl.ptr;                                  // [nw] counters, [0] is used
         LongChain *long_list = (LongChain *)((char *)ws.seg_lvl.ptr + (((size_t)nw * 4 + 15) / 16) * 16);
+        const size_t piece_sums_off = ((list_cap * 4 + 15) / 16) * 16;
+        if ((rc = ws.long_pieces.ensure(piece_sums_off + list_cap * REC))) return rc;
+        uint32_t *piece_done = (uint32_t *)ws.long_pieces.ptr;
+        void *piece_sums = (char *)ws.long_pieces.ptr + piece_sums_off;
+        // oversized partitions of the fine sort (k_part_rowscan lists them, k_heavy_* sort them): a window has at most
+        // n / (stage_cap + 1) of them, and their sub-runs of HEAVY_SUB references number at most n / HEAVY_SUB + that
+        const uint32_t hcap = (uint32_t)std::min<size_t>(nparts, n / ((size_t)stage_cap + 1) + 1);
+        const uint32_t scap = (uint32_t)(n / HEAVY_SUB) + hcap;
+        const size_t hparts_bytes = (((size_t)nw * hcap * sizeof(HeavyPart) + 15) / 16) * 16, hcount_bytes = (((size_t)nw * 8 + 15) / 16) * 16;
+        if ((rc = ws.heavy.ensure(hparts_bytes + hcount_bytes + ((size_t)nw * scap << fbits) * 4))) return rc;
+        HeavyPart *hparts = (HeavyPart *)ws.heavy.ptr;
+        uint32_t *hcount = (uint32_t *)((char *)ws.heavy.ptr + hparts_bytes);
+        uint32_t *subhist = (uint32_t *)((char *)ws.heavy.ptr + hparts_bytes + hcount_bytes);
+        if (nw > HEAVY_MAX_WINDOWS) return fail(GMSM_ERR_ARG, "more than 256 windows in one pipeline run");
+        // workgroups of the heavy kernels (the sub-runs of all windows are taken round-robin): the chip twice over
+        const uint32_t heavy_wg = (uint32_t)std::min<size_t>((size_t)2 * ctx.num_cus, std::max<size_t>((size_t)nw * scap, 1));
         uint32_t *bh = (uint32_t *)ws.blockhist.ptr, *part_base = (uint32_t *)ws.counts.ptr;
         uint32_t *part_pop = part_base + (size_t)nw * (nparts + 1);
 
@@ -420,6 +436,9 @@ struct Group {
         if ((rc = ctx.allow_lds((const void *)k_part_scatter<uint16_t, PART_CHUNK_BIG>, 152 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_part_scatter<uint32_t, PART_CHUNK_BIG>, 152 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_fine_sort, 160 * 1024))) return rc;
+        if ((rc = ctx.allow_lds((const void *)k_heavy_hist, 128 * 1024))) return rc;
+        if ((rc = ctx.allow_lds((const void *)k_heavy_scan, 128 * 1024))) return rc;
+        if ((rc = ctx.allow_lds((const void *)k_heavy_place, 128 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_fixup_long<U>, (int)(128 * sizeof(QRec<U>))))) return rc;
         if constexpr (FIXUP_QUAD)
             if ((rc = ctx.allow_lds((const void *)k_fixup_seg_q<U>, (int)(128 * sizeof(QRec<U>))))) return rc;
@@ -486,7 +505,8 @@ struct Group {
             hipLaunchKernelGGL(k_part_colscan<32>, dim3((nparts + 31) / 32, nw), dim3(1024), 0, stream, bh, pchunks, nparts, part_pop);
         else
             hipLaunchKernelGGL(k_part_colscan<8>, dim3((nparts + 31) / 32, nw), dim3(256), 0, stream, bh, pchunks, nparts, part_pop);
-        hipLaunchKernelGGL(k_part_rowscan, dim3(nw), dim3(1024), 0, stream, part_pop, nparts, part_base, long_flag);
+        hipLaunchKernelGGL(k_part_rowscan, dim3(nw), dim3(1024), 0, stream, part_pop, nparts, part_base, long_flag, stage_cap, hparts,
+                           hcount, hcap);
         timer.mark(T_SCATTER, stream);
         {
             const dim3 grid(pchunks, nw), block(1024);
@@ -501,6 +521,13 @@ struct Group {
         }
         hipLaunchKernelGGL(k_fine_sort, dim3(nparts, nw), dim3(1024), ((size_t)4 << fbits) + (size_t)stage_cap * 4, stream,
                            parted, n, NB, fbits, lidx, part_base, sorted, starts, stage_cap);
+        // partitions beyond the staging slots (crowded buckets, narrow top windows): sorted by many workgroups each
+        hipLaunchKernelGGL(k_heavy_hist, dim3(heavy_wg), dim3(1024), (size_t)4 << fbits, stream, parted, n, nw, nparts, fbits, lidx,
+                           part_base, (const HeavyPart *)hparts, (const uint32_t *)hcount, hcap, scap, subhist);
+        hipLaunchKernelGGL(k_heavy_scan, dim3(std::min<uint32_t>(hcap, 64u), nw), dim3(1024), (size_t)4 << fbits, stream, nparts, NB, fbits,
+                           part_base, (const HeavyPart *)hparts, (const uint32_t *)hcount, hcap, scap, subhist, starts);
+        hipLaunchKernelGGL(k_heavy_place, dim3(heavy_wg), dim3(1024), (size_t)4 << fbits, stream, parted, n, nw, nparts, fbits, lidx,
+                           part_base, (const HeavyPart *)hparts, (const uint32_t *)hcount, hcap, scap, (const uint32_t *)subhist, sorted);
         // ---- 2. bucket accumulation
         if (forked) HIP_TRY(hipStreamWaitEvent(stream, ws.ev_conv, 0));  // the rewritten bases are complete
         timer.mark(T_ACCUMULATE, stream);
@@ -515,17 +542,18 @@ struct Group {
         if (shared && n / NB >= 2 * (size_t)q.seg)  // buckets of several threads' worth of entries (dense chains): one thread per bucket
             hipLaunchKernelGGL((k_fixup_bucket<OpsSerial>), dim3((NB + 255) / 256, nw), dim3(256), 0, stream, NB,
                                (const uint32_t *)starts, q.seg, (const void *)seg_partials, q.tpw, (void *)buckets, long_flag, long_list,
-                               FIX_MAXWALK);
+                               piece_done, FIX_MAXWALK);
         else if constexpr (FIXUP_QUAD)
             hipLaunchKernelGGL((k_fixup_seg_q<U>), dim3((q.tpw + 63) / 64, nw), dim3(256), 128 * sizeof(QRec<U>), stream, NB,
                                (const void *)seg_partials, (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw,
-                               (void *)buckets, long_flag, long_list, FIX_MAXWALK);
+                               (void *)buckets, long_flag, long_list, piece_done, FIX_MAXWALK, (const uint32_t *)starts, q.seg);
         else
             hipLaunchKernelGGL((k_fixup_seg<OpsSerial>), dim3((q.tpw + 255) / 256, nw), dim3(256), 0, stream, NB, seg_partials,
-                               (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets, long_flag, long_list, FIX_MAXWALK);
+                               (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets, long_flag, long_list, piece_done,
+                               FIX_MAXWALK, (const uint32_t *)starts, q.seg);
         hipLaunchKernelGGL((k_fixup_long<U>), dim3(2 * ctx.num_cus), dim3(256), 128 * sizeof(QRec<U>), stream, NB, seg_partials,
-                           (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets,
-                           (const uint32_t *)long_flag, (const LongChain *)long_list);
+                           (const uint32_t *)seg_bucket, q.tpw, buckets, (const uint32_t *)long_flag, (const LongChain *)long_list,
+                           piece_done, piece_sums, (const uint32_t *)starts, q.seg);
         // ---- 3. bucket reduction -> window totals (empty buckets are never written: the reduction consults starts[])
         timer.mark(T_REDUCE, stream);
         if (!buckets_only) {

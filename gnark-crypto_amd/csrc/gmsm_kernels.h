@@ -157,6 +157,51 @@ __global__ void __launch_bounds__(256) k_decompose_c(const uint32_t *__restrict_
 
 __device__ __forceinline__ uint32_t code_bucket(uint32_t code) { return (code >> 1) - ((code & 1u) ^ 1u); }
 
+// LDS counters under repeated keys. The counting sorts below keep one counter per partition / bucket in LDS and bump it
+// once per entry; lanes of a wave that hit the SAME counter are serialised by the LDS. Uniform scalars hardly do that, the
+// reference's own benchmark distributions do (multiexp_test.go:319-334): runs of 100 equal scalars put the same key in 12-25
+// adjacent lanes, a scalar repeated n/5 times makes one bucket hold 96 % of its partition, equal scalars all of it. Measured
+// (tools/ubench_ldsagg.hip, profiles/r05_ldsagg.log; ns per wave-level update and CU): uniform keys 4.2, runs of 25 lanes 36,
+// 96 % one key 52. What helps is aggregating RUNS of equal keys in adjacent lanes - which is how such entries arrive, the
+// passes keep index order -: heads = lanes whose key differs from the lane before (row_shr:1, so a 16-lane row always starts
+// a run); the head adds the run's length, the other lanes take base + rank through one ds_bpermute: 14 / 15 ns for the two
+// patterns above. (Peeling the first lane's key with readlane + ballot rounds, the first form tried, costs more than the
+// conflicts it removes for runs of 25 and 60 % extra on uniform keys.) It is not free on uniform keys either (5.6 ns), so
+// the callers decide per BATCH of entries from one sample (wave_runny) and use plain atomics otherwise.
+constexpr uint32_t AGG_MAX_HEADS = 16;  // a sample with at most this many runs per wave (average run >= 4 lanes) aggregates
+__device__ __forceinline__ uint64_t run_heads(uint32_t key, bool active) {
+    const uint32_t keyx = active ? key : 0xFFFFFFFFu;  // lanes without an entry form runs of their own
+    const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)~keyx, (int)keyx, 0x111, 0xf, 0xf, false);
+    return __ballot(prev != keyx);
+}
+__device__ __forceinline__ bool wave_runny(uint32_t key, bool active) {
+    return (uint32_t)__popcll((unsigned long long)run_heads(key, active)) <= AGG_MAX_HEADS;
+}
+// RET: returns the lane's slot (the counter's value before its own increment)
+template <bool RET>
+__device__ __forceinline__ uint32_t lds_count_runs(uint32_t *cnt, uint32_t key, bool active) {
+    const uint64_t H = run_heads(key, active);
+    const uint32_t lane = __lane_id();
+    const uint64_t le = ~0ull >> (63u - lane);  // lanes <= this one
+    const uint32_t head = 63u - (uint32_t)__clzll((long long)(H & le));
+    const uint64_t above = (H | ~__ballot(true)) & ~le;  // a run ends at the next head or at the first lane that is not executing
+    const uint32_t next = above ? (uint32_t)__ffsll((long long)above) - 1u : 64u;
+    uint32_t base = 0;
+    if (lane == head && active) {
+        const uint32_t r = atomicAdd(&cnt[key], next - head);
+        if constexpr (RET) base = r;
+    }
+    if constexpr (RET) return (uint32_t)__shfl((int)base, (int)head, 64) + (lane - head);
+    return 0u;
+}
+template <bool RET>
+__device__ __forceinline__ uint32_t lds_count(uint32_t *cnt, uint32_t key, bool active, bool runny /* wave-uniform */) {
+    if (runny) return lds_count_runs<RET>(cnt, key, active);
+    uint32_t r = 0;
+    if (active) r = atomicAdd(&cnt[key], 1u);
+    return RET ? r : 0u;
+}
+
 // ------------------------------------------------------------------ two-level grouping (coarse partition, fine sort)
 // A single-pass counting sort would write every 4-byte reference to an effectively random address of the window's
 // sorted array: rocprofv3 showed 32 B of HBM write per 4-byte store (r01f: 8.5 GB for 268 M references at 2^24).
@@ -213,28 +258,28 @@ __global__ void __launch_bounds__(1024) k_part_hist(const D *__restrict__ digits
     // the latency of its loads, not at the rate of HBM or of the LDS atomics (2^24: 0.335 ms for 1 GB, the same with half
     // the bytes - profiles/r04_dig17_ab.log). The order of the codes does not matter to a histogram.
     constexpr size_t PERV = 16 / sizeof(D);
-    auto count = [&](uint32_t code) {
-        if (code) atomicAdd(&lds_cnt[code_bucket(code) >> fbits], 1u);
-    };
+    auto count = [&](uint32_t code, bool runny) { lds_count<false>(lds_cnt, code_bucket(code) >> fbits, code != 0u, runny); };
     size_t a0 = lo + ((16u - (uint32_t)(reinterpret_cast<uintptr_t>(d + lo) & 15u)) & 15u) / sizeof(D);  // first aligned code
     if (a0 > hi) a0 = hi;
     const size_t nvec = (hi - a0) / PERV, a1 = a0 + nvec * PERV;
-    for (size_t i = lo + threadIdx.x; i < a0; i += blockDim.x) count(d[i]);
+    for (size_t i = lo + threadIdx.x; i < a0; i += blockDim.x) count(d[i], false);
     const uint4 *dv = reinterpret_cast<const uint4 *>(d + a0);
     for (size_t v = threadIdx.x; v < nvec; v += blockDim.x) {
         const uint4 q = dv[v];
         const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        const uint32_t c0 = sizeof(D) == 4 ? w[0] : (w[0] & 0xffffu);
+        const bool runny = wave_runny(code_bucket(c0) >> fbits, c0 != 0u);  // lanes hold consecutive groups of codes
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if constexpr (sizeof(D) == 4) {
-                count(w[j]);
+                count(w[j], runny);
             } else {
-                count(w[j] & 0xffffu);
-                count(w[j] >> 16);
+                count(w[j] & 0xffffu, runny);
+                count(w[j] >> 16, runny);
             }
         }
     }
-    for (size_t i = a1 + threadIdx.x; i < hi; i += blockDim.x) count(d[i]);
+    for (size_t i = a1 + threadIdx.x; i < hi; i += blockDim.x) count(d[i], false);
     __syncthreads();
     uint32_t *out = blockhist + ((size_t)k * nchunks + chunk) * nparts;
     for (uint32_t p = threadIdx.x; p < nparts; p += blockDim.x) out[p] = lds_cnt[p];
@@ -272,13 +317,37 @@ __global__ void __launch_bounds__(32 * SEGS) k_part_colscan(uint32_t *__restrict
     if (s == SEGS - 1u) part_pop[(size_t)k * nparts + p] = run;
 }
 
-// grid = nwin, block = 1024: exclusive scan of the partition populations -> part_base[k][0..nparts]
+// Oversized partitions. A coarse partition normally holds ~2^13..2^15 references and one k_fine_sort workgroup sorts it
+// inside LDS. A partition that exceeds the staging slots (stage_cap) is "oversized": a bucket that very many scalars
+// share (a repeated scalar value fills the same bucket of every window, the value 1 fills bucket 0 of window 0, all
+// scalars equal fill one bucket per window with all n references) or a narrow top window (BW6-761: 2^8 buckets of
+// n / 2^8 references). Rounds 1-4 sorted such a partition with ONE workgroup, same-address LDS atomics and scattered
+// 4-byte stores: 6.1 ms per launch at 2^24 under the reference's "smallvalues" distribution, 29 ms with all scalars equal
+// (profiles/r05_distributions_before.log). Now k_part_rowscan lists them, and three kernels sort each one with as many
+// workgroups as it has sub-runs of HEAVY_SUB references: k_heavy_hist (per-sub-run bucket counts) -> k_heavy_scan
+// (bucket starts + per-sub-run write cursors) -> k_heavy_place (placement; the references of a crowded bucket get
+// consecutive slots from one ballot, so their stores coalesce). With no oversized partition the three launches exit on
+// their first load.
+struct HeavyPart {
+    uint32_t p, first, nsub, pad;  // partition, first row of its sub-run counts in the window's table, sub-runs
+};
+constexpr uint32_t HEAVY_SUB = 8192;
+
+// grid = nwin, block = 1024: exclusive scan of the partition populations -> part_base[k][0..nparts]; lists the window's
+// oversized partitions in hparts[k][0..hcount[2k]), hcount[2k + 1] = their sub-runs (hparts == nullptr: none wanted)
 static __global__ void __launch_bounds__(1024) k_part_rowscan(const uint32_t *__restrict__ part_pop, uint32_t nparts,
                                                               uint32_t *__restrict__ part_base,
-                                                              uint32_t *__restrict__ clear_flag /* [nwin], may be null */) {
+                                                              uint32_t *__restrict__ clear_flag /* [nwin], may be null */,
+                                                              uint32_t stage_cap, HeavyPart *__restrict__ hparts,
+                                                              uint32_t *__restrict__ hcount, uint32_t hcap) {
     __shared__ uint32_t sums[1024];
+    __shared__ uint32_t s_np, s_first;
     const uint32_t k = blockIdx.x, t = threadIdx.x, T = blockDim.x;
-    if (clear_flag != nullptr && t == 0) clear_flag[k] = 0;  // the window's long-chain flag (k_fixup_seg raises it)
+    if (clear_flag != nullptr && t == 0) clear_flag[k] = 0;  // the window's long-chain counter (the fix-up kernels raise it)
+    if (t == 0) {
+        s_np = 0;
+        s_first = 0;
+    }
     const uint32_t *pp = part_pop + (size_t)k * nparts;
     uint32_t *pb = part_base + (size_t)k * (nparts + 1);
     const uint32_t per = (nparts + T - 1) / T;
@@ -295,10 +364,24 @@ static __global__ void __launch_bounds__(1024) k_part_rowscan(const uint32_t *__
     }
     uint32_t run = sums[t] - mine;
     for (uint32_t p = plo; p < phi; ++p) {
+        const uint32_t pop = pp[p];
         pb[p] = run;
-        run += pp[p];
+        run += pop;
+        if (hparts != nullptr && pop > stage_cap) {
+            const uint32_t nsub = (pop + HEAVY_SUB - 1) / HEAVY_SUB;
+            const uint32_t j = atomicAdd(&s_np, 1u);
+            const uint32_t first = atomicAdd(&s_first, nsub);
+            if (j < hcap) hparts[(size_t)k * hcap + j] = HeavyPart{p, first, nsub, 0u};
+        }
     }
     if (t == T - 1) pb[nparts] = sums[T - 1];
+    if (hparts != nullptr) {
+        __syncthreads();
+        if (t == 0) {
+            hcount[2 * k] = s_np < hcap ? s_np : hcap;
+            hcount[2 * k + 1] = s_first;  // sub-runs = rows of the window's table
+        }
+    }
 }
 
 // grid = (nchunks, nwin), block = 1024, chunk_len <= CHUNK. The chunk is first sorted by partition inside LDS
@@ -370,10 +453,12 @@ __global__ void __launch_bounds__(1024) k_part_scatter(const D *__restrict__ dig
     }
     __syncthreads();
     const uint32_t total = scan_tmp[0];
+    const bool runny = wave_runny(pid[0], pid[0] != 0xFFFFFFFFu);  // one sample decides for the thread's PER entries
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-        if (pid[j] != 0xFFFFFFFFu) {
-            const uint32_t slot = atomicAdd(&cnt[pid[j]], 1u);
+        const bool act = pid[j] != 0xFFFFFFFFu;
+        const uint32_t slot = lds_count<true>(cnt, pid[j], act, runny);
+        if (act) {
             stage[slot] = ent[j];
             spid[slot] = (uint16_t)pid[j];
         }
@@ -387,6 +472,7 @@ __global__ void __launch_bounds__(1024) k_part_scatter(const D *__restrict__ dig
 }
 
 // grid = (nparts, nwin), block = 1024. Counting sort of one partition by fine bucket; also emits starts[] of its buckets.
+// Partitions of more than stage_cap references are the heavy kernels' (below).
 static __global__ void __launch_bounds__(1024) k_fine_sort(const uint32_t *__restrict__ parted, size_t n, uint32_t nbuckets,
                                                           uint32_t fbits, uint32_t lidx,
                                                           const uint32_t *__restrict__ part_base,
@@ -400,68 +486,216 @@ static __global__ void __launch_bounds__(1024) k_fine_sort(const uint32_t *__res
     const uint32_t *in = parted + (size_t)k * n;
     uint32_t *out = sorted + (size_t)k * n;
     uint32_t *st = starts + (size_t)k * (nbuckets + 1);
+    if (p == nparts - 1 && t == 0) st[nbuckets] = hi;
+    const uint32_t pop = hi - lo;
+    if (pop > stage_cap) return;  // oversized: k_heavy_hist / k_heavy_scan / k_heavy_place
     for (uint32_t f = t; f < nf; f += T) lds_f[f] = 0;
     __syncthreads();
     {   // 4 loads in flight per thread
         uint32_t e = lo + t;
         for (; e + 3 * T < hi; e += 4 * T) {
             const uint32_t v0 = in[e], v1 = in[e + T], v2 = in[e + 2 * T], v3 = in[e + 3 * T];
-            atomicAdd(&lds_f[v0 >> lidx], 1u);
-            atomicAdd(&lds_f[v1 >> lidx], 1u);
-            atomicAdd(&lds_f[v2 >> lidx], 1u);
-            atomicAdd(&lds_f[v3 >> lidx], 1u);
+            const bool runny = wave_runny(v0 >> lidx, true);
+            lds_count<false>(lds_f, v0 >> lidx, true, runny);
+            lds_count<false>(lds_f, v1 >> lidx, true, runny);
+            lds_count<false>(lds_f, v2 >> lidx, true, runny);
+            lds_count<false>(lds_f, v3 >> lidx, true, runny);
         }
         for (; e < hi; e += T) atomicAdd(&lds_f[in[e] >> lidx], 1u);
     }
     __syncthreads();
     // exclusive scan of the nf counters -> write cursors (in place) and starts[]
     wave0_exclusive_scan(lds_f, nf, lo, lds_f, st + (size_t)p * nf);
-    if (p == nparts - 1 && t == 0) st[nbuckets] = hi;
     __syncthreads();
     const uint32_t pmask = (1u << lidx) - 1u;
-    const uint32_t pop = hi - lo;
-    if (pop <= stage_cap) {
-        // the usual case: place the references inside LDS and write the sorted run out contiguously (scattered 4-byte
-        // global stores are limited to well under one lane per cycle per CU; this path has none)
-        uint32_t *stage = lds_f + nf;
-        uint32_t e = lo + t;
-        for (; e + 3 * T < hi; e += 4 * T) {
-            const uint32_t v0 = in[e], v1 = in[e + T], v2 = in[e + 2 * T], v3 = in[e + 3 * T];
-            const uint32_t p0 = atomicAdd(&lds_f[v0 >> lidx], 1u);
-            const uint32_t p1 = atomicAdd(&lds_f[v1 >> lidx], 1u);
-            const uint32_t p2 = atomicAdd(&lds_f[v2 >> lidx], 1u);
-            const uint32_t p3 = atomicAdd(&lds_f[v3 >> lidx], 1u);
-            stage[p0 - lo] = v0 & pmask;
-            stage[p1 - lo] = v1 & pmask;
-            stage[p2 - lo] = v2 & pmask;
-            stage[p3 - lo] = v3 & pmask;
-        }
-        for (; e < hi; e += T) {
-            const uint32_t v = in[e];
-            const uint32_t pos = atomicAdd(&lds_f[v >> lidx], 1u);
-            stage[pos - lo] = v & pmask;
-        }
-        __syncthreads();
-        for (uint32_t i = t; i < pop; i += T) out[lo + i] = stage[i];
-        return;
-    }
-    // oversized partition (skewed scalars): direct placement
+    // place the references inside LDS and write the sorted run out contiguously (scattered 4-byte global stores are
+    // limited to well under one lane per cycle per CU; this path has none)
+    uint32_t *stage = lds_f + nf;
     uint32_t e = lo + t;
     for (; e + 3 * T < hi; e += 4 * T) {
         const uint32_t v0 = in[e], v1 = in[e + T], v2 = in[e + 2 * T], v3 = in[e + 3 * T];
-        const uint32_t p0 = atomicAdd(&lds_f[v0 >> lidx], 1u);
-        const uint32_t p1 = atomicAdd(&lds_f[v1 >> lidx], 1u);
-        const uint32_t p2 = atomicAdd(&lds_f[v2 >> lidx], 1u);
-        const uint32_t p3 = atomicAdd(&lds_f[v3 >> lidx], 1u);
-        out[p0] = v0 & pmask;
-        out[p1] = v1 & pmask;
-        out[p2] = v2 & pmask;
-        out[p3] = v3 & pmask;
+        const bool runny = wave_runny(v0 >> lidx, true);
+        const uint32_t p0 = lds_count<true>(lds_f, v0 >> lidx, true, runny);
+        const uint32_t p1 = lds_count<true>(lds_f, v1 >> lidx, true, runny);
+        const uint32_t p2 = lds_count<true>(lds_f, v2 >> lidx, true, runny);
+        const uint32_t p3 = lds_count<true>(lds_f, v3 >> lidx, true, runny);
+        stage[p0 - lo] = v0 & pmask;
+        stage[p1 - lo] = v1 & pmask;
+        stage[p2 - lo] = v2 & pmask;
+        stage[p3 - lo] = v3 & pmask;
     }
     for (; e < hi; e += T) {
         const uint32_t v = in[e];
         const uint32_t pos = atomicAdd(&lds_f[v >> lidx], 1u);
-        out[pos] = v & pmask;
+        stage[pos - lo] = v & pmask;
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < pop; i += T) out[lo + i] = stage[i];
+}
+
+// ---- the sort of the oversized partitions (see HeavyPart above). subhist: [nwin][scap rows][2^fbits] counters.
+// hcount[2k] = listed partitions of window k, hcount[2k + 1] = their sub-runs (= rows of the window's table).
+// Work items of k_heavy_hist / k_heavy_place = the rows of all windows, numbered window by window, taken round-robin by the
+// workgroups of a 1-D grid (a window alone may hold all of them: the narrow top window of uniform scalars).
+constexpr uint32_t HEAVY_MAX_WINDOWS = 256;
+struct HeavyItem {
+    uint32_t k, row, s0, s1;  // window, row of the window's table, the sub-run's references [s0, s1) of parted[k]
+};
+// Call from all threads of a 1024-thread workgroup. s_pref: [HEAVY_MAX_WINDOWS + 1] LDS words, s_hp: one LDS HeavyPart.
+__device__ __forceinline__ uint32_t heavy_prefix(const uint32_t *hcount, uint32_t nw, uint32_t *s_pref) {
+    const uint32_t t = threadIdx.x;
+    if (t < nw) s_pref[t] = hcount[2 * t + 1];
+    __syncthreads();
+    const uint32_t tot = wave0_exclusive_scan(s_pref, nw, 0u, s_pref);
+    if (t == 0) s_pref[nw] = tot;
+    __syncthreads();
+    return s_pref[nw];
+}
+__device__ __forceinline__ HeavyItem heavy_item(uint32_t g, uint32_t nw, const uint32_t *s_pref, HeavyPart *s_hp,
+                                                const uint32_t *hcount, const HeavyPart *hparts, uint32_t hcap,
+                                                const uint32_t *part_base, uint32_t nparts) {
+    uint32_t lo = 0, hi = nw;  // largest k with s_pref[k] <= g
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s_pref[mid] <= g) lo = mid; else hi = mid;
+    }
+    const uint32_t k = lo, row = g - s_pref[k], np = hcount[2 * k];
+    for (uint32_t j = threadIdx.x; j < np; j += blockDim.x) {
+        const HeavyPart hp = hparts[(size_t)k * hcap + j];
+        if (row - hp.first < hp.nsub) *s_hp = hp;  // exactly one partition owns the row
+    }
+    __syncthreads();
+    const HeavyPart hp = *s_hp;
+    const uint32_t *pb = part_base + (size_t)k * (nparts + 1);
+    const uint32_t plo = pb[hp.p], phi = pb[hp.p + 1];
+    const uint32_t s0 = plo + (row - hp.first) * HEAVY_SUB;
+    return HeavyItem{k, row, s0, s0 + HEAVY_SUB < phi ? s0 + HEAVY_SUB : phi};
+}
+
+// k_heavy_hist: grid = G, block = 1024, dynamic LDS = 4 << fbits. Leaves the fine-bucket counts of every sub-run in its row.
+static __global__ void __launch_bounds__(1024) k_heavy_hist(const uint32_t *__restrict__ parted, size_t n, uint32_t nw, uint32_t nparts,
+                                                           uint32_t fbits, uint32_t lidx,
+                                                           const uint32_t *__restrict__ part_base,
+                                                           const HeavyPart *__restrict__ hparts,
+                                                           const uint32_t *__restrict__ hcount, uint32_t hcap, uint32_t scap,
+                                                           uint32_t *__restrict__ subhist) {
+    extern __shared__ uint32_t lds_h[];
+    __shared__ uint32_t s_pref[HEAVY_MAX_WINDOWS + 1];
+    __shared__ HeavyPart s_hp;
+    const uint32_t t = threadIdx.x, T = blockDim.x;
+    const uint32_t total = heavy_prefix(hcount, nw, s_pref);
+    const uint32_t nf = 1u << fbits;
+    constexpr uint32_t PER = HEAVY_SUB / 1024;
+    for (uint32_t g = blockIdx.x; g < total; g += gridDim.x) {
+        const HeavyItem it = heavy_item(g, nw, s_pref, &s_hp, hcount, hparts, hcap, part_base, nparts);
+        const uint32_t *in = parted + (size_t)it.k * n;
+        uint32_t v[PER];
+#pragma unroll
+        for (uint32_t i = 0; i < PER; ++i) {
+            const uint32_t e = it.s0 + i * T + t;
+            v[i] = e < it.s1 ? in[e] : 0xFFFFFFFFu;
+        }
+        for (uint32_t f = t; f < nf; f += T) lds_h[f] = 0;
+        __syncthreads();
+        const bool runny = wave_runny(v[0] >> lidx, it.s0 + t < it.s1);
+#pragma unroll
+        for (uint32_t i = 0; i < PER; ++i) lds_count<false>(lds_h, v[i] >> lidx, it.s0 + i * T + t < it.s1, runny);
+        __syncthreads();
+        uint32_t *row = subhist + ((size_t)it.k * scap + it.row) * nf;
+        for (uint32_t f = t; f < nf; f += T) row[f] = lds_h[f];
+        __syncthreads();
+    }
+}
+
+// k_heavy_scan: grid = (G, nwin), block = 1024, dynamic LDS = 4 << fbits. One workgroup per listed partition: column sums
+// of its rows -> exclusive scan over the fine buckets (starts[], from the partition's base) -> every row rewritten with
+// the write cursors of its sub-run (bucket start + counts of the sub-runs before it). Thread (f, s) walks segment s of
+// column f; adjacent threads take adjacent columns.
+static __global__ void __launch_bounds__(1024) k_heavy_scan(uint32_t nparts, uint32_t nbuckets, uint32_t fbits,
+                                                           const uint32_t *__restrict__ part_base,
+                                                           const HeavyPart *__restrict__ hparts,
+                                                           const uint32_t *__restrict__ hcount, uint32_t hcap, uint32_t scap,
+                                                           uint32_t *__restrict__ subhist, uint32_t *__restrict__ starts) {
+    extern __shared__ uint32_t lds_tot[];
+    __shared__ uint32_t seg[1024];
+    const uint32_t k = blockIdx.y, t = threadIdx.x;
+    const uint32_t np = hcount[2 * k];
+    const uint32_t nf = 1u << fbits;
+    const uint32_t FC = nf < 1024u ? nf : 1024u, SEGS = 1024u / FC;
+    const uint32_t col = t % FC, s = t / FC;
+    const uint32_t *pb = part_base + (size_t)k * (nparts + 1);
+    uint32_t *st = starts + (size_t)k * (nbuckets + 1);
+    for (uint32_t j = blockIdx.x; j < np; j += gridDim.x) {
+        const HeavyPart hp = hparts[(size_t)k * hcap + j];
+        uint32_t *rows = subhist + ((size_t)k * scap + hp.first) * nf;
+        const uint32_t per = (hp.nsub + SEGS - 1) / SEGS;
+        const uint32_t a = s * per < hp.nsub ? s * per : hp.nsub, b = a + per < hp.nsub ? a + per : hp.nsub;
+        for (uint32_t f0 = 0; f0 < nf; f0 += FC) {
+            const uint32_t f = f0 + col;
+            uint32_t mine = 0;
+            for (uint32_t sub = a; sub < b; ++sub) mine += rows[(size_t)sub * nf + f];
+            seg[t] = mine;
+            __syncthreads();
+            if (s == 0) {
+                uint32_t tot = 0;
+                for (uint32_t q = 0; q < SEGS; ++q) tot += seg[q * FC + col];
+                lds_tot[f] = tot;
+            }
+            __syncthreads();  // (nf <= 1024: one pass, seg[] stays valid for the rewrite below)
+        }
+        wave0_exclusive_scan(lds_tot, nf, pb[hp.p], lds_tot, st + (size_t)hp.p * nf);
+        __syncthreads();
+        for (uint32_t f0 = 0; f0 < nf; f0 += FC) {
+            const uint32_t f = f0 + col;
+            uint32_t run = lds_tot[f];
+            for (uint32_t q = 0; q < s; ++q) run += seg[q * FC + col];  // SEGS > 1 only when nf <= 1024
+            for (uint32_t sub = a; sub < b; ++sub) {
+                const uint32_t v = rows[(size_t)sub * nf + f];
+                rows[(size_t)sub * nf + f] = run;
+                run += v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// k_heavy_place: grid and LDS as k_heavy_hist. The sub-run's cursors come from its row; a reference goes straight to its
+// slot of `sorted` (a run of lanes that share a bucket holds consecutive slots: coalescing stores).
+static __global__ void __launch_bounds__(1024) k_heavy_place(const uint32_t *__restrict__ parted, size_t n, uint32_t nw, uint32_t nparts,
+                                                            uint32_t fbits, uint32_t lidx,
+                                                            const uint32_t *__restrict__ part_base,
+                                                            const HeavyPart *__restrict__ hparts,
+                                                            const uint32_t *__restrict__ hcount, uint32_t hcap, uint32_t scap,
+                                                            const uint32_t *__restrict__ subhist, uint32_t *__restrict__ sorted) {
+    extern __shared__ uint32_t lds_h[];
+    __shared__ uint32_t s_pref[HEAVY_MAX_WINDOWS + 1];
+    __shared__ HeavyPart s_hp;
+    const uint32_t t = threadIdx.x, T = blockDim.x;
+    const uint32_t total = heavy_prefix(hcount, nw, s_pref);
+    const uint32_t nf = 1u << fbits;
+    const uint32_t pmask = (1u << lidx) - 1u;
+    constexpr uint32_t PER = HEAVY_SUB / 1024;
+    for (uint32_t g = blockIdx.x; g < total; g += gridDim.x) {
+        const HeavyItem it = heavy_item(g, nw, s_pref, &s_hp, hcount, hparts, hcap, part_base, nparts);
+        const uint32_t *in = parted + (size_t)it.k * n;
+        uint32_t *out = sorted + (size_t)it.k * n;
+        const uint32_t *row = subhist + ((size_t)it.k * scap + it.row) * nf;
+        for (uint32_t f = t; f < nf; f += T) lds_h[f] = row[f];
+        uint32_t v[PER];
+#pragma unroll
+        for (uint32_t i = 0; i < PER; ++i) {
+            const uint32_t e = it.s0 + i * T + t;
+            v[i] = e < it.s1 ? in[e] : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        const bool runny = wave_runny(v[0] >> lidx, it.s0 + t < it.s1);
+#pragma unroll
+        for (uint32_t i = 0; i < PER; ++i) {
+            const bool act = it.s0 + i * T + t < it.s1;
+            const uint32_t pos = lds_count<true>(lds_h, v[i] >> lidx, act, runny);
+            if (act) out[pos] = v[i] & pmask;
+        }
+        __syncthreads();
     }
 }
 
@@ -638,77 +872,74 @@ __global__ void __launch_bounds__(256, AccWaves<U>::value) k_accumulate_seg(cons
 }
 
 // Chain fixup. A split bucket is a chain  P1[t0], P0[t0+1], ..., P0[t1]  of partial sums of consecutive accumulation
-// threads.  k_fixup_seg: the thread that owns the chain head adds up to MAXWALK followers (random scalars: 1-3). A
-// longer chain (a narrow top window - BW6-761's has 9 bits, 256 buckets of n/256 entries -, repeated scalars, every
-// scalar equal) is appended to a list and closed by k_fixup_long: one workgroup per chain, every thread sums a strided
-// share of the partials, then a tree over the workgroup through LDS - depth m/256 + 8 additions instead of m.
-// (Round 1 closed long chains with two hierarchical passes that were serial inside their spans: 32-link chains cost
-// BW6-761 4 ms once the accumulation ran three times as many threads.)
+// threads; its length follows from starts[] alone: the bucket's entries [lo, hi) lie in the threads lo / seg .. (hi - 1) /
+// seg.  k_fixup_seg: the thread that owns the chain head adds up to MAXWALK followers (random scalars: 1-3). A longer
+// chain (a narrow top window - BW6-761's has 9 bits, 256 buckets of n/256 entries -, repeated scalars, every scalar
+// equal) goes to a list as PIECES of at most LONG_PIECE links, and k_fixup_long gives every piece a workgroup of 64 lane
+// quads: strided sums, then a tree - LONG_PIECE/64 + 6 quad steps; the workgroup that finishes a chain's last piece adds the
+// pieces' sums the same way. (Round 1 closed long chains with two hierarchical passes that were serial inside their
+// spans. Rounds 2-4 gave a whole chain to ONE workgroup, m/64 + 6 steps: fine for BW6-761's 9-link chains, 0.9 ms for the
+// 13 K-link chain every window gets at 2^20 when all scalars are equal, 2.7 ms at 2^24 - profiles/r05_distributions_before.log.)
 struct LongChain {
-    uint32_t window, head;  // window index inside the launch, head thread (the chain's destination is pbucket[head])
+    uint32_t window, head;    // window index inside the launch, head thread (the chain's destination is pbucket[head])
+    uint32_t piece, npieces;  // this item: links [piece * LONG_PIECE, ...) of the chain; items of a chain are consecutive
 };
 constexpr uint32_t FIXUP_MAXWALK = 8;  // upper limit of the `maxwalk` argument of k_fixup_seg
+constexpr uint32_t LONG_PIECE = 256;   // links per item of the long-chain list
+
+// Appends the pieces of one long chain of m links (m > 1) to the list; called by the one thread that found it.
+__device__ __forceinline__ void long_chain_append(uint32_t *long_count, LongChain *long_list, uint32_t *piece_done,
+                                                  uint32_t window, uint32_t head, uint32_t m) {
+    const uint32_t np = (m + LONG_PIECE - 1) / LONG_PIECE;
+    const uint32_t slot = atomicAdd(long_count, np);
+    for (uint32_t i = 0; i < np; ++i) long_list[slot + i] = LongChain{window, head, i, np};
+    piece_done[slot] = 0;  // pieces finished so far (k_fixup_long: the last one to finish adds the pieces up)
+}
 
 template <class A>
 __global__ void __launch_bounds__(256) k_fixup_seg(uint32_t nbuckets, const void *__restrict__ partials,
                                                    const uint32_t *__restrict__ pflags, const uint32_t *__restrict__ pbucket,
                                                    uint32_t threads_per_win, void *__restrict__ buckets,
                                                    uint32_t *__restrict__ long_count, LongChain *__restrict__ long_list,
-                                                   uint32_t maxwalk /* followers a head adds itself; longer chains -> list */) {
+                                                   uint32_t *__restrict__ piece_done,
+                                                   uint32_t maxwalk /* followers a head adds itself; longer chains -> list */,
+                                                   const uint32_t *__restrict__ starts, uint32_t seg) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
     if (t >= threads_per_win) return;
     const size_t base = (size_t)k * threads_per_win;
     // The usual chain is P1[t] + P0[t+1]: fetch all of it (and the destination) before looking at any flag, so that the
-    // four dependent memory round trips of the straightforward walk overlap.
+    // dependent memory round trips of the straightforward walk overlap.
     const uint32_t f0 = pflags[base + t];
     const bool has_next = t + 1 < threads_per_win;
-    uint32_t f = has_next ? pflags[base + t + 1] : 0u;
     typename A::Elem acc = A::load(partials, (base + t) * 2 + 1);  // raw: made fresh below, by the chain heads only
     typename A::Elem q = A::load(partials, (base + (has_next ? t + 1 : t)) * 2 + 0);
     const uint32_t dest = pbucket[base + t];
     if (!(f0 & SegFlags::HAS_P1)) return;
-    // length of the chain from the flags alone (no arithmetic yet): long ones are handed over untouched
-    bool closed = false;
-    {
-        uint32_t fu = f;
-        for (uint32_t u = t + 1; u < threads_per_win && u <= t + maxwalk; ++u) {
-            if (u != t + 1) fu = pflags[base + u];
-            if (!(fu & SegFlags::HAS_P0) || !(fu & SegFlags::P0_OPEN_RIGHT)) {
-                closed = true;
-                break;
-            }
-        }
-        if (!closed && t + maxwalk + 1 >= threads_per_win) closed = true;  // runs off the end of the window: short
-    }
-    if (!closed) {
-        const uint32_t slot = atomicAdd(long_count, 1u);
-        long_list[slot] = LongChain{k, t};
+    // followers of the chain: the accumulation threads t + 1 .. (end of the bucket - 1) / seg
+    const uint32_t followers = (starts[(size_t)k * (nbuckets + 1) + dest + 1] - 1u) / seg - t;
+    if (followers > maxwalk) {  // long: handed over untouched
+        long_chain_append(long_count, long_list, piece_done, k, t, followers + 1u);
         return;
     }
     A::fresh(acc);
-    for (uint32_t u = t + 1; u < threads_per_win; ++u) {
-        if (u != t + 1) {
-            f = pflags[base + u];
-            if (f & SegFlags::HAS_P0) q = A::load(partials, (base + u) * 2 + 0);
-        }
-        if (!(f & SegFlags::HAS_P0)) break;
+    for (uint32_t u = 1; u <= followers; ++u) {
+        if (u != 1) q = A::load(partials, (base + t + u) * 2 + 0);
         A::fresh(q);
         A::add(acc, q);
-        if (!(f & SegFlags::P0_OPEN_RIGHT)) break;
     }
     A::store(buckets, (size_t)k * nbuckets + dest, acc);
 }
 
 // The same fix-up with one thread per BUCKET, for a shared bucket set (window tables): there a bucket holds nwin times
 // the entries (BN254 G1, 2^20 points, c = 17: 240 against a thread's 80), so nearly every bucket is a chain of 3-4 partial
-// sums and k_fixup_seg's heads - one lane in three - walk them with the other lanes of their wave idle (0.100 ms). The
-// chain of bucket b follows from starts[] alone: its entries [lo, hi) lie in the accumulation threads lo / seg .. (hi -
-// 1) / seg, the first holds P1, the others P0. Chains longer than maxwalk go to the same list as before.
+// sums and k_fixup_seg's heads - one lane in three - walk them with the other lanes of their wave idle (0.100 ms).
+// Chains longer than maxwalk go to the same list as before.
 template <class A>
 __global__ void __launch_bounds__(256) k_fixup_bucket(uint32_t nbuckets, const uint32_t *__restrict__ starts, uint32_t seg,
                                                       const void *__restrict__ partials, uint32_t threads_per_win,
                                                       void *__restrict__ buckets, uint32_t *__restrict__ long_count,
-                                                      LongChain *__restrict__ long_list, uint32_t maxwalk) {
+                                                      LongChain *__restrict__ long_list, uint32_t *__restrict__ piece_done,
+                                                      uint32_t maxwalk) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
     if (b >= nbuckets) return;
     const uint32_t *st = starts + (size_t)k * (nbuckets + 1);
@@ -718,8 +949,7 @@ __global__ void __launch_bounds__(256) k_fixup_bucket(uint32_t nbuckets, const u
     if (t0 == t1) return;  // the bucket lies inside one thread's range: stored by the accumulation itself
     const size_t base = (size_t)k * threads_per_win;
     if (t1 - t0 > maxwalk) {
-        const uint32_t slot = atomicAdd(long_count, 1u);
-        long_list[slot] = LongChain{k, t0};
+        long_chain_append(long_count, long_list, piece_done, k, t0, t1 - t0 + 1u);
         return;
     }
     typename A::Elem acc = A::load_fresh(partials, (base + t0) * 2 + 1);
@@ -730,61 +960,83 @@ __global__ void __launch_bounds__(256) k_fixup_bucket(uint32_t nbuckets, const u
     A::store(buckets, (size_t)k * nbuckets + b, acc);
 }
 
-// grid = any (grid-stride over the list), block = 256 = 64 quads, dynamic LDS = 128 * sizeof(QRec<U>).
-// Additions on lane quads with the operands in LDS (gmsm_quad.h): quad j first adds up the partial sums j, j + 64, ... of
-// the chain (each fetched into the quad's staging record, one coordinate per lane), then a tree over the 64 quads - for a
-// chain of m links m/64 + 6 quad steps instead of m one-lane additions. (Round 2 ran this with one-lane additions out of
-// line: 2.9 KB of scratch per lane for the 28-limb field, 0.77 ms for the 256 nine-link chains of BW6-761's top window.)
+// grid = any (grid-stride over the list's items), block = 256 = 64 quads, dynamic LDS = 128 * sizeof(QRec<U>).
+// Additions on lane quads with the operands in LDS (gmsm_quad.h): quad j first adds up the links j, j + 64, ... of the
+// item's piece (each fetched into the quad's staging record, one coordinate per lane), then a tree over the 64 quads. A
+// chain of one piece is stored to its bucket; otherwise the sum goes to piece_sums[item] and the workgroup whose
+// increment of the chain's counter completes it (release / acquire at device scope around the counter) adds the pieces'
+// sums the same way. (Round 2 ran this with one-lane additions out of line: 2.9 KB of scratch per lane for the 28-limb
+// field, 0.77 ms for the 256 nine-link chains of BW6-761's top window.)
+template <class U>
+__device__ __forceinline__ void quad_sum_links(QRec<U> *acc, QRec<U> *stage, uint32_t m, uint32_t tid, const void *src,
+                                               size_t first_index, size_t stride, size_t head_index, bool fresh_records) {
+    // sums the m records src[idx(i)], idx(i) = first_index + i * stride (idx(0) = head_index when that is not ~0), into acc[0]
+    const uint32_t j = tid >> 2, lane = tid & 63u;
+    if ((tid & 3u) == 0) acc[j].inf = 1u;
+    for (uint32_t i0 = 0; i0 < m; i0 += 64) {
+        const uint32_t i = i0 + j;
+        const size_t idx = (i == 0 && head_index != ~(size_t)0) ? head_index : first_index + (size_t)i * stride;
+        if (fresh_records) quad_rec_load<U, true>(&stage[j], src, idx, i < m, lane);
+        else quad_rec_load<U, false>(&stage[j], src, idx, i < m, lane);
+        __syncthreads();  // the lanes of a quad exchange coordinates through the record: stores before loads
+        const QAddOps<U> o = quad_add_load<U>(&acc[j], &stage[j], lane);  // both records belong to this quad
+        quad_add_store<U, true>(&acc[j], o, i < m, lane);
+    }
+    __syncthreads();
+    uint32_t active = 64;
+    while (active / 2 >= m && active > 1) active >>= 1;  // smallest power of two >= min(m, 64)
+#pragma nounroll
+    for (uint32_t d = active >> 1; d >= 1; d >>= 1) {
+        const bool act = j < d;
+        const QAddOps<U> o = quad_add_load<U>(&acc[j], &acc[act ? j + d : j], lane);
+        __syncthreads();
+        quad_add_store<U, true>(&acc[j], o, act, lane);
+        __syncthreads();
+    }
+}
+
 template <class U>
 __global__ void __launch_bounds__(256) k_fixup_long(uint32_t nbuckets, const void *__restrict__ partials,
-                                                    const uint32_t *__restrict__ pflags, const uint32_t *__restrict__ pbucket,
-                                                    uint32_t threads_per_win, void *__restrict__ buckets,
-                                                    const uint32_t *__restrict__ long_count,
-                                                    const LongChain *__restrict__ long_list) {
+                                                    const uint32_t *__restrict__ pbucket, uint32_t threads_per_win,
+                                                    void *__restrict__ buckets, const uint32_t *__restrict__ long_count,
+                                                    const LongChain *__restrict__ long_list, uint32_t *__restrict__ piece_done,
+                                                    void *__restrict__ piece_sums, const uint32_t *__restrict__ starts,
+                                                    uint32_t seg) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     QRec<U> *acc = reinterpret_cast<QRec<U> *>(lds_raw), *stage = acc + 64;
-    __shared__ uint32_t s_len;
+    __shared__ uint32_t s_last;
     const uint32_t tid = threadIdx.x, j = tid >> 2, lane = tid & 63u, count = *long_count;
     for (uint32_t c = blockIdx.x; c < count; c += gridDim.x) {
         const LongChain lc = long_list[c];
         const size_t base = (size_t)lc.window * threads_per_win;
-        // chain length m (head included): followers continue while they carry an open-right P0
-        if (tid == 0) s_len = 0xffffffffu;
+        const uint32_t dest = pbucket[base + lc.head];
+        // chain length m (head included): the bucket's entries end in thread (hi - 1) / seg
+        const uint32_t m = (starts[(size_t)lc.window * (nbuckets + 1) + dest + 1] - 1u) / seg - lc.head + 1u;
+        const uint32_t l0 = lc.piece * LONG_PIECE;
+        const uint32_t len = m - l0 < LONG_PIECE ? m - l0 : LONG_PIECE;
+        // link i of the chain is P1[head] for i = 0 and P0[head + i] otherwise
+        quad_sum_links<U>(acc, stage, len, tid, partials, (base + lc.head + l0) * 2 + 0, 2,
+                          l0 == 0 ? (base + lc.head) * 2 + 1 : ~(size_t)0, true);
+        const size_t bucket_index = (size_t)lc.window * nbuckets + dest;
+        if (lc.npieces == 1) {
+            if (j == 0) quad_rec_store<U>(buckets, bucket_index, &acc[0], lane);
+            __syncthreads();
+            continue;
+        }
+        const uint32_t c0 = c - lc.piece;  // the chain's first item: its counter and the base of its pieces' sums
+        if (j == 0) quad_rec_store<U>(piece_sums, c, &acc[0], lane);
         __syncthreads();
-        for (uint32_t u0 = lc.head + 1; u0 < threads_per_win; u0 += 256) {
-            const uint32_t u = u0 + tid;
-            if (u < threads_per_win) {
-                const uint32_t fu = pflags[base + u];
-                if (!(fu & SegFlags::HAS_P0)) atomicMin(&s_len, u - lc.head);          // chain ended before u
-                else if (!(fu & SegFlags::P0_OPEN_RIGHT)) atomicMin(&s_len, u - lc.head + 1);  // u closes it
-            }
-            __syncthreads();
-            if (s_len != 0xffffffffu) break;
-            __syncthreads();
+        if (tid == 0) {
+            __threadfence();  // the piece's sum is visible device-wide before the counter says so
+            const uint32_t done = __hip_atomic_fetch_add(&piece_done[c0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = done + 1u == lc.npieces ? 1u : 0u;
         }
         __syncthreads();
-        const uint32_t m = s_len != 0xffffffffu ? s_len : threads_per_win - lc.head;
-        // strided sums: link i of the chain is P1[head] for i = 0 and P0[head + i] otherwise
-        if ((tid & 3u) == 0) acc[j].inf = 1u;
-        for (uint32_t i0 = 0; i0 < m; i0 += 64) {
-            const uint32_t i = i0 + j;
-            quad_rec_load<U, true>(&stage[j], partials, i == 0 ? (base + lc.head) * 2 + 1 : (base + lc.head + i) * 2 + 0, i < m, lane);
-            __syncthreads();  // the lanes of a quad exchange coordinates through the record: stores before loads
-            const QAddOps<U> o = quad_add_load<U>(&acc[j], &stage[j], lane);  // both records belong to this quad
-            quad_add_store<U, true>(&acc[j], o, i < m, lane);
+        if (s_last) {
+            __threadfence();
+            quad_sum_links<U>(acc, stage, lc.npieces, tid, piece_sums, (size_t)c0, 1, ~(size_t)0, false);
+            if (j == 0) quad_rec_store<U>(buckets, bucket_index, &acc[0], lane);
         }
-        __syncthreads();
-        uint32_t active = 64;
-        while (active / 2 >= m && active > 1) active >>= 1;  // smallest power of two >= min(m, 64)
-#pragma nounroll
-        for (uint32_t d = active >> 1; d >= 1; d >>= 1) {
-            const bool act = j < d;
-            const QAddOps<U> o = quad_add_load<U>(&acc[j], &acc[act ? j + d : j], lane);
-            __syncthreads();
-            quad_add_store<U, true>(&acc[j], o, act, lane);
-            __syncthreads();
-        }
-        if (j == 0) quad_rec_store<U>(buckets, (size_t)lc.window * nbuckets + pbucket[base + lc.head], &acc[0], lane);
         __syncthreads();
     }
 }

@@ -324,6 +324,77 @@ def test_msm_skewed_bucket_distributions(gm, oracle_mod, curve, which):
         assert (g.jac_to_affine(g.fold_windows(w, c)) == o.msm_affine(pts, sc, c=min(c, 16), nthreads=8)).all(), c
 
 
+# ------------------------------------------------------------------ the reference's benchmark distributions, at benchmark size
+def _bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("kind", ["smallvalues", "redundancy", "value_one", "all_equal"])
+def test_msm_benchmark_distribution_2p20(gm, oracle_mod, kind):
+    """BenchmarkMultiExpG1's scalar distributions (multiexp_test.go:319-334) plus value-one / all-equal at 2^20 points, BN254
+    G1: the crowded buckets take the multi-workgroup sort of oversized partitions (k_heavy_*) and the piece-wise long-chain
+    fix-up. Closed form: bases [a_i]G built on the device, expected [sum a_i b_i]G from the oracle. The same vector through
+    the host entry (point ranges + bucket merges) and over registered bases with window tables (one shared bucket set)."""
+    import torch
+    bench = _bench()
+    g = gm.G1Jac("bn254")
+    n = 1 << 20
+    rng = rng_for(31, len(kind))
+    a = random_scalars(rng, g.curve, n)
+    b = bench.skewed_scalars(kind, random_scalars(rng, g.curve, n), g, rng)
+    d_a = torch.from_numpy(a.view(np.int64)).cuda()
+    d_b = torch.from_numpy(b.view(np.int64)).cuda()
+    d_pts = torch.empty((n, g.aff_limbs), dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    g.batch_scalar_mul_device(g.generator, d_a.data_ptr(), n, d_pts.data_ptr(), stream)
+    expected = oracle_mod.Oracle("bn254", "g1").fixed_base_msm_affine(a, b)
+    assert (g.jac_to_affine(g.multiexp_device(d_pts.data_ptr(), d_b.data_ptr(), n, stream)) == expected).all()
+    pts = d_pts.cpu().numpy().view(np.uint64)
+    jac, err = g.MultiExp(pts, b, gm.MultiExpConfig())
+    assert err is None and (g.jac_to_affine(jac) == expected).all()
+    rb = g.register_bases(d_points=d_pts.data_ptr(), n=n)
+    try:
+        rb.precompute(0)
+        with gm.options(tables=2):
+            assert (g.jac_to_affine(rb.multiexp_device(d_b.data_ptr(), n, stream)) == expected).all()
+    finally:
+        rb.release()
+
+
+@pytest.mark.parametrize("curve,which", ALL_GROUPS)
+def test_msm_crowded_buckets_all_groups(gm, oracle_mod, curve, which):
+    """Crowded buckets for every group at sizes where a partition exceeds the fine sort's staging slots (so the k_heavy_*
+    kernels and the piece-wise k_fixup_long run with every element type), against the oracle's MSM; several window widths
+    through window_sums_device (narrow and wide fine-bucket tables), and point-range splits of the same call."""
+    import torch
+    bench = _bench()
+    g = _group(gm, curve, which)
+    o = oracle_mod.Oracle(curve, which)
+    n = 70000 if which == "g1" and curve != "bw6_761" else 40000
+    rng = rng_for(32, g.gid)
+    pts = o.gen_points(n, 4242, 777, nthreads=8)
+    base = random_scalars(rng, g.curve, n)
+    d_pts = torch.from_numpy(pts.view(np.int64)).cuda()
+    for kind in ("smallvalues", "value_one", "all_equal", "redundancy"):
+        sc = bench.skewed_scalars(kind, base, g, rng)
+        expected = o.msm_affine(pts, sc, nthreads=8)
+        assert (_msm_gpu_affine(g, pts, sc) == expected).all(), kind
+        d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+        for c in (8, 13, 16):
+            w = g.window_sums_device(d_pts.data_ptr(), d_sc.data_ptr(), n, c)
+            assert (g.jac_to_affine(g.fold_windows(w, c)) == expected).all(), (kind, c)
+    # infinities and duplicated bases inside the crowded bucket
+    pts2 = pts.copy()
+    pts2[::7] = 0
+    pts2[1::2] = pts2[1]
+    sc = bench.skewed_scalars("all_equal", base, g, rng)
+    assert (_msm_gpu_affine(g, pts2, sc) == o.msm_affine(pts2, sc, nthreads=8)).all()
+
+
 # ------------------------------------------------------------------ BASELINE.json configurations at their full sizes
 FULL_CONFIGS = [
     ("bn254", "g1", 24),      # C3: BN254 G1 2^24
