@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "gmsm_get_stage_launches", "gmsm_points_from_raw", "gmsm_points_validate", "gmsm_bases_register_raw",
     "gmsm_bases_register_dump", "gmsm_fft_domain_new", "gmsm_fft_domain_release", "gmsm_fft_domain_info", "gmsm_fft",
     "gmsm_fft_bit_reverse",
-    "gmsm_bases_precompute", "gmsm_bases_table_bits", "gmsm_debug_table_runs", "gmsm_multiexp_sharded", "gmsm_bases_register_sharded", "gmsm_multiexp_bases_sharded", "gmsm_set_devices",
+    "gmsm_bases_precompute", "gmsm_bases_table_bits", "gmsm_debug_table_runs", "gmsm_debug_small_runs", "gmsm_multiexp_sharded", "gmsm_bases_register_sharded", "gmsm_multiexp_bases_sharded", "gmsm_set_devices",
     "gmsm_get_devices", "gmsm_set_option", "gmsm_get_option", "gmsm_trim", "gmsm_shutdown",
     "gmsm_device_count", "gmsm_set_device", "gmsm_last_error",
     "gmsm_version",
@@ -86,6 +86,8 @@ def load():
     L.gmsm_bases_table_bits.argtypes = [ctypes.c_uint64]
     L.gmsm_debug_table_runs.restype = ctypes.c_ulong
     L.gmsm_debug_table_runs.argtypes = []
+    L.gmsm_debug_small_runs.restype = ctypes.c_ulong
+    L.gmsm_debug_small_runs.argtypes = []
     L.gmsm_multiexp_bases.restype = ctypes.c_int
     L.gmsm_multiexp_bases.argtypes = [ctypes.c_uint64, u64p, sz, ctypes.c_int, u64p]
     L.gmsm_multiexp_bases_device.restype = ctypes.c_int
@@ -200,7 +202,7 @@ def last_error():
 
 
 # enum gmsm_option (include/gmsm.h)
-OPTIONS = {"window_bits": 0, "tables": 1, "max_run": 2, "host_ranges": 3, "fixed_base_bits": 4, "spin_wait_us": 5}
+OPTIONS = {"window_bits": 0, "tables": 1, "max_run": 2, "host_ranges": 3, "fixed_base_bits": 4, "spin_wait_us": 5, "small_bits": 6, "small_max": 7}
 
 
 def set_option(name, value):

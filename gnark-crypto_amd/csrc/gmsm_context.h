@@ -63,9 +63,12 @@ struct Options {
     std::atomic<unsigned> host_ranges{0};  // GMSM_OPT_HOST_RANGES: force the point ranges of a host-buffer call (0 = off)
     std::atomic<unsigned> fixed_base_bits{0};  // GMSM_OPT_FIXED_BASE_BITS: table width of the fixed-base batch (0 = by size)
     std::atomic<unsigned> spin_wait_us{0};     // GMSM_OPT_SPIN_WAIT_US: poll a call's stream this long before blocking on it (0 = park at once)
+    std::atomic<unsigned> small_bits{0};       // GMSM_OPT_SMALL_BITS: the fused small-n kernel: 0 = on, width by size; 1 = off; 2..7 = on, this width
+    std::atomic<unsigned> small_max{0};        // GMSM_OPT_SMALL_MAX: largest call the fused kernel takes (0 = the measured default)
 };
 Options &options();
 
+extern std::atomic<unsigned long> g_small_runs;  // calls served by the fused small-n kernel (gmsm_debug_small_runs)
 extern std::atomic<unsigned long> g_table_runs;  // pipeline runs that went through window tables (gmsm_debug_table_runs)
 
 // Bases rewritten once into the lazy Montgomery domain and kept in HBM (gmsm_bases_register): the resident-SRS path.
@@ -149,6 +152,7 @@ struct Workspace {
     DeviceBuffer parted;         // coarse-partitioned references (two-level grouping)
     DeviceBuffer heavy;          // oversized partitions of the fine sort: their list, the count per window, sub-run bucket counts
     DeviceBuffer long_pieces;    // long chains of the fix-up: per-chain piece counters, the pieces' sums
+    DeviceBuffer small_sums, small_done;  // fused small-n kernel: the slices' window totals, per-window arrival counters (kept zero)
     DeviceBuffer digits, sorted, blockhist, counts, starts, buckets, partials, totals;
     DeviceBuffer red_pre;        // per-thread (S, W) of the bucket reduction (k_reduce_serial -> k_combine_q)
     DeviceBuffer carry;          // running bucket sums of a multi-range host call (k_merge_buckets)
@@ -180,7 +184,7 @@ struct Workspace {
     // gmsm_trim / gmsm_shutdown: give back every scratch buffer larger than `keep` bytes (the caller holds the lease and
     // has synchronised the workspace's streams). Returns the device bytes released.
     size_t trim(size_t keep) {
-        DeviceBuffer *all[] = {&upoints, &skip, &seg_lvl, &seg_partials, &seg_flags, &seg_bucket, &parted, &heavy, &long_pieces, &digits, &sorted,
+        DeviceBuffer *all[] = {&upoints, &skip, &seg_lvl, &seg_partials, &seg_flags, &seg_bucket, &parted, &heavy, &long_pieces, &small_sums, &small_done, &digits, &sorted,
                                &blockhist, &counts, &starts, &buckets, &partials, &totals, &red_pre, &carry, &h2d_points,
                                &h2d_scalars, &raw_bytes, &flagword};
         size_t freed = 0;

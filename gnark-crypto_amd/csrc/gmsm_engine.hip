@@ -23,6 +23,7 @@ static std::string g_any_error;
 static thread_local int g_device = -1;
 static std::atomic<int> g_default_device{0};
 std::atomic<unsigned long> g_table_runs{0};
+std::atomic<unsigned long> g_small_runs{0};
 
 // Process-wide switches; GMSM_C and GMSM_TABLES are read here ONCE (first use), never on a call path.
 Options &options() {
@@ -858,6 +859,7 @@ GMSM_EXPORT int gmsm_bases_precompute(uint64_t handle, unsigned c) {
 }
 
 GMSM_EXPORT unsigned long gmsm_debug_table_runs(void) { return g_table_runs.load(); }
+GMSM_EXPORT unsigned long gmsm_debug_small_runs(void) { return g_small_runs.load(); }
 
 // 0 = no tables; else the window width of the handle's tables
 GMSM_EXPORT unsigned gmsm_bases_table_bits(uint64_t handle) {
@@ -1446,6 +1448,11 @@ GMSM_EXPORT int gmsm_set_option(int key, unsigned value) {
             if (value != 0 && (value < 2 || value > 14)) return fail(GMSM_ERR_ARG, "GMSM_OPT_FIXED_BASE_BITS: 0 (by batch size) or 2..14");
             o.fixed_base_bits.store(value);
             return GMSM_OK;
+        case GMSM_OPT_SMALL_BITS:
+            if (value > 7) return fail(GMSM_ERR_ARG, "GMSM_OPT_SMALL_BITS: 0 (on, width by size), 1 (off) or 2..7 (on, forced width)");
+            o.small_bits.store(value);
+            return GMSM_OK;
+        case GMSM_OPT_SMALL_MAX: o.small_max.store(value); return GMSM_OK;
         case GMSM_OPT_SPIN_WAIT_US:
             if (value > 1000000) return fail(GMSM_ERR_ARG, "GMSM_OPT_SPIN_WAIT_US: at most 1000000");
             o.spin_wait_us.store(value);
@@ -1463,6 +1470,8 @@ GMSM_EXPORT unsigned gmsm_get_option(int key) {
         case GMSM_OPT_HOST_RANGES: return o.host_ranges.load();
         case GMSM_OPT_FIXED_BASE_BITS: return o.fixed_base_bits.load();
         case GMSM_OPT_SPIN_WAIT_US: return o.spin_wait_us.load();
+        case GMSM_OPT_SMALL_BITS: return o.small_bits.load();
+        case GMSM_OPT_SMALL_MAX: return o.small_max.load();
         default: return 0;
     }
 }

@@ -12,6 +12,7 @@
 #include "gmsm_context.h"
 #include "gmsm_kernels.h"
 #include "gmsm_fixup_q.h"
+#include "gmsm_small.h"
 #include "gmsm_fixedbase.h"
 #include "gmsm_ingest.h"
 #include "gmsm_fft.h"
@@ -1016,8 +1017,78 @@ struct Group {
         return nr;
     }
 
+    // ---- the fused small-n kernel (gmsm_small.h): calls of at most small_max_points() points that neither force a window
+    // width nor are served by window tables. The width minimises the depth of the kernel's dependency chain -
+    // log2(points per bucket) + 2 (c - 1) additions - against the number of windows the host has to fold.
+    static constexpr uint32_t SMALL_SL = SmallSlice<U>::value;
+    // Measured against the sorted pipeline (profiles/r05_small_n.log, resident ms, fused / pipeline): BN254 G1 2^5 0.147 / 0.27,
+    // 2^10 0.18 / 0.29-0.35, 2^12 0.28 / 0.41, 2^13 0.38 / 0.47; BN254 G2 2^11 0.65 / 0.91, 2^13 1.29 / 0.99; BLS12-381 G1 2^11 0.41 /
+    // 0.62, 2^13 0.73 / 0.70; BLS12-381 G2 2^11 1.19 / 1.62, 2^13 2.5 / 1.7; BW6-761 2^11 1.60 / 2.09, 2^13 4.2 / 2.2.
+    static size_t small_max_points() {
+        const size_t forced = options().small_max.load(std::memory_order_relaxed);
+        return std::min<size_t>(forced ? forced : GMSM_TUNE(SMALL_MAX, AFF_BYTES == 64 ? 8192 : 2048), (size_t)SMALL_SL * SMALL_MAX_SLICES);
+    }
+    static unsigned small_c(size_t n) {
+        const unsigned forced = options().small_bits.load(std::memory_order_relaxed);
+        if (forced >= 2 && forced <= SMALL_MAX_C) return forced;
+        // flat over 5..7 for the narrow types (fewer windows = less host fold, more buckets = more quad steps); the 28-limb
+        // field and large calls take 7
+        if (n <= 128) return 5;
+        return (FR_BITS > 300 || n > 4096) ? 7 : 6;
+    }
+    static bool small_serves(size_t n, const ResidentBases *rb) {
+        if (options().small_bits.load(std::memory_order_relaxed) == 1) return false;
+        if (options().window_bits.load(std::memory_order_relaxed) != 0) return false;  // a forced width: the sorted pipeline
+        return n >= 1 && n <= small_max_points() && !use_tables(rb, n);
+    }
+    // Enqueues the kernel and the copy of the totals into ws.pinned on ws.stream; d_points == nullptr: `resident`.
+    static int enqueue_small(Context &ctx, Workspace &ws, const void *d_points, const void *d_scalars, size_t n,
+                             const WindowPlan &plan, const ResidentBases *resident, size_t resident_offset = 0) {
+        const uint32_t nw = plan.nwin_total, nslices = (uint32_t)((n + SMALL_SL - 1) / SMALL_SL);
+        constexpr size_t REC = sizeof(typename OpsSerial::Mem);
+        int rc;
+        ws.pending_timed = false;
+        if ((rc = begin_use(ws, ws.stream))) return rc;
+        if ((rc = ws.totals.ensure((size_t)nw * sizeof(Ext)))) return rc;
+        if ((rc = ws.ensure_pinned((size_t)nw * sizeof(Ext)))) return rc;
+        if ((rc = ws.small_sums.ensure((size_t)nw * nslices * REC))) return rc;
+        {
+            const size_t had = ws.small_done.cap;
+            if ((rc = ws.small_done.ensure((size_t)HEAVY_MAX_WINDOWS * 4))) return rc;
+            if (ws.small_done.cap != had) HIP_TRY(hipMemsetAsync(ws.small_done.ptr, 0, ws.small_done.cap, ws.stream));
+        }
+        if ((rc = ctx.allow_lds((const void *)k_msm_small<U, FrP, SMALL_SL>, (int)(SMALL_SL * REC)))) return rc;
+        const void *upoints = nullptr;
+        const uint8_t *skip = nullptr;
+        if (d_points == nullptr) {
+            upoints = (const char *)resident->upoints.ptr + resident_offset * AFF_BYTES;
+            skip = (const uint8_t *)resident->skip.ptr + resident_offset;
+        }
+        g_small_runs.fetch_add(1, std::memory_order_relaxed);
+        // the window totals go straight into the pinned result buffer (host memory mapped into the device: nwin 128-byte
+        // stores over PCIe instead of a copy kernel and its launch, 5-8 us of a 0.15 ms call)
+        hipLaunchKernelGGL((k_msm_small<U, FrP, SMALL_SL>), dim3(nslices, nw), dim3(SMALL_SL), (size_t)SMALL_SL * REC, ws.stream,
+                           d_points, upoints, skip, (const uint32_t *)d_scalars, (uint32_t)n, plan, ws.small_sums.ptr,
+                           (uint32_t *)ws.small_done.ptr, ws.pinned);
+        HIP_TRY(hipGetLastError());
+        return end_use(ws, ws.stream);
+    }
+    static int multiexp_small(Context &ctx, Workspace &ws, const void *d_points, const void *d_scalars, size_t n,
+                              hipStream_t caller_stream, J *out, const ResidentBases *resident) {
+        const WindowPlan plan = make_plan(small_c(n), 0, 1);
+        if (plan.nwin_total > HEAVY_MAX_WINDOWS) return fail(GMSM_ERR_ARG, "small path: too many windows");
+        int rc = order_after(ws, caller_stream);
+        if (rc) return rc;
+        if ((rc = enqueue_small(ctx, ws, d_points, d_scalars, n, plan, resident))) return rc;
+        std::vector<Ext> totals(plan.nwin_total);
+        if ((rc = collect_window_sums(ws, ws.stream, plan.nwin_total, totals.data()))) return rc;
+        *out = fold(totals.data(), plan.c);
+        return GMSM_OK;
+    }
+
     static int multiexp_device(Context &ctx, Workspace &ws, const void *d_points, const void *d_scalars, size_t n,
                                hipStream_t caller_stream, J *out, const ResidentBases *resident = nullptr) {
+        if (small_serves(n, resident)) return multiexp_small(ctx, ws, d_points, d_scalars, n, caller_stream, out, resident);
         const WindowPlan plan = plan_for(resident, n);
         const unsigned c = plan.c;
         const unsigned nr = device_ranges(n, plan);
@@ -1230,6 +1301,24 @@ struct Group {
     // MultiExp with the scalars (and, unless `resident`, the points) in host memory.
     static int multiexp_from_host(Context &ctx, Workspace &first, const uint64_t *points, const ResidentBases *resident,
                                   const uint64_t *scalars, size_t n, J *out) {
+        if (small_serves(n, resident)) {  // one copy, one launch (gmsm_small.h)
+            Workspace &ws = first;
+            int rc;
+            if ((rc = ws.h2d_scalars.ensure(n * SCALAR_BYTES))) return rc;
+            HIP_TRY(hipMemcpyAsync(ws.h2d_scalars.ptr, scalars, n * SCALAR_BYTES, hipMemcpyHostToDevice, ws.stream));
+            const void *dp = nullptr;
+            if (points) {
+                if ((rc = ws.h2d_points.ensure(n * AFF_BYTES))) return rc;
+                HIP_TRY(hipMemcpyAsync(ws.h2d_points.ptr, points, n * AFF_BYTES, hipMemcpyHostToDevice, ws.stream));
+                dp = ws.h2d_points.ptr;
+            }
+            const WindowPlan splan = make_plan(small_c(n), 0, 1);
+            if ((rc = enqueue_small(ctx, ws, dp, ws.h2d_scalars.ptr, n, splan, resident))) return rc;
+            std::vector<Ext> totals(splan.nwin_total);
+            if ((rc = collect_window_sums(ws, ws.stream, splan.nwin_total, totals.data()))) return rc;
+            *out = fold(totals.data(), splan.c);
+            return GMSM_OK;
+        }
         const WindowPlan plan = plan_for(resident, n);  // the ranges share one bucket set and one reduction
         const unsigned c = plan.c;
         const unsigned nr = host_range_count(n, points != nullptr, plan);

@@ -137,6 +137,7 @@ int gmsm_multiexp_bases_sharded(uint64_t handle, const uint64_t *scalars, size_t
 int gmsm_bases_precompute(uint64_t handle, unsigned c);
 unsigned gmsm_bases_table_bits(uint64_t handle);
 unsigned long gmsm_debug_table_runs(void); /* pipeline runs that went through window tables so far (tests) */
+unsigned long gmsm_debug_small_runs(void); /* calls served by the fused small-n kernel so far (tests) */
 /* The devices the drop-in entries shard over (one entry per logical rank); count = 0 restores the default (GMSM_DEVICES
  * if set, else no spreading: one device).  gmsm_get_devices returns the number of configured ranks (1 and the calling
  * thread's device when nothing is configured; -1 when GMSM_DEVICES is malformed) and writes up to max_devices of them
@@ -313,9 +314,13 @@ enum gmsm_option {
     GMSM_OPT_MAX_RUN = 2,     /* lower the 2^27-point cap of one pipeline run: larger calls split into point ranges */
     GMSM_OPT_HOST_RANGES = 3, /* force the number of point ranges a host-buffer call is cut into */
     GMSM_OPT_FIXED_BASE_BITS = 4, /* table width of gmsm_batch_scalar_mul*: 0 = by batch size (8, and 11 from 2^21 scalars), 2..14 */
-    GMSM_OPT_SPIN_WAIT_US = 5 /* a blocking MultiExp polls its stream for this many microseconds before it parks on it
+    GMSM_OPT_SPIN_WAIT_US = 5, /* a blocking MultiExp polls its stream for this many microseconds before it parks on it
                                  (default 0 = park at once; polling was measured at 5-6 us per call, 0.3-1 %, for a
                                  core kept busy as long as the call runs) */
+    GMSM_OPT_SMALL_BITS = 6,  /* the fused small-n kernel (one launch, LDS buckets; calls of at most a few thousand points
+                                 that neither force a window width nor are served by window tables): 0 (default) = on, width
+                                 by size; 1 = off (the sorted pipeline for every size); 2..7 = on with this window width */
+    GMSM_OPT_SMALL_MAX = 7    /* largest call the fused small-n kernel takes (0 = the measured default) */
 };
 int gmsm_set_option(int key, unsigned value);
 unsigned gmsm_get_option(int key);

@@ -1,0 +1,107 @@
+"""GPU parity tests of the fused small-n kernel (gnark-crypto_amd/csrc/gmsm_small.h: one launch, one workgroup per window and
+slice, buckets in LDS) against the CPU oracle: the sizes the reference benches from (multiexp_test.go:344) and Pedersen /
+KZG batch verification issue (fr/pedersen/pedersen.go:100-131)."""
+import numpy as np
+import pytest
+
+from conftest import ALL_GROUPS, random_scalars, rng_for, scalars_from_ints
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [1, 2, 3, 31, 73, 257, 1023, 4099]
+
+
+def _small_runs(gm):
+    return int(gm._lib.load().gmsm_debug_small_runs())
+
+
+def _inputs(o, g, n, seed):
+    rng = rng_for(41, g.gid, n, seed)
+    pts = o.gen_points(n, 1234 + n, 77, nthreads=8)
+    sc = random_scalars(rng, g.curve, n)
+    if n >= 31:  # infinities, duplicated (point, scalar) pairs, zero scalars, edge values (SURVEY.md 8(d) adversarial set)
+        pts[[5, 17]] = 0
+        pts[11] = pts[3]
+        sc[11] = sc[3]
+        pts[13] = pts[7]
+        sc[20] = 0
+        sc[21:26] = scalars_from_ints(g.curve, [1, 2, g.curve.r - 1, 1 << 64, (1 << 128) + 5])
+    return pts, sc
+
+
+@pytest.mark.parametrize("curve,which", ALL_GROUPS)
+def test_small_kernel_matches_oracle(gm, oracle_mod, curve, which):
+    """Every size through the fused kernel (one and several slices per window), host entry and device entry, against the
+    oracle's MultiExp on the same input."""
+    import torch
+    g = (gm.G1Affine if which == "g1" else gm.G2Affine)(curve)
+    o = oracle_mod.Oracle(curve, which)
+    with gm.options(small_max=8192):
+        for n in SIZES:
+            pts, sc = _inputs(o, g, n, 0)
+            expected = o.msm_affine(pts, sc, nthreads=8)
+            before = _small_runs(gm)
+            aff, err = g.MultiExp(pts, sc)
+            assert err is None and (aff == expected).all(), n
+            d_pts = torch.from_numpy(pts.view(np.int64)).cuda()
+            d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+            jac = g.multiexp_device(d_pts.data_ptr(), d_sc.data_ptr(), n)
+            assert (g.jac_to_affine(jac) == expected).all(), n
+            assert _small_runs(gm) == before + 2, n  # both calls took the fused kernel
+
+
+@pytest.mark.parametrize("curve,which", [("bn254", "g1"), ("bls12_381", "g2"), ("bw6_761", "g1")])
+def test_small_kernel_every_width_and_skew(gm, oracle_mod, curve, which):
+    """Forced window widths 2..7 (the top window's short digit, the borrow chain), all scalars equal / all points equal
+    (one run of maximal length: the doubling steps inside a run, the P + P and P - P cases of the addition), all-zero
+    scalars and all points at infinity."""
+    g = (gm.G1Affine if which == "g1" else gm.G2Affine)(curve)
+    o = oracle_mod.Oracle(curve, which)
+    n = 600
+    pts, sc = _inputs(o, g, n, 1)
+    expected = o.msm_affine(pts, sc, nthreads=8)
+    for c in range(2, 8):
+        with gm.options(small_bits=c):
+            before = _small_runs(gm)
+            aff, err = g.MultiExp(pts, sc)
+            assert err is None and (aff == expected).all(), c
+            assert _small_runs(gm) == before + 1
+    equal = np.tile(sc[:1], (n, 1))
+    assert (g.MultiExp(pts, equal)[0] == o.msm_affine(pts, equal, nthreads=8)).all()
+    same = np.tile(pts[:1], (n, 1))
+    assert (g.MultiExp(same, equal)[0] == o.msm_affine(same, equal, nthreads=8)).all()
+    assert (g.MultiExp(same, sc)[0] == o.msm_affine(same, sc, nthreads=8)).all()
+    neg = same.copy()  # P and -P alternate with equal scalars: the running sums pass through infinity
+    neg[1::2] = o.msm_affine(same[:1], scalars_from_ints(g.curve, [g.curve.r - 1]))
+    assert (g.MultiExp(neg, equal)[0] == o.msm_affine(neg, equal, nthreads=8)).all()
+    zeros = np.zeros_like(sc)
+    assert (g.MultiExp(pts, zeros)[0] == 0).all()
+    assert (g.MultiExp(np.zeros_like(pts), sc)[0] == 0).all()
+
+
+def test_small_kernel_over_registered_bases_and_off_switch(gm, oracle_mod):
+    """Registered bases (the rewritten form + infinity flags) through the fused kernel; GMSM_OPT_SMALL_BITS = 1 switches it
+    off and the sorted pipeline returns the same point."""
+    import torch
+    g = gm.G1Affine("bn254")
+    gj = gm.G1Jac("bn254")
+    o = oracle_mod.Oracle("bn254", "g1")
+    n = 1500
+    pts, sc = _inputs(o, g, n, 2)
+    expected = o.msm_affine(pts, sc, nthreads=8)
+    rb = gj.register_bases(points=pts)
+    try:
+        for m in (n, 700, 3):
+            before = _small_runs(gm)
+            jac, err = rb.MultiExp(sc[:m], gm.MultiExpConfig())
+            assert err is None and (gj.jac_to_affine(jac) == o.msm_affine(pts[:m], sc[:m], nthreads=8)).all(), m
+            d_sc = torch.from_numpy(sc[:m].view(np.int64)).cuda()
+            assert (gj.jac_to_affine(rb.multiexp_device(d_sc.data_ptr(), m)) == o.msm_affine(pts[:m], sc[:m], nthreads=8)).all(), m
+            assert _small_runs(gm) == before + 2
+    finally:
+        rb.release()
+    with gm.options(small_bits=1):
+        before = _small_runs(gm)
+        aff, err = g.MultiExp(pts, sc)
+        assert err is None and (aff == expected).all()
+        assert _small_runs(gm) == before

@@ -38,7 +38,7 @@ for step in "$@"; do
                set -- $cg; timeout 600 python tools/bench_small_n.py $1 $2 --no-cpu --logns=5,8,10,12 > $O/small_$1_$2.json 2> $O/small_$1_$2.log; echo "== $cg"; grep -v Warning $O/small_$1_$2.log
              done ;;
     profile) timeout 1500 tools/profile_round.sh $L/prof > $O/profile_round.log 2>&1; tail -3 $O/profile_round.log ;;
-    cmd:*)   k=$((k+1)); ( eval "timeout ${GMSM_CMD_TIMEOUT:-600} ${step#cmd:}" ) > $O/cmd_$k.log 2>&1; echo "[cmd_$k rc=$?]"; tail -30 $O/cmd_$k.log ;;
+    cmd:*)   k=$((k+1)); ( timeout ${GMSM_CMD_TIMEOUT:-600} bash -c "${step#cmd:}" ) > $O/cmd_$k.log 2>&1; echo "[cmd_$k rc=$?]"; tail -30 $O/cmd_$k.log ;;
     *)       echo "unknown step $step" ;;
   esac
   echo "[$step: $(( $(date +%s) - t0 )) s]"
