@@ -27,6 +27,10 @@ Rank 0 prints one JSON line.  Besides the contract fields it carries
   replica_batch (--batch K) K MultiExp over the same registered bases spread over the ranks, one all-gather of results
   fft           fr/fft beside the MSM (BN254 2^20 / 2^24, BLS12-381 and BW6-761 fr 2^24, one coset + inverse timing)
   next_rows     SURVEY.md §8(f) N3 / N4-ingest: fixed-base batch 2^20 / 2^24, raw decode + validation 2^22, SRS dump 2^24
+  distributions the reference's BenchmarkMultiExpG1 scalar distributions (smallvalues, redundancy) + value_one / all_equal at 2^20 and
+                2^24 (BN254 G1) and BLS12-381 G2 2^22: ms, ratio to uniform, stage_ms, cold ms, closed-form bit_exact per row
+  small_n       2^5 .. 2^16 points (BN254 G1): resident ms, cold ms through the drop-in entry, the CPU port with one thread
+                (NbTasks 1) and with all cores; the measured crossover
   n24, tail     LAST keys of the line (the driver keeps the last 2000 characters): the 2^24 half of the metric in compact
                 form, and the headline's value_cold / value_warm_bases / bit_exact
 N > 1 adds backend / rccl_ranks / devices_seen (what the process group really was).  --oversubscribe (or
@@ -466,20 +470,71 @@ def dist_max(torch, dist, seconds):
     return float(t.item())
 
 
-def sharded_also(gm, torch, dist, sharding, rank, world, dev_index, mode, rank_devices, logn=24, steps=5):
+SHARD_CHUNK_LOG = 20  # synthetic inputs of the sharded rows are generated in chunks of 2^20, seeded per chunk: a rank builds only what it owns
+
+
+def chunked_scalars(g, logn, tag, lo, hi):
+    """Rows [lo, hi) of the (2^logn, fr_limbs) uniform scalar array `tag` (0: the a_i of the bases [a_i]G, 1: the b_i), the
+    same on every rank whatever its slice: chunk k is seeded by (logn, tag, k)."""
+    ch = 1 << min(SHARD_CHUNK_LOG, logn)
+    out = np.empty((hi - lo, g.fr_limbs), dtype=np.uint64)
+    for k in range(lo // ch, (hi + ch - 1) // ch):
+        rows = uniform_scalars(np.random.default_rng([0x6D736D, logn, 5, tag, k]), g, ch)
+        s0, s1 = max(lo, k * ch), min(hi, (k + 1) * ch)
+        out[s0 - lo:s1 - lo] = rows[s0 - k * ch:s1 - k * ch]
+    return out
+
+
+def max_over_ranks(dist, world, value):
+    """max over the ranks of a dict of floats (or a float), through the process group's object gather."""
+    if world == 1:
+        return value
+    got = [None] * world
+    dist.all_gather_object(got, value)
+    if isinstance(value, dict):
+        return {k: max(v[k] for v in got) for k in value}
+    return max(got)
+
+
+def exchange_breakdown(torch, g, sharding, plan, enqueue, exchange, reps=3):
+    """One sharded MultiExp cut at its two joints (a synchronize after the local pipeline, one after the gather): ms of
+    the local compute, of the exchange (all-gather + copy of the gathered block to the host) and of the fold. A breakdown,
+    measured outside the timed loop - the timed loop runs the three back to back."""
+    comp = gath = fold = 0.0
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        enqueue(plan, exchange.local)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        gathered = exchange.gather()
+        t2 = time.perf_counter()
+        if plan["mode"] == "points":
+            g.fold_window_sets(gathered, plan["c"])
+        else:
+            g.fold_windows(sharding.unpack_gathered(gathered, plan["nwin"], exchange.world, g.xyzz_limbs), plan["c"])
+        t3 = time.perf_counter()
+        comp, gath, fold = comp + (t1 - t0), gath + (t2 - t1), fold + (t3 - t2)
+    return {"compute_ms": comp / reps * 1e3, "gather_ms": gath / reps * 1e3, "fold_ms": fold / reps * 1e3}
+
+
+def sharded_also(gm, lib, torch, dist, sharding, rank, world, dev_index, mode, rank_devices, logn=24, steps=5, with_c_abi=True):
     """BASELINE.json configs[2]: BN254 G1 2^logn as ONE MultiExp over all ranks, timed like the headline loop (barrier +
-    synchronize on both sides, max over ranks). Every rank builds the same bases [a_i]G on its device from the same
-    seed; the result is checked against the closed form [sum a_i b_i]G on rank 0."""
+    synchronize on both sides, max over ranks). Every rank builds ITS bases [a_i]G on its device from per-chunk seeds; the
+    result is checked against the closed form [sum a_i b_i]G (every rank contributes the dot product of its point slice).
+    stage_ms = max over ranks of the per-stage device times, exchange_ms = all-gather + D2H + fold (max over ranks)."""
+    t_leg = time.perf_counter()
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle  # test infrastructure: the checker
     g = gm.G1Jac("bn254")
     n = 1 << logn
-    rng = np.random.default_rng([0x6D736D, logn, 5, 0])
-    a = uniform_scalars(rng, g, n)
-    b = uniform_scalars(rng, g, n)
     stream = torch.cuda.current_stream().cuda_stream
     plan = sharding.shard_plan(g, n, rank, world, mode)
     lo, hi = plan["lo"], plan["hi"]
-    d_a = torch.from_numpy(a[lo:hi].view(np.int64)).cuda()
-    d_b = torch.from_numpy(b[lo:hi].view(np.int64)).cuda()
+    a = chunked_scalars(g, logn, 0, lo, hi)
+    b = chunked_scalars(g, logn, 1, lo, hi)
+    d_a = torch.from_numpy(a.view(np.int64)).cuda()
+    d_b = torch.from_numpy(b.view(np.int64)).cuda()
     d_pts = torch.empty((hi - lo, g.aff_limbs), dtype=torch.int64, device="cuda")
     g.batch_scalar_mul_device(g.generator, d_a.data_ptr(), hi - lo, d_pts.data_ptr(), stream)
     del d_a
@@ -504,30 +559,54 @@ def sharded_also(gm, torch, dist, sharding, rank, world, dev_index, mode, rank_d
     dt = time.perf_counter() - t0
     if world > 1:
         dt = dist_max(torch, dist, dt)
+    prof = StageProfile(lib)  # the stage breakdown: the same steps once more, outside the timed region
+    prof.start()
+    for _ in range(steps):
+        sharding.sharded_multiexp_exchange(g, plan, enqueue, exchange)
+    sync()
+    stages, _ = prof.stop()
+    stages = max_over_ranks(dist, world, {k: v for k, v in stages.items() if k != "reserved"})
+    brk = max_over_ranks(dist, world, exchange_breakdown(torch, g, sharding, plan, enqueue, exchange))
+    sync()
+    # closed form: sum a_i b_i over this rank's share of the points (window mode: every rank holds them all)
+    fr = oracle.Field("bn254_fr", g.fr_limbs)
+    s_lo, s_hi = sharding.point_slice(n, rank, world) if plan["mode"] == "windows" else (lo, hi)
+    part = fr.from_mont(fr.dot(a[s_lo - lo:s_hi - lo], b[s_lo - lo:s_hi - lo]))
+    part = sum(int(v) << (64 * i) for i, v in enumerate(part))
+    parts = [part]
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, part)
     out = {"workload": f"BN254 G1 MultiExp 2^{logn} points, {plan['mode']}-sharded x{world} + one all-gather ({dist.get_backend()})",
            "value": steps / dt, "unit": "MSM/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "n_gpus": world,
-           "scaling": "strong"}
+           "scaling": "strong", "window_bits": plan["c"], "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+           "stage_ms_note": "max over the ranks of each stage's device time, measured outside the timed loop",
+           "compute_ms": round(brk["compute_ms"], 4), "exchange_ms": round(brk["gather_ms"] + brk["fold_ms"], 4),
+           "exchange_parts_ms": {"all_gather_and_d2h": round(brk["gather_ms"], 4), "fold": round(brk["fold_ms"], 4)}}
     expected = None
     if rank == 0:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle  # test infrastructure: the checker
-        expected = oracle.Oracle("bn254", "g1").fixed_base_msm_affine(a, b)
+        o = oracle.Oracle("bn254", "g1")
+        expected = o.jac_to_affine(o.scalar_mul(o.generator, sum(parts) % g.curve.r))
         out["bit_exact"] = bool((g.jac_to_affine(jac) == expected).all())
     del d_pts, d_b
     torch.cuda.empty_cache()
 
     def through_the_c_abi():  # rank 0 alone drives all `world` devices from its one process
-        d_a0 = torch.from_numpy(a.view(np.int64)).cuda()
+        a0 = chunked_scalars(g, logn, 0, 0, n)
+        b0 = chunked_scalars(g, logn, 1, 0, n)
+        d_a0 = torch.from_numpy(a0.view(np.int64)).cuda()
         d_p0 = torch.empty((n, g.aff_limbs), dtype=torch.int64, device="cuda")
         g.batch_scalar_mul_device(g.generator, d_a0.data_ptr(), n, d_p0.data_ptr(), stream)
         pts_host = d_p0.cpu().numpy().view(np.uint64)
         del d_a0, d_p0
         torch.cuda.empty_cache()
-        return c_abi_sharded(gm, g, pts_host, b, rank_devices, expected, reps=3)
-    if world > 1:
+        return c_abi_sharded(gm, g, pts_host, b0, rank_devices, expected, reps=3)
+    if world > 1 and with_c_abi:
         rec = host_side_wait(dist, rank, f"c_abi_{logn}", through_the_c_abi)
         if rank == 0:
             out["c_abi_sharded"] = rec
+    out["leg_elapsed_s"] = round(time.perf_counter() - t_leg, 1)
+    print(f"[bench] sharded 2^{logn} x{world}: {out['ms_per_step']:.3f} ms/step, leg {out['leg_elapsed_s']} s", file=sys.stderr, flush=True)
     return out
 
 
@@ -736,7 +815,8 @@ def main():
                     help="also time K MultiExp over the same registered bases spread over the ranks (replica mode)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="N>1 rehearsal on fewer devices than ranks: rank r on device r %% device_count, gloo process group")
-    ap.add_argument("--also-logn", type=int, default=24, help="N>1: size of the second sharded MultiExp (the 2^24 half of the metric)")
+    ap.add_argument("--also-logn", type=int, default=24, help="N>1: the sharded row that also runs through the C ABI (the 2^24 half of the metric)")
+    ap.add_argument("--sharded-logns", default="22,24,26", help="N>1: sizes of the sharded rows beside the headline (north_star: 2^20-2^26)")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the N3 / N4-ingest rows")
     ap.add_argument("--curve", default="bn254", help="exploration only: bn254 | bls12_381 | bw6_761")
     ap.add_argument("--group", default="g1", help="exploration only: g1 | g2")
@@ -994,10 +1074,21 @@ def main():
             c_abi = through_the_c_abi()
 
     # N > 1: the 2^24 half of BASELINE.json's metric, sharded the same way (every rank takes part; rank 0 reports)
-    also_sharded = None
+    also_sharded, sharded_rows = None, []
+    headline_parts = None
+    if sharded:
+        # the headline's stage times (max over ranks) and its exchange, cut at the joints (outside the timed loop)
+        stages = max_over_ranks(dist, world, stages)
+        headline_parts = max_over_ranks(dist, world, exchange_breakdown(torch, g, sharding, plan, enqueue, exchange))
     if sharded and not args.no_also and (args.curve, args.group) == ("bn254", "g1"):
         del d_pts_loc, d_sc_loc
-        also_sharded = sharded_also(gm, torch, dist, sharding, rank, world, dev_index, args.shard, rank_devices, logn=args.also_logn)
+        logns = sorted({int(x) for x in args.sharded_logns.split(",") if x} | {args.also_logn})
+        for ln in logns:
+            row = sharded_also(gm, lib, torch, dist, sharding, rank, world, dev_index, args.shard, rank_devices, logn=ln,
+                               steps=3 if ln >= 26 else 5, with_c_abi=(ln == args.also_logn))
+            sharded_rows.append(row)
+            if ln == args.also_logn:
+                also_sharded = row
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -1040,11 +1131,19 @@ def main():
             # the sharded result against the same MultiExp computed by this rank alone (after the timed region)
             single = g.multiexp_device(d_pts.data_ptr(), d_sc.data_ptr(), n, stream)
             out["equal_to_single_gpu_result"] = bool((g.jac_to_affine(single) == g.jac_to_affine(jac)).all())
+            if headline_parts is not None:
+                out["compute_ms"] = round(headline_parts["compute_ms"], 4)
+                out["exchange_ms"] = round(headline_parts["gather_ms"] + headline_parts["fold_ms"], 4)
+                out["exchange_parts_ms"] = {"all_gather_and_d2h": round(headline_parts["gather_ms"], 4), "fold": round(headline_parts["fold_ms"], 4)}
+                out["stage_ms_note"] = "max over the ranks; " + STAGE_NOTE
             if also_sharded is not None:
-                out["also"] = [also_sharded]
+                out["also"] = [r for r in sharded_rows if r is not also_sharded] + [also_sharded]  # the 2^24 row last
                 cab = also_sharded.get("c_abi_sharded") or {}
                 out["n24"] = {"workload": also_sharded["workload"], "ms_per_step": round(also_sharded["ms_per_step"], 4),
                               "value": round(also_sharded["value"], 3), "bit_exact": also_sharded.get("bit_exact"),
+                              "compute_ms": also_sharded["compute_ms"], "exchange_ms": also_sharded["exchange_ms"],
+                              "sharded_rows": {r["workload"].split(" points")[0].split()[-1]: [round(r["ms_per_step"], 3), r.get("bit_exact")]
+                                               for r in sharded_rows},  # "2^22": [ms_per_step, bit_exact], ...
                               "c_abi_cold_ms": cab.get("cold_ms"), "c_abi_warm_bases_ms": cab.get("warm_bases_ms"),
                               "c_abi_equal_to_reference_result": cab.get("equal_to_reference_result")}
             tail = {"backend": out["backend"], "rccl_ranks": out["rccl_ranks"], "devices_seen": rank_devices,
@@ -1061,6 +1160,13 @@ def main():
             if not args.no_next_rows:
                 out["next_rows"] = next_rows(gm, lib, torch)
                 torch.cuda.empty_cache()
+            # the reference's own benchmark matrix: every size under skewed scalar distributions, and the sizes below 2^20
+            out["distributions"] = distributions_block(gm, lib, torch)
+            g2 = distributions_block(gm, lib, torch, configs=(("bls12_381", "g2", 22, 3),), kinds=["uniform", "smallvalues"], cold=False)
+            out["distributions"]["rows"] += g2["rows"]
+            out["distributions"]["worst_vs_uniform"] = max(out["distributions"]["worst_vs_uniform"], g2["worst_vs_uniform"])
+            out["distributions"]["all_bit_exact"] = out["distributions"]["all_bit_exact"] and g2["all_bit_exact"]
+            out["small_n"] = small_n_block(gm, torch)
             out["also"] = [also_config(gm, lib, torch, *cfg_) for cfg_ in ALSO
                            if (cfg_[0], cfg_[1], cfg_[2]) != (args.curve, args.group, args.logn)]
             r24 = next((r for r in out["also"] if r["workload"].startswith("BN254 G1 MultiExp 2^24")), None)
@@ -1076,6 +1182,11 @@ def main():
         for k in ("value_cold", "value_warm_bases", "bit_exact"):
             if k in out:
                 tail[k] = out[k]
+        if "distributions" in out:
+            tail["distributions_worst_vs_uniform"] = out["distributions"]["worst_vs_uniform"]
+            tail["distributions_all_bit_exact"] = out["distributions"]["all_bit_exact"]
+        if "small_n" in out:
+            tail["small_n_ms"] = {f"2^{r['logn']}": r["resident_ms"] for r in out["small_n"]["rows"]}
         tail.update({"value": round(value, 3), "ms_per_step": round(ms_per_step, 4), "n_gpus": world})
         out["tail"] = tail
         print(json.dumps(out), file=json_out, flush=True)

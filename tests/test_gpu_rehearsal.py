@@ -25,8 +25,8 @@ def run_bench(*args, timeout=900):
     return json.loads(lines[0]), lines[0]
 
 
-@pytest.mark.parametrize("world,extra", [(2, ["--logn", "20", "--also-logn", "21"]),              # windows, then points
-                                         (8, ["--logn", "18", "--also-logn", "20", "--shard", "points"])])
+@pytest.mark.parametrize("world,extra", [(2, ["--logn", "20", "--also-logn", "21", "--sharded-logns", "19,21,22"]),   # windows, then points
+                                         (8, ["--logn", "18", "--also-logn", "20", "--sharded-logns", "19,20", "--shard", "points"])])
 def test_bench_sharded_branch_oversubscribed(world, extra):
     rec, line = run_bench("--gpus", str(world), "--oversubscribe", "--steps", "3", "--warmup", "1", *extra)
     assert rec["n_gpus"] == world and rec["steps"] == 3 and rec["scaling"] == "strong"
@@ -35,9 +35,16 @@ def test_bench_sharded_branch_oversubscribed(world, extra):
     assert rec["equal_to_single_gpu_result"] is True
     assert rec["c_abi_sharded"]["equal_to_reference_result"] is True
     assert rec["c_abi_sharded"]["devices"] == rec["devices_seen"]
-    also = rec["also"][0]
+    also = rec["also"][-1]  # the --also-logn row comes last; the other sharded rows before it
     assert also["n_gpus"] == world and also["bit_exact"] is True
     assert also["c_abi_sharded"]["equal_to_reference_result"] is True
+    for row in rec["also"]:  # every sharded row is attributable: per-stage device times (max over ranks) and the exchange
+        assert row["bit_exact"] is True and row["n_gpus"] == world
+        assert row["stage_ms"]["accumulate"] > 0 and row["exchange_ms"] > 0 and row["compute_ms"] > 0
+        assert ("c_abi_sharded" in row) == (row is also)
+    assert len(rec["also"]) == len(extra[extra.index("--sharded-logns") + 1].split(","))
+    assert rec["exchange_ms"] > 0 and rec["stage_ms"]["accumulate"] > 0
+    assert all(v[1] is True for v in rec["n24"]["sharded_rows"].values())
     assert rec["n24"]["bit_exact"] is True and rec["n24"]["c_abi_equal_to_reference_result"] is True
     # the driver keeps the last 2000 characters of the line: the verdict fields must sit there
     kept = line[-2000:]

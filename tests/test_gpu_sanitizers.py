@@ -1,7 +1,8 @@
 """ThreadSanitizer / AddressSanitizer runs of the host shim (SURVEY.md §5 "ASan for the host shim"; the reference's CI runs
 `go test -race ./ecc/bn254/...`, .github/workflows/pr.yml:63).  The sanitizer libraries are separate builds
-(`make -C gnark-crypto_amd/csrc tsan asan`, ~4 minutes each, not part of build()): the tests skip when they have not been
-built.  tests/c/race_client.c - six threads over every kind of entry, handles released under use, tables appearing under
+(`make -C gnark-crypto_amd/csrc tsan asan`, ~4 minutes each; build() makes them when GMSM_BUILD_SANITIZERS=1): the tests
+skip when they have not been built - unless GMSM_REQUIRE_SANITIZERS=1 (tools/gpu_session.sh sets it for the round's suite
+runs), which turns the skip into a failure so that a clean clone cannot report green without them unnoticed.  tests/c/race_client.c - six threads over every kind of entry, handles released under use, tables appearing under
 use, first-use coset tables, trim under load, shutdown and restart - must finish with equal results and without a
 sanitizer report that names libgmsm code."""
 import os
@@ -31,6 +32,8 @@ TEARDOWN_CHECK = 'CHECK failed: sanitizer_allocator_device.h'
 def test_race_client_under_sanitizer(kind, flag, tmp_path):
     lib = os.path.join(CSRC, f"build_{kind}", f"libgmsm_{kind}.so")
     if not os.path.exists(lib):
+        if os.environ.get("GMSM_REQUIRE_SANITIZERS") == "1":
+            pytest.fail(f"{lib} not built and GMSM_REQUIRE_SANITIZERS=1 (GMSM_BUILD_SANITIZERS=1 python -c 'import __graft_entry__ as g; g.build()')")
         pytest.skip(f"{lib} not built (make -C gnark-crypto_amd/csrc {kind})")
     rt = clang_rt_dir()
     exe = str(tmp_path / f"race_client_{kind}")
