@@ -372,7 +372,7 @@ def distributions_block(gm, lib, torch, configs=(("bn254", "g1", 20, 10), ("bn25
                     "ms = resident inputs, cold_ms = host buffers through the drop-in entry (median of 3); bit_exact = closed form"}
 
 
-def small_n_block(gm, torch, curve="bn254", group="g1", logns=(5, 6, 8, 10, 12, 14, 16), reps=30, with_cpu=True):
+def small_n_block(gm, torch, curve="bn254", group="g1", logns=(2, 3, 4, 5, 6, 8, 10, 12, 14, 16), reps=30, with_cpu=True):
     """Sizes below 2^20 (the reference benches from 2^5, multiexp_test.go:344; Pedersen commits with NbTasks: 1,
     fr/pedersen/pedersen.go:100-131): per size the resident ms, the cold drop-in entry (host buffers in, Jacobian out), and
     the CPU port with one thread (NbTasks 1) and with all cores - the measured GPU/CPU crossover the Go stub routes by."""

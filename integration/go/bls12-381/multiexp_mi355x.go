@@ -1,9 +1,9 @@
 //go:build mi355x
 
-// MI355X drop-in for (*G1Jac).MultiExp / (*G2Jac).MultiExp of package bn254.
+// MI355X drop-in for (*G1Jac).MultiExp / (*G2Jac).MultiExp of package bls12381.
 //
 // Go build constraints select FILES, not methods, so the patch to the package has three parts (integration/go/README.md):
-//  1. in the generated multiexp.go the two methods (*G1Jac).MultiExp (:32) and (*G2Jac).MultiExp (:357) are renamed
+//  1. in the generated multiexp.go the two methods (*G1Jac).MultiExp (:32) and (*G2Jac).MultiExp (:355) are renamed
 //     multiExpCPU (one line each in internal/generator/ecc/template/multiexp.go.tmpl:247; the recursive calls at :350/:353
 //     follow the rename) - the reference's own code, always compiled;
 //  2. multiexp_purego.go (//go:build !mi355x) keeps the exported methods as one-line wrappers around multiExpCPU;
@@ -11,7 +11,7 @@
 //
 // NOT compiled in the build environment of this repository (no Go toolchain there); the behaviour of the C entry
 // points it calls is covered by tests/ through the same C ABI.  See INTEGRATION.md.
-package bn254
+package bls12381
 
 /*
 #cgo CFLAGS: -I${SRCDIR}/../../third_party/gmsm/include
@@ -25,7 +25,7 @@ import (
 	"unsafe"
 
 	"github.com/consensys/gnark-crypto/ecc"
-	"github.com/consensys/gnark-crypto/ecc/bn254/fr"
+	"github.com/consensys/gnark-crypto/ecc/bls12-381/fr"
 )
 
 // MinDevicePoints is the smallest MultiExp that goes to the GPU; shorter ones run the package's own Go code
@@ -59,7 +59,7 @@ func (p *G1Jac) MultiExp(points []G1Affine, scalars []fr.Element, config ecc.Mul
 	if len(points) < MinDevicePoints { // includes len == 0: the reference returns infinity
 		return p.multiExpCPU(points, scalars, config)
 	}
-	rc := C.gmsm_bn254_g1_multiexp(
+	rc := C.gmsm_bls12_381_g1_multiexp(
 		(*C.uint64_t)(unsafe.Pointer(&points[0])), C.size_t(len(points)),
 		(*C.uint64_t)(unsafe.Pointer(&scalars[0])), C.size_t(len(scalars)),
 		C.int(config.NbTasks), (*C.uint64_t)(unsafe.Pointer(p)))
@@ -80,7 +80,7 @@ func (p *G2Jac) MultiExp(points []G2Affine, scalars []fr.Element, config ecc.Mul
 	if len(points) < MinDevicePoints {
 		return p.multiExpCPU(points, scalars, config)
 	}
-	rc := C.gmsm_bn254_g2_multiexp(
+	rc := C.gmsm_bls12_381_g2_multiexp(
 		(*C.uint64_t)(unsafe.Pointer(&points[0])), C.size_t(len(points)),
 		(*C.uint64_t)(unsafe.Pointer(&scalars[0])), C.size_t(len(scalars)),
 		C.int(config.NbTasks), (*C.uint64_t)(unsafe.Pointer(p)))
