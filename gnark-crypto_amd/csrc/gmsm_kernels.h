@@ -751,13 +751,16 @@ struct SegFlags {
 };
 
 // waves per SIMD the accumulation kernel is compiled for: 3 for 9-limb coordinates (160 VGPRs, no spills), 2 for 14-limb
-// ones and Fp2 over 9 limbs, 1 (all 512 registers) beyond
+// ones, 1 (all 512 registers) beyond and for Fp2
 #ifndef GMSM_W9
 #define GMSM_W9 3
 #endif
 template <class U> struct AccWaves { static constexpr int value = 1; };
 template <class P> struct AccWaves<FpU<P>> { static constexpr int value = P::UL <= 9 ? GMSM_W9 : (P::UL <= 14 ? 2 : 1); };
-template <class P> struct AccWaves<Fp2U<P>> { static constexpr int value = P::UL <= 9 ? 2 : 1; };
+// Fp2: one wave per SIMD for both base fields. (BN254 G2 ran two waves on 256 registers through round 4; once the signed-limb
+// addition needed 300, that form spilled 67-75 of them into a 212-byte scratch frame inside the loop: one wave on the full
+// register file is 12 % faster - 2^20 accumulate 4.12 -> 3.62 ms, 2^22 15.3 -> 13.0, profiles/r05_g2_waves_ab.log.)
+template <class P> struct AccWaves<Fp2U<P>> { static constexpr int value = 1; };
 
 // The accumulation loop inlines its field products for every element type. (Tried for the two largest - Fp2 over 14
 // limbs, 90 KB of loop body, and 28 limbs, 130 KB, both beyond the 64 KB instruction cache: calling one shared copy of
