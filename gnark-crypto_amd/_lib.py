@@ -202,7 +202,7 @@ def last_error():
 
 
 # enum gmsm_option (include/gmsm.h)
-OPTIONS = {"window_bits": 0, "tables": 1, "max_run": 2, "host_ranges": 3, "fixed_base_bits": 4, "spin_wait_us": 5, "small_bits": 6, "small_max": 7}
+OPTIONS = {"window_bits": 0, "tables": 1, "max_run": 2, "host_ranges": 3, "fixed_base_bits": 4, "spin_wait_us": 5, "small_bits": 6, "small_max": 7, "split": 8}
 
 
 def set_option(name, value):

@@ -64,6 +64,7 @@ struct Options {
     std::atomic<unsigned> fixed_base_bits{0};  // GMSM_OPT_FIXED_BASE_BITS: table width of the fixed-base batch (0 = by size)
     std::atomic<unsigned> spin_wait_us{0};     // GMSM_OPT_SPIN_WAIT_US: poll a call's stream this long before blocking on it (0 = park at once)
     std::atomic<unsigned> small_bits{0};       // GMSM_OPT_SMALL_BITS: the fused small-n kernel: 0 = on, width by size; 1 = off; 2..7 = on, this width
+    std::atomic<unsigned> split{0};            // GMSM_OPT_SPLIT (experiment): two window groups, the first group's fix-up + reduction beside the second's accumulation
     std::atomic<unsigned> small_max{0};        // GMSM_OPT_SMALL_MAX: largest call the fused kernel takes (0 = the measured default)
 };
 Options &options();

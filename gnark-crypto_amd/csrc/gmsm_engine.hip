@@ -1453,6 +1453,7 @@ GMSM_EXPORT int gmsm_set_option(int key, unsigned value) {
             o.small_bits.store(value);
             return GMSM_OK;
         case GMSM_OPT_SMALL_MAX: o.small_max.store(value); return GMSM_OK;
+        case GMSM_OPT_SPLIT: o.split.store(value ? 1 : 0); return GMSM_OK;
         case GMSM_OPT_SPIN_WAIT_US:
             if (value > 1000000) return fail(GMSM_ERR_ARG, "GMSM_OPT_SPIN_WAIT_US: at most 1000000");
             o.spin_wait_us.store(value);
@@ -1472,6 +1473,7 @@ GMSM_EXPORT unsigned gmsm_get_option(int key) {
         case GMSM_OPT_SPIN_WAIT_US: return o.spin_wait_us.load();
         case GMSM_OPT_SMALL_BITS: return o.small_bits.load();
         case GMSM_OPT_SMALL_MAX: return o.small_max.load();
+        case GMSM_OPT_SPLIT: return o.split.load();
         default: return 0;
     }
 }

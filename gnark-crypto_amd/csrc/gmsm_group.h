@@ -407,7 +407,7 @@ struct Group {
         if ((rc = ws.seg_bucket.ensure(tot_thr * 4))) return rc;
         // long-chain list of the fixup (the fix-up kernels append pieces of LONG_PIECE links, k_fixup_long consumes): one counter
         // (slot of the first window; k_part_rowscan zeroes it) + the items: chains have more than FIX_MAXWALK followers
-        const size_t list_cap = tot_thr / FIX_MAXWALK + tot_thr / LONG_PIECE + nw + 16;
+        const size_t list_cap = 2 * (tot_thr / FIX_MAXWALK + tot_thr / LONG_PIECE + nw + 16);  // two halves: one per window group (GMSM_OPT_SPLIT)
         if ((rc = ws.seg_lvl.ensure((size_t)nw * 4 + 16 + list_cap * sizeof(LongChain)))) return rc;
         uint32_t *long_flag = (uint32_t *)ws.seg_lvl.ptr;                                  // [nw] counters, [0] is used
         LongChain *long_list = (LongChain *)((char *)ws.seg_lvl.ptr + (((size_t)nw * 4 + 15) / 16) * 16);
@@ -529,39 +529,67 @@ struct Group {
                            part_base, (const HeavyPart *)hparts, (const uint32_t *)hcount, hcap, scap, subhist, starts);
         hipLaunchKernelGGL(k_heavy_place, dim3(heavy_wg), dim3(1024), (size_t)4 << fbits, stream, parted, n, nw, nparts, fbits, lidx,
                            part_base, (const HeavyPart *)hparts, (const uint32_t *)hcount, hcap, scap, (const uint32_t *)subhist, sorted);
-        // ---- 2. bucket accumulation
+        // ---- 2. bucket accumulation, 3. fix-up, 4. bucket reduction: for the windows [k0, k0 + nk) of the launch - all of
+        // them, or (GMSM_OPT_SPLIT, experiment) two groups: the fix-up and reduction of the first group run on the merge stream
+        // beside the accumulation of the second. Every array is window-major, so a group is the same kernels over shifted
+        // base pointers; each group has its own long-chain counter and its own half of the list.
         if (forked) HIP_TRY(hipStreamWaitEvent(stream, ws.ev_conv, 0));  // the rewritten bases are complete
+        const auto accumulate = [&](uint32_t k0, uint32_t nk, hipStream_t st) {
+            const uint32_t *st_g = starts + (size_t)k0 * (NB + 1);
+            const uint32_t *sorted_g = sorted + (size_t)k0 * n;
+            char *buckets_g = buckets + (size_t)k0 * NB * REC, *part_g = seg_partials + (size_t)k0 * q.tpw * 2 * REC;
+            if (shared)
+                hipLaunchKernelGGL((k_accumulate_seg<U, true>), dim3((q.tpw + 255) / 256, nk), dim3(256), 0, st, upoints, n, NB,
+                                   q.seg, st_g, sorted_g, buckets_g, part_g, seg_flags + (size_t)k0 * q.tpw, seg_bucket + (size_t)k0 * q.tpw,
+                                   q.tpw, (uint32_t)n_points, (uint32_t)resident->n);
+            else
+                hipLaunchKernelGGL((k_accumulate_seg<U, false>), dim3((q.tpw + 255) / 256, nk), dim3(256), 0, st, upoints, n, NB,
+                                   q.seg, st_g, sorted_g, buckets_g, part_g, seg_flags + (size_t)k0 * q.tpw, seg_bucket + (size_t)k0 * q.tpw,
+                                   q.tpw, 0u, 0u);
+        };
+        const auto fixup_and_reduce = [&](uint32_t k0, uint32_t nk, size_t list_off, hipStream_t st, bool mark) {
+            const uint32_t *st_g = starts + (size_t)k0 * (NB + 1);
+            char *buckets_g = buckets + (size_t)k0 * NB * REC, *part_g = seg_partials + (size_t)k0 * q.tpw * 2 * REC;
+            const uint32_t *flags_g = seg_flags + (size_t)k0 * q.tpw, *pb_g = seg_bucket + (size_t)k0 * q.tpw;
+            uint32_t *cnt_g = long_flag + k0;  // k_part_rowscan zeroed every window's slot
+            LongChain *list_g = long_list + list_off;
+            uint32_t *done_g = piece_done + list_off;
+            void *sums_g = (char *)piece_sums + list_off * REC;
+            if (shared && n / NB >= 2 * (size_t)q.seg)  // buckets of several threads' worth of entries (dense chains): one thread per bucket
+                hipLaunchKernelGGL((k_fixup_bucket<OpsSerial>), dim3((NB + 255) / 256, nk), dim3(256), 0, st, NB, st_g, q.seg,
+                                   (const void *)part_g, q.tpw, (void *)buckets_g, cnt_g, list_g, done_g, FIX_MAXWALK);
+            else if constexpr (FIXUP_QUAD)
+                hipLaunchKernelGGL((k_fixup_seg_q<U>), dim3((q.tpw + 63) / 64, nk), dim3(256), 128 * sizeof(QRec<U>), st, NB,
+                                   (const void *)part_g, flags_g, pb_g, q.tpw, (void *)buckets_g, cnt_g, list_g, done_g, FIX_MAXWALK, st_g, q.seg);
+            else
+                hipLaunchKernelGGL((k_fixup_seg<OpsSerial>), dim3((q.tpw + 255) / 256, nk), dim3(256), 0, st, NB, part_g, flags_g, pb_g,
+                                   q.tpw, buckets_g, cnt_g, list_g, done_g, FIX_MAXWALK, st_g, q.seg);
+            hipLaunchKernelGGL((k_fixup_long<U>), dim3(2 * ctx.num_cus), dim3(256), 128 * sizeof(QRec<U>), st, NB, part_g, pb_g, q.tpw,
+                               buckets_g, (const uint32_t *)cnt_g, (const LongChain *)list_g, done_g, sums_g, st_g, q.seg);
+            // ---- bucket reduction -> window totals (empty buckets are never written: the reduction consults starts[])
+            if (mark) timer.mark(T_REDUCE, st);
+            if (!buckets_only) enqueue_reduce_kernels(ctx, ws, q, T, buckets_g, st_g, nk, NB, st, k0);
+        };
+        const bool split = options().split.load(std::memory_order_relaxed) != 0 && !buckets_only && !shared && nw >= 4 && q.nblocks2 == 0;
         timer.mark(T_ACCUMULATE, stream);
-        if (shared)
-            hipLaunchKernelGGL((k_accumulate_seg<U, true>), dim3((q.tpw + 255) / 256, nw), dim3(256), 0, stream, upoints, n, NB,
-                               q.seg, starts, sorted, buckets, seg_partials, seg_flags, seg_bucket, q.tpw, (uint32_t)n_points,
-                               (uint32_t)resident->n);
-        else
-            hipLaunchKernelGGL((k_accumulate_seg<U, false>), dim3((q.tpw + 255) / 256, nw), dim3(256), 0, stream, upoints, n, NB,
-                               q.seg, starts, sorted, buckets, seg_partials, seg_flags, seg_bucket, q.tpw, 0u, 0u);
-        timer.mark(T_FIXUP, stream);
-        if (shared && n / NB >= 2 * (size_t)q.seg)  // buckets of several threads' worth of entries (dense chains): one thread per bucket
-            hipLaunchKernelGGL((k_fixup_bucket<OpsSerial>), dim3((NB + 255) / 256, nw), dim3(256), 0, stream, NB,
-                               (const uint32_t *)starts, q.seg, (const void *)seg_partials, q.tpw, (void *)buckets, long_flag, long_list,
-                               piece_done, FIX_MAXWALK);
-        else if constexpr (FIXUP_QUAD)
-            hipLaunchKernelGGL((k_fixup_seg_q<U>), dim3((q.tpw + 63) / 64, nw), dim3(256), 128 * sizeof(QRec<U>), stream, NB,
-                               (const void *)seg_partials, (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw,
-                               (void *)buckets, long_flag, long_list, piece_done, FIX_MAXWALK, (const uint32_t *)starts, q.seg);
-        else
-            hipLaunchKernelGGL((k_fixup_seg<OpsSerial>), dim3((q.tpw + 255) / 256, nw), dim3(256), 0, stream, NB, seg_partials,
-                               (const uint32_t *)seg_flags, (const uint32_t *)seg_bucket, q.tpw, buckets, long_flag, long_list, piece_done,
-                               FIX_MAXWALK, (const uint32_t *)starts, q.seg);
-        hipLaunchKernelGGL((k_fixup_long<U>), dim3(2 * ctx.num_cus), dim3(256), 128 * sizeof(QRec<U>), stream, NB, seg_partials,
-                           (const uint32_t *)seg_bucket, q.tpw, buckets, (const uint32_t *)long_flag, (const LongChain *)long_list,
-                           piece_done, piece_sums, (const uint32_t *)starts, q.seg);
-        // ---- 3. bucket reduction -> window totals (empty buckets are never written: the reduction consults starts[])
-        timer.mark(T_REDUCE, stream);
-        if (!buckets_only) {
-            enqueue_reduce_kernels(ctx, ws, q, T, buckets, starts, nw, NB, stream);
-            if (nwd > nw)
-                hipLaunchKernelGGL((k_fill_infinity<Ext>), dim3((nwd - nw + 63) / 64), dim3(64), 0, stream, ws.totals.ptr, nw, nwd - nw);
+        if (!split) {
+            accumulate(0, nw, stream);
+            timer.mark(T_FIXUP, stream);
+            fixup_and_reduce(0, nw, 0, stream, true);
+        } else {
+            const uint32_t ha = nw / 2;
+            accumulate(0, ha, stream);
+            HIP_TRY(hipEventRecord(ws.ev_buckets, stream));
+            HIP_TRY(hipStreamWaitEvent(ws.mstream, ws.ev_buckets, 0));
+            fixup_and_reduce(0, ha, 0, ws.mstream, false);
+            HIP_TRY(hipEventRecord(ws.ev_merged, ws.mstream));
+            accumulate(ha, nw - ha, stream);
+            timer.mark(T_FIXUP, stream);
+            fixup_and_reduce(ha, nw - ha, list_cap / 2, stream, true);
+            HIP_TRY(hipStreamWaitEvent(stream, ws.ev_merged, 0));
         }
+        if (!buckets_only && nwd > nw)
+            hipLaunchKernelGGL((k_fill_infinity<Ext>), dim3((nwd - nw + 63) / 64), dim3(64), 0, stream, ws.totals.ptr, nw, nwd - nw);
         timer.mark(T_END, stream);
         HIP_TRY(hipGetLastError());
         if (!buckets_only) {
@@ -578,16 +606,21 @@ struct Group {
     // The three kernels of the bucket reduction: buckets (nw x NB lazy records; starts == nullptr: every record is
     // stored, infinity as zz = 0) -> ws.totals. Scratch: ws.red_pre, ws.partials.
     static void enqueue_reduce_kernels(Context &ctx, Workspace &ws, const Geometry &q, uint32_t T, const void *buckets,
-                                       const uint32_t *starts, uint32_t nw, uint32_t NB, hipStream_t stream) {
+                                       const uint32_t *starts, uint32_t nw, uint32_t NB, hipStream_t stream,
+                                       uint32_t k0 = 0 /* first window of a group: offsets into the scratch and the totals */) {
+        constexpr size_t RECB = sizeof(typename OpsSerial::Mem);
+        void *red_pre = (char *)ws.red_pre.ptr + (size_t)k0 * T * 2 * RECB;
+        void *partials = (char *)ws.partials.ptr + (size_t)k0 * q.nblocks1 * 2 * RECB;  // (groups only with two levels)
+        void *totals = (char *)ws.totals.ptr + (size_t)k0 * sizeof(Ext);
         // level 1 leaves S_blk already multiplied by the width of the level-2 spans (an otherwise idle quad doubles it
         // log2span times while the trees run): level 2 then has no serial doubling tail
         const uint32_t prescale = q.log2span;
         if constexpr (SERIAL_QUAD)
             hipLaunchKernelGGL((k_reduce_serial_q<U>), dim3((T + 63) / 64, nw), dim3(256), 192 * sizeof(QRec<U>), stream, buckets,
-                               NB, q.log2L, T, starts, ws.red_pre.ptr);
+                               NB, q.log2L, T, starts, red_pre);
         else
             hipLaunchKernelGGL((k_reduce_serial<OpsSerial>), dim3((T + 255) / 256, nw), dim3(256), 0, stream, buckets, NB,
-                               q.log2L, T, starts, ws.red_pre.ptr);
+                               q.log2L, T, starts, red_pre);
         // one combine level: `pairs` (S, W) pairs per window, each the sum of 2^l2 buckets (S prescaled by the caller's
         // factor when l2 == 0) -> `blocks` pairs per window
         const auto combine = [&](const void *in, uint32_t pairs, void *out, uint32_t blocks, uint32_t l2, uint32_t pre) {
@@ -601,17 +634,17 @@ struct Group {
             hipLaunchKernelGGL((k_combine_q<U, true, COMBINE_N>), dim3(blocks, nw), dim3(4 * COMBINE_N),
                                (2 * COMBINE_N + 1) * sizeof(QRec<U>), stream, l2, out, pre, in, pairs);
         };
-        combine(ws.red_pre.ptr, T, ws.partials.ptr, q.nblocks1, q.log2L, prescale);
-        const void *last = ws.partials.ptr;
+        combine(red_pre, T, partials, q.nblocks1, q.log2L, prescale);
+        const void *last = partials;
         uint32_t nlast = q.nblocks1, rest = q.log2span - prescale;
         if (q.nblocks2) {
             // second combine: its input pairs carry S already multiplied by their own span (the prescale above), so the
             // pairs count as single buckets (L = 1); its S_blk is doubled log2 N more times for the last level
             constexpr size_t REC = sizeof(typename OpsSerial::Mem);
-            void *out2 = (char *)ws.partials.ptr + (size_t)nw * q.nblocks1 * 2 * REC;
+            void *out2 = (char *)partials + (size_t)nw * q.nblocks1 * 2 * REC;
             uint32_t lgN = 0;
             for (size_t t = COMBINE_N; t > 1; t >>= 1) ++lgN;
-            combine(ws.partials.ptr, q.nblocks1, out2, q.nblocks2, 0, lgN);
+            combine(partials, q.nblocks1, out2, q.nblocks2, 0, lgN);
             last = out2;
             nlast = q.nblocks2;
             rest = 0;
@@ -619,7 +652,7 @@ struct Group {
         uint32_t active = 2;
         while (active < nlast) active <<= 1;
         hipLaunchKernelGGL((k_reduce2_q<U, true>), dim3(nw), dim3(4 * active), 2 * active * sizeof(QRec<U>), stream, last, nlast,
-                           rest, active, ws.totals.ptr);
+                           rest, active, totals);
         (void)ctx;
     }
 

@@ -320,7 +320,9 @@ enum gmsm_option {
     GMSM_OPT_SMALL_BITS = 6,  /* the fused small-n kernel (one launch, LDS buckets; calls of at most a few thousand points
                                  that neither force a window width nor are served by window tables): 0 (default) = on, width
                                  by size; 1 = off (the sorted pipeline for every size); 2..7 = on with this window width */
-    GMSM_OPT_SMALL_MAX = 7    /* largest call the fused small-n kernel takes (0 = the measured default) */
+    GMSM_OPT_SMALL_MAX = 7,   /* largest call the fused small-n kernel takes (0 = the measured default) */
+    GMSM_OPT_SPLIT = 8        /* experiment (default 0 = off): a call's windows in two groups, the fix-up + reduction of the first on a
+                                 second stream beside the accumulation of the second (measured: profiles/r05_split_groups.log) */
 };
 int gmsm_set_option(int key, unsigned value);
 unsigned gmsm_get_option(int key);
