@@ -351,7 +351,11 @@ struct Group {
         constexpr size_t REC = sizeof(typename OpsSerial::Mem);  // bucket / partial record (lazy representation on the fast path)
 
         const Geometry q = plan_geometry(ctx, nw, n, NB, shared);
-        const size_t tot_thr = (size_t)nw * q.tpw;
+        // GMSM_OPT_SPLIT (experiment): two window groups; each group's accumulation gets the segment length that fills the chip
+        // with HALF the windows (the reduction geometry stays the call's)
+        const bool split = options().split.load(std::memory_order_relaxed) != 0 && !buckets_only && !shared && nw >= 4 && q.nblocks2 == 0;
+        const Geometry qa = split ? plan_geometry(ctx, nw / 2, n, NB, shared) : q;  // accumulation + fix-up geometry
+        const size_t tot_thr = (size_t)nw * qa.tpw;
         const size_t tot_blk = (size_t)nw * q.nblocks1;
 
         // ---- grouping geometry
@@ -537,40 +541,39 @@ struct Group {
         const auto accumulate = [&](uint32_t k0, uint32_t nk, hipStream_t st) {
             const uint32_t *st_g = starts + (size_t)k0 * (NB + 1);
             const uint32_t *sorted_g = sorted + (size_t)k0 * n;
-            char *buckets_g = buckets + (size_t)k0 * NB * REC, *part_g = seg_partials + (size_t)k0 * q.tpw * 2 * REC;
+            char *buckets_g = buckets + (size_t)k0 * NB * REC, *part_g = seg_partials + (size_t)k0 * qa.tpw * 2 * REC;
             if (shared)
-                hipLaunchKernelGGL((k_accumulate_seg<U, true>), dim3((q.tpw + 255) / 256, nk), dim3(256), 0, st, upoints, n, NB,
-                                   q.seg, st_g, sorted_g, buckets_g, part_g, seg_flags + (size_t)k0 * q.tpw, seg_bucket + (size_t)k0 * q.tpw,
-                                   q.tpw, (uint32_t)n_points, (uint32_t)resident->n);
+                hipLaunchKernelGGL((k_accumulate_seg<U, true>), dim3((qa.tpw + 255) / 256, nk), dim3(256), 0, st, upoints, n, NB,
+                                   qa.seg, st_g, sorted_g, buckets_g, part_g, seg_flags + (size_t)k0 * qa.tpw, seg_bucket + (size_t)k0 * qa.tpw,
+                                   qa.tpw, (uint32_t)n_points, (uint32_t)resident->n);
             else
-                hipLaunchKernelGGL((k_accumulate_seg<U, false>), dim3((q.tpw + 255) / 256, nk), dim3(256), 0, st, upoints, n, NB,
-                                   q.seg, st_g, sorted_g, buckets_g, part_g, seg_flags + (size_t)k0 * q.tpw, seg_bucket + (size_t)k0 * q.tpw,
-                                   q.tpw, 0u, 0u);
+                hipLaunchKernelGGL((k_accumulate_seg<U, false>), dim3((qa.tpw + 255) / 256, nk), dim3(256), 0, st, upoints, n, NB,
+                                   qa.seg, st_g, sorted_g, buckets_g, part_g, seg_flags + (size_t)k0 * qa.tpw, seg_bucket + (size_t)k0 * qa.tpw,
+                                   qa.tpw, 0u, 0u);
         };
         const auto fixup_and_reduce = [&](uint32_t k0, uint32_t nk, size_t list_off, hipStream_t st, bool mark) {
             const uint32_t *st_g = starts + (size_t)k0 * (NB + 1);
-            char *buckets_g = buckets + (size_t)k0 * NB * REC, *part_g = seg_partials + (size_t)k0 * q.tpw * 2 * REC;
-            const uint32_t *flags_g = seg_flags + (size_t)k0 * q.tpw, *pb_g = seg_bucket + (size_t)k0 * q.tpw;
+            char *buckets_g = buckets + (size_t)k0 * NB * REC, *part_g = seg_partials + (size_t)k0 * qa.tpw * 2 * REC;
+            const uint32_t *flags_g = seg_flags + (size_t)k0 * qa.tpw, *pb_g = seg_bucket + (size_t)k0 * qa.tpw;
             uint32_t *cnt_g = long_flag + k0;  // k_part_rowscan zeroed every window's slot
             LongChain *list_g = long_list + list_off;
             uint32_t *done_g = piece_done + list_off;
             void *sums_g = (char *)piece_sums + list_off * REC;
-            if (shared && n / NB >= 2 * (size_t)q.seg)  // buckets of several threads' worth of entries (dense chains): one thread per bucket
-                hipLaunchKernelGGL((k_fixup_bucket<OpsSerial>), dim3((NB + 255) / 256, nk), dim3(256), 0, st, NB, st_g, q.seg,
-                                   (const void *)part_g, q.tpw, (void *)buckets_g, cnt_g, list_g, done_g, FIX_MAXWALK);
+            if (shared && n / NB >= 2 * (size_t)qa.seg)  // buckets of several threads' worth of entries (dense chains): one thread per bucket
+                hipLaunchKernelGGL((k_fixup_bucket<OpsSerial>), dim3((NB + 255) / 256, nk), dim3(256), 0, st, NB, st_g, qa.seg,
+                                   (const void *)part_g, qa.tpw, (void *)buckets_g, cnt_g, list_g, done_g, FIX_MAXWALK);
             else if constexpr (FIXUP_QUAD)
-                hipLaunchKernelGGL((k_fixup_seg_q<U>), dim3((q.tpw + 63) / 64, nk), dim3(256), 128 * sizeof(QRec<U>), st, NB,
-                                   (const void *)part_g, flags_g, pb_g, q.tpw, (void *)buckets_g, cnt_g, list_g, done_g, FIX_MAXWALK, st_g, q.seg);
+                hipLaunchKernelGGL((k_fixup_seg_q<U>), dim3((qa.tpw + 63) / 64, nk), dim3(256), 128 * sizeof(QRec<U>), st, NB,
+                                   (const void *)part_g, flags_g, pb_g, qa.tpw, (void *)buckets_g, cnt_g, list_g, done_g, FIX_MAXWALK, st_g, qa.seg);
             else
-                hipLaunchKernelGGL((k_fixup_seg<OpsSerial>), dim3((q.tpw + 255) / 256, nk), dim3(256), 0, st, NB, part_g, flags_g, pb_g,
-                                   q.tpw, buckets_g, cnt_g, list_g, done_g, FIX_MAXWALK, st_g, q.seg);
-            hipLaunchKernelGGL((k_fixup_long<U>), dim3(2 * ctx.num_cus), dim3(256), 128 * sizeof(QRec<U>), st, NB, part_g, pb_g, q.tpw,
-                               buckets_g, (const uint32_t *)cnt_g, (const LongChain *)list_g, done_g, sums_g, st_g, q.seg);
+                hipLaunchKernelGGL((k_fixup_seg<OpsSerial>), dim3((qa.tpw + 255) / 256, nk), dim3(256), 0, st, NB, part_g, flags_g, pb_g,
+                                   qa.tpw, buckets_g, cnt_g, list_g, done_g, FIX_MAXWALK, st_g, qa.seg);
+            hipLaunchKernelGGL((k_fixup_long<U>), dim3(2 * ctx.num_cus), dim3(256), 128 * sizeof(QRec<U>), st, NB, part_g, pb_g, qa.tpw,
+                               buckets_g, (const uint32_t *)cnt_g, (const LongChain *)list_g, done_g, sums_g, st_g, qa.seg);
             // ---- bucket reduction -> window totals (empty buckets are never written: the reduction consults starts[])
             if (mark) timer.mark(T_REDUCE, st);
             if (!buckets_only) enqueue_reduce_kernels(ctx, ws, q, T, buckets_g, st_g, nk, NB, st, k0);
         };
-        const bool split = options().split.load(std::memory_order_relaxed) != 0 && !buckets_only && !shared && nw >= 4 && q.nblocks2 == 0;
         timer.mark(T_ACCUMULATE, stream);
         if (!split) {
             accumulate(0, nw, stream);
