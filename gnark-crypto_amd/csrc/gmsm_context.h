@@ -161,6 +161,7 @@ struct Workspace {
     hipEvent_t ev_buckets = nullptr, ev_merged = nullptr;  // a range's buckets are complete / have been merged
     hipStream_t cstream = nullptr;                         // the base rewrite of an unregistered call, beside its scalar pipeline
     hipEvent_t ev_fork = nullptr, ev_conv = nullptr;       // inputs are ready on the call's stream / the rewrite is complete
+    bool conv_pending = false;  // a forked base rewrite was launched on cstream and its join has not been enqueued (error path): begin_use joins it
     hipEvent_t events[12] = {nullptr};  // stage boundaries of the call in flight when profiling is on
     bool timed = false;                 // events[] were recorded by the last enqueue
     int timed_level = 0;                // ... at this profiling level (1: every stage, 2: the accumulation kernel only)
@@ -175,7 +176,7 @@ struct Workspace {
     int pending_group = -1;
     unsigned pending_c = 0;
     uint32_t pending_nw = 0;
-    uint32_t pending_gen = 0;   // ticket generation: a stale or repeated ticket is refused
+    uint32_t pending_gen = 0;   // ticket generation (drawn from a process-wide counter: unique across gmsm_shutdown): a stale or repeated ticket is refused
     std::shared_ptr<ResidentBases> bases_ref;  // keeps the registered bases of the call in flight on this workspace alive
     hipEvent_t dep = nullptr;   // orders the workspace stream after the caller's stream (scalars produced there)
     bool uncollected = false;          // stage events of an enqueue-only call not yet added to the profile
@@ -269,16 +270,22 @@ struct Context {
         lds_allowed.push_back(kernel);
         return GMSM_OK;
     }
-    // for_ticket (gmsm_multiexp_bases_submit; never waits): nullptr when MAX_TICKETS tickets are outstanding or no
-    // workspace is free right now. Otherwise wait = false: nullptr when every workspace is leased; wait = true: blocks
-    // until one is free - which always happens, because at least one workspace is never held by a ticket.
-    Workspace *acquire(bool wait, bool for_ticket = false) {
+    // for_ticket (gmsm_multiexp_bases_submit): nullptr at once when MAX_TICKETS tickets are outstanding (*why = 1: only a
+    // collect can help). With fewer tickets out a workspace is merely leased for the moment - a blocking caller, or
+    // gmsm_trim walking the workspaces one at a time - and the submit waits for it like a blocking entry would (*why = 2 is
+    // never returned with wait semantics; kept for the non-waiting callers). Otherwise wait = false: nullptr when every
+    // workspace is leased; wait = true: blocks until one is free - which always happens, because at least one workspace
+    // is never held by a ticket.
+    Workspace *acquire(bool wait, bool for_ticket = false, int *why = nullptr) {
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
             if (for_ticket) {
                 int out = 0;
                 for (auto &w : ws) out += (w.busy && w.ticket) ? 1 : 0;
-                if (out >= MAX_TICKETS) return nullptr;
+                if (out >= MAX_TICKETS) {
+                    if (why) *why = 1;
+                    return nullptr;
+                }
             }
             for (auto &w : ws)
                 if (!w.busy) {
@@ -286,9 +293,32 @@ struct Context {
                     w.ticket = for_ticket;
                     return &w;
                 }
-            if (!wait || for_ticket) return nullptr;
+            if (!wait && !for_ticket) {
+                if (why) *why = 2;
+                return nullptr;
+            }
             cv.wait(lk);
         }
+    }
+    // workspace i, waiting for a blocking caller to finish with it; nullptr when a ticket holds it (gmsm_shutdown)
+    Workspace *acquire_unless_ticket(int i) {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            if (ws[i].busy && ws[i].ticket) return nullptr;
+            if (!ws[i].busy) {
+                ws[i].busy = true;
+                ws[i].ticket = false;
+                return &ws[i];
+            }
+            cv.wait(lk);
+        }
+    }
+    Workspace *acquire_this(int i) {  // workspace i if it is free right now (gmsm_trim)
+        std::lock_guard<std::mutex> lk(mu);
+        if (ws[i].busy) return nullptr;
+        ws[i].busy = true;
+        ws[i].ticket = false;
+        return &ws[i];
     }
     void release(Workspace *w) {
         {
@@ -309,7 +339,7 @@ struct Lease {
     // work before touching any scratch buffer (entries that run on another stream do the same through begin_use).
     // A reference to registered bases that an enqueue-only call parked on the workspace is dropped here, outside the
     // context lock (the last owner's destructor synchronises the device before it frees the SRS).
-    Lease(Context &c, bool wait = true, bool for_ticket = false) : ctx(c), w(c.acquire(wait, for_ticket)) {
+    Lease(Context &c, bool wait = true, bool for_ticket = false, int *why = nullptr) : ctx(c), w(c.acquire(wait, for_ticket, why)) {
         if (!w) return;
         if (w->last_use && w->last_stream != w->stream) (void)hipStreamWaitEvent(w->stream, w->last_use, 0);
         std::shared_ptr<ResidentBases> parked;
@@ -365,6 +395,10 @@ static inline int order_after(Workspace &ws, hipStream_t caller) {
 // workspace, end_use publishes the end of this call's work.
 static inline int begin_use(Workspace &ws, hipStream_t stream) {
     if (ws.last_use && ws.last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, ws.last_use, 0));
+    if (ws.conv_pending) {  // a call failed between forking its base rewrite and joining it: the rewrite may still be writing ws.upoints
+        HIP_TRY(hipStreamSynchronize(ws.cstream));
+        ws.conv_pending = false;
+    }
     return GMSM_OK;
 }
 static inline int end_use(Workspace &ws, hipStream_t stream) {

@@ -13,11 +13,8 @@
 
 namespace gmsm {
 
-// Y3 of the additions as one double product with a single Montgomery reduction (fpu_mul_add): measured on BN254 G1,
-// k_accumulate_seg 1.385 -> 1.286 ms at 2^20 (-7 %), 20.96 -> 20.10 ms at 2^24. GMSM_Y3_MERGE=0 builds the two-product form.
-#ifndef GMSM_Y3_MERGE
-#define GMSM_Y3_MERGE 1
-#endif
+// Y3 of the additions is one double product with a single Montgomery reduction (fpu_mul_add): measured on BN254 G1 against
+// the two-product form, k_accumulate_seg 1.385 -> 1.286 ms at 2^20 (-7 %), 20.96 -> 20.10 ms at 2^24 (round 2).
 
 template <class U>
 struct XYZZL {  // extended-Jacobian point over a lazy element type (FpU<P> or Fp2U<P>)
@@ -83,13 +80,8 @@ GMSM_HD void madd_u(XYZZU<P> &acc, bool &inf, const FpU<P> &px, const FpU<P> &py
     const FpU<P> Q = fmul<INL>(acc.x, PP);                             // < 2
     const FpU<P> RR = fsqr<INL>(Rv);                                   // < 3
     const FpU<P> X3 = fpu_sub_sub2<P>(RR, PPP, Q);                                              // < 3 + 8 = 11
-    FpU<P> Y3;
-    if constexpr (GMSM_Y3_MERGE) {
-        // Y3 = (Q - X3) R - y PPP as ONE reduced product: (Q - X3) R + (8q - y) PPP  (18*18 + 8*2 = 340 < 3*169 -> < 4)
-        Y3 = fmuladd<INL>(fpu_sub<P, 16>(Q, X3), Rv, fpu_neg8c<P>(acc.y), PPP);
-    } else {
-        Y3 = fpu_sub<P, 4>(fmul<INL>(fpu_sub<P, 16>(Q, X3), Rv), fmul<INL>(acc.y, PPP));  // < 7
-    }
+    // Y3 = (Q - X3) R - y PPP as ONE reduced product: (Q - X3) R + (8q - y) PPP  (18*18 + 8*2 = 340 < 3*169 -> < 4)
+    const FpU<P> Y3 = fmuladd<INL>(fpu_sub<P, 16>(Q, X3), Rv, fpu_neg8c<P>(acc.y), PPP);
     acc.x = X3;
     acc.y = Y3;
     acc.zz = fmul<INL>(acc.zz, PP);
@@ -181,13 +173,8 @@ GMSM_HD void add_u(XYZZU<P> &p, bool &pinf, const XYZZU<P> &q, bool qinf) {
     const FpU<P> PPP = fmul<INL>(A, PP);                                  // < 2
     const FpU<P> Q = fmul<INL>(U1, PP);                                   // < 2
     const FpU<P> X3 = fpu_sub<P, 4>(fpu_sub<P, 4>(fsqr<INL>(B), PPP), fpu_dbl(Q));  // < 2 + 4 + 4
-    if constexpr (GMSM_Y3_MERGE) {
-        // Y3 = (Q - X3) B - S1 PPP with one reduction: (Q - X3) B + (8q - S1) PPP  (18*6 + 8*2 = 124 -> < 2)
-        p.y = fmuladd<INL>(fpu_sub<P, 16>(Q, X3), B, fpu_neg8c<P>(S1), PPP);
-    } else {
-        const FpU<P> V = fmul<INL>(S1, PPP);                              // < 2
-        p.y = fpu_sub<P, 4>(fmul<INL>(fpu_sub<P, 16>(Q, X3), B), V);      // < 6
-    }
+    // Y3 = (Q - X3) B - S1 PPP with one reduction: (Q - X3) B + (8q - S1) PPP  (18*6 + 8*2 = 124 -> < 2)
+    p.y = fmuladd<INL>(fpu_sub<P, 16>(Q, X3), B, fpu_neg8c<P>(S1), PPP);
     p.x = X3;
     p.zz = fmul<INL>(fmul<INL>(p.zz, q.zz), PP);
     p.zzz = fmul<INL>(fmul<INL>(p.zzz, q.zzz), PPP);
@@ -287,99 +274,14 @@ GMSM_HD void add_g(XYZZL<U> &p, bool &pinf, const XYZZL<U> &q, bool qinf) {
     p.zzz = lz_mul<INL>(lz_mul<INL>(p.zzz, q.zzz), PPP);
 }
 
-// ------------------------------------------------------------------ bound-tracked mixed addition over Fp2
-// The reduced class pays for its exactness with sequential borrow chains: every lz_sub / lz_add is two carry-dependent
-// passes over the limbs plus a conditional +-4q, 14 of them per mixed addition, on a kernel that runs ONE wave per SIMD
-// (BLS12-381 G2: 35 % of the accumulation loop's instructions are not multiplies, against 16-20 % on the prime-field
-// path). Where the radix leaves 11 spare bits (BLS12-381: 2^392 / q > 2048; BN254's 169 is too little) the prime-field
-// recipe carries over to Fp2 unchanged: limb-parallel subtractions with a redundant K*q added, bounds stated per formula
-// (multiples of q, per component), no comparison with q inside the loop. Components of a product:
-//   c0 = a0 b0 + (K q - b1) a1,  c1 = a0 b1 + a1 b0        bound (b(a0) b(b0) + K b(a1)) / 2048 + 1, resp. the plain sum,
-// and Y3 = (Q - X3) R - Y1 PPP is ONE four-product form per component (fpu_mul_add4): 8 products, 2 reductions.
-// Stored coordinates: x < 12, y <= 4, zz, zzz < 2. The bucket leaves this class only when it is flushed
-// (lz_acc_finish: back to R = [0, 4q), exactly normalised, which is what k_fixup_* and k_reduce* work on).
-#ifndef GMSM_FP2_TRACKED
-#define GMSM_FP2_TRACKED 1
-#endif
-// the prime-field groups run the accumulation loop on signed limbs (madd_s); GMSM_SIGNED_MADD=0 builds madd_u there
-#ifndef GMSM_SIGNED_MADD
-#define GMSM_SIGNED_MADD 1
-#endif
-#ifndef GMSM_SIGNED_MADD2
-#define GMSM_SIGNED_MADD2 1   // the same for the Fp2 groups (madd_ts; 0: madd_t for BLS12-381, madd_g for BN254)
-#endif
+// ------------------------------------------------------------------ which mixed addition the accumulation loops run
+// Both families run on SIGNED limbs: madd_s (prime fields) and madd_ts (Fp2), below. The unsigned forms above - madd_u,
+// madd_g - stay as what the host checks compare them with (tests/c/lazy_signed_check.cpp) and for the few additions
+// outside the loops (ingest). (Rounds 2-4 also carried a bound-tracked Fp2 form, madd_t, for BLS12-381 G2 and compile-time
+// switches between all five; madd_ts replaced it for both Fp2 groups - profiles/r04_fp2_signed_ab.log - and it is gone.)
 template <class U> struct LzSigned { static constexpr bool value = false; };
-template <class P> struct LzSigned<FpU<P>> { static constexpr bool value = GMSM_SIGNED_MADD != 0; };
-template <class P> struct LzSigned<Fp2U<P>> { static constexpr bool value = GMSM_SIGNED_MADD2 != 0; };
-template <class U> struct LzTracked { static constexpr bool value = false; };
-template <class P> struct LzTracked<Fp2U<P>> { static constexpr bool value = GMSM_FP2_TRACKED && (P::UL * P::UW - P::BITS) >= 11; };
-
-template <class P, int K>
-GMSM_HD Fp2U<P> f2_sub(const Fp2U<P> &a, const Fp2U<P> &b) { return Fp2U<P>{fpu_sub<P, K>(a.a0, b.a0), fpu_sub<P, K>(a.a1, b.a1)}; }
-// x * y with y.a1 < K q
-template <bool INL, int K, class P>
-GMSM_HD Fp2U<P> f2_mul(const Fp2U<P> &x, const Fp2U<P> &y) {
-    Fp2U<P> z;
-    z.a0 = fmuladd<INL>(x.a0, y.a0, fpu_negc<P, K>(y.a1), x.a1);
-    z.a1 = fmuladd<INL>(x.a0, y.a1, x.a1, y.a0);
-    return z;
-}
-// x^2 with x.a1 < K q: a0 = (x0 + x1)(x0 - x1), a1 = 2 x0 x1 (e2_bls381.go:28-38). `half1` = x0 x1 (for the zero test).
-template <bool INL, int K, class P>
-GMSM_HD Fp2U<P> f2_sqr(const Fp2U<P> &x, FpU<P> &half1) {
-    Fp2U<P> z;
-    z.a0 = fmul<INL>(fpu_add(x.a0, x.a1), fpu_sub<P, K>(x.a0, x.a1));
-    half1 = fmul<INL>(x.a0, x.a1);
-    z.a1 = fpu_dbl(half1);
-    return z;
-}
-
-template <class P, bool INL>
-GMSM_HD void madd_t(XYZZL<Fp2U<P>> &acc, bool &inf, const Fp2U<P> &px, const Fp2U<P> &py_in, bool negate) {
-    using U = Fp2U<P>;
-    static_assert(LzTracked<U>::value, "needs 2^(L W) / q >= 2048");
-    const U py = negate ? U{fpu_negc<P, 4>(py_in.a0), fpu_negc<P, 4>(py_in.a1)} : py_in;  // <= 4
-    if (inf) {
-        acc.x = px;
-        acc.y = py;
-        acc.zz = lz_one((const U *)nullptr);
-        acc.zzz = lz_one((const U *)nullptr);
-        inf = false;
-        return;
-    }
-    const U Pv = f2_sub<P, 16>(f2_mul<INL, 8>(acc.zz, px), acc.x);    // < 2 + 16
-    const U Rv = f2_sub<P, 8>(f2_mul<INL, 8>(acc.zzz, py), acc.y);    // < 2 + 8
-    FpU<P> hp, hr;
-    const U PP = f2_sqr<INL, 32>(Pv, hp);                             // a0 < 2, a1 < 4
-    if (fpu_prod_is_zero(PP.a0) && fpu_prod_is_zero(hp)) {            // Pv == 0 <=> Pv^2 == 0: same x (g2.go, as g1.go:846-854)
-        const U RR0 = f2_sqr<INL, 16>(Rv, hr);
-        if (fpu_prod_is_zero(RR0.a0) && fpu_prod_is_zero(hr))         // P + P: the reduced-class doubling (rare)
-            double_mixed_g<U, INL>(acc, px, negate ? lz_sub(lz_zero((const U *)nullptr), py_in) : py_in);
-        else inf = true;                                              // P + (-P)
-        return;
-    }
-    const U PPP = f2_mul<INL, 8>(Pv, PP);                             // (18*2 + 8*18) / 2048 + 1 < 2
-    const U Q = f2_mul<INL, 8>(acc.x, PP);                            // < 2
-    const U RR = f2_sqr<INL, 16>(Rv, hr);                             // a0 < 2, a1 < 4
-    const U X3{fpu_sub_sub2<P>(RR.a0, PPP.a0, Q.a0), fpu_sub_sub2<P>(RR.a1, PPP.a1, Q.a1)};  // < 4 + 8
-    const U D = f2_sub<P, 16>(Q, X3);                                 // < 18
-    // Y3 = D R - Y PPP, one reduction per component:
-    //   a0 = D0 R0 + (32q - D1) R1 + (8q - P0) Y0 + P1 Y1      (18*10 + 32*10 + 8*4 + 2*4) / 2048 + 1 < 2
-    //   a1 = D0 R1 + D1 R0 + (8q - P1) Y0 + (8q - P0) Y1
-    const FpU<P> nP0 = fpu_negc<P, 8>(PPP.a0), nP1 = fpu_negc<P, 8>(PPP.a1);
-    U Y3;
-    if constexpr (INL) {
-        Y3.a0 = fpu_mul_add4(D.a0, Rv.a0, fpu_negc<P, 32>(D.a1), Rv.a1, nP0, acc.y.a0, PPP.a1, acc.y.a1);
-        Y3.a1 = fpu_mul_add4(D.a0, Rv.a1, D.a1, Rv.a0, nP1, acc.y.a0, nP0, acc.y.a1);
-    } else {
-        Y3.a0 = fpu_add(fmuladd<INL>(D.a0, Rv.a0, fpu_negc<P, 32>(D.a1), Rv.a1), fmuladd<INL>(nP0, acc.y.a0, PPP.a1, acc.y.a1));
-        Y3.a1 = fpu_add(fmuladd<INL>(D.a0, Rv.a1, D.a1, Rv.a0), fmuladd<INL>(nP1, acc.y.a0, nP0, acc.y.a1));
-    }
-    acc.x = X3;
-    acc.y = Y3;
-    acc.zz = f2_mul<INL, 8>(acc.zz, PP);
-    acc.zzz = f2_mul<INL, 8>(acc.zzz, PPP);
-}
+template <class P> struct LzSigned<FpU<P>> { static constexpr bool value = true; };
+template <class P> struct LzSigned<Fp2U<P>> { static constexpr bool value = true; };
 
 // back to the reduced class R (exactly normalised, < 4q) before a record leaves the accumulation loop
 template <class P>
@@ -393,7 +295,7 @@ GMSM_HD void fpu_to_class_r(FpU<P> &a) {  // a < 12q, nearly normalised
 // madd_s carried over to Fp2 = Fp[u]/(u^2 + 1): components are signed numbers on signed limbs, a difference is one
 // subtraction per limb, a product component is ONE signed two-product scan (c0 = a0 b0 + (-a1) b1, c1 = a0 b1 + a1 b0: a
 // negation is one instruction per limb, where the unsigned forms pay K q - a1 and a carry pass), and nothing is ever
-// compared with q inside the loop. Unlike madd_t's bound tracking this needs no spare bits beyond the 7 of BN254's radix:
+// compared with q inside the loop. This needs no spare bits beyond the 7 of BN254's radix:
 // without K q offsets the values stay within +-8q, so BN254 G2 leaves the reduced class R of madd_g - whose every
 // subtraction is two sequential borrow chains and a conditional +4q - as well.
 // Values in multiples of q, per component (A = 2^(L W)/q >= 169; m(.) = largest |component|; a product component lies in
@@ -539,31 +441,18 @@ GMSM_HD void lz_rec_fresh(XYZZL<U> &v) {
 // wider class than the records in memory use; lz_acc_finish brings them back before the store
 template <bool INL, class U>
 GMSM_HD void lz_madd_acc(XYZZL<U> &acc, bool &inf, const U &px, const U &py, bool negate) {
-    if constexpr (LzSigned<U>::value) {
-        if constexpr (IsLazyPrimeField<U>::value) madd_s<typename U::Params, INL>(acc, inf, px, py, negate);
-        else madd_ts<typename U::Params, INL>(acc, inf, px, py, negate);
-    } else if constexpr (LzTracked<U>::value) {
-        madd_t<typename U::Params, INL>(acc, inf, px, py, negate);
-    } else {
-        lz_madd<INL>(acc, inf, px, py, negate);
-    }
+    static_assert(LzSigned<U>::value, "the accumulation loops run on signed limbs");
+    if constexpr (IsLazyPrimeField<U>::value) madd_s<typename U::Params, INL>(acc, inf, px, py, negate);
+    else madd_ts<typename U::Params, INL>(acc, inf, px, py, negate);
 }
 // TO_RECORD: the value goes to a bucket / partial-sum record whose readers apply lz_rec_fresh (k_accumulate_seg: the
 // flush sits on the divergent bucket-boundary path of the hot loop, executed by the whole wave for the one or two lanes
-// whose bucket ends - 87 % of the iterations at 32 entries per bucket -, the readers run it once per record).
+// whose bucket ends - 87 % of the iterations at 32 entries per bucket -, the readers run it once per record: measured
+// -1.1 % with the conversion inside the loop's flush, profiles/r04_signed_limbs.log).
 template <bool TO_RECORD = false, class U>
 GMSM_HD void lz_acc_finish(XYZZL<U> &acc, bool inf) {
-    if constexpr (LzSigned<U>::value) {
-        if constexpr (!TO_RECORD) {
-            if (!inf) lz_rec_fresh(acc);
-        }
-    } else if constexpr (LzTracked<U>::value) {
-        if (!inf) {
-            fpu_to_class_r(acc.x.a0);
-            fpu_to_class_r(acc.x.a1);
-            fpu_to_class_r(acc.y.a0);
-            fpu_to_class_r(acc.y.a1);
-        }
+    if constexpr (!TO_RECORD) {
+        if (!inf) lz_rec_fresh(acc);
     }
 }
 template <bool INL, class P>

@@ -24,14 +24,20 @@ static thread_local int g_device = -1;
 static std::atomic<int> g_default_device{0};
 std::atomic<unsigned long> g_table_runs{0};
 std::atomic<unsigned long> g_small_runs{0};
+static std::atomic<uint32_t> g_ticket_gen{0};  // ticket generations: process-wide and monotonic, so a ticket of before a gmsm_shutdown never matches one issued after it
 
 // Process-wide switches; GMSM_C and GMSM_TABLES are read here ONCE (first use), never on a call path.
+std::string g_env_error;  // a malformed GMSM_C / GMSM_TABLES: reported by the next drop-in entry (shard_devices), not dropped
 Options &options() {
     static Options *o = [] {
         Options *x = new Options();
         const unsigned c = env_uint("GMSM_C", 0);
         x->window_bits.store(c >= 2 && c <= 20 ? c : 0);
-        x->tables.store(std::min(2u, env_uint("GMSM_TABLES", 1)));
+        const unsigned t = env_uint("GMSM_TABLES", 1);
+        x->tables.store(std::min(2u, t));
+        // an out-of-range initial value is not dropped silently: the next MultiExp entry reports it (g_env_error)
+        if (c != 0 && (c < 2 || c > 20)) g_env_error = "GMSM_C=" + std::to_string(c) + ": the window width must be 2..20 (or unset)";
+        else if (t > 2) g_env_error = "GMSM_TABLES=" + std::to_string(t) + ": 0 never, 1 the measured call sizes, 2 every call size";
         return x;
     }();
     return *o;
@@ -220,7 +226,10 @@ static const EnvDevices &env_devices() {
         const char *v = getenv("GMSM_DEVICES");
         if (!v || !*v) return x;
         int ndev = 0;
-        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return x;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+            x->err = std::string("GMSM_DEVICES=\"") + v + "\": the device count could not be obtained (hipGetDeviceCount failed)";
+            return x;
+        }
         if (strcmp(v, "all") == 0) {
             for (int d = 0; d < ndev; ++d) x->list.push_back(d);
             return x;
@@ -256,6 +265,8 @@ static int shard_devices(std::vector<int> &out) {
             return GMSM_OK;
         }
     }
+    (void)options();
+    if (!g_env_error.empty()) return fail(GMSM_ERR_ARG, g_env_error);
     if (g_pinned.load()) return GMSM_OK;
     const EnvDevices &e = env_devices();
     if (!e.err.empty()) return fail(GMSM_ERR_ARG, e.err);
@@ -967,9 +978,12 @@ GMSM_EXPORT int gmsm_multiexp_bases_submit(uint64_t handle, const void *d_scalar
     int rc = get_context_for(rb->device, &ctx);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
-    Lease lease(*ctx, /*wait=*/false, /*for_ticket=*/true);
+    int why = 0;
+    Lease lease(*ctx, /*wait=*/false, /*for_ticket=*/true, &why);
     Workspace *ws = lease.w;
-    if (!ws) return fail(GMSM_ERR_ARG, "two MultiExp calls are already in flight: collect one first");
+    if (!ws)
+        return fail(GMSM_ERR_ARG, why == 1 ? "two submitted MultiExp calls are outstanding on this device: collect one first"
+                                           : "every workspace of the device is leased by a running call");
     // the scalars are produced on the caller's stream (NULL = the default stream): order our stream behind it
     if ((rc = order_after(*ws, (hipStream_t)hip_stream))) return rc;
     if ((rc = vt->submit(*ctx, *ws, d_scalars, n_scalars, rb.get()))) return rc;
@@ -979,7 +993,7 @@ GMSM_EXPORT int gmsm_multiexp_bases_submit(uint64_t handle, const void *d_scalar
         ws->bases_ref = rb;  // the ticket owns a reference until it is collected
         ws->pending = true;
         ws->pending_group = rb->group;
-        ++ws->pending_gen;
+        ws->pending_gen = g_ticket_gen.fetch_add(1, std::memory_order_relaxed) + 1;  // unique across gmsm_shutdown
     }
     *out_ticket = ((uint64_t)ctx->device << 40) | ((uint64_t)(ws->pending_gen & 0xffffffffu) << 8) | (uint64_t)(ws - ctx->ws + 1);
     return GMSM_OK;
@@ -1494,19 +1508,23 @@ GMSM_EXPORT int gmsm_trim(size_t keep_bytes, size_t *out_freed) {
     for (Context *c : ctxs) {
         if (!c) continue;
         (void)hipSetDevice(c->device);
-        std::vector<Workspace *> mine;
-        while (Workspace *w = c->acquire(false)) mine.push_back(w);
-        for (Workspace *w : mine) {
+        // one workspace at a time - lease, drain, trim, release - so that a submit or a blocking entry arriving meanwhile
+        // always finds the other workspaces (holding all of them at once turned "trim under load" into spurious
+        // "already in flight" errors for unrelated callers)
+        for (int i = 0; i < Context::NUM_WS; ++i) {
+            Workspace *w = c->acquire_this(i);
+            if (!w) continue;  // leased by a running call or a ticket: its scratch is in use
             // an enqueue-only call (gmsm_window_sums_enqueue) may have left work on the caller's stream
             if (w->last_use) (void)hipEventSynchronize(w->last_use);
             (void)hipStreamSynchronize(w->stream);
             (void)hipStreamSynchronize(w->mstream);
             (void)hipStreamSynchronize(w->cstream);
+            w->conv_pending = false;
             std::shared_ptr<ResidentBases> parked;
             parked.swap(w->bases_ref);
             freed += w->trim(keep_bytes);
+            c->release(w);
         }
-        for (Workspace *w : mine) c->release(w);
     }
     (void)hipSetDevice(prev);
     if (out_freed) *out_freed = freed;
@@ -1522,11 +1540,20 @@ GMSM_EXPORT int gmsm_shutdown(void) {
         std::lock_guard<std::mutex> lk(g_ctx_mu);
         ctxs = g_ctx;
     }
+    // Every workspace of every context is leased FIRST - blocking callers still inside finish, new ones wait behind the
+    // lease - and the check for uncollected tickets happens under the same lock as each lease, so no submit can slip in
+    // between the check and the teardown (it used to: shutdown then waited for ever on a ticket nobody would collect).
+    std::vector<std::pair<Context *, Workspace *>> held;
     for (Context *c : ctxs) {
         if (!c) continue;
-        std::lock_guard<std::mutex> lk(c->mu);
-        for (auto &w : c->ws)
-            if (w.busy && w.ticket) return fail(GMSM_ERR_ARG, "gmsm_shutdown: a submitted MultiExp has not been collected");
+        for (int i = 0; i < Context::NUM_WS; ++i) {
+            Workspace *w = c->acquire_unless_ticket(i);
+            if (!w) {
+                for (auto &h : held) h.first->release(h.second);
+                return fail(GMSM_ERR_ARG, "gmsm_shutdown: a submitted MultiExp has not been collected");
+            }
+            held.emplace_back(c, w);
+        }
     }
     {
         // The handle tables keep their length (a handle is index + 1: an old handle must stay unknown, not come to name
@@ -1549,10 +1576,8 @@ GMSM_EXPORT int gmsm_shutdown(void) {
     for (Context *c : ctxs) {
         if (!c) continue;
         (void)hipSetDevice(c->device);
-        Workspace *all[Context::NUM_WS];
-        for (int i = 0; i < Context::NUM_WS; ++i) all[i] = c->acquire(true);  // blocking callers still inside finish first
         (void)hipDeviceSynchronize();
-        for (Workspace *w : all) w->destroy();
+        for (auto &w : c->ws) w.destroy();  // all of them are in `held`
     }
     {
         std::lock_guard<std::mutex> lk(g_ctx_mu);

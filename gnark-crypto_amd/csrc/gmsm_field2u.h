@@ -7,8 +7,7 @@
 // conditional +-4q, products come out < 2q by themselves (operands up to 8q are fine: 64 q^2 / 2^261 < 0.4 q).
 // (The accumulation LOOP of both G2 groups left R in round 4: on signed limbs nothing needs a K q offset, the values stay
 // within +-8q, and 7 spare bits are enough - gmsm_curveu.h madd_ts; its records return to R when they are read. Fixup and
-// reduction work on R throughout. Before: madd_g on R for BN254, madd_t - bounds tracked as on the prime-field path, 11
-// spare bits - for BLS12-381; both still build with -DGMSM_SIGNED_MADD2=0.)
+// reduction work on R throughout. Before: madd_g on R for BN254, a bound-tracked form (11 spare bits) for BLS12-381.)
 //
 // Replaces: fptower.E2 Add/Sub/Double/Neg/Mul/Square (ecc/bn254/internal/fptower/e2_fallback.go:10-28,
 // e2_bn254.go:28-50; BLS12-381: e2_bls381.go:15-38). Exact arithmetic mod q: converting back with f2u_to_sat gives the
@@ -132,24 +131,13 @@ template <class P> GMSM_HD FpU<P> lz_one(const FpU<P> *) {
 //   c0 = a0 b0 + (8q - a1) b1,   c1 = a0 b1 + a1 b0        (operands in R = [0,4q): 48 q^2 / 2^(L W) + q < 2q, in R;
 //   8q and not 4q: a1 may be as large as 4q - 1, one unit above the top limb of the borrow form of 4q)
 // Same number of multiplies as Karatsuba's three reduced products (6 L^2 + 2 L against 6 L^2 + 3 L) but none of its
-// three exact subtractions, each a sequential borrow chain with a conditional +4q (GMSM_FP2_KARATSUBA=1 builds the
-// Karatsuba form for A/B measurements: BLS12-381 G2 accumulates ~20 % slower with it).
-#ifndef GMSM_FP2_KARATSUBA
-#define GMSM_FP2_KARATSUBA 0
-#endif
+// three exact subtractions, each a sequential borrow chain with a conditional +4q (measured in round 2: BLS12-381 G2
+// accumulates ~20 % slower with the Karatsuba form; tests/c/lazy_field_check.cpp keeps one as the reference).
 template <bool INL, class P>
 GMSM_HD Fp2U<P> lz_mul(const Fp2U<P> &x, const Fp2U<P> &y) {
     Fp2U<P> z;
-#if GMSM_FP2_KARATSUBA
-    const FpU<P> t0 = fmul<INL>(x.a0, y.a0);                                          // < 2q
-    const FpU<P> t1 = fmul<INL>(x.a1, y.a1);                                          // < 2q
-    const FpU<P> t2 = fmul<INL>(fpu_add_raw(x.a0, x.a1), fpu_add_raw(y.a0, y.a1));    // operands < 8q -> < 2q
-    z.a0 = fpu_subr(t0, t1);
-    z.a1 = fpu_subr(fpu_subr(t2, t0), t1);
-#else
     z.a0 = fmuladd<INL>(x.a0, y.a0, fpu_neg8n<P>(x.a1), y.a1);
     z.a1 = fmuladd<INL>(x.a0, y.a1, x.a1, y.a0);
-#endif
     return z;
 }
 

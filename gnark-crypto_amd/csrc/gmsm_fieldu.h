@@ -242,7 +242,7 @@ GMSM_HD FpU<P> fpu_mul_add(const FpU<P> &a, const FpU<P> &b, const FpU<P> &c, co
 }
 
 // (a*b + c*d + e*f + g*h) * 2^-(L*W) mod q with ONE reduction: one component of the difference of two Fp2 products
-// (gmsm_curveu.h, madd_t). Every operand nearly normalised (limbs <= 2^W + 2^(32-W)): 5L products per column.
+// (gmsm_curveu.h, madd_ts). Every operand nearly normalised (limbs <= 2^W + 2^(32-W)): 5L products per column.
 // Bound: (sum of the four bound products) / (2^(L*W)/q) + 1.
 template <class P, bool SIGNED = false>
 GMSM_HD FpU<P> fpu_mul_add4(const FpU<P> &a, const FpU<P> &b, const FpU<P> &c, const FpU<P> &d, const FpU<P> &e,

@@ -483,7 +483,10 @@ struct Group {
             }
             hipLaunchKernelGGL((k_convert_points<U>), dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0,
                                cs, d_points, n_points, ws.upoints.ptr, (uint8_t *)nullptr);
-            if (forked) HIP_TRY(hipEventRecord(ws.ev_conv, cs));
+            if (forked) {
+                ws.conv_pending = true;  // until the join below is enqueued (an error return in between leaves cstream running)
+                HIP_TRY(hipEventRecord(ws.ev_conv, cs));
+            }
             upoints = ws.upoints.ptr;
             skip = nullptr;
         }
@@ -537,7 +540,10 @@ struct Group {
         // them, or (GMSM_OPT_SPLIT, experiment) two groups: the fix-up and reduction of the first group run on the merge stream
         // beside the accumulation of the second. Every array is window-major, so a group is the same kernels over shifted
         // base pointers; each group has its own long-chain counter and its own half of the list.
-        if (forked) HIP_TRY(hipStreamWaitEvent(stream, ws.ev_conv, 0));  // the rewritten bases are complete
+        if (forked) {
+            HIP_TRY(hipStreamWaitEvent(stream, ws.ev_conv, 0));  // the rewritten bases are complete
+            ws.conv_pending = false;
+        }
         const auto accumulate = [&](uint32_t k0, uint32_t nk, hipStream_t st) {
             const uint32_t *st_g = starts + (size_t)k0 * (NB + 1);
             const uint32_t *sorted_g = sorted + (size_t)k0 * n;

@@ -393,9 +393,6 @@ static __global__ void __launch_bounds__(1024) k_part_rowscan(const uint32_t *__
 // session, profiles/r03_part_chunk.log). Beyond 2^25 points the coarse pass has 2048 partitions and the longer chunk's
 // longer runs win again (2^26: 9.5 against 10.3 ms): PART_CHUNK_BIG.
 constexpr uint32_t PART_CHUNK = 12288, PART_CHUNK_BIG = 16384;
-#ifndef GMSM_SCATTER_COUNT
-#define GMSM_SCATTER_COUNT 0
-#endif
 template <class D, uint32_t CHUNK>
 __global__ void __launch_bounds__(1024) k_part_scatter(const D *__restrict__ digits, size_t n, uint32_t nparts,
                                                               uint32_t fbits, uint32_t lidx, size_t chunk_len,
@@ -413,16 +410,12 @@ __global__ void __launch_bounds__(1024) k_part_scatter(const D *__restrict__ dig
     const uint32_t *pbase = part_base + (size_t)k * (nparts + 1);
     // The chunk's population of every partition is already known: k_part_hist counted it and k_part_colscan turned the
     // counts into prefixes over the chunks, so it is the difference to the next chunk's prefix (the last chunk: to the
-    // partition's population) - no counting pass of LDS atomics over the entries (GMSM_SCATTER_COUNT=1 builds that pass).
-#if GMSM_SCATTER_COUNT
-    for (uint32_t p = t; p < nparts; p += T) cnt[p] = 0;
-    __syncthreads();
-#else
+    // partition's population) - no counting pass of LDS atomics over the entries (measured against that pass in round 4:
+    // profiles/r04_scatter_count_ab.log).
     {
         const bool last = chunk + 1 == nchunks;
         for (uint32_t p = t; p < nparts; p += T) cnt[p] = (last ? pbase[p + 1] - pbase[p] : goff[nparts + p]) - goff[p];
     }
-#endif
     const size_t lo = (size_t)chunk * chunk_len;
     const size_t hi = lo + chunk_len < n ? lo + chunk_len : n;
     const D *d = digits + (size_t)k * n;
@@ -440,9 +433,6 @@ __global__ void __launch_bounds__(1024) k_part_scatter(const D *__restrict__ dig
             const uint32_t b = code_bucket(code);
             pid[j] = b >> fbits;
             ent[j] = ((b & fmask) << lidx) | ((uint32_t)i << 1) | (code & 1u);
-#if GMSM_SCATTER_COUNT
-            atomicAdd(&cnt[pid[j]], 1u);
-#endif
         }
     }
     __syncthreads();
@@ -779,10 +769,6 @@ __device__ __forceinline__ size_t point_slot(uint32_t index, uint32_t tab_m, uin
     }
 }
 
-// GMSM_ACC_RAW_RECORDS=0 builds the flush that converts to the unsigned class inside the loop (A/B: profiles/r04_signed_limbs.log)
-#ifndef GMSM_ACC_RAW_RECORDS
-#define GMSM_ACC_RAW_RECORDS 1
-#endif
 template <class U, bool TAB = false>
 __global__ void __launch_bounds__(256, AccWaves<U>::value) k_accumulate_seg(const void *__restrict__ upoints, size_t n, uint32_t nbuckets,
                                                            uint32_t seg, const uint32_t *__restrict__ starts,
@@ -831,7 +817,7 @@ __global__ void __launch_bounds__(256, AccWaves<U>::value) k_accumulate_seg(cons
     UAffine<U> p = load_struct<UAffine<U>>(upoints, point_slot<TAB>(v >> 1, tab_m, tab_stride));
     for (uint32_t e = e0; e < e1; ++e) {
         if (e == bend) {  // the current run is complete on the right
-            lz_acc_finish<GMSM_ACC_RAW_RECORDS != 0>(acc, inf);  // raw: the readers finish (lz_rec_fresh)
+            lz_acc_finish<true>(acc, inf);  // a raw record: its readers finish it (lz_rec_fresh)
             if (open_left) {
                 lazy_store<U>(partials, tg * 2 + 0, acc, inf);
                 flags |= SegFlags::HAS_P0;
@@ -859,7 +845,7 @@ __global__ void __launch_bounds__(256, AccWaves<U>::value) k_accumulate_seg(cons
     }
     {
         const bool open_right = bend > e1;
-        lz_acc_finish<GMSM_ACC_RAW_RECORDS != 0>(acc, inf);  // raw: the readers finish (lz_rec_fresh)
+        lz_acc_finish<true>(acc, inf);  // a raw record: its readers finish it (lz_rec_fresh)
         if (open_left) {
             lazy_store<U>(partials, tg * 2 + 0, acc, inf);
             flags |= SegFlags::HAS_P0 | (open_right ? SegFlags::P0_OPEN_RIGHT : 0u);
@@ -1186,10 +1172,7 @@ __global__ void __launch_bounds__(256) k_table_double(const void *__restrict__ s
         p.y = T::unpack(a.y);
         p.zz = p.zzz = lz_one((const U *)nullptr);
 #pragma nounroll
-        for (uint32_t l = 0; l < c; ++l) {
-            p = lz_pdbl<INL>(p);
-            lz_acc_finish(p, false);
-        }
+        for (uint32_t l = 0; l < c; ++l) p = lz_pdbl<INL>(p);  // double_u / double_g return the class they take
         inf = T::template to_sat<INL>(p.zz).is_zero();
     }
     lazy_store<U>(recs, i, p, inf);

@@ -612,7 +612,7 @@ def test_two_multiexp_in_flight(gm, oracle_mod, curve, which):
         jac_sync = rb.multiexp_device(d_sc[1].data_ptr(), sets[1][1])  # one slot busy: the other one serves
         assert (g.jac_to_affine(jac_sync) == expect[1]).all()
         t1 = rb.submit(d_sc[1].data_ptr(), sets[1][1], stream=torch.cuda.current_stream().cuda_stream)
-        with pytest.raises(RuntimeError, match="already in flight"):
+        with pytest.raises(RuntimeError, match="two submitted MultiExp calls are outstanding"):
             rb.submit(d_sc[2].data_ptr(), sets[2][1])
         # two tickets outstanding: a blocking call still goes through at once (the third workspace, which tickets can
         # never hold) - round 3 gave up here after two seconds, whoever held the tickets
