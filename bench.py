@@ -55,7 +55,7 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md
 
 # BASELINE.json configs beyond the headline one: (curve, group, logn, steps, host-entry legs too)
 # (BN254 G1 2^24 - the other half of BASELINE.json's metric - comes LAST: the driver keeps the tail of the line)
-ALSO = [("bn254", "g1", 22, 5, True), ("bn254", "g1", 26, 3, False), ("bls12_381", "g1", 22, 5, False),
+ALSO = [("bn254", "g1", 22, 5, True), ("bn254", "g1", 26, 3, False), ("bn254", "g2", 20, 5, False), ("bls12_381", "g1", 22, 5, False),
         ("bls12_381", "g2", 22, 3, False), ("bw6_761", "g1", 20, 3, False), ("bn254", "g1", 24, 5, True)]
 
 
@@ -139,13 +139,14 @@ def int_roofline_record(madds, acc_ms_total):
 
 def measured_traffic(curve, group, logn, world, nwin=None):
     """HBM/fabric bytes per k_accumulate_seg launch from the committed rocprofv3 PMC passes of THIS round's build
-    (FETCH_SIZE + WRITE_SIZE, separate passes; profiles/traffic_r04.json, keyed curve_group_logn).  Counters cannot be
+    (FETCH_SIZE + WRITE_SIZE, separate passes; profiles/traffic_r05.json, keyed curve_group_logn).  Counters cannot be
     read from inside the timed run, so this is the profiled value for the same workload - or None when that workload was
     not profiled."""
     if world != 1:
         return None
     try:
-        with open(os.path.join(ROOT, "profiles", "traffic_r04.json")) as f:
+        path = os.path.join(ROOT, "profiles", "traffic_r05.json")
+        with open(path if os.path.exists(path) else os.path.join(ROOT, "profiles", "traffic_r04.json")) as f:
             rec = json.load(f)
         key = f"{curve}_{group}_{logn}"
         if nwin is not None and rec.get("windows", {}).get(key, nwin) != nwin:

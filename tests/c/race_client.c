@@ -2,7 +2,8 @@
  * tsan` / `asan`; the reference's CI runs `go test -race ./ecc/bn254/...`, .github/workflows/pr.yml:63).  Plain C +
  * pthreads, links only the library: NTHREADS threads hammer every kind of entry at once - the blocking drop-in call, the
  * registered-bases call, submit/collect tickets, handle registration and release under use, gmsm_bases_precompute while
- * other threads run MultiExp over the same handle, first-use coset FFTs on a shared domain, gmsm_trim and the option
+ * other threads run MultiExp over the same handle, small calls (the fused kernel's per-workspace counters), first-use coset
+ * FFTs on a shared domain, gmsm_trim and the option
  * switches - and every result must equal the one computed single-threaded before the race started.
  *
  *   race_client [iterations per thread, default 6] [n, default 20000]
@@ -22,7 +23,8 @@
 
 static size_t N = 20000, ITER = 6;
 static uint64_t *pts, *sc, *fft_in, *fft_ref;
-static uint64_t ref_aff[AL], shared_handle, fft_domain;
+static uint64_t ref_aff[AL], ref_small_aff[AL], shared_handle, fft_domain;
+static const size_t N_SMALL = 700; /* a call the fused small-n kernel takes (three slices per window) */
 static const size_t FFT_N = 1 << 12;
 static int failures = 0;
 static pthread_mutex_t fail_mu = PTHREAD_MUTEX_INITIALIZER;
@@ -41,13 +43,26 @@ static void check_jac(const char *what, int rc, const uint64_t *jac) {
     if (memcmp(aff, ref_aff, sizeof aff) != 0) bad(what, -1);
 }
 
+static void check_small(const char *what, int rc, const uint64_t *jac) {
+    uint64_t aff[AL];
+    if (rc != GMSM_OK) { bad(what, rc); return; }
+    gmsm_jac_to_affine(G, jac, aff);
+    if (memcmp(aff, ref_small_aff, sizeof aff) != 0) bad(what, -1);
+}
+
 static void *worker(void *arg) {
     const int id = (int)(intptr_t)arg;
     uint64_t jac[3 * 4];
     for (size_t it = 0; it < ITER; ++it) {
         switch ((id + it) % 6) {
-            case 0: check_jac("drop-in", gmsm_bn254_g1_multiexp(pts, N, sc, N, 0, jac), jac); break;
-            case 1: check_jac("bases", gmsm_multiexp_bases(shared_handle, sc, N, 0, jac), jac); break;
+            case 0:
+                check_jac("drop-in", gmsm_bn254_g1_multiexp(pts, N, sc, N, 0, jac), jac);
+                check_small("drop-in, small", gmsm_bn254_g1_multiexp(pts, N_SMALL, sc, N_SMALL, 1, jac), jac);
+                break;
+            case 1:
+                check_jac("bases", gmsm_multiexp_bases(shared_handle, sc, N, 0, jac), jac);
+                check_small("bases, small prefix", gmsm_multiexp_bases(shared_handle, sc, N_SMALL, 1, jac), jac);
+                break;
             case 2: {  /* a handle of its own, released while its own call has just finished and others keep going */
                 uint64_t h = 0;
                 int rc = gmsm_bases_register(G, pts, NULL, N, &h);
@@ -110,6 +125,9 @@ int main(int argc, char **argv) {
     uint64_t jac[12];
     if ((rc = gmsm_bn254_g1_multiexp(pts, N, sc, N, 0, jac))) { fprintf(stderr, "reference call: %s\n", gmsm_last_error()); return 3; }
     gmsm_jac_to_affine(G, jac, ref_aff);
+    if (N < N_SMALL) { fprintf(stderr, "race_client: n must be at least %zu\n", N_SMALL); return 3; }
+    if ((rc = gmsm_bn254_g1_multiexp(pts, N_SMALL, sc, N_SMALL, 1, jac))) { fprintf(stderr, "small reference call: %s\n", gmsm_last_error()); return 3; }
+    gmsm_jac_to_affine(G, jac, ref_small_aff);
     if ((rc = gmsm_bases_register(G, pts, NULL, N, &shared_handle))) return 4;
     fft_in = malloc(FFT_N * FL * 8);
     fft_ref = malloc(FFT_N * FL * 8);
