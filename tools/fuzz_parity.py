@@ -23,7 +23,7 @@ def main():
     g = (gm.G1Affine if which == "g1" else gm.G2Affine)(curve)
     o = oracle.Oracle(curve, which)
     rng = np.random.default_rng(20260924)
-    nmax = 1 << 17
+    nmax = 1 << 18
     pts_all = o.gen_points(nmax, 99, 5, nthreads=8)
     rb = g.register_bases(points=pts_all)
     # the same bases with window tables (gmsm_bases_precompute), the library's width and a narrow one; GMSM_OPT_TABLES = 2: every
@@ -36,7 +36,11 @@ def main():
     cases = bad = 0
     while time.time() - t0 < budget:
         n = int(rng.choice([rng.integers(1, 64), rng.integers(64, 5000), rng.integers(5000, nmax)]))
-        kind = int(rng.integers(0, 8))
+        kind = int(rng.integers(0, 11))
+        # the fused small-n kernel on / off / forced widths and sizes; the experimental window-group split
+        gm.set_option("small_bits", int(rng.choice([0, 0, 0, 1, 4, 5, 6, 7])))
+        gm.set_option("small_max", int(rng.choice([0, 0, 300, 16384])))
+        gm.set_option("split", int(rng.choice([0, 0, 0, 1])))
         if kind == 0:
             sc = random_scalars(rng, g.curve, n)
         elif kind == 1:  # small values
@@ -53,6 +57,15 @@ def main():
         elif kind == 5:  # powers of two and r - small
             sc = scalars_from_ints(g.curve, [(1 << int(e)) % g.curve.r if e >= 0 else g.curve.r + int(e)
                                              for e in rng.integers(-5, g.curve.fr_bits, size=n)])
+        elif kind == 8:  # the reference's "smallvalues": every 5th STORED scalar = limbs [1, 0, ..] (multiexp_test.go:319-325)
+            sc = random_scalars(rng, g.curve, n)
+            sc[::5] = 0
+            sc[::5, 0] = 1
+        elif kind == 9:  # "redundancy": runs of 100 equal scalars (multiexp_test.go:327-334)
+            sc = np.ascontiguousarray(np.repeat(random_scalars(rng, g.curve, (n + 99) // 100), 100, axis=0)[:n])
+        elif kind == 10:  # 30 % of the scalars are the field element 1
+            sc = random_scalars(rng, g.curve, n)
+            sc[rng.random(n) < 0.3] = scalars_from_ints(g.curve, [1])[0]
         else:
             sc = random_scalars(rng, g.curve, n)
         pts = pts_all[:n]
@@ -95,6 +108,8 @@ def main():
         if not (got == want).all():
             bad += 1
             print("MISMATCH", dict(n=n, kind=kind, entry=entry), flush=True)
+    for k in ("small_bits", "small_max", "split"):
+        gm.set_option(k, 0)
     for h in handles:
         h.release()
     print(f"{curve} {which}: {cases} cases, {bad} mismatches", flush=True)
