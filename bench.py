@@ -391,6 +391,8 @@ def small_n_block(gm, torch, curve="bn254", group="g1", logns=(2, 3, 4, 5, 6, 8,
     cfg = gm.MultiExpConfig()
     cores = effective_cpus()
     rows = []
+    rb = g.register_bases(d_points=d_pts.data_ptr(), n=nmax)  # registered bases with window tables (a resident SRS): the third column
+    rb.precompute(0)
     for logn in logns:
         n = 1 << logn
         jac = g.multiexp_device(d_pts.data_ptr(), d_sc.data_ptr(), n, stream)
@@ -403,9 +405,17 @@ def small_n_block(gm, torch, curve="bn254", group="g1", logns=(2, 3, 4, 5, 6, 8,
         p_, s_ = np.ascontiguousarray(pts[:n]), np.ascontiguousarray(sc[:n])
         cold_ms = median_ms(lambda: g.MultiExp(p_, s_, cfg), reps=9)
         jc, _ = g.MultiExp(p_, s_, cfg)
-        row = {"logn": logn, "resident_ms": round(res_ms, 4), "cold_ms": round(cold_ms, 4)}
+        jt = rb.multiexp_device(d_sc.data_ptr(), n, stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            jt = rb.multiexp_device(d_sc.data_ptr(), n, stream)
+        torch.cuda.synchronize()
+        tab_ms = (time.perf_counter() - t0) / reps * 1e3
+        row = {"logn": logn, "resident_ms": round(res_ms, 4), "cold_ms": round(cold_ms, 4), "registered_tables_ms": round(tab_ms, 4)}
         expected = o.msm_affine(p_, s_, nthreads=2 * cores)
-        row["bit_exact"] = bool((g.jac_to_affine(jac) == expected).all() and (g.jac_to_affine(jc) == expected).all())
+        row["bit_exact"] = bool((g.jac_to_affine(jac) == expected).all() and (g.jac_to_affine(jc) == expected).all()
+                                and (g.jac_to_affine(jt) == expected).all())
         if with_cpu:
             def cpu_ms(nb_tasks, threads):
                 k, t_tot = 0, 0.0
@@ -419,10 +429,12 @@ def small_n_block(gm, torch, curve="bn254", group="g1", logns=(2, 3, 4, 5, 6, 8,
             row["cpu_port_allcores_ms"] = round(cpu_ms(0, min(2 * cores, len(os.sched_getaffinity(0)))), 4)
             row["gpu_cold_over_cpu_allcores"] = round(cold_ms / row["cpu_port_allcores_ms"], 3)
         rows.append(row)
+    rb.release()
     cross = next((r["logn"] for r in rows if with_cpu and r["cold_ms"] < min(r["cpu_port_1thread_ms"], r["cpu_port_allcores_ms"])), None)
     return {"group": f"{curve}_{group}", "rows": rows, "cpu_cores": cores, "cpu_kind": "port",
             "crossover_logn_cold_vs_cpu_port": cross,
-            "note": "resident: bases+scalars in HBM; cold: gmsm_<curve>_<group>_multiexp with host buffers (median of 9); CPU: the "
+            "note": "resident: bases+scalars in HBM; cold: gmsm_<curve>_<group>_multiexp with host buffers (median of 9); registered_tables: "
+                    "gmsm_multiexp_bases_device over registered bases with window tables (narrow tables up to 2^12 points: one total, no host fold); CPU: the "
                     "oracle's restatement of the reference's MultiExp with NbTasks 1 / all cores on this box"}
 
 

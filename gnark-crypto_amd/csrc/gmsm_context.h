@@ -90,11 +90,17 @@ struct ResidentBases {
     unsigned tab_nw = 0;
     std::mutex tab_mu;
     DeviceBuffer tables;
+    // narrow tables for the fused small-n kernel (Group::precompute_tables builds them next to the wide ones): slab w =
+    // 2^(small_c w) P_i for the first small_m bases, small_nw slabs; small_c is their publication point (as tab_c)
+    std::atomic<unsigned> small_c{0};
+    unsigned small_nw = 0;
+    size_t small_m = 0;
+    DeviceBuffer small_tables;
     ResidentBases() = default;
     ResidentBases(const ResidentBases &) = delete;
     ResidentBases &operator=(const ResidentBases &) = delete;
     ~ResidentBases() {
-        if (!upoints.ptr && !skip.ptr && !tables.ptr) return;
+        if (!upoints.ptr && !skip.ptr && !tables.ptr && !small_tables.ptr) return;
         int prev = 0;
         (void)hipGetDevice(&prev);
         if (device >= 0) (void)hipSetDevice(device);
@@ -102,6 +108,7 @@ struct ResidentBases {
         if (upoints.ptr) (void)hipFree(upoints.ptr);
         if (skip.ptr) (void)hipFree(skip.ptr);
         if (tables.ptr) (void)hipFree(tables.ptr);
+        if (small_tables.ptr) (void)hipFree(small_tables.ptr);
         (void)hipSetDevice(prev);
     }
 };

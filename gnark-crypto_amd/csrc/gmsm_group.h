@@ -1007,6 +1007,35 @@ struct Group {
     // entries of more than 32 bits.
     static size_t table_min_points() { return (size_t)1 << (AFF_BYTES == 64 ? 13 : 15); }
     static size_t table_max_points() { return (size_t)3 << (FR_BITS == 255 && AFF_BYTES == 96 ? 19 : 20); }
+    // slabs 1 .. nw-1 of a table over the first m registered bases (slab 0 = the bases themselves, copied): slab w = slab
+    // w-1 doubled c times. `bad` != 0 afterwards: a multiple of a base reached the identity.
+    static int build_table_slabs(Workspace &ws, const ResidentBases *rb, size_t m, unsigned c, uint32_t nw, void *tables, uint32_t *bad) {
+        const size_t slab = m * AFF_BYTES;
+        int rc;
+        if ((rc = ws.buckets.ensure(m * sizeof(XYZZL<U>)))) return rc;
+        if ((rc = ws.h2d_points.ensure(slab))) return rc;
+        if ((rc = ws.skip.ensure(m))) return rc;
+        if ((rc = ws.flagword.ensure(8))) return rc;
+        HIP_TRY(hipMemsetAsync(ws.flagword.ptr, 0, 8, ws.stream));
+        HIP_TRY(hipMemcpyAsync(tables, rb->upoints.ptr, slab, hipMemcpyDeviceToDevice, ws.stream));
+        const dim3 grid((unsigned)((m + 255) / 256)), block(256);
+        for (uint32_t w = 1; w < nw; ++w) {
+            char *prev = (char *)tables + (size_t)(w - 1) * slab;
+            hipLaunchKernelGGL((k_table_double<U, INLINE_OPS>), grid, block, 0, ws.stream, (const void *)prev,
+                               (const uint8_t *)rb->skip.ptr, m, c, ws.buckets.ptr);
+            if ((rc = normalize_records(ws, m, ws.h2d_points.ptr))) return rc;
+            hipLaunchKernelGGL((k_convert_points<U>), grid, block, 0, ws.stream, (const void *)ws.h2d_points.ptr, m,
+                               (void *)(prev + slab), (uint8_t *)ws.skip.ptr);
+            hipLaunchKernelGGL(k_skip_mismatch, grid, block, 0, ws.stream, (const uint8_t *)rb->skip.ptr,
+                               (const uint8_t *)ws.skip.ptr, m, (uint32_t *)ws.flagword.ptr);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(bad, ws.flagword.ptr, 4, hipMemcpyDeviceToHost, ws.stream));
+        HIP_TRY(hipStreamSynchronize(ws.stream));
+        return GMSM_OK;
+    }
+    static constexpr unsigned SMALL_TABLE_C = 6;          // width of the narrow tables: 2^5 buckets, one lane quad each
+    static constexpr size_t SMALL_TABLE_POINTS = 4096;    // ... over the first so many bases (43 x 4096 x 64 B = 11 MiB for BN254 G1)
     static int precompute_tables(Context &ctx, Workspace &ws, ResidentBases *rb, unsigned c) {
         if (c == 0) c = table_c(rb->n);
         if (c < 2 || c > 20) return fail(GMSM_ERR_ARG, "table window width must be 2..20");
@@ -1017,33 +1046,26 @@ struct Group {
         int rc;
         if ((rc = rb->tables.ensure((size_t)nw * slab))) return rc;
         if ((rc = order_after(ws, nullptr))) return rc;
-        if ((rc = ws.buckets.ensure(n * sizeof(XYZZL<U>)))) return rc;
-        if ((rc = ws.h2d_points.ensure(slab))) return rc;
-        if ((rc = ws.skip.ensure(n))) return rc;
-        if ((rc = ws.flagword.ensure(8))) return rc;
-        HIP_TRY(hipMemsetAsync(ws.flagword.ptr, 0, 8, ws.stream));
-        HIP_TRY(hipMemcpyAsync(rb->tables.ptr, rb->upoints.ptr, slab, hipMemcpyDeviceToDevice, ws.stream));
-        const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-        for (uint32_t w = 1; w < nw; ++w) {
-            char *prev = (char *)rb->tables.ptr + (size_t)(w - 1) * slab;
-            hipLaunchKernelGGL((k_table_double<U, INLINE_OPS>), grid, block, 0, ws.stream, (const void *)prev,
-                               (const uint8_t *)rb->skip.ptr, n, c, ws.buckets.ptr);
-            if ((rc = normalize_records(ws, n, ws.h2d_points.ptr))) return rc;
-            hipLaunchKernelGGL((k_convert_points<U>), grid, block, 0, ws.stream, (const void *)ws.h2d_points.ptr, n,
-                               (void *)(prev + slab), (uint8_t *)ws.skip.ptr);
-            hipLaunchKernelGGL(k_skip_mismatch, grid, block, 0, ws.stream, (const uint8_t *)rb->skip.ptr,
-                               (const uint8_t *)ws.skip.ptr, n, (uint32_t *)ws.flagword.ptr);
-        }
-        HIP_TRY(hipGetLastError());
         uint32_t bad = 0;
-        HIP_TRY(hipMemcpyAsync(&bad, ws.flagword.ptr, 4, hipMemcpyDeviceToHost, ws.stream));
-        HIP_TRY(hipStreamSynchronize(ws.stream));
+        if ((rc = build_table_slabs(ws, rb, n, c, nw, rb->tables.ptr, &bad))) return rc;
         if (bad) {  // a base of even order (not a subgroup point): its multiples reach the identity - no tables, plain path
             rb->tables.release();
             return fail(GMSM_ERR_ARG, "window tables: a multiple 2^k P of a base is the identity (bases outside the prime-order subgroup)");
         }
         rb->tab_nw = nw;
         rb->tab_c.store(c, std::memory_order_release);  // publication: everything above is complete (stream synchronised)
+        // the narrow tables of the fused small-n kernel: calls of a few thousand points over these bases then fill ONE
+        // bucket set per workgroup and need no host-side fold at all (enqueue_small, shared form)
+        {
+            const WindowPlan sp = make_plan(SMALL_TABLE_C, 0, 1);
+            const size_t m = std::min<size_t>(n, SMALL_TABLE_POINTS);
+            if (rb->small_tables.ensure((size_t)sp.nwin_total * m * AFF_BYTES) == GMSM_OK &&
+                build_table_slabs(ws, rb, m, SMALL_TABLE_C, sp.nwin_total, rb->small_tables.ptr, &bad) == GMSM_OK && !bad) {
+                rb->small_nw = sp.nwin_total;
+                rb->small_m = m;
+                rb->small_c.store(SMALL_TABLE_C, std::memory_order_release);
+            }
+        }
         (void)ctx;
         return GMSM_OK;
     }
@@ -1081,51 +1103,88 @@ struct Group {
     static bool small_serves(size_t n, const ResidentBases *rb) {
         if (options().small_bits.load(std::memory_order_relaxed) == 1) return false;
         if (options().window_bits.load(std::memory_order_relaxed) != 0) return false;  // a forced width: the sorted pipeline
+        if (small_shared(n, rb)) return true;
         return n >= 1 && n <= small_max_points() && !use_tables(rb, n);
     }
-    // Enqueues the kernel and the copy of the totals into ws.pinned on ws.stream; d_points == nullptr: `resident`.
+    // the narrow window tables of registered bases serve the call: every (window, point) pair is an entry of ONE bucket set
+    static bool small_shared(size_t n, const ResidentBases *rb) {
+        if (!rb || n < 1 || options().tables.load(std::memory_order_relaxed) == 0) return false;
+        const unsigned c = rb->small_c.load(std::memory_order_acquire);
+        if (c == 0 || n > rb->small_m) return false;
+        const unsigned forced = options().small_bits.load(std::memory_order_relaxed);
+        if (forced >= 2 && forced != c) return false;
+        return n * rb->small_nw <= (size_t)SMALL_SL * SMALL_SHARED_MAX_SLICES;
+    }
+    // Enqueues the kernel on ws.stream; the window totals (shared form: ONE total) land in ws.pinned. d_points == nullptr:
+    // `resident`.
     static int enqueue_small(Context &ctx, Workspace &ws, const void *d_points, const void *d_scalars, size_t n,
-                             const WindowPlan &plan, const ResidentBases *resident, size_t resident_offset = 0) {
-        const uint32_t nw = plan.nwin_total, nslices = (uint32_t)((n + SMALL_SL - 1) / SMALL_SL);
+                             const WindowPlan &plan, const ResidentBases *resident, bool shared = false) {
+        const uint32_t nw = shared ? 1u : plan.nwin_total;
+        const size_t entries = shared ? n * plan.nwin_total : n;
+        const uint32_t nslices = (uint32_t)((entries + SMALL_SL - 1) / SMALL_SL);
         constexpr size_t REC = sizeof(typename OpsSerial::Mem);
         int rc;
         ws.pending_timed = false;
         if ((rc = begin_use(ws, ws.stream))) return rc;
-        if ((rc = ws.totals.ensure((size_t)nw * sizeof(Ext)))) return rc;
-        if ((rc = ws.ensure_pinned((size_t)nw * sizeof(Ext)))) return rc;
+        if ((rc = ws.ensure_pinned((size_t)plan.nwin_total * sizeof(Ext)))) return rc;
         if ((rc = ws.small_sums.ensure((size_t)nw * nslices * REC))) return rc;
         {
             const size_t had = ws.small_done.cap;
             if ((rc = ws.small_done.ensure((size_t)HEAVY_MAX_WINDOWS * 4))) return rc;
             if (ws.small_done.cap != had) HIP_TRY(hipMemsetAsync(ws.small_done.ptr, 0, ws.small_done.cap, ws.stream));
         }
-        if ((rc = ctx.allow_lds((const void *)k_msm_small<U, FrP, SMALL_SL>, (int)(SMALL_SL * REC)))) return rc;
         const void *upoints = nullptr;
         const uint8_t *skip = nullptr;
         if (d_points == nullptr) {
-            upoints = (const char *)resident->upoints.ptr + resident_offset * AFF_BYTES;
-            skip = (const uint8_t *)resident->skip.ptr + resident_offset;
+            upoints = shared ? resident->small_tables.ptr : resident->upoints.ptr;
+            skip = (const uint8_t *)resident->skip.ptr;
         }
         g_small_runs.fetch_add(1, std::memory_order_relaxed);
         // the window totals go straight into the pinned result buffer (host memory mapped into the device: nwin 128-byte
         // stores over PCIe instead of a copy kernel and its launch, 5-8 us of a 0.15 ms call)
-        hipLaunchKernelGGL((k_msm_small<U, FrP, SMALL_SL>), dim3(nslices, nw), dim3(SMALL_SL), (size_t)SMALL_SL * REC, ws.stream,
-                           d_points, upoints, skip, (const uint32_t *)d_scalars, (uint32_t)n, plan, ws.small_sums.ptr,
-                           (uint32_t *)ws.small_done.ptr, ws.pinned);
+        if (shared) {
+            g_table_runs.fetch_add(1, std::memory_order_relaxed);
+            if ((rc = ctx.allow_lds((const void *)k_msm_small<U, FrP, SMALL_SL, true>, (int)(SMALL_SL * REC)))) return rc;
+            hipLaunchKernelGGL((k_msm_small<U, FrP, SMALL_SL, true>), dim3(nslices, 1), dim3(SMALL_SL), (size_t)SMALL_SL * REC, ws.stream,
+                               d_points, upoints, skip, (const uint32_t *)d_scalars, (uint32_t)n, plan, (uint32_t)resident->small_m,
+                               ws.small_sums.ptr, (uint32_t *)ws.small_done.ptr, ws.pinned);
+        } else {
+            if ((rc = ctx.allow_lds((const void *)k_msm_small<U, FrP, SMALL_SL, false>, (int)(SMALL_SL * REC)))) return rc;
+            hipLaunchKernelGGL((k_msm_small<U, FrP, SMALL_SL, false>), dim3(nslices, nw), dim3(SMALL_SL), (size_t)SMALL_SL * REC, ws.stream,
+                               d_points, upoints, skip, (const uint32_t *)d_scalars, (uint32_t)n, plan, 0u, ws.small_sums.ptr,
+                               (uint32_t *)ws.small_done.ptr, ws.pinned);
+        }
         HIP_TRY(hipGetLastError());
         return end_use(ws, ws.stream);
     }
+    // waits for an enqueue_small and turns what it left in ws.pinned into the result
+    static int collect_small(Workspace &ws, const WindowPlan &plan, bool shared, J *out) {
+        if (shared) {  // one total, nothing to fold
+            Ext total;
+            int rc = collect_window_sums(ws, ws.stream, 1, &total);
+            if (rc) return rc;
+            *out = total.zz.is_zero() ? J{F::one(), F::one(), F::zero()} : jac_from_xyzz(total);
+            return GMSM_OK;
+        }
+        std::vector<Ext> totals(plan.nwin_total);
+        int rc = collect_window_sums(ws, ws.stream, plan.nwin_total, totals.data());
+        if (rc) return rc;
+        *out = fold(totals.data(), plan.c);
+        return GMSM_OK;
+    }
+    static WindowPlan small_plan(size_t n, const ResidentBases *rb, bool *shared) {
+        *shared = small_shared(n, rb);
+        return make_plan(*shared ? rb->small_c.load() : small_c(n), 0, 1);
+    }
     static int multiexp_small(Context &ctx, Workspace &ws, const void *d_points, const void *d_scalars, size_t n,
                               hipStream_t caller_stream, J *out, const ResidentBases *resident) {
-        const WindowPlan plan = make_plan(small_c(n), 0, 1);
+        bool shared = false;
+        const WindowPlan plan = small_plan(n, d_points ? nullptr : resident, &shared);
         if (plan.nwin_total > HEAVY_MAX_WINDOWS) return fail(GMSM_ERR_ARG, "small path: too many windows");
         int rc = order_after(ws, caller_stream);
         if (rc) return rc;
-        if ((rc = enqueue_small(ctx, ws, d_points, d_scalars, n, plan, resident))) return rc;
-        std::vector<Ext> totals(plan.nwin_total);
-        if ((rc = collect_window_sums(ws, ws.stream, plan.nwin_total, totals.data()))) return rc;
-        *out = fold(totals.data(), plan.c);
-        return GMSM_OK;
+        if ((rc = enqueue_small(ctx, ws, d_points, d_scalars, n, plan, resident, shared))) return rc;
+        return collect_small(ws, plan, shared, out);
     }
 
     static int multiexp_device(Context &ctx, Workspace &ws, const void *d_points, const void *d_scalars, size_t n,
@@ -1354,12 +1413,10 @@ struct Group {
                 HIP_TRY(hipMemcpyAsync(ws.h2d_points.ptr, points, n * AFF_BYTES, hipMemcpyHostToDevice, ws.stream));
                 dp = ws.h2d_points.ptr;
             }
-            const WindowPlan splan = make_plan(small_c(n), 0, 1);
-            if ((rc = enqueue_small(ctx, ws, dp, ws.h2d_scalars.ptr, n, splan, resident))) return rc;
-            std::vector<Ext> totals(splan.nwin_total);
-            if ((rc = collect_window_sums(ws, ws.stream, splan.nwin_total, totals.data()))) return rc;
-            *out = fold(totals.data(), splan.c);
-            return GMSM_OK;
+            bool shared = false;
+            const WindowPlan splan = small_plan(n, points ? nullptr : resident, &shared);
+            if ((rc = enqueue_small(ctx, ws, dp, ws.h2d_scalars.ptr, n, splan, resident, shared))) return rc;
+            return collect_small(ws, splan, shared, out);
         }
         const WindowPlan plan = plan_for(resident, n);  // the ranges share one bucket set and one reduction
         const unsigned c = plan.c;

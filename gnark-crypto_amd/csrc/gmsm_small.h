@@ -31,7 +31,8 @@ namespace gmsm {
 
 constexpr uint32_t SMALL_MAX_C = 7;                         // at most 2^6 buckets per window: one lane quad each
 constexpr uint32_t SMALL_NB_MAX = 1u << (SMALL_MAX_C - 1);
-constexpr uint32_t SMALL_MAX_SLICES = 64;
+constexpr uint32_t SMALL_MAX_SLICES = 64;          // slices per window of the plain form
+constexpr uint32_t SMALL_SHARED_MAX_SLICES = 1024;  // slices of the shared form (one bucket set: nwin * n entries)
 
 // points per workgroup (= threads): 256 = one wave per SIMD. A step of the kernel is one addition per lane, and two waves
 // on a SIMD take turns at its issue port: with 512 points per workgroup every step of phase 3 took twice as long (measured:
@@ -42,10 +43,14 @@ template <class U> struct SmallSlice { static constexpr uint32_t value = 256u; }
 // points: Go-layout affine bases (device) or nullptr when upoints (+ skip) are the registered, rewritten bases.
 // slice_sums: [nwin][nslices] lazy records, done: [nwin] counters (zero before the launch; the kernel leaves them zero),
 // totals: [nwin] canonical XYZZ.
-template <class U, class FrP, uint32_t SL>
+//
+// SHARED (narrow window tables of registered bases, Group::precompute_tables): `upoints` holds slab w = 2^(c w) P_i for
+// every window, tab_m points per slab; the entries are the nwin * n (window, point) pairs, e = w n + i, grid = (slices, 1);
+// every workgroup reduces its own bucket set and the last one adds all slice totals: ONE total, no host-side fold.
+template <class U, class FrP, uint32_t SL, bool SHARED>
 __global__ void __launch_bounds__(SL) k_msm_small(const void *__restrict__ points, const void *__restrict__ upoints,
                                                   const uint8_t *__restrict__ skip, const uint32_t *__restrict__ scalars,
-                                                  uint32_t n, WindowPlan plan, void *__restrict__ slice_sums,
+                                                  uint32_t n, WindowPlan plan, uint32_t tab_m, void *__restrict__ slice_sums,
                                                   uint32_t *__restrict__ done, void *__restrict__ totals) {
     using T = LzTraits<U>;
     using A = UnsatOps<U>;
@@ -56,16 +61,20 @@ __global__ void __launch_bounds__(SL) k_msm_small(const void *__restrict__ point
     __shared__ uint32_t cnt[SMALL_NB_MAX], pos[SMALL_NB_MAX], start[SMALL_NB_MAX + 1];
     __shared__ uint16_t sorted[SL], sbkt[SL];
     __shared__ uint32_t s_maxrun, s_last;
-    const uint32_t t = threadIdx.x, slice = blockIdx.x, nslices = gridDim.x, w = blockIdx.y;
+    const uint32_t t = threadIdx.x, slice = blockIdx.x, nslices = gridDim.x;
     const uint32_t NB = plan.nbuckets;
-    const uint32_t i = slice * SL + t;
+    const uint32_t e_mine = slice * SL + t;                  // entry of this thread
+    const uint32_t w = SHARED ? e_mine / n : blockIdx.y;     // its window (SHARED: per thread) ...
+    const uint32_t i = SHARED ? e_mine - w * n : e_mine;     // ... and point
+    const uint32_t wout = SHARED ? 0u : blockIdx.y;          // row of the totals / slice sums / counters this workgroup feeds
+    const bool have = SHARED ? e_mine < n * plan.nwin_total : i < n;
     if (t < NB) cnt[t] = 0;
     if (t == 0) s_maxrun = 0;
     __syncthreads();
 
     // ---- 1. the digit of scalar i in window w
     uint32_t code = 0;
-    if (i < n) {
+    if (have) {
         Fp<FrP> s;
         {
             const uint4 *src = reinterpret_cast<const uint4 *>(scalars + (size_t)i * NR);
@@ -127,7 +136,11 @@ __global__ void __launch_bounds__(SL) k_msm_small(const void *__restrict__ point
 
     // ---- 3a. E_t = P(sorted[t]) (+ P(sorted[t + 1]) inside the same bucket)
     auto fetch = [&](uint32_t ref, U &px, U &py) {
-        const uint32_t idx = slice * SL + (ref >> 1);
+        uint32_t idx = slice * SL + (ref >> 1);
+        if constexpr (SHARED) {  // entry -> (window, point) -> slot of the table
+            const uint32_t we = idx / n;
+            idx = we * tab_m + (idx - we * n);
+        }
         if (points != nullptr) {
             const Affine<typename T::Sat> a = load_struct<Affine<typename T::Sat>>(points, idx);
             UAffine<U> u;  // the class the registered bases are stored in (k_convert_points)
@@ -222,7 +235,7 @@ __global__ void __launch_bounds__(SL) k_msm_small(const void *__restrict__ point
         if (nslices == 1 || !scan) {
             if (t < 4) {  // quad 0 converts the total: canonical saturated XYZZ for the host (as k_reduce2_q)
                 using Mem = XYZZ<typename T::Sat>;
-                typename T::Sat *dst = reinterpret_cast<typename T::Sat *>(reinterpret_cast<char *>(totals) + (size_t)w * sizeof(Mem));
+                typename T::Sat *dst = reinterpret_cast<typename T::Sat *>(reinterpret_cast<char *>(totals) + (size_t)wout * sizeof(Mem));
                 typename T::Sat v = T::template to_sat<true>(S[0].c[t]);
                 if (S[0].inf) {
                     const Mem inf = Mem::infinity();
@@ -232,22 +245,32 @@ __global__ void __launch_bounds__(SL) k_msm_small(const void *__restrict__ point
             }
             return;
         }
-        if (j == 0) quad_rec_store<U>(slice_sums, (size_t)w * nslices + slice, &S[0], lane);
+        if (j == 0) quad_rec_store<U>(slice_sums, (size_t)wout * nslices + slice, &S[0], lane);
         __syncthreads();
         if (t == 0) {
             __threadfence();  // the slice's total is visible device-wide before the counter says so
-            const uint32_t seen = __hip_atomic_fetch_add(&done[w], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t seen = __hip_atomic_fetch_add(&done[wout], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             s_last = seen + 1u == nslices ? 1u : 0u;
         }
         __syncthreads();
         if (!s_last) return;
         __threadfence();
-        if (t == 0) done[w] = 0;  // re-armed for the next call on this workspace
-        width = 1;
-        while (width < nslices) width <<= 1;
-        // the slices' totals, 64 at a time: quad j sums the records j, j + 64, ... first (nslices <= 64: one each)
-        quad_rec_load<U>(&S[j], slice_sums, (size_t)w * nslices + (j < nslices ? j : 0), j < nslices, lane);
+        if (t == 0) done[wout] = 0;  // re-armed for the next call on this workspace
+        // the slices' totals: quad j adds up the records j, j + 64, ... (plain form: at most 64 slices, one each), then the tree
+        QRec<U> *Tq = S + 64;
+        if ((t & 3u) == 0) S[j].inf = 1u;
         __syncthreads();
+        for (uint32_t b0 = 0; b0 < nslices; b0 += 64) {
+            const uint32_t idx = b0 + j;
+            quad_rec_load<U>(&Tq[j], slice_sums, (size_t)wout * nslices + (idx < nslices ? idx : 0), idx < nslices, lane);
+            __syncthreads();
+            const QAddOps<U> o = quad_add_load<U>(&S[j], &Tq[j], lane);
+            __syncthreads();
+            quad_add_store<U, true>(&S[j], o, idx < nslices, lane);
+            __syncthreads();
+        }
+        width = 1;
+        while (width < nslices && width < 64) width <<= 1;
         scan = false;
     }
 }

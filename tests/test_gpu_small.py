@@ -105,3 +105,44 @@ def test_small_kernel_over_registered_bases_and_off_switch(gm, oracle_mod):
         aff, err = g.MultiExp(pts, sc)
         assert err is None and (aff == expected).all()
         assert _small_runs(gm) == before
+
+
+@pytest.mark.parametrize("curve,which", ALL_GROUPS)
+def test_small_kernel_over_narrow_window_tables(gm, oracle_mod, curve, which):
+    """gmsm_bases_precompute also builds narrow tables (2^(6 w) P_i for the first 4096 bases): calls of a few thousand points
+    over the handle then run the fused kernel with ONE bucket set per workgroup and no host-side fold. Every size (one slice,
+    many slices, a slice that straddles two windows), infinities / duplicates / zero scalars, host and device scalars, a
+    prefix longer than the narrow tables (falls back to the plain forms), and the tables switched off."""
+    import torch
+    g = (gm.G1Affine if which == "g1" else gm.G2Affine)(curve)
+    gj = (gm.G1Jac if which == "g1" else gm.G2Jac)(curve)
+    o = oracle_mod.Oracle(curve, which)
+    nreg = 5000
+    pts, sc = _inputs(o, g, nreg, 3)
+    rb = gj.register_bases(points=pts)
+    table_runs = lambda: int(gm._lib.load().gmsm_debug_table_runs())
+    try:
+        rb.precompute(0)
+        for m in (1, 2, 5, 6, 31, 257, 1023, 4096):
+            expected = o.msm_affine(pts[:m], sc[:m], nthreads=8)
+            before, tb = _small_runs(gm), table_runs()
+            jac, err = rb.MultiExp(sc[:m], gm.MultiExpConfig())
+            assert err is None and (gj.jac_to_affine(jac) == expected).all(), m
+            d_sc = torch.from_numpy(np.ascontiguousarray(sc[:m]).view(np.int64)).cuda()
+            assert (gj.jac_to_affine(rb.multiexp_device(d_sc.data_ptr(), m)) == expected).all(), m
+            assert _small_runs(gm) == before + 2 and table_runs() == tb + 2, m  # fused kernel, through the narrow tables
+        # all scalars zero / equal: the total is infinity / one crowded bucket
+        zeros = np.zeros_like(sc[:300])
+        assert (gj.jac_to_affine(rb.MultiExp(zeros, gm.MultiExpConfig())[0]) == 0).all()
+        equal = np.tile(sc[:1], (900, 1))
+        assert (gj.jac_to_affine(rb.MultiExp(equal, gm.MultiExpConfig())[0]) == o.msm_affine(pts[:900], equal, nthreads=8)).all()
+        # a prefix beyond the narrow tables, and the tables switched off: same points from the other forms
+        m = 4500
+        expected = o.msm_affine(pts[:m], sc[:m], nthreads=8)
+        assert (gj.jac_to_affine(rb.MultiExp(sc[:m], gm.MultiExpConfig())[0]) == expected).all()
+        with gm.options(tables=0):
+            tb = table_runs()
+            assert (gj.jac_to_affine(rb.MultiExp(sc[:700], gm.MultiExpConfig())[0]) == o.msm_affine(pts[:700], sc[:700], nthreads=8)).all()
+            assert table_runs() == tb
+    finally:
+        rb.release()

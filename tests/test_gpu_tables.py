@@ -179,8 +179,9 @@ def test_tables_on_sharded_handle(gm, oracle_mod):
 
 
 def test_tables_default_call_sizes(gm, oracle_mod, forced_options):
-    """Without the test switch the tables serve the measured range only: a 2^13-point call over BN254 G1 runs through
-    them, a prefix below n/16 and a call below 2^13 points take the plain path; results agree either way."""
+    """Without the test switch the tables serve the measured ranges only: a 2^13-point call over BN254 G1 runs through the
+    wide tables, calls of at most 2^12 points through the narrow ones (the fused small-n kernel, round 5), a call between
+    the two ranges and a prefix below n/16 take the plain paths; results agree either way."""
     forced_options(tables=1)
     g = gm.G1Jac("bn254")
     o = oracle_mod.Oracle("bn254", "g1")
@@ -189,7 +190,7 @@ def test_tables_default_call_sizes(gm, oracle_mod, forced_options):
     rb = g.register_bases(points=pts)
     try:
         assert rb.precompute(0) == 16
-        for m, through in ((n, True), (1 << 13, True), ((1 << 13) - 1, False), (n // 16 - 1, False)):
+        for m, through in ((n, True), (1 << 13, True), ((1 << 13) - 1, False), (n // 16 - 1, True), (1 << 12, True), ((1 << 12) + 1, False)):
             before = table_runs(gm)
             jac, err = rb.MultiExp(sc[:m])
             assert err is None and (g.jac_to_affine(jac) == o.msm_affine(pts[:m], sc[:m], nthreads=16)).all(), m
