@@ -1087,10 +1087,11 @@ struct Group {
     static constexpr uint32_t SMALL_SL = SmallSlice<U>::value;
     // Measured against the sorted pipeline (profiles/r05_small_n.log, resident ms, fused / pipeline): BN254 G1 2^5 0.147 / 0.27,
     // 2^10 0.18 / 0.29-0.35, 2^12 0.28 / 0.41, 2^13 0.38 / 0.47; BN254 G2 2^11 0.65 / 0.91, 2^13 1.29 / 0.99; BLS12-381 G1 2^11 0.41 /
-    // 0.62, 2^13 0.73 / 0.70; BLS12-381 G2 2^11 1.19 / 1.62, 2^13 2.5 / 1.7; BW6-761 2^11 1.60 / 2.09, 2^13 4.2 / 2.2.
+    // 0.62, 2^12 0.50 / 0.65, 2^13 0.73 / 0.70; BLS12-381 G2 2^11 1.19 / 1.62, 2^12 1.68 / 1.65; BN254 G2 2^12 0.86 / 0.86; BW6-761 2^11 1.57 / 2.05,
+    // 2^12 2.5 / 2.1.
     static size_t small_max_points() {
         const size_t forced = options().small_max.load(std::memory_order_relaxed);
-        return std::min<size_t>(forced ? forced : GMSM_TUNE(SMALL_MAX, AFF_BYTES == 64 ? 8192 : 2048), (size_t)SMALL_SL * SMALL_MAX_SLICES);
+        return std::min<size_t>(forced ? forced : GMSM_TUNE(SMALL_MAX, AFF_BYTES == 64 ? 8192 : AFF_BYTES == 96 ? 4096 : 2048), (size_t)SMALL_SL * SMALL_MAX_SLICES);
     }
     static unsigned small_c(size_t n) {
         const unsigned forced = options().small_bits.load(std::memory_order_relaxed);
