@@ -85,10 +85,22 @@ struct FpHost64 {
         }
     }
     static inline unsigned long long q(int i) { return (unsigned long long)P::Q[2 * i] | ((unsigned long long)P::Q[2 * i + 1] << 32); }
+    // add / subtract with carry on 128-bit intermediates (adc / sbb in the generated code; portable across clang and gcc -
+    // the host checks under tests/c compile this header with g++)
+    static inline unsigned long long addc(unsigned long long a, unsigned long long b, unsigned long long &c) {
+        const unsigned __int128 t = (unsigned __int128)a + b + c;
+        c = (unsigned long long)(t >> 64);
+        return (unsigned long long)t;
+    }
+    static inline unsigned long long subb(unsigned long long a, unsigned long long b, unsigned long long &bw) {
+        const unsigned __int128 t = (unsigned __int128)a - b - bw;
+        bw = (unsigned long long)(t >> 64) & 1ull;
+        return (unsigned long long)t;
+    }
     // t < 2q -> t mod q
     static inline void reduce_once(unsigned long long *t) {
         unsigned long long d[M], b = 0;
-        for (int i = 0; i < M; ++i) d[i] = __builtin_subcll(t[i], q(i), b, &b);
+        for (int i = 0; i < M; ++i) d[i] = subb(t[i], q(i), b);
         for (int i = 0; i < M; ++i) t[i] = b ? t[i] : d[i];
     }
 };
@@ -127,7 +139,7 @@ GMSM_HD Fp<P> fp_add(const Fp<P> &x, const Fp<P> &y) {
         unsigned long long a[H::M], b[H::M], c = 0;
         H::load(x, a);
         H::load(y, b);
-        for (int i = 0; i < H::M; ++i) a[i] = __builtin_addcll(a[i], b[i], c, &c);
+        for (int i = 0; i < H::M; ++i) a[i] = H::addc(a[i], b[i], c);
         H::reduce_once(a);  // top word of q leaves a spare bit: no carry out of the top word
         H::store(z, a);
         return z;
@@ -155,8 +167,8 @@ GMSM_HD Fp<P> fp_sub(const Fp<P> &x, const Fp<P> &y) {
         unsigned long long a[H::M], b[H::M], bw = 0, c = 0;
         H::load(x, a);
         H::load(y, b);
-        for (int i = 0; i < H::M; ++i) a[i] = __builtin_subcll(a[i], b[i], bw, &bw);
-        for (int i = 0; i < H::M; ++i) a[i] = __builtin_addcll(a[i], bw ? H::q(i) : 0ull, c, &c);  // if borrow: += q
+        for (int i = 0; i < H::M; ++i) a[i] = H::subb(a[i], b[i], bw);
+        for (int i = 0; i < H::M; ++i) a[i] = H::addc(a[i], bw ? H::q(i) : 0ull, c);  // if borrow: += q
         H::store(z, a);
         return z;
     }

@@ -423,7 +423,7 @@ struct Group {
         // n / (stage_cap + 1) of them, and their sub-runs of HEAVY_SUB references number at most n / HEAVY_SUB + that
         const uint32_t hcap = (uint32_t)std::min<size_t>(nparts, n / ((size_t)stage_cap + 1) + 1);
         const uint32_t scap = (uint32_t)(n / HEAVY_SUB) + hcap;
-        const size_t hparts_bytes = (((size_t)nw * hcap * sizeof(HeavyPart) + 15) / 16) * 16, hcount_bytes = (((size_t)nw * 8 + 15) / 16) * 16;
+        const size_t hparts_bytes = (((size_t)nw * hcap * sizeof(HeavyPart) + 15) / 16) * 16, hcount_bytes = (((size_t)nw * 8 + 4 + 15) / 16) * 16;
         if ((rc = ws.heavy.ensure(hparts_bytes + hcount_bytes + ((size_t)nw * scap << fbits) * 4))) return rc;
         HeavyPart *hparts = (HeavyPart *)ws.heavy.ptr;
         uint32_t *hcount = (uint32_t *)((char *)ws.heavy.ptr + hparts_bytes);
@@ -510,9 +510,9 @@ struct Group {
                                (const uint32_t *)digits, n, nparts, fbits, pchunk_len, bh);
         timer.mark(T_SCAN, stream);
         if ((size_t)((nparts + 31) / 32) * nw < (size_t)ctx.num_cus && pchunks >= 256)
-            hipLaunchKernelGGL(k_part_colscan<32>, dim3((nparts + 31) / 32, nw), dim3(1024), 0, stream, bh, pchunks, nparts, part_pop);
+            hipLaunchKernelGGL(k_part_colscan<32>, dim3((nparts + 31) / 32, nw), dim3(1024), 0, stream, bh, pchunks, nparts, part_pop, hcount + 2 * nw);
         else
-            hipLaunchKernelGGL(k_part_colscan<8>, dim3((nparts + 31) / 32, nw), dim3(256), 0, stream, bh, pchunks, nparts, part_pop);
+            hipLaunchKernelGGL(k_part_colscan<8>, dim3((nparts + 31) / 32, nw), dim3(256), 0, stream, bh, pchunks, nparts, part_pop, hcount + 2 * nw);
         hipLaunchKernelGGL(k_part_rowscan, dim3(nw), dim3(1024), 0, stream, part_pop, nparts, part_base, long_flag, stage_cap, hparts,
                            hcount, hcap);
         timer.mark(T_SCATTER, stream);
@@ -529,13 +529,16 @@ struct Group {
         }
         hipLaunchKernelGGL(k_fine_sort, dim3(nparts, nw), dim3(1024), ((size_t)4 << fbits) + (size_t)stage_cap * 4, stream,
                            parted, n, NB, fbits, lidx, part_base, sorted, starts, stage_cap);
-        // partitions beyond the staging slots (crowded buckets, narrow top windows): sorted by many workgroups each
-        hipLaunchKernelGGL(k_heavy_hist, dim3(heavy_wg), dim3(1024), (size_t)4 << fbits, stream, parted, n, nw, nparts, fbits, lidx,
-                           part_base, (const HeavyPart *)hparts, (const uint32_t *)hcount, hcap, scap, subhist);
-        hipLaunchKernelGGL(k_heavy_scan, dim3(std::min<uint32_t>(hcap, 64u), nw), dim3(1024), (size_t)4 << fbits, stream, nparts, NB, fbits,
-                           part_base, (const HeavyPart *)hparts, (const uint32_t *)hcount, hcap, scap, subhist, starts);
-        hipLaunchKernelGGL(k_heavy_place, dim3(heavy_wg), dim3(1024), (size_t)4 << fbits, stream, parted, n, nw, nparts, fbits, lidx,
-                           part_base, (const HeavyPart *)hparts, (const uint32_t *)hcount, hcap, scap, (const uint32_t *)subhist, sorted);
+        // partitions beyond the staging slots (crowded buckets, narrow top windows): sorted by many workgroups each. A run of at
+        // most stage_cap entries per window cannot have one: no launches (14 us of a 0.4 ms call)
+        if (n > stage_cap) {
+            hipLaunchKernelGGL(k_heavy_hist, dim3(heavy_wg), dim3(1024), (size_t)4 << fbits, stream, parted, n, nw, nparts, fbits, lidx,
+                               part_base, (const HeavyPart *)hparts, (const uint32_t *)hcount, hcap, scap, subhist);
+            hipLaunchKernelGGL(k_heavy_scan, dim3(std::min<uint32_t>(hcap, 64u), nw), dim3(1024), (size_t)4 << fbits, stream, nparts, NB, fbits,
+                               part_base, (const HeavyPart *)hparts, (const uint32_t *)hcount, hcap, scap, subhist, starts);
+            hipLaunchKernelGGL(k_heavy_place, dim3(heavy_wg), dim3(1024), (size_t)4 << fbits, stream, parted, n, nw, nparts, fbits, lidx,
+                               part_base, (const HeavyPart *)hparts, (const uint32_t *)hcount, hcap, scap, (const uint32_t *)subhist, sorted);
+        }
         // ---- 2. bucket accumulation, 3. fix-up, 4. bucket reduction: for the windows [k0, k0 + nk) of the launch - all of
         // them, or (GMSM_OPT_SPLIT, experiment) two groups: the fix-up and reduction of the first group run on the merge stream
         // beside the accumulation of the second. Every array is window-major, so a group is the same kernels over shifted

@@ -293,9 +293,11 @@ __global__ void __launch_bounds__(1024) k_part_hist(const D *__restrict__ digits
 // entries: thousands of chunks, 16-64 workgroups - a thread's walk over its chunks is what the kernel takes).
 template <uint32_t SEGS>
 __global__ void __launch_bounds__(32 * SEGS) k_part_colscan(uint32_t *__restrict__ blockhist, uint32_t nchunks, uint32_t nparts,
-                                                            uint32_t *__restrict__ part_pop) {
+                                                            uint32_t *__restrict__ part_pop,
+                                                            uint32_t *__restrict__ zero_word /* may be null */) {
     __shared__ uint32_t seg_sum[SEGS][32];
     const uint32_t lane = threadIdx.x & 31u, s = threadIdx.x >> 5, k = blockIdx.y;
+    if (zero_word != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *zero_word = 0;  // the launch's count of oversized sub-runs (k_part_rowscan adds to it)
     const uint32_t p = blockIdx.x * 32u + lane;
     const uint32_t per = (nchunks + SEGS - 1u) / SEGS;
     const uint32_t c0 = s * per < nchunks ? s * per : nchunks;
@@ -380,6 +382,7 @@ static __global__ void __launch_bounds__(1024) k_part_rowscan(const uint32_t *__
         if (t == 0) {
             hcount[2 * k] = s_np < hcap ? s_np : hcap;
             hcount[2 * k + 1] = s_first;  // sub-runs = rows of the window's table
+            if (s_first) atomicAdd(&hcount[2 * gridDim.x], s_first);  // all windows: what the k_heavy_* launches test first
         }
     }
 }
@@ -524,7 +527,8 @@ static __global__ void __launch_bounds__(1024) k_fine_sort(const uint32_t *__res
 }
 
 // ---- the sort of the oversized partitions (see HeavyPart above). subhist: [nwin][scap rows][2^fbits] counters.
-// hcount[2k] = listed partitions of window k, hcount[2k + 1] = their sub-runs (= rows of the window's table).
+// hcount[2k] = listed partitions of window k, hcount[2k + 1] = their sub-runs (= rows of the window's table), hcount[2 nwin] = the
+// sub-runs of all windows (zeroed by k_part_colscan, summed by k_part_rowscan).
 // Work items of k_heavy_hist / k_heavy_place = the rows of all windows, numbered window by window, taken round-robin by the
 // workgroups of a 1-D grid (a window alone may hold all of them: the narrow top window of uniform scalars).
 constexpr uint32_t HEAVY_MAX_WINDOWS = 256;
@@ -573,6 +577,7 @@ static __global__ void __launch_bounds__(1024) k_heavy_hist(const uint32_t *__re
     __shared__ uint32_t s_pref[HEAVY_MAX_WINDOWS + 1];
     __shared__ HeavyPart s_hp;
     const uint32_t t = threadIdx.x, T = blockDim.x;
+    if (hcount[2 * nw] == 0) return;  // no oversized partition in this launch (the usual case): one load
     const uint32_t total = heavy_prefix(hcount, nw, s_pref);
     const uint32_t nf = 1u << fbits;
     constexpr uint32_t PER = HEAVY_SUB / 1024;
@@ -661,6 +666,7 @@ static __global__ void __launch_bounds__(1024) k_heavy_place(const uint32_t *__r
     __shared__ uint32_t s_pref[HEAVY_MAX_WINDOWS + 1];
     __shared__ HeavyPart s_hp;
     const uint32_t t = threadIdx.x, T = blockDim.x;
+    if (hcount[2 * nw] == 0) return;
     const uint32_t total = heavy_prefix(hcount, nw, s_pref);
     const uint32_t nf = 1u << fbits;
     const uint32_t pmask = (1u << lidx) - 1u;
