@@ -1098,11 +1098,13 @@ struct Group {
     }
     static unsigned small_c(size_t n) {
         const unsigned forced = options().small_bits.load(std::memory_order_relaxed);
-        if (forced >= 2 && forced <= SMALL_MAX_C) return forced;
         // flat over 5..7 for the narrow types (fewer windows = less host fold, more buckets = more quad steps); the 28-limb
         // field and large calls take 7
-        if (n <= 128) return 5;
-        return (FR_BITS > 300 || n > 4096) ? 7 : 6;
+        unsigned c = (forced >= 2 && forced <= SMALL_MAX_C) ? forced : n <= 128 ? 5 : (FR_BITS > 300 || n > 4096) ? 7 : 6;
+        // the kernel holds one lane quad per bucket: a width whose top window needs c + 1 bits (the scalar field's bit
+        // length a multiple of c) doubles the buckets - step down until they fit
+        while (c > 2 && make_plan(c, 0, 1).nbuckets > SMALL_NB_MAX) --c;
+        return c;
     }
     static bool small_serves(size_t n, const ResidentBases *rb) {
         if (options().small_bits.load(std::memory_order_relaxed) == 1) return false;
