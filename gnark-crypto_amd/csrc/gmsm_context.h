@@ -448,9 +448,8 @@ struct StageTimer {
     void mark(int ev, hipStream_t stream) {
         if (level == 1 || (level == 2 && (ev == T_ACCUMULATE || ev == T_FIXUP))) (void)hipEventRecord(ws.events[ev], stream);
     }
-    static void collect(Workspace &ws) {  // call after the stream has been synchronised
-        float ms[STAGE_COUNT] = {0};
-        unsigned launches[STAGE_COUNT] = {0};
+    // adds the stage times of the run whose events ws holds to ms[] / launches[] (call after the stream has been synchronised)
+    static void collect_add(Workspace &ws, float *ms, unsigned *launches) {
         for (int i = T_DECOMPOSE; i < T_END; ++i) {
             if (ws.timed_level == 2 && i != T_ACCUMULATE) continue;
             float t = 0.f;
@@ -458,6 +457,11 @@ struct StageTimer {
             ms[T_TO_STAGE[i]] += t;
             ++launches[T_TO_STAGE[i]];
         }
+    }
+    static void collect(Workspace &ws) {  // one pipeline run = one call of the profile
+        float ms[STAGE_COUNT] = {0};
+        unsigned launches[STAGE_COUNT] = {0};
+        collect_add(ws, ms, launches);
         record_stage_times(ms, launches);
     }
 };

@@ -316,7 +316,8 @@ struct Group {
     static int enqueue_window_sums(Context &ctx, Workspace &ws, const void *d_points, const void *d_scalars, size_t n,
                                    const WindowPlan &plan, hipStream_t stream, const ResidentBases *resident,
                                    void *d_out = nullptr, size_t resident_offset = 0 /* first registered base used */,
-                                   bool buckets_only = false) {
+                                   bool buckets_only = false, bool time_range = false /* buckets_only: the caller collects the
+                                   stage events of this range before it enqueues the next (multiexp_device) */) {
         const uint32_t nwd = plan.nwin_local;  // windows of the digit decomposition = totals handed out
         ws.pending_timed = false;
         if (nwd == 0) return GMSM_OK;
@@ -457,7 +458,7 @@ struct Group {
         // Stage times cover single-run calls: the ranges of a multi-range call (buckets_only) reuse a workspace's events
         // before anybody could read them, and their merges and the one reduction run on another stream - such calls are
         // left out of the profile instead of being reported with two of their ranges and no reduction.
-        StageTimer timer(ws, /*enabled=*/!buckets_only);
+        StageTimer timer(ws, /*enabled=*/!buckets_only || time_range);
         ws.timed = timer.on;
         // ---- 0. inputs: rewrite the bases into the lazy Montgomery domain + infinity flags (unless registered earlier),
         // signed-digit decomposition of every scalar
@@ -1077,7 +1078,12 @@ struct Group {
     // and (b) - experiment, GMSM_DEVICE_RANGES - to keep the bases of a range inside the 256 MiB Infinity Cache while
     // all windows gather from them.
     static unsigned device_ranges(size_t n, const WindowPlan &plan) {
-        const size_t run = max_run_points(plan);
+        size_t run = max_run_points(plan);
+        // BN254 G1 beyond 2^24 points: ranges of 2^24. The coarse sort of a longer run has 2048+ partitions and writes
+        // 8-entry runs (scatter + fine sort 4.2 ms at 2^25, 9.0 at 2^26, against 1.45 per 2^24 points); the ranges share one
+        // bucket set and one reduction, a merge costs 0.1 ms: 2^25 43.8 -> 42.0 ms, 2^26 86.3 -> 83.0 (profiles/r05_device_ranges.log).
+        // Neutral for BLS12-381 G1 (84.6 / 84.4-84.7 ms at 2^25) and worse below 2^24 (BN254 G1 2^24 in two ranges: 21.5 -> 22.0).
+        if (AFF_BYTES == 64 && !plan.shared && options().max_run.load(std::memory_order_relaxed) == 0) run = std::min<size_t>(run, (size_t)1 << 24);
         unsigned nr = (unsigned)((n + run - 1) / run);
         const unsigned forced = GMSM_TUNE(DEVICE_RANGES, 0);
         if (forced > nr) nr = (unsigned)std::min<size_t>(forced, n);
@@ -1213,17 +1219,28 @@ struct Group {
         int rc = order_after(ws, caller_stream);
         if (rc) return rc;
         if ((rc = ws.carry.ensure((size_t)bucket_sets(plan) * plan.nbuckets * REC))) return rc;
+        // stage profile of a multi-range call: every range's events are collected before the next range reuses them (one
+        // stream synchronisation per range, profiling only), the call counts once; the final reduction is not in it
+        const bool prof = profiling_level() != 0;
+        float pms[STAGE_COUNT] = {0};
+        unsigned plaunch[STAGE_COUNT] = {0};
         for (unsigned r = 0; r * per < n; ++r) {
             const size_t lo = (size_t)r * per, len = std::min(per, n - lo);
             const void *dp = d_points ? (const char *)d_points + lo * AFF_BYTES : nullptr;
             if ((rc = enqueue_window_sums(ctx, ws, dp, (const char *)d_scalars + lo * SCALAR_BYTES, len, plan, ws.stream, resident,
-                                          nullptr, lo, /*buckets_only=*/true)))
+                                          nullptr, lo, /*buckets_only=*/true, /*time_range=*/prof)))
                 return rc;
+            if (prof && ws.pending_timed) {
+                HIP_TRY(wait_stream(ws.stream));
+                StageTimer::collect_add(ws, pms, plaunch);
+                ws.pending_timed = false;
+            }
             hipLaunchKernelGGL((k_merge_buckets<OpsSerial>), dim3((plan.nbuckets + 255) / 256, bucket_sets(plan)), dim3(256), 0, ws.stream,
                                ws.carry.ptr, (const void *)ws.buckets.ptr, (const uint32_t *)ws.starts.ptr, plan.nbuckets, r == 0 ? 1 : 0);
         }
         if ((rc = enqueue_reduce(ctx, ws, ws.carry.ptr, plan, per, ws.stream))) return rc;
         if ((rc = collect_window_sums(ws, ws.stream, plan.nwin_local, totals.data()))) return rc;
+        if (prof) record_stage_times(pms, plaunch);
         *out = fold(totals.data(), c);
         return GMSM_OK;
     }
