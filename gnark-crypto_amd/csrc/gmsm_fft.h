@@ -116,9 +116,6 @@ __global__ void __launch_bounds__(256) k_fft_scale_const_lz(Fp<FrP> *__restrict_
 #ifndef GMSM_FFT_LOWB
 #define GMSM_FFT_LOWB 10
 #endif
-#ifndef GMSM_FFT_FUSE2
-#define GMSM_FFT_FUSE2 0  // 1: two stages per LDS round trip (A/B only: measured no faster, profiles/r05_fft_fuse2.log)
-#endif
 template <class FrP, bool TOPDOWN>
 __global__ void __launch_bounds__(512) k_fft_pass_lz(Fp<FrP> *__restrict__ a, unsigned log2n, unsigned bl, unsigned B, unsigned log2C,
                                                      const Fp<FrP> *__restrict__ twz, const Fp<FrP> *__restrict__ pre, int pre_rev,
@@ -153,47 +150,6 @@ __global__ void __launch_bounds__(512) k_fft_pass_lz(Fp<FrP> *__restrict__ a, un
             else Z::template dit_free<false>(x, y, fft_load(twz, tw));
         }
     };
-#if GMSM_FFT_FUSE2
-    // A/B (-DGMSM_FFT_FUSE2=1, profiles/r05_fft_fuse2.log): two stages per trip through LDS - a work item owns the four
-    // elements that differ in two adjacent tile bits and runs both stages in registers (half the LDS round trips, barriers
-    // and index arithmetic per butterfly; the same four twiddle products: in a prime field the "trivial" fourth root of
-    // unity of a radix-4 butterfly is a full product).
-    for (unsigned st = 0; st < B;) {
-        const bool carry0 = ((B - 1 - st) & 1u) != 0;
-        if (B - st >= 2) {
-            const unsigned bbA = TOPDOWN ? B - 1 - st : st, bbB = TOPDOWN ? bbA - 1 : bbA + 1;  // stage A first, then B
-            const unsigned low = bbA < bbB ? bbA : bbB;
-            for (unsigned q = t; q < (elems >> 2); q += T) {
-                const unsigned c = q & (C - 1), p = q >> log2C;
-                const unsigned m00 = ((p >> low) << (low + 2)) | (p & ((1u << low) - 1));
-                const unsigned mA = 1u << bbA, mB = 1u << bbB;
-                U e00 = tile[(m00 << log2C) + c], eA = tile[((m00 | mA) << log2C) + c], eB = tile[((m00 | mB) << log2C) + c],
-                  eAB = tile[((m00 | mA | mB) << log2C) + c];
-                butterfly(e00, eA, bbA, base + ((size_t)m00 << bl) + c, carry0);
-                butterfly(eB, eAB, bbA, base + ((size_t)(m00 | mB) << bl) + c, carry0);
-                butterfly(e00, eB, bbB, base + ((size_t)m00 << bl) + c, !carry0);
-                butterfly(eA, eAB, bbB, base + ((size_t)(m00 | mA) << bl) + c, !carry0);
-                tile[(m00 << log2C) + c] = e00;
-                tile[((m00 | mA) << log2C) + c] = eA;
-                tile[((m00 | mB) << log2C) + c] = eB;
-                tile[((m00 | mA | mB) << log2C) + c] = eAB;
-            }
-            st += 2;
-        } else {
-            const unsigned bb = TOPDOWN ? B - 1 - st : st;
-            for (unsigned q = t; q < nbf; q += T) {
-                const unsigned c = q & (C - 1), p = q >> log2C;
-                const unsigned mid0 = ((p >> bb) << (bb + 1)) | (p & ((1u << bb) - 1)), mid1 = mid0 | (1u << bb);
-                U x = tile[(mid0 << log2C) + c], y = tile[(mid1 << log2C) + c];
-                butterfly(x, y, bb, base + ((size_t)mid0 << bl) + c, carry0);
-                tile[(mid0 << log2C) + c] = x;
-                tile[(mid1 << log2C) + c] = y;
-            }
-            st += 1;
-        }
-        __syncthreads();
-    }
-#else
     for (unsigned st = 0; st < B; ++st) {
         const unsigned bb = TOPDOWN ? B - 1 - st : st;
         const bool carry = ((B - 1 - st) & 1u) != 0;  // every second stage, never the last of the pass (FftLz: LIMBS)
@@ -207,7 +163,6 @@ __global__ void __launch_bounds__(512) k_fft_pass_lz(Fp<FrP> *__restrict__ a, un
         }
         __syncthreads();
     }
-#endif
     for (unsigned e = t; e < elems; e += T) {
         const unsigned mid = e >> log2C, c = e & (C - 1);
         const size_t g = base + ((size_t)mid << bl) + c;
@@ -221,6 +176,9 @@ __global__ void __launch_bounds__(512) k_fft_pass_lz(Fp<FrP> *__restrict__ a, un
     }
 }
 
+// (Round 5 retried the same on the reduction-free lazy butterflies - the verdict's "radix 4"; the product count cannot drop, the fourth root
+// of unity being a full product in a prime field -: 8 % slower at 2^24, profiles/r05_fft_fuse2.log; the code is in the history, commit "fr/fft: two
+// stages per LDS round trip".)
 // (Round 3 tried two radix-2 stages per trip through LDS - "radix 2^2": a thread owns the four elements that differ in
 // two adjacent bits and runs both stages in registers, half the LDS round trips and barriers per butterfly. Slower at every
 // size - 2^24 2.87 against 2.72 ms, 2^20 0.245 against 0.197 with 256 threads; 128 and 512 threads per tile are worse still
