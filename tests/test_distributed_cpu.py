@@ -237,3 +237,28 @@ def test_bench_launcher_asks_for_the_devices_it_needs():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        env=dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"), timeout=300)
     assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
+
+
+def test_bench_sharded_inputs_are_the_same_on_every_rank(gm):
+    """bench.py's N > 1 rows generate their synthetic inputs per rank and per chunk (chunked_scalars): whatever the point
+    slices, the ranks must see slices of ONE array - otherwise the closed-form check (every rank contributes the dot product
+    of its slice) and the window decomposition (every rank holds all points) would disagree on the MultiExp being computed."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module_cpu", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    g = gm.G1Jac("bn254")
+    logn = 21  # two chunks of 2^20
+    n = 1 << logn
+    for tag in (0, 1):
+        full = bench.chunked_scalars(g, logn, tag, 0, n)
+        assert full.shape == (n, g.fr_limbs)
+        for world in (2, 3, 8):
+            parts = [bench.chunked_scalars(g, logn, tag, r * n // world, (r + 1) * n // world) for r in range(world)]
+            assert (np.concatenate(parts) == full).all(), (tag, world)
+        lo, hi = 1048570, 1048590  # a slice across the chunk boundary
+        assert (bench.chunked_scalars(g, logn, tag, lo, hi) == full[lo:hi]).all()
+    assert not (bench.chunked_scalars(g, logn, 0, 0, 64) == bench.chunked_scalars(g, logn, 1, 0, 64)).all()
+    small = bench.chunked_scalars(g, 10, 0, 0, 1 << 10)  # sizes below one chunk
+    assert small.shape == (1 << 10, g.fr_limbs) and (bench.chunked_scalars(g, 10, 0, 100, 200) == small[100:200]).all()
+    assert bench.max_over_ranks(None, 1, {"a": 1.0}) == {"a": 1.0}
