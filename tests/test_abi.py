@@ -181,7 +181,14 @@ def test_options_and_lifecycle_entries_need_no_device(gm):
         assert [gm.get_option(k) for k in ("window_bits", "tables", "max_run", "host_ranges", "fixed_base_bits")] == [13, 0, 4096, 3, 11]
         assert gm.G1Jac("bn254").default_window_bits(1 << 20) == 13
     assert gm.get_option("max_run") == 0 and gm.get_option("host_ranges") == 0
-    for name, bad in (("window_bits", 1), ("window_bits", 21), ("tables", 3), ("fixed_base_bits", 15)):
+    # round 5: the fused small-n kernel's switches and the window-group experiment (off by default)
+    assert [gm.get_option(k) for k in ("small_bits", "small_max", "split")] == [0, 0, 0]
+    with gm.options(small_bits=6, small_max=1024, split=1):
+        assert [gm.get_option(k) for k in ("small_bits", "small_max", "split")] == [6, 1024, 1]
+    with gm.options(small_bits=1):  # 1 = off
+        assert gm.get_option("small_bits") == 1
+    assert [gm.get_option(k) for k in ("small_bits", "small_max", "split")] == [0, 0, 0]
+    for name, bad in (("window_bits", 1), ("window_bits", 21), ("tables", 3), ("fixed_base_bits", 15), ("small_bits", 8)):
         with pytest.raises(ValueError):
             gm.set_option(name, bad)
     assert lib.gmsm_set_option(99, 1) == gm._lib.GMSM_ERR_ARG and lib.gmsm_get_option(99) == 0
