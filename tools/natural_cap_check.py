@@ -47,7 +47,7 @@ def main():
     k = sum(int(v) << (64 * i) for i, v in enumerate(k_limbs)) * reps % g.curve.r
     expected = o.jac_to_affine(o.scalar_mul(o.generator, k))
     ok = bool((g.jac_to_affine(jac) == expected).all())
-    print(f"n = 2^27 + 2^22 = {n} points, two natural point ranges: parity {'OK' if ok else 'MISMATCH'}; "
+    print(f"n = 2^27 + 2^22 = {n} points, point ranges cut by the library itself: parity {'OK' if ok else 'MISMATCH'}; "
           f"ms per call {', '.join(f'{v:.1f}' for v in ms)} (first includes workspace growth)")
     return 0 if ok else 1
 
