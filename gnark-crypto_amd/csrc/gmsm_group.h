@@ -1039,7 +1039,9 @@ struct Group {
         return GMSM_OK;
     }
     static constexpr unsigned SMALL_TABLE_C = 6;          // width of the narrow tables: 2^5 buckets, one lane quad each
-    static constexpr size_t SMALL_TABLE_POINTS = 4096;    // ... over the first so many bases (43 x 4096 x 64 B = 11 MiB for BN254 G1)
+    // ... over the first so many bases (43 x 4096 x 64 B = 11 MiB for BN254 G1). Measured against the other forms (profiles/r05_small_n.log,
+    // last block): ahead up to 2^12 points for every group but BW6-761 (2^12: 2.36 ms against 2.08 for the sorted pipeline; 2^10: 0.70 against 1.07)
+    static constexpr size_t SMALL_TABLE_POINTS = FR_BITS > 300 ? 2048 : 4096;
     static int precompute_tables(Context &ctx, Workspace &ws, ResidentBases *rb, unsigned c) {
         if (c == 0) c = table_c(rb->n);
         if (c < 2 || c > 20) return fail(GMSM_ERR_ARG, "table window width must be 2..20");

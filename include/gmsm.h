@@ -130,7 +130,7 @@ int gmsm_multiexp_bases_sharded(uint64_t handle, const uint64_t *scalars, size_t
  * shorter than n/16, call sizes outside the range where the tables were measured to win (about 2^13..2^21 points, by
  * group) and calls with GMSM_OPT_WINDOW_BITS forced to another width use the plain path; GMSM_OPT_TABLES = 0 switches the
  * tables off, 2 uses them for every call size (tests).
- * The same call also builds NARROW tables (width 6) over the first 4096 bases: a MultiExp of at most 4096 points over the
+ * The same call also builds NARROW tables (width 6) over the first 4096 bases (2048 for BW6-761): a MultiExp of at most that many points over the
  * handle (Pedersen commitments, small KZG commitments over a fixed SRS) then runs the fused small-n kernel with one bucket
  * set per workgroup and needs no host-side fold of window totals at all - BN254 G1, 2^10 points: 0.146 ms against 0.181 ms
  * for the same call without tables.
