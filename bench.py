@@ -831,6 +831,7 @@ def main():
     ap.add_argument("--also-logn", type=int, default=24, help="N>1: the sharded row that also runs through the C ABI (the 2^24 half of the metric)")
     ap.add_argument("--sharded-logns", default="22,24,26", help="N>1: sizes of the sharded rows beside the headline (north_star: 2^20-2^26)")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the N3 / N4-ingest rows")
+    ap.add_argument("--full-out", default=None, help="where the full record goes (default bench_full_n<N>.json beside this file, and gpurun_out/)")
     ap.add_argument("--curve", default="bn254", help="exploration only: bn254 | bls12_381 | bw6_761")
     ap.add_argument("--group", default="g1", help="exploration only: g1 | g2")
     args = ap.parse_args()
@@ -1202,10 +1203,32 @@ def main():
             tail["small_n_ms"] = {f"2^{r['logn']}": r["resident_ms"] for r in out["small_n"]["rows"]}
         tail.update({"value": round(value, 3), "ms_per_step": round(ms_per_step, 4), "n_gpus": world})
         out["tail"] = tail
-        print(json.dumps(out), file=json_out, flush=True)
+        emit(out, world, args.full_out, json_out)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def emit(full, world, full_out, json_out):
+    """Write the full record to the side file(s) and print the slim line (tools/bench_line.py: at most MAX_LINE_BYTES, with the
+    contract keys, roofline, int_roofline, cpu_baseline and one compact row per other configuration)."""
+    from tools import bench_line
+    paths = [full_out or os.path.join(ROOT, f"bench_full_n{world}.json")]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")) and not full_out:  # on the GPU box: what gpurun merges back
+        paths.append(os.path.join(ROOT, "gpurun_out", f"bench_full_n{world}.json"))
+    written = None
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                json.dump(full, f)
+            written = written or os.path.relpath(p, ROOT)
+        except OSError as e:  # a read-only tree must not cost the line
+            print(f"[bench] could not write {p}: {e}", file=sys.stderr)
+    line = bench_line.encode(bench_line.fit(bench_line.slim_line(full, full_path=written)))
+    assert len(line.encode()) <= bench_line.MAX_LINE_BYTES, len(line)
+    for problem in bench_line.validate(line):
+        print(f"[bench] line problem: {problem}", file=sys.stderr)
+    print(line, file=json_out, flush=True)
 
 
 def effective_cpus():

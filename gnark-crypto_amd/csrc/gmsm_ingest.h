@@ -13,15 +13,16 @@
 //   BLS12-381, BW6-761: 3 bits, 000 = uncompressed, 010 = uncompressed infinity (every other bit must be zero).
 //   Compressed encodings (Bytes()) are refused here: this is the RawBytes / RawEncoding() ingest path.
 //
-// Subgroup membership is decided as the definition says - on the curve and [r]P = infinity - instead of through the
-// reference's endomorphism shortcuts (x^2 phi(P) + P etc.): the same predicate for every point ON the curve, one
-// generic routine for all six groups, and an ingest is a one-off (a 2^20-point BLS12-381 G1 SRS validates in ~0.06 s).
+// Subgroup membership (check level 2) is decided by the reference's endomorphism identities (gmsm_subgroup.h: [x^2] phi(P) + P
+// etc., 2-6 x fewer group operations than the definition); level 3 decides it as the definition says - [r]P = infinity -,
+// the same predicate for every point ON the curve, kept as the cross-check of level 2 (rounds 1-5 ran it for level 2).
 // Points that are not on the curve are always rejected, whatever the subgroup flag says for the rest.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gmsm_context.h"
 #include "gmsm_curve.h"
 #include "gmsm_curveu.h"
+#include "gmsm_subgroup.h"
 
 namespace gmsm {
 
@@ -68,12 +69,6 @@ GMSM_HD bool point_on_curve(const Affine<F> &a) {
 // at 31 G products/s for BLS12-381 G1, the lazy one runs the accumulation kernel at twice that. Same special cases: the
 // doubling of a 2-torsion point (zz becomes 0 mod q: tested after every doubling, exactly) and P + (-P) (inside the
 // mixed addition) both lead to the infinity flag.
-template <class F> struct IngestLazy;
-template <class P> struct IngestLazy<Fp<P>> { using type = FpU<P>; };
-template <class P> struct IngestLazy<Fp2<P>> { using type = Fp2U<P>; };
-template <class P> __device__ __forceinline__ bool ingest_zz_is_zero(const FpU<P> &zz) { return fpu_prod_is_zero(zz); }   // a product: < 3q
-template <class P> __device__ __forceinline__ bool ingest_zz_is_zero(const Fp2U<P> &zz) { return lz_is_zero(zz); }       // class R
-
 template <class F, class FrP>
 __device__ bool point_in_r_torsion(const Affine<F> &a) {
     using U = typename IngestLazy<F>::type;
@@ -94,13 +89,19 @@ __device__ bool point_in_r_torsion(const Affine<F> &a) {
     return inf;
 }
 
-// level 0: nothing, 1: on the curve, 2: on the curve and in the r-torsion (NEEDS_TORSION false: prime-order curve, the
-// curve check is the subgroup check - BN254 G1, g1.go:475-482)
+// level 0: nothing, 1: on the curve, 2: on the curve and in the r-torsion by the reference's endomorphism identity, 3: the
+// same decided by [r]P = infinity (NEEDS_TORSION false: prime-order curve, the curve check is the subgroup check - BN254 G1,
+// g1.go:475-482)
 template <class F, class FrP, class C, bool NEEDS_TORSION>
 __device__ uint32_t validate_point(const Affine<F> &a, int level) {
     if (level <= 0) return PT_OK;
     if (!point_on_curve<F, C>(a)) return PT_NOT_ON_CURVE;
-    if (level >= 2 && NEEDS_TORSION && !point_in_r_torsion<F, FrP>(a)) return PT_NOT_IN_SUBGROUP;
+    if constexpr (NEEDS_TORSION) {
+        if (level >= 2 && !a.is_infinity()) {
+            const bool in = (level == 2) ? point_in_subgroup_endo<F, C>(a) : point_in_r_torsion<F, FrP>(a);
+            if (!in) return PT_NOT_IN_SUBGROUP;
+        }
+    }
     return PT_OK;
 }
 

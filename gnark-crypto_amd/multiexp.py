@@ -254,17 +254,18 @@ class _Group:
             return None, "short buffer"
         return self.DecodeRaw(b[4:4 + n * self.raw_point_bytes], subgroup_check)
 
-    def ValidatePoints(self, points=None, d_points=None, n=None, subgroup_check=True):
+    def ValidatePoints(self, points=None, d_points=None, n=None, subgroup_check=True, by_definition=False):
         """IsOnCurve / IsInSubGroup over a whole vector of limb-form points (host array or device pointer): returns
-        (True, None) or (False, error text)."""
+        (True, None) or (False, error text).  by_definition: decide membership as [r]P = infinity (check level 3)
+        instead of through the reference's endomorphism identities (level 2) - the same predicate, the cross-check."""
         L = _lib.load()
         bad = _lib.ctypes.c_int64(-1)
+        level = (3 if by_definition else 2) if subgroup_check else 1
         if points is not None:
             points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, self.aff_limbs)
-            rc = L.gmsm_points_validate(self.gid, _ptr(points), None, points.shape[0], 2 if subgroup_check else 1,
-                                        _lib.ctypes.byref(bad))
+            rc = L.gmsm_points_validate(self.gid, _ptr(points), None, points.shape[0], level, _lib.ctypes.byref(bad))
         else:
-            rc = L.gmsm_points_validate(self.gid, None, d_points, n, 2 if subgroup_check else 1, _lib.ctypes.byref(bad))
+            rc = L.gmsm_points_validate(self.gid, None, d_points, n, level, _lib.ctypes.byref(bad))
         return (True, None) if rc == 0 else (False, self._error(rc))
 
     def register_bases_raw(self, buf, subgroup_check=True):

@@ -207,8 +207,10 @@ int gmsm_batch_jac_to_affine(int group, const uint64_t *jac, size_t n, uint64_t 
 
 /* ---- point ingest: the step before the MSM - points arrive as bytes and must become validated
  *      Montgomery limbs in HBM.  `check`: 0 decode only, 1 + on the curve, 2 + in the r-torsion (the Decoder's default,
- *      ecc/bn254/marshal.go:250-275; membership is decided as "on the curve and [r]P = infinity", the predicate the
- *      reference's endomorphism-based IsInSubGroup computes).  On a bad point the call returns GMSM_ERR_POINT,
+ *      ecc/bn254/marshal.go:250-275), decided by the reference's own endomorphism identities (IsInSubGroup:
+ *      ecc/bls12-381/g1.go:481-492, g2.go:484-491, ecc/bn254/g2.go:483-497, ecc/bw6-761/g1.go:482-496), 3 = the same
+ *      predicate decided as the definition says, "on the curve and [r]P = infinity" (2-6 x the group operations; the
+ *      cross-check of level 2).  On a bad point the call returns GMSM_ERR_POINT,
  *      *bad_index is the first offender and gmsm_last_error() carries the reference's error text; otherwise *bad_index = -1.
  *
  *      gmsm_points_from_raw: raw = n points in the uncompressed wire format of (*G1Affine).RawBytes() /

@@ -193,3 +193,64 @@ _G2_B_FP2 = {
     "bn254": lambda p: Fp2(9, 1, p).inv() * 3,
     "bls12_381": lambda p: Fp2(4, 4, p),
 }
+
+
+# ---- IsInSubGroup as the reference computes it: one endomorphism identity per group (affine big-int model) ----
+def _mul_plain(pg, k, P):
+    """[k]P by double-and-add WITHOUT reducing k mod r (P need not be in the r-torsion)."""
+    R = None
+    for bit in bin(k)[2:] if k else "":
+        R = pg.add(R, R)
+        if bit == "1":
+            R = pg.add(R, P)
+    return R
+
+
+def endo_phi(pg, P):
+    """phi(x, y) = (w x, y), w = thirdRootOneG1 on G1 and its square on G2 (bls12-381/g1.go:530-534, bw6-761/g2.go:540-544)."""
+    if P is None:
+        return None
+    w = pg.c.third_root_one_g1 if pg.which == "g1" else pg.c.third_root_one_g1 ** 2 % pg.p
+    return (P[0] * w % pg.p, P[1]) if pg.ext == 1 else (P[0] * Fp2(w, 0, pg.p), P[1])
+
+
+def endo_psi(pg, P):
+    """psi(x, y) = (conj(x) u, conj(y) v): untwist-Frobenius-twist on G2 over Fp2 (bn254/g2.go:534-540)."""
+    if P is None:
+        return None
+    u, v = Fp2(*pg.c.endo_u, pg.p), Fp2(*pg.c.endo_v, pg.p)
+    conj = lambda a: Fp2(a.a0, -a.a1, pg.p)
+    return (conj(P[0]) * u, conj(P[1]) * v)
+
+
+def is_in_subgroup_endo(pg, P):
+    """The predicate of (*G1Jac).IsInSubGroup / (*G2Jac).IsInSubGroup for a point ON the curve, identity for identity:
+    bn254/g1.go:475-482 (prime order), bn254/g2.go:483-497, bls12-381/g1.go:481-492, bls12-381/g2.go:484-491,
+    bw6-761/g1.go:482-496, bw6-761/g2.go:488-502."""
+    x = pg.c.x_gen
+    name, which = pg.c.name, pg.which
+    if P is None:
+        return True
+    if name == "bn254" and which == "g1":
+        return True
+    if name == "bls12_381" and which == "g1":
+        res = _mul_plain(pg, x, _mul_plain(pg, x, endo_phi(pg, P)))
+        return pg.add(res, P) is None
+    if name == "bls12_381":
+        return pg.add(_mul_plain(pg, x, P), endo_psi(pg, P)) is None
+    if name == "bn254":
+        a = _mul_plain(pg, x, P)
+        b = endo_psi(pg, a)
+        a = pg.add(a, P)
+        res = endo_psi(pg, b)
+        c = pg.add(pg.add(res, b), a)
+        res = endo_psi(pg, res)
+        res = pg.add(pg.add(res, res), pg.neg(c))
+        return res is None
+    # BW6-761, both groups
+    phip = endo_phi(pg, P)
+    res = pg.add(_mul_plain(pg, x, phip), pg.neg(phip))
+    res = _mul_plain(pg, x, _mul_plain(pg, x, res))
+    res = pg.add(res, phip)
+    t = pg.add(pg.add(_mul_plain(pg, x, P), P), res)
+    return t is None

@@ -40,72 +40,7 @@ def encode_raw(pg, P):
     return b"".join(v.to_bytes(nb, "big") for v in coord_values(pg, P))  # mUncompressed = 0: nothing to OR in
 
 
-def sqrt_fp(a, p):
-    r = pow(a, (p + 1) // 4, p)  # every base field in scope is 3 mod 4
-    return r if r * r % p == a % p else None
-
-
-def fp2_pow(pyref, a, e):
-    r = pyref.Fp2(1, 0, a.p)
-    while e:
-        if e & 1:
-            r = r * a
-        a = a * a
-        e >>= 1
-    return r
-
-
-def sqrt_fp2(pyref, a):
-    """Square root in Fp[u]/(u^2+1), p = 3 mod 4 (complex method)."""
-    p = a.p
-    if a.is_zero():
-        return a
-    a1 = fp2_pow(pyref, a, (p - 3) // 4)
-    alpha = a1 * a1 * a
-    a0 = pyref.Fp2(alpha.a0, -alpha.a1, p) * alpha  # alpha^p * alpha
-    if a0 == pyref.Fp2(-1, 0, p):
-        return None
-    x0 = a1 * a
-    if alpha == pyref.Fp2(-1, 0, p):
-        return pyref.Fp2(0, 1, p) * x0
-    b = fp2_pow(pyref, pyref.Fp2(1, 0, p) + alpha, (p - 1) // 2)
-    return b * x0
-
-
-def curve_b(pyref, pg):
-    if pg.ext == 2:
-        return pyref._G2_B_FP2[pg.c.name](pg.p)
-    return pg.c.b if pg.which == "g1" else pyref._G2_B_FP[pg.c.name]
-
-
-def curve_point_outside_subgroup(pyref, pg):
-    """A point ON the curve whose order does not divide r (exists whenever the cofactor is not 1)."""
-    for t in range(1, 200):
-        if pg.ext == 1:
-            x = t
-            y = sqrt_fp((x * x * x + curve_b(pyref, pg)) % pg.p, pg.p)
-        else:
-            x = pyref.Fp2(t, 1, pg.p)
-            y = sqrt_fp2(pyref, x * x * x + curve_b(pyref, pg))
-            if y is not None and not (y * y == x * x * x + curve_b(pyref, pg)):
-                y = None
-        if y is None:
-            continue
-        P = (x, y)
-        assert pg.on_curve(P)
-        if times_r(pg, P) is not None:
-            return P
-    raise AssertionError("no point outside the subgroup found")
-
-
-def times_r(pg, P):
-    """[r]P with the group order itself as the scalar (pyref.Group.mul reduces its scalar mod r)."""
-    R = None
-    for bit in bin(pg.c.r)[2:]:
-        R = pg.add(R, R)
-        if bit == "1":
-            R = pg.add(R, P)
-    return R
+from subgroup_points import curve_b, curve_point_outside_subgroup, curve_points, sqrt_fp, sqrt_fp2, times_r  # noqa: E402,F401
 
 
 def group_fixture(gm, pyref_mod, curve, which):
@@ -202,6 +137,32 @@ def test_subgroup_check(gm, pyref_mod, curve, which):
     assert ok and err is None
     ok, err = g.ValidatePoints(points=pts)
     assert ok
+
+
+@pytest.mark.parametrize("curve,which", [gw for gw in ALL_GROUPS if gw != ("bn254", "g1")])
+def test_subgroup_identity_against_the_definition(gm, pyref_mod, curve, which):
+    """Level 2 (the reference's endomorphism identity, gmsm_subgroup.h) and level 3 ([r]P = infinity) decide the same on
+    every kind of curve point: r-torsion points, points with a cofactor component, points whose order divides the cofactor
+    (the ones a shortcut is most likely to let through), sums of both kinds, infinity - point by point."""
+    g, pg = group_fixture(gm, pyref_mod, curve, which)
+    good = [pg.point_from_limbs(p) for p in g.generate_points(6, 11, 7)]
+    outside = curve_points(pyref_mod, pg, 5, start=3)
+    cof = [times_r(pg, P) for P in outside]                       # order divides the cofactor
+    mixed = [pg.add(T, good[i]) for i, T in enumerate(cof)]      # r-torsion + cofactor-torsion
+    cases = [(P, True) for P in good] + [(None, True)] + [(P, times_r(pg, P) is None) for P in outside + cof + mixed]
+    assert sum(not ok for _, ok in cases) >= 12
+    for P, expect in cases:
+        limbs = np.array(pg.point_to_limbs(P), dtype=np.uint64)
+        assert pyref_mod.is_in_subgroup_endo(pg, P) == expect
+        for by_def in (False, True):
+            ok, err = g.ValidatePoints(points=limbs[None, :], by_definition=by_def)
+            assert ok == expect, (P, by_def, err)
+            assert ok or "subgroup check failed" in err
+    # a vector: the first offender is reported, by both levels
+    vec = np.array([pg.point_to_limbs(P) for P in good[:3] + [mixed[1]] + good[3:] + [cof[0]]], dtype=np.uint64)
+    for by_def in (False, True):
+        ok, err = g.ValidatePoints(points=vec, by_definition=by_def)
+        assert not ok and "point 3" in err
 
 
 def test_bn254_g1_has_no_torsion_check(gm, pyref_mod):

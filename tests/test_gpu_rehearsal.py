@@ -25,10 +25,26 @@ def run_bench(*args, timeout=900):
     return json.loads(lines[0]), lines[0]
 
 
+def load_full(tmp_path):
+    with open(tmp_path) as f:
+        return json.load(f)
+
+
 @pytest.mark.parametrize("world,extra", [(2, ["--logn", "20", "--also-logn", "21", "--sharded-logns", "19,21,22"]),   # windows, then points
                                          (8, ["--logn", "18", "--also-logn", "20", "--sharded-logns", "19,20", "--shard", "points"])])
-def test_bench_sharded_branch_oversubscribed(world, extra):
-    rec, line = run_bench("--gpus", str(world), "--oversubscribe", "--steps", "3", "--warmup", "1", *extra)
+def test_bench_sharded_branch_oversubscribed(world, extra, tmp_path):
+    sys.path.insert(0, ROOT)
+    from tools import bench_line
+    full_path = str(tmp_path / "full.json")
+    slim, line = run_bench("--gpus", str(world), "--oversubscribe", "--steps", "3", "--warmup", "1", "--full-out", full_path, *extra)
+    # the printed line: bounded, schema-clean, and carrying the verdict fields in compact form
+    assert len(line.encode()) <= bench_line.MAX_LINE_BYTES and bench_line.validate(line) == []
+    assert slim["n_gpus"] == world and slim["backend"] == "gloo" and slim["equal_to_single_gpu_result"] is True
+    assert slim["c_abi_sharded"]["equal"] is True and slim["also"][-1]["c_abi_sharded"]["equal"] is True
+    assert all(r["bit_exact"] is True and r["n_gpus"] == world and r["exchange_ms"] > 0 and r["stage_ms"]["accumulate"] > 0
+               for r in slim["also"])
+    assert slim["full_record"] == os.path.relpath(full_path, ROOT)
+    rec = load_full(full_path)  # the full record (side file): everything the line summarises
     assert rec["n_gpus"] == world and rec["steps"] == 3 and rec["scaling"] == "strong"
     assert rec["backend"] == "gloo" and rec["rccl_ranks"] == 0 and rec["oversubscribed"] is True
     assert len(rec["devices_seen"]) == world and all(0 <= d < rec["device_count"] for d in rec["devices_seen"])

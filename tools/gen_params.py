@@ -161,12 +161,27 @@ def group_consts(c):
     else:
         b2 = words(4)
         flag_bits, inf_flag = 3, 0b010   # bw6-761/marshal.go:25-35
+    # IsInSubGroup by endomorphism (gmsm_subgroup.h): which identity the reference tests, and its constants
+    #   0 prime order (BN254 G1, g1.go:475-482)        1 [x^2] phi(P) + P = 0 (bls12-381/g1.go:481-492)
+    #   2 [x] P + psi(P) = 0 (bls12-381/g2.go:484-491)   3 BN254 G2 (bn254/g2.go:483-497)   4 BW6-761 G1 / G2 (bw6-761/g1.go:482-496)
+    w1 = c.third_root_one_g1 % c.p
+    assert pow(w1, 3, c.p) == 1 and w1 != 1
+    kinds = {"bn254": (0, 3), "bls12_381": (1, 2), "bw6_761": (4, 4)}[c.name]
     out = ""
-    for gname, b in (("g1", b1), ("g2", b2)):
+    for gname, b, kind in (("g1", b1, kinds[0]), ("g2", b2, kinds[1])):
         out += f"struct {c.name}_{gname}_consts {{\n"
         out += f"    static constexpr uint32_t B[{len(b)}] = {{" + ", ".join(f"0x{x:08x}u" for x in b) + "};  /* curve coefficient, Montgomery */\n"
         out += f"    static constexpr int RAW_FLAG_BITS = {flag_bits};      /* metadata bits on top of the first byte */\n"
         out += f"    static constexpr int RAW_INFINITY_FLAG = {inf_flag};  /* flag value of an uncompressed point at infinity; -1: none */\n"
+        out += f"    static constexpr int SUBGROUP_TEST = {kind};   /* which endomorphism identity IsInSubGroup tests (gmsm_subgroup.h) */\n"
+        out += f"    static constexpr unsigned long long X_GEN = 0x{c.x_gen:016x}ULL;  /* xGen */\n"
+        if kind in (1, 4):
+            w = words(w1 if gname == "g1" else w1 * w1)
+            out += f"    static constexpr uint32_t ENDO_W[{len(w)}] = {{" + ", ".join(f"0x{x:08x}u" for x in w) + "};  /* thirdRootOne of this group, Montgomery */\n"
+        if kind in (2, 3):
+            for nm, v in (("ENDO_U", c.endo_u), ("ENDO_V", c.endo_v)):
+                ww = words(v[0]) + words(v[1])
+                out += f"    static constexpr uint32_t {nm}[{len(ww)}] = {{" + ", ".join(f"0x{x:08x}u" for x in ww) + "};  /* psi: a0 then a1, Montgomery */\n"
         out += "};\n"
     return out
 
