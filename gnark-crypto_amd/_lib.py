@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "gmsm_multiexp_bases_device", "gmsm_multiexp_bases_submit", "gmsm_multiexp_collect", "gmsm_multiexp_bases_batch", "gmsm_default_window_bits", "gmsm_num_windows", "gmsm_window_sums_device",
     "gmsm_window_sums_enqueue", "gmsm_fold_window_sets", "gmsm_fold_windows", "gmsm_batch_scalar_mul", "gmsm_batch_scalar_mul_device",
     "gmsm_batch_jac_to_affine", "gmsm_jac_to_affine", "gmsm_affine_limbs", "gmsm_scalar_limbs", "gmsm_debug_decompose",
-    "gmsm_debug_field_op", "gmsm_debug_group_op", "gmsm_generate_points", "gmsm_set_profiling", "gmsm_get_stage_times",
+    "gmsm_debug_field_op", "gmsm_debug_group_op", "gmsm_debug_glv_split", "gmsm_generate_points", "gmsm_set_profiling", "gmsm_get_stage_times",
     "gmsm_get_stage_launches", "gmsm_points_from_raw", "gmsm_points_validate", "gmsm_bases_register_raw",
     "gmsm_bases_register_dump", "gmsm_fft_domain_new", "gmsm_fft_domain_release", "gmsm_fft_domain_info", "gmsm_fft",
     "gmsm_fft_bit_reverse",
@@ -168,6 +168,8 @@ def load():
     L.gmsm_set_devices.argtypes = [ip, ctypes.c_int]
     L.gmsm_get_devices.restype = ctypes.c_int
     L.gmsm_get_devices.argtypes = [ip, ctypes.c_int]
+    L.gmsm_debug_glv_split.restype = ctypes.c_int
+    L.gmsm_debug_glv_split.argtypes = [ctypes.c_int, u64p, sz, vp]
     L.gmsm_set_option.restype = ctypes.c_int
     L.gmsm_set_option.argtypes = [ctypes.c_int, ctypes.c_uint]
     L.gmsm_get_option.restype = ctypes.c_uint
@@ -202,7 +204,7 @@ def last_error():
 
 
 # enum gmsm_option (include/gmsm.h)
-OPTIONS = {"window_bits": 0, "tables": 1, "max_run": 2, "host_ranges": 3, "fixed_base_bits": 4, "spin_wait_us": 5, "small_bits": 6, "small_max": 7, "split": 8}
+OPTIONS = {"window_bits": 0, "tables": 1, "max_run": 2, "host_ranges": 3, "fixed_base_bits": 4, "spin_wait_us": 5, "small_bits": 6, "small_max": 7, "split": 8, "glv": 9, "small_quad": 10}
 
 
 def set_option(name, value):

@@ -66,6 +66,8 @@ struct Options {
     std::atomic<unsigned> small_bits{0};       // GMSM_OPT_SMALL_BITS: the fused small-n kernel: 0 = on, width by size; 1 = off; 2..7 = on, this width
     std::atomic<unsigned> split{0};            // GMSM_OPT_SPLIT (experiment): two window groups, the first group's fix-up + reduction beside the second's accumulation
     std::atomic<unsigned> small_max{0};        // GMSM_OPT_SMALL_MAX: largest call the fused kernel takes (0 = the measured default)
+    std::atomic<unsigned> glv{1};              // GMSM_OPT_GLV: half scalars (gmsm_glv.h): 0 never, 1 the fused small-n kernel, 2 the sorted pipeline too
+    std::atomic<unsigned> small_quad{0};       // GMSM_OPT_SMALL_QUAD: bucket phase of the fused kernel on lane quads: 0 by size, 1 never (narrow types), 2 always
 };
 Options &options();
 
@@ -249,6 +251,11 @@ struct Context {
     int device = -1;
     Workspace ws[NUM_WS];
     int num_cus = 256;
+    // gmsm_shutdown never deletes a Context (a caller may be parked on its condition variable): it destroys the
+    // workspaces' device resources, clears `live` and bumps `epoch`; waiters that wake into another epoch give up
+    // (acquire returns nullptr, *why = 3) and the next get_context_for() runs init() again.
+    uint64_t epoch = 0;
+    std::atomic<bool> live{false};
     int init(int dev) {
         device = dev;
         HIP_TRY(hipSetDevice(dev));
@@ -264,7 +271,23 @@ struct Context {
             HIP_TRY(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&w.ev_conv, hipEventDisableTiming));
         }
+        std::lock_guard<std::mutex> lk(mu);
+        live = true;
         return GMSM_OK;
+    }
+    // gmsm_shutdown, after it has leased and destroyed every workspace: the leases are dropped, waiters are told to give up
+    void retire() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (auto &w : ws) {
+                w.busy = false;
+                w.ticket = false;
+                w.pending = false;
+            }
+            live = false;
+            ++epoch;
+        }
+        cv.notify_all();
     }
     // Kernels that need more than the default 64 KiB of dynamic LDS: raise the limit once per kernel on this device.
     std::mutex attr_mu;
@@ -279,13 +302,18 @@ struct Context {
     }
     // for_ticket (gmsm_multiexp_bases_submit): nullptr at once when MAX_TICKETS tickets are outstanding (*why = 1: only a
     // collect can help). With fewer tickets out a workspace is merely leased for the moment - a blocking caller, or
-    // gmsm_trim walking the workspaces one at a time - and the submit waits for it like a blocking entry would (*why = 2 is
-    // never returned with wait semantics; kept for the non-waiting callers). Otherwise wait = false: nullptr when every
-    // workspace is leased; wait = true: blocks until one is free - which always happens, because at least one workspace
-    // is never held by a ticket.
+    // gmsm_trim walking the workspaces one at a time - and the submit waits for it like a blocking entry would (what
+    // include/gmsm.h says of submit). Otherwise wait = false: nullptr when every workspace is leased (*why = 2);
+    // wait = true: blocks until one is free - which always happens, because at least one workspace is never held by a
+    // ticket. A waiter that wakes after gmsm_shutdown retired the context gives up (*why = 3).
     Workspace *acquire(bool wait, bool for_ticket = false, int *why = nullptr) {
         std::unique_lock<std::mutex> lk(mu);
+        const uint64_t epoch0 = epoch;
         for (;;) {
+            if (epoch != epoch0) {
+                if (why) *why = 3;
+                return nullptr;
+            }
             if (for_ticket) {
                 int out = 0;
                 for (auto &w : ws) out += (w.busy && w.ticket) ? 1 : 0;
@@ -310,7 +338,9 @@ struct Context {
     // workspace i, waiting for a blocking caller to finish with it; nullptr when a ticket holds it (gmsm_shutdown)
     Workspace *acquire_unless_ticket(int i) {
         std::unique_lock<std::mutex> lk(mu);
+        const uint64_t epoch0 = epoch;
         for (;;) {
+            if (epoch != epoch0) return nullptr;  // a concurrent gmsm_shutdown got there first
             if (ws[i].busy && ws[i].ticket) return nullptr;
             if (!ws[i].busy) {
                 ws[i].busy = true;
@@ -366,7 +396,7 @@ struct Lease {
 
 #define GMSM_LEASE_OR_FAIL(name, context)                                                                    \
     Lease name(context);                                                                                     \
-    if (!name.w) return fail(GMSM_ERR_DEVICE, "no workspace could be leased (internal error)")
+    if (!name.w) return fail(GMSM_ERR_DEVICE, "gmsm_shutdown ran while this call waited for a workspace")
 
 // Waits for a call's stream. hipStreamSynchronize parks the thread and wakes it when the stream has drained; with
 // GMSM_OPT_SPIN_WAIT_US = t the stream is polled for up to t microseconds first. Measured (profiles/r04_spin_wait.log, same
@@ -609,6 +639,7 @@ struct GroupVTable {
                        const uint64_t *scalars, size_t n, unsigned c, unsigned win_first, unsigned win_stride,
                        uint64_t *out_xyzz);
     unsigned (*host_piece_ranges)(size_t n, bool with_points);  // point ranges a host-buffer piece of n points runs as
+    int (*debug_glv_split)(const uint64_t *scalars, size_t n, uint32_t *out);  // test hook of gmsm_glv.h
 };
 
 }  // namespace gmsm

@@ -80,14 +80,10 @@ int get_context_for(int device, Context **out) {
                                          "); libgmsm has no CPU fallback");
     if (device < 0 || device >= ndev) return fail(GMSM_ERR_DEVICE, "gmsm_set_device: device index out of range");
     if ((int)g_ctx.size() < ndev) g_ctx.resize(ndev, nullptr);
-    if (!g_ctx[device]) {
-        Context *c = new Context();
-        int rc = c->init(device);
-        if (rc != GMSM_OK) {
-            delete c;
-            return rc;
-        }
-        g_ctx[device] = c;
+    if (!g_ctx[device]) g_ctx[device] = new Context();  // never deleted: gmsm_shutdown retires it (Context::retire)
+    if (!g_ctx[device]->live) {  // first use, or first use after a gmsm_shutdown
+        int rc = g_ctx[device]->init(device);
+        if (rc != GMSM_OK) return rc;
     }
     *out = g_ctx[device];
     return GMSM_OK;
@@ -982,8 +978,8 @@ GMSM_EXPORT int gmsm_multiexp_bases_submit(uint64_t handle, const void *d_scalar
     Lease lease(*ctx, /*wait=*/false, /*for_ticket=*/true, &why);
     Workspace *ws = lease.w;
     if (!ws)
-        return fail(GMSM_ERR_ARG, why == 1 ? "two submitted MultiExp calls are outstanding on this device: collect one first"
-                                           : "every workspace of the device is leased by a running call");
+        return why == 1 ? fail(GMSM_ERR_ARG, "two submitted MultiExp calls are outstanding on this device: collect one first")
+                        : fail(GMSM_ERR_DEVICE, "gmsm_shutdown ran while this submit waited for a workspace");
     // the scalars are produced on the caller's stream (NULL = the default stream): order our stream behind it
     if ((rc = order_after(*ws, (hipStream_t)hip_stream))) return rc;
     if ((rc = vt->submit(*ctx, *ws, d_scalars, n_scalars, rb.get()))) return rc;
@@ -1350,6 +1346,11 @@ GMSM_EXPORT int gmsm_debug_decompose(int group, const uint64_t *scalars, size_t 
     return vt->debug_decompose(scalars, n, c, out_digits);
 }
 
+GMSM_EXPORT int gmsm_debug_glv_split(int group, const uint64_t *scalars, size_t n, uint32_t *out) {
+    VT_OR_FAIL(group);
+    return vt->debug_glv_split(scalars, n, out);
+}
+
 GMSM_EXPORT int gmsm_debug_field_op(int group, int field, int op, const uint64_t *a, const uint64_t *b, size_t count,
                                     uint64_t *out) {
     VT_OR_FAIL(group);
@@ -1468,6 +1469,14 @@ GMSM_EXPORT int gmsm_set_option(int key, unsigned value) {
             return GMSM_OK;
         case GMSM_OPT_SMALL_MAX: o.small_max.store(value); return GMSM_OK;
         case GMSM_OPT_SPLIT: o.split.store(value ? 1 : 0); return GMSM_OK;
+        case GMSM_OPT_GLV:
+            if (value > 2) return fail(GMSM_ERR_ARG, "GMSM_OPT_GLV: 0 never, 1 the fused small-n kernel, 2 the sorted pipeline too");
+            o.glv.store(value);
+            return GMSM_OK;
+        case GMSM_OPT_SMALL_QUAD:
+            if (value > 2) return fail(GMSM_ERR_ARG, "GMSM_OPT_SMALL_QUAD: 0 by call size, 1 never, 2 always");
+            o.small_quad.store(value);
+            return GMSM_OK;
         case GMSM_OPT_SPIN_WAIT_US:
             if (value > 1000000) return fail(GMSM_ERR_ARG, "GMSM_OPT_SPIN_WAIT_US: at most 1000000");
             o.spin_wait_us.store(value);
@@ -1488,6 +1497,8 @@ GMSM_EXPORT unsigned gmsm_get_option(int key) {
         case GMSM_OPT_SMALL_BITS: return o.small_bits.load();
         case GMSM_OPT_SMALL_MAX: return o.small_max.load();
         case GMSM_OPT_SPLIT: return o.split.load();
+        case GMSM_OPT_GLV: return o.glv.load();
+        case GMSM_OPT_SMALL_QUAD: return o.small_quad.load();
         default: return 0;
     }
 }
@@ -1506,7 +1517,7 @@ GMSM_EXPORT int gmsm_trim(size_t keep_bytes, size_t *out_freed) {
     (void)hipGetDevice(&prev);
     size_t freed = 0;
     for (Context *c : ctxs) {
-        if (!c) continue;
+        if (!c || !c->live) continue;
         (void)hipSetDevice(c->device);
         // one workspace at a time - lease, drain, trim, release - so that a submit or a blocking entry arriving meanwhile
         // always finds the other workspaces (holding all of them at once turned "trim under load" into spurious
@@ -1545,7 +1556,7 @@ GMSM_EXPORT int gmsm_shutdown(void) {
     // between the check and the teardown (it used to: shutdown then waited for ever on a ticket nobody would collect).
     std::vector<std::pair<Context *, Workspace *>> held;
     for (Context *c : ctxs) {
-        if (!c) continue;
+        if (!c || !c->live) continue;
         for (int i = 0; i < Context::NUM_WS; ++i) {
             Workspace *w = c->acquire_unless_ticket(i);
             if (!w) {
@@ -1574,17 +1585,15 @@ GMSM_EXPORT int gmsm_shutdown(void) {
     int prev = 0;
     (void)hipGetDevice(&prev);
     for (Context *c : ctxs) {
-        if (!c) continue;
+        if (!c || !c->live) continue;
         (void)hipSetDevice(c->device);
         (void)hipDeviceSynchronize();
         for (auto &w : c->ws) w.destroy();  // all of them are in `held`
-    }
-    {
-        std::lock_guard<std::mutex> lk(g_ctx_mu);
-        for (Context *&c : g_ctx) {
-            delete c;
-            c = nullptr;
-        }
+        // the leases end here: a caller that was parked on this context's condition variable (a submit or a blocking entry
+        // that arrived while everything was leased) wakes into another epoch and returns GMSM_ERR_DEVICE; the Context
+        // object itself stays (advisor, round 5: deleting it left such a waiter on a destroyed mutex) and init() runs
+        // again on the next use
+        c->retire();
     }
     (void)hipSetDevice(prev);
     return GMSM_OK;

@@ -104,6 +104,17 @@ struct Group {
         p.win_stride = win_stride ? win_stride : 1;
         p.nwin_local = win_first < p.nwin_total ? (p.nwin_total - win_first + p.win_stride - 1) / p.win_stride : 0;
         p.shared = 0;
+        p.glv = 0;
+        return p;
+    }
+    // the windows of the GLV half scalars (gmsm_glv.h): same rules over GLV_BITS bits
+    static constexpr unsigned GLV_BITS = (unsigned)FrP::GLV_BITS;
+    static WindowPlan make_plan_glv(unsigned c, unsigned win_first, unsigned win_stride) {
+        WindowPlan p = make_plan(c, win_first, win_stride);
+        p.nwin_total = num_windows(GLV_BITS, c);
+        p.nbuckets = 1u << (std::max(c, last_c(GLV_BITS, c)) - 1);
+        p.nwin_local = win_first < p.nwin_total ? (p.nwin_total - win_first + p.win_stride - 1) / p.win_stride : 0;
+        p.glv = 1;
         return p;
     }
 
@@ -710,8 +721,8 @@ struct Group {
     // in Jacobian coordinates (2M + 5S per doubling against the 6M + 3S of the extended form; over Fp2 a square is two
     // base products, a product three: 16 against 24) and the running sum changes form around each window's addition.
     // Windows at infinity (all but the first under window tables) cost nothing.
-    static J fold(const Ext *totals, unsigned c) {
-        const unsigned nwin = num_windows(FR_BITS, c);
+    static J fold(const Ext *totals, unsigned c, unsigned nwin = 0 /* 0: the windows of a full scalar */) {
+        if (nwin == 0) nwin = num_windows(FR_BITS, c);
         J acc = jac_from_xyzz(totals[nwin - 1]);
         for (int j = (int)nwin - 2; j >= 0; --j) {
             if (!acc.z.is_zero())
@@ -949,7 +960,7 @@ struct Group {
     // (the point decomposition of sharding.py, on one device). GMSM_OPT_MAX_RUN lowers the cap (tests).
     // A shared-bucket plan (window tables) sorts nwin * n entries as one window: a sort entry is 32 bits - the low
     // bucket bits of the coarse pass next to (index, sign) - and the coarse pass takes at most 2^13 partitions.
-    static size_t max_run_points(const WindowPlan &plan = WindowPlan{0, 0, 0, 0, 1, 0, 0}) {
+    static size_t max_run_points(const WindowPlan &plan = WindowPlan{0, 0, 0, 0, 1, 0, 0, 0}) {
         size_t cap = (size_t)1 << 27;
         if (plan.shared) {
             uint32_t log2NB = 0;
@@ -1096,22 +1107,38 @@ struct Group {
     // width nor are served by window tables. The width minimises the depth of the kernel's dependency chain -
     // log2(points per bucket) + 2 (c - 1) additions - against the number of windows the host has to fold.
     static constexpr uint32_t SMALL_SL = SmallSlice<U>::value;
+    static constexpr bool SMALL_QUAD_ONLY = SmallQuadOnly<U>::value;
     // Measured against the sorted pipeline (profiles/r05_small_n.log, resident ms, fused / pipeline): BN254 G1 2^5 0.147 / 0.27,
     // 2^10 0.18 / 0.29-0.35, 2^12 0.28 / 0.41, 2^13 0.38 / 0.47; BN254 G2 2^11 0.65 / 0.91, 2^13 1.29 / 0.99; BLS12-381 G1 2^11 0.41 /
     // 0.62, 2^12 0.50 / 0.65, 2^13 0.73 / 0.70; BLS12-381 G2 2^11 1.19 / 1.62, 2^12 1.68 / 1.65; BN254 G2 2^12 0.86 / 0.86; BW6-761 2^11 1.57 / 2.05,
-    // 2^12 2.5 / 2.1.
+    // 2^12 2.5 / 2.1. Round 6 (GLV half scalars, lane quads for the bucket phase): profiles/r06_small_n.log.
+    // Largest call the fused kernel takes, from the same-process sweeps of profiles/r06_small_forms.log (fused / sorted pipeline,
+    // resident ms): BN254 G1 2^13 0.36 / 0.46; BLS12-381 G1 2^12 0.47 / 0.65, 2^13 0.69 / 0.69; BN254 G2 2^12 0.83 / 0.88, 2^13
+    // 1.12 / 0.90; BLS12-381 G2 2^10 0.98 / 1.87, 2^11 1.60-1.68 / 1.63; BW6-761 2^10 1.61 / 2.41, 2^11 2.73 / 2.07 (the quad form
+    // keeps one workgroup per CU at 310 registers: beyond ~1000 points the wide types are throughput-bound there).
     static size_t small_max_points() {
         const size_t forced = options().small_max.load(std::memory_order_relaxed);
-        return std::min<size_t>(forced ? forced : GMSM_TUNE(SMALL_MAX, AFF_BYTES == 64 ? 8192 : AFF_BYTES == 96 ? 4096 : 2048), (size_t)SMALL_SL * SMALL_MAX_SLICES);
+        return std::min<size_t>(forced ? forced : GMSM_TUNE(SMALL_MAX, sizeof(U) <= 36 ? 8192 : sizeof(U) <= 72 ? 4096 : 1024),
+                                small_entry_cap() / 2);
     }
-    static unsigned small_c(size_t n) {
+    // entries one window's slices can hold: 64 slices of 256 entries (one-lane form) or of 8 chunks of 64 (quad form)
+    static constexpr size_t small_entry_cap() {
+        return SMALL_QUAD_ONLY ? (size_t)SMALL_QUAD_ENTRIES * SMALL_QUAD_MAX_CHUNKS * SMALL_MAX_SLICES : (size_t)SMALL_SL * SMALL_MAX_SLICES;
+    }
+    // GLV half scalars in the fused kernel: GMSM_OPT_GLV 0 = never, 1 (default) = the fused kernel, 2 = the sorted pipeline too
+    static bool small_glv() { return options().glv.load(std::memory_order_relaxed) >= 1; }
+    static WindowPlan small_make_plan(unsigned c, bool glv) { return glv ? make_plan_glv(c, 0, 1) : make_plan(c, 0, 1); }
+    static unsigned small_c(size_t n, bool glv) {
         const unsigned forced = options().small_bits.load(std::memory_order_relaxed);
         // flat over 5..7 for the narrow types (fewer windows = less host fold, more buckets = more quad steps); the 28-limb
         // field and large calls take 7
-        unsigned c = (forced >= 2 && forced <= SMALL_MAX_C) ? forced : n <= 128 ? 5 : (FR_BITS > 300 || n > 4096) ? 7 : 6;
-        // the kernel holds one lane quad per bucket: a width whose top window needs c + 1 bits (the scalar field's bit
+        const size_t entries = glv ? 2 * n : n;
+        unsigned c = (forced >= 2 && forced <= SMALL_MAX_C) ? forced
+                     : FR_BITS > 300 ? (entries <= 512 ? 6 : 7)
+                                     : entries <= 256 ? 5 : entries <= 4096 ? 6 : 7;
+        // the kernel holds one lane quad per bucket: a width whose top window needs c + 1 bits (the scalar's bit
         // length a multiple of c) doubles the buckets - step down until they fit
-        while (c > 2 && make_plan(c, 0, 1).nbuckets > SMALL_NB_MAX) --c;
+        while (c > 2 && small_make_plan(c, glv).nbuckets > SMALL_NB_MAX) --c;
         return c;
     }
     static bool small_serves(size_t n, const ResidentBases *rb) {
@@ -1129,76 +1156,130 @@ struct Group {
         if (forced >= 2 && forced != c) return false;
         return n * rb->small_nw <= (size_t)SMALL_SL * SMALL_SHARED_MAX_SLICES;
     }
+    // What one call of the fused kernel looks like; decided ONCE per call (options and the publication of the narrow tables
+    // are read here and nowhere else on the call's path).
+    struct SmallPlan {
+        WindowPlan plan;
+        bool shared, glv, quad;
+        uint32_t chunks, nslices;
+    };
+    static SmallPlan small_plan(size_t n, const ResidentBases *rb) {
+        SmallPlan sp;
+        sp.shared = small_shared(n, rb);
+        sp.glv = !sp.shared && small_glv();
+        sp.plan = sp.shared ? make_plan(rb->small_c.load(), 0, 1) : small_make_plan(small_c(n, sp.glv), sp.glv);
+        const size_t entries = sp.shared ? n * sp.plan.nwin_total : (sp.glv ? 2 * n : n);
+        // the bucket phase on lane quads (64 entries per chunk): always for the wide element types; for the narrow ones while
+        // the call is so small that a workgroup per 64 entries still leaves CUs idle (GMSM_OPT_SMALL_QUAD: 0 = this rule,
+        // 1 = never, 2 = always)
+        const unsigned fq = options().small_quad.load(std::memory_order_relaxed);
+        const size_t wgs64 = (entries + SMALL_QUAD_ENTRIES - 1) / SMALL_QUAD_ENTRIES * (sp.shared ? 1 : sp.plan.nwin_total);
+        sp.quad = SMALL_QUAD_ONLY || fq == 2 || (fq == 0 && wgs64 <= (size_t)GMSM_TUNE(SMALL_QUAD_WGS, 512));
+        if (sp.quad) {
+            const size_t max_slices = sp.shared ? SMALL_SHARED_MAX_SLICES : SMALL_MAX_SLICES;
+            size_t chunks = 1;
+            while ((entries + chunks * SMALL_QUAD_ENTRIES - 1) / (chunks * SMALL_QUAD_ENTRIES) > max_slices) chunks *= 2;
+            sp.chunks = (uint32_t)chunks;
+            sp.nslices = (uint32_t)((entries + chunks * SMALL_QUAD_ENTRIES - 1) / (chunks * SMALL_QUAD_ENTRIES));
+        } else {
+            sp.chunks = 0;
+            sp.nslices = (uint32_t)((entries + SMALL_SL - 1) / SMALL_SL);
+        }
+        return sp;
+    }
     // Enqueues the kernel on ws.stream; the window totals (shared form: ONE total) land in ws.pinned. d_points == nullptr:
     // `resident`.
     static int enqueue_small(Context &ctx, Workspace &ws, const void *d_points, const void *d_scalars, size_t n,
-                             const WindowPlan &plan, const ResidentBases *resident, bool shared = false) {
-        const uint32_t nw = shared ? 1u : plan.nwin_total;
-        const size_t entries = shared ? n * plan.nwin_total : n;
-        const uint32_t nslices = (uint32_t)((entries + SMALL_SL - 1) / SMALL_SL);
+                             const SmallPlan &sp, const ResidentBases *resident) {
+        const WindowPlan &plan = sp.plan;
+        const uint32_t nw = sp.shared ? 1u : plan.nwin_total;
         constexpr size_t REC = sizeof(typename OpsSerial::Mem);
         int rc;
         ws.pending_timed = false;
         if ((rc = begin_use(ws, ws.stream))) return rc;
         if ((rc = ws.ensure_pinned((size_t)plan.nwin_total * sizeof(Ext)))) return rc;
-        if ((rc = ws.small_sums.ensure((size_t)nw * nslices * REC))) return rc;
-        {
-            const size_t had = ws.small_done.cap;
-            if ((rc = ws.small_done.ensure((size_t)HEAVY_MAX_WINDOWS * 4))) return rc;
-            if (ws.small_done.cap != had) HIP_TRY(hipMemsetAsync(ws.small_done.ptr, 0, ws.small_done.cap, ws.stream));
-        }
-        const void *upoints = nullptr;
-        const uint8_t *skip = nullptr;
+        if ((rc = ws.small_sums.ensure((size_t)nw * sp.nslices * REC))) return rc;
+        if ((rc = ws.small_done.ensure((size_t)HEAVY_MAX_WINDOWS * 4))) return rc;
+        // the slice counters start at zero: cleared before every launch that uses them (a launch that died half-way must not
+        // leave a later call without its last workgroup - advisor, round 5)
+        if (sp.nslices > 1) HIP_TRY(hipMemsetAsync(ws.small_done.ptr, 0, (size_t)nw * 4, ws.stream));
+        SmallArgs a;
+        a.points = d_points;
+        a.upoints = nullptr;
+        a.skip = nullptr;
         if (d_points == nullptr) {
-            upoints = shared ? resident->small_tables.ptr : resident->upoints.ptr;
-            skip = (const uint8_t *)resident->skip.ptr;
+            a.upoints = sp.shared ? resident->small_tables.ptr : resident->upoints.ptr;
+            a.skip = (const uint8_t *)resident->skip.ptr;
         }
-        g_small_runs.fetch_add(1, std::memory_order_relaxed);
+        a.scalars = (const uint32_t *)d_scalars;
+        a.n = (uint32_t)n;
+        a.glv = sp.glv ? 1u : 0u;
+        a.tab_m = sp.shared ? (uint32_t)resident->small_m : 0u;
+        a.chunks = sp.chunks;
+        a.slice_sums = ws.small_sums.ptr;
+        a.done = (uint32_t *)ws.small_done.ptr;
         // the window totals go straight into the pinned result buffer (host memory mapped into the device: nwin 128-byte
         // stores over PCIe instead of a copy kernel and its launch, 5-8 us of a 0.15 ms call)
-        if (shared) {
-            g_table_runs.fetch_add(1, std::memory_order_relaxed);
-            if ((rc = ctx.allow_lds((const void *)k_msm_small<U, FrP, SMALL_SL, true>, (int)(SMALL_SL * REC)))) return rc;
-            hipLaunchKernelGGL((k_msm_small<U, FrP, SMALL_SL, true>), dim3(nslices, 1), dim3(SMALL_SL), (size_t)SMALL_SL * REC, ws.stream,
-                               d_points, upoints, skip, (const uint32_t *)d_scalars, (uint32_t)n, plan, (uint32_t)resident->small_m,
-                               ws.small_sums.ptr, (uint32_t *)ws.small_done.ptr, ws.pinned);
+        a.totals = ws.pinned;
+        g_small_runs.fetch_add(1, std::memory_order_relaxed);
+        if (sp.shared) g_table_runs.fetch_add(1, std::memory_order_relaxed);
+        // profiling: the one launch counts as the call's accumulation stage (two events, whatever the level)
+        StageTimer timer(ws, true);
+        ws.timed = timer.on;
+        if (timer.on) {
+            ws.timed_level = 2;
+            (void)hipEventRecord(ws.events[T_ACCUMULATE], ws.stream);
+        }
+        const dim3 grid(sp.nslices, nw);
+        if (sp.quad) {
+            const size_t lds = (size_t)192 * sizeof(QRec<U>);
+            if (sp.shared) {
+                if ((rc = ctx.allow_lds((const void *)k_msm_small_q<U, FrP, Consts, true>, (int)lds))) return rc;
+                hipLaunchKernelGGL((k_msm_small_q<U, FrP, Consts, true>), grid, dim3(256), lds, ws.stream, a, plan);
+            } else {
+                if ((rc = ctx.allow_lds((const void *)k_msm_small_q<U, FrP, Consts, false>, (int)lds))) return rc;
+                hipLaunchKernelGGL((k_msm_small_q<U, FrP, Consts, false>), grid, dim3(256), lds, ws.stream, a, plan);
+            }
         } else {
-            if ((rc = ctx.allow_lds((const void *)k_msm_small<U, FrP, SMALL_SL, false>, (int)(SMALL_SL * REC)))) return rc;
-            hipLaunchKernelGGL((k_msm_small<U, FrP, SMALL_SL, false>), dim3(nslices, nw), dim3(SMALL_SL), (size_t)SMALL_SL * REC, ws.stream,
-                               d_points, upoints, skip, (const uint32_t *)d_scalars, (uint32_t)n, plan, 0u, ws.small_sums.ptr,
-                               (uint32_t *)ws.small_done.ptr, ws.pinned);
+            if constexpr (!SMALL_QUAD_ONLY) {
+                const size_t lds = (size_t)SMALL_SL * REC;
+                if (sp.shared) {
+                    if ((rc = ctx.allow_lds((const void *)k_msm_small<U, FrP, Consts, SMALL_SL, true>, (int)lds))) return rc;
+                    hipLaunchKernelGGL((k_msm_small<U, FrP, Consts, SMALL_SL, true>), grid, dim3(SMALL_SL), lds, ws.stream, a, plan);
+                } else {
+                    if ((rc = ctx.allow_lds((const void *)k_msm_small<U, FrP, Consts, SMALL_SL, false>, (int)lds))) return rc;
+                    hipLaunchKernelGGL((k_msm_small<U, FrP, Consts, SMALL_SL, false>), grid, dim3(SMALL_SL), lds, ws.stream, a, plan);
+                }
+            }
         }
         HIP_TRY(hipGetLastError());
+        if (timer.on) (void)hipEventRecord(ws.events[T_FIXUP], ws.stream);
+        ws.pending_timed = timer.on;
         return end_use(ws, ws.stream);
     }
     // waits for an enqueue_small and turns what it left in ws.pinned into the result
-    static int collect_small(Workspace &ws, const WindowPlan &plan, bool shared, J *out) {
-        if (shared) {  // one total, nothing to fold
+    static int collect_small(Workspace &ws, const SmallPlan &sp, J *out) {
+        if (sp.shared) {  // one total, nothing to fold
             Ext total;
             int rc = collect_window_sums(ws, ws.stream, 1, &total);
             if (rc) return rc;
             *out = total.zz.is_zero() ? J{F::one(), F::one(), F::zero()} : jac_from_xyzz(total);
             return GMSM_OK;
         }
-        std::vector<Ext> totals(plan.nwin_total);
-        int rc = collect_window_sums(ws, ws.stream, plan.nwin_total, totals.data());
+        std::vector<Ext> totals(sp.plan.nwin_total);
+        int rc = collect_window_sums(ws, ws.stream, sp.plan.nwin_total, totals.data());
         if (rc) return rc;
-        *out = fold(totals.data(), plan.c);
+        *out = fold(totals.data(), sp.plan.c, sp.plan.nwin_total);
         return GMSM_OK;
-    }
-    static WindowPlan small_plan(size_t n, const ResidentBases *rb, bool *shared) {
-        *shared = small_shared(n, rb);
-        return make_plan(*shared ? rb->small_c.load() : small_c(n), 0, 1);
     }
     static int multiexp_small(Context &ctx, Workspace &ws, const void *d_points, const void *d_scalars, size_t n,
                               hipStream_t caller_stream, J *out, const ResidentBases *resident) {
-        bool shared = false;
-        const WindowPlan plan = small_plan(n, d_points ? nullptr : resident, &shared);
-        if (plan.nwin_total > HEAVY_MAX_WINDOWS) return fail(GMSM_ERR_ARG, "small path: too many windows");
+        const SmallPlan sp = small_plan(n, d_points ? nullptr : resident);
+        if (sp.plan.nwin_total > HEAVY_MAX_WINDOWS) return fail(GMSM_ERR_ARG, "small path: too many windows");
         int rc = order_after(ws, caller_stream);
         if (rc) return rc;
-        if ((rc = enqueue_small(ctx, ws, d_points, d_scalars, n, plan, resident, shared))) return rc;
-        return collect_small(ws, plan, shared, out);
+        if ((rc = enqueue_small(ctx, ws, d_points, d_scalars, n, sp, resident))) return rc;
+        return collect_small(ws, sp, out);
     }
 
     static int multiexp_device(Context &ctx, Workspace &ws, const void *d_points, const void *d_scalars, size_t n,
@@ -1438,10 +1519,9 @@ struct Group {
                 HIP_TRY(hipMemcpyAsync(ws.h2d_points.ptr, points, n * AFF_BYTES, hipMemcpyHostToDevice, ws.stream));
                 dp = ws.h2d_points.ptr;
             }
-            bool shared = false;
-            const WindowPlan splan = small_plan(n, points ? nullptr : resident, &shared);
-            if ((rc = enqueue_small(ctx, ws, dp, ws.h2d_scalars.ptr, n, splan, resident, shared))) return rc;
-            return collect_small(ws, splan, shared, out);
+            const SmallPlan splan = small_plan(n, points ? nullptr : resident);
+            if ((rc = enqueue_small(ctx, ws, dp, ws.h2d_scalars.ptr, n, splan, resident))) return rc;
+            return collect_small(ws, splan, out);
         }
         const WindowPlan plan = plan_for(resident, n);  // the ranges share one bucket set and one reduction
         const unsigned c = plan.c;
@@ -1675,6 +1755,28 @@ static int debug_decompose_impl(const uint64_t *scalars, size_t n, unsigned c, u
 }
 
 
+template <class G>
+static int debug_glv_split_impl(const uint64_t *scalars, size_t n, uint32_t *out) {
+    using FrP = typename G::FrP;
+    Context *ctx;
+    int rc = get_context(&ctx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (n == 0) return GMSM_OK;
+    GMSM_LEASE_OR_FAIL(lease, *ctx);
+    Workspace &ws = *lease.w;
+    const size_t ob = n * 2 * (FrP::GLV_HL + 1) * 4;
+    if ((rc = ws.h2d_scalars.ensure(n * G::SCALAR_BYTES))) return rc;
+    if ((rc = ws.digits.ensure(ob))) return rc;
+    HIP_TRY(hipMemcpyAsync(ws.h2d_scalars.ptr, scalars, n * G::SCALAR_BYTES, hipMemcpyHostToDevice, ws.stream));
+    hipLaunchKernelGGL((k_glv_split_debug<FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ws.stream,
+                       (const uint32_t *)ws.h2d_scalars.ptr, n, (uint32_t *)ws.digits.ptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, ws.digits.ptr, ob, hipMemcpyDeviceToHost, ws.stream));
+    HIP_TRY(hipStreamSynchronize(ws.stream));
+    return GMSM_OK;
+}
+
 // ------------------------------------------------------------------ function table
 
 template <class G>
@@ -1825,6 +1927,7 @@ struct VTableOf {
     static int debug_decompose(const uint64_t *scalars, size_t n, unsigned c, uint32_t *out_digits) {
         return debug_decompose_impl<G>(scalars, n, c, out_digits);
     }
+    static int debug_glv_split(const uint64_t *scalars, size_t n, uint32_t *out) { return debug_glv_split_impl<G>(scalars, n, out); }
     static int debug_field_op(int field, int op, const uint64_t *a, const uint64_t *b, size_t count, uint64_t *out) {
         using BaseP = typename G::F::Params;
         if (field == 0) {
@@ -1869,7 +1972,7 @@ struct VTableOf {
         static const GroupVTable vt = {G::FR_BITS,      G::AFF_BYTES,   G::SCALAR_BYTES, sizeof(typename G::J),
                                        sizeof(typename G::Ext), &multiexp_host, &multiexp_device, &window_sums,
                                        &fold,           &jac_to_affine, &debug_decompose, &debug_field_op,
-                                       &debug_group_op, &generate_points, &register_bases, &submit, &collect, &window_sums_enqueue, &fold_sets, &fold_powers, &multiexp_bases_host, &batch_scalar_mul, &batch_jac_to_affine, &decode_raw, &validate_points, &fft_domain_new, &fft_run, &fft_bit_reverse, &precompute_tables, &tables_serve, &shard_piece, &host_piece_ranges};
+                                       &debug_group_op, &generate_points, &register_bases, &submit, &collect, &window_sums_enqueue, &fold_sets, &fold_powers, &multiexp_bases_host, &batch_scalar_mul, &batch_jac_to_affine, &decode_raw, &validate_points, &fft_domain_new, &fft_run, &fft_bit_reverse, &precompute_tables, &tables_serve, &shard_piece, &host_piece_ranges, &debug_glv_split};
         return &vt;
     }
 };

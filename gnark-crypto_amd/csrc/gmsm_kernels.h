@@ -35,6 +35,8 @@ struct WindowPlan {
     uint32_t nwin_local;
     uint32_t shared;     // 1: window tables (Group::precompute_tables) - the digits of all windows index ONE bucket set,
                          // entry (w, i) gathers 2^(c w) P_i; the launch reports the total as window 0 and infinity above
+    uint32_t glv;        // 1: the windows are those of the GLV half scalars (gmsm_glv.h): nwin_total = ceil(GLV_BITS / c), a window
+                         // has 2 n entries - entry i = (P_i, k1_i), entry n + i = (phi(P_i), k2_i)
 };
 
 template <class T>

@@ -33,6 +33,7 @@ class Curve:
     third_root_one_g1: int = 0  # w with w^3 = 1: phi(x, y) = (w x, y) on G1; G2 uses w^2 (thirdRootOneG2)
     endo_u: tuple = ()          # psi(x, y) = (conj(x) u, conj(y) v) on G2 over Fp2 (endo.u, endo.v as (a0, a1))
     endo_v: tuple = ()
+    lambda_glv: int = 0         # phi(P) = [lambda]P on the r-torsion (lambdaGLV): lambda^2 + lambda + 1 = 0 mod r
 
     @property
     def fp_limbs(self) -> int:      # 64-bit limbs of an fp.Element
@@ -70,6 +71,7 @@ BN254 = Curve(
     fr_max_order=28,
     fr_mult_gen=5,
     x_gen=4965661367192848881,  # bn254.go:146
+    lambda_glv=4407920970296243842393367215006156084916469457145843978461,  # bn254.go:133
     third_root_one_g1=2203960485148121921418603742825762020974279258880205651966,  # bn254.go:131
     endo_u=(21575463638280843010398324269430826099269044274347216827212613867836435027261,  # bn254.go:137-140
             10307601595873709700152284273816112264069230130616436755625194854815875713954),
@@ -92,6 +94,7 @@ BLS12_381 = Curve(
     fr_root_of_unity=10238227357739495823651030575849232062558860180284477541189508159991286009131,
     fr_max_order=32,
     fr_mult_gen=7,
+    lambda_glv=228988810152649578064853576960394133503,  # bls12-381.go:128
     x_gen=15132376222941642752,  # bls12-381.go:141 (the seed is -x_gen; the tests below are written for the stored value)
     third_root_one_g1=4002409555221667392624310435006688643935503118305586438271171395842971157480381377015405980053539358417135540939436,  # :126
     endo_u=(0, 4002409555221667392624310435006688643935503118305586438271171395842971157480381377015405980053539358417135540939437),  # :132-135
@@ -113,7 +116,79 @@ BW6_761 = Curve(
     fr_max_order=46,
     fr_mult_gen=15,
     x_gen=9586122913090633729,  # bw6-761.go:128
+    lambda_glv=80949648264912719408558363140637477264845294720710499478137287262712535938301461879813459410945,  # bw6-761.go:123
     third_root_one_g1=1968985824090209297278610739700577151397666382303825728450741611566800370218827257750865013421937292370006175842381275743914023380727582819905021229583192207421122272650305267822868639090213645505120388400344940985710520836292650,  # :121
 )
 
 CURVES = {c.name: c for c in (BN254, BLS12_381, BW6_761)}
+
+
+# ---- GLV scalar decomposition (ecc/utils.go:62-170: PrecomputeLattice / SplitScalar), restated for the device ----
+def glv_lattice(r, lam):
+    """Two short vectors (a, b) with a + b lam = 0 mod r, by the extended Euclidean walk of PrecomputeLattice
+    (ecc/utils.go:62-122): the remainder sequence of (r, lam) is followed until it drops below sqrt(r)."""
+    from math import isqrt
+    rst = [[r, 1, 0], [lam, 0, 1]]
+    root = isqrt(r)
+    while rst[1][0] >= root:
+        q, rem = divmod(rst[0][0], rst[1][0])
+        rst[0], rst[1] = rst[1], [rem, rst[0][1] - rst[1][1] * q, rst[0][2] - rst[1][2] * q]
+    q, rem = divmod(rst[0][0], rst[1][0])
+    t = rst[0][2] - rst[1][2] * q
+    v1 = (rst[1][0], -rst[1][2])
+    v2 = (rem, -t) if rst[0][0] ** 2 + rst[0][2] ** 2 > rem * rem + t * t else (rst[0][0], -rst[0][2])
+    return v1, v2
+
+
+class GlvParams:
+    """What the device needs to split s into (k1, k2) with k1 + k2 lam = s mod r and |k1|, |k2| < 2^bits:
+        m1 = (s |b1|) >> 32 sh,  m2 = (s |b2|) >> 32 sh          (b_i = round(2^(32 sh) v_2i / det), SplitScalar's b1 / b2)
+        k1 = s - m1 a11 - m2 a21,  k2 = - m1 a12 - m2 a22        mod 2^(32 hl), read as two's complement
+    with a11 = sgn(b1) v11, a12 = sgn(b1) v12, a21 = -sgn(b2) v21, a22 = -sgn(b2) v22.  ANY integers m1, m2 give the
+    congruence (v1, v2 are lattice vectors); the roundings only decide how short k1, k2 are: (k1, k2) = e1 v1 + e2 v2 with
+    |e_i| < 1 + 2^-32, hence |k1| <= |v11| + |v21|, |k2| <= |v12| + |v22| (checked below on the extreme and on random s)."""
+
+    def __init__(self, c):
+        r, lam = c.r, c.lambda_glv
+        assert (lam * lam + lam + 1) % r == 0
+        v1, v2 = glv_lattice(r, lam)
+        assert (v1[0] + v1[1] * lam) % r == 0 and (v2[0] + v2[1] * lam) % r == 0
+        det = v1[0] * v2[1] - v1[1] * v2[0]
+        assert abs(det) == r
+        nr = 2 * c.fr_limbs                      # 32-bit limbs of a scalar
+        self.sh = nr + 1                         # 32 more bits than the scalar: the rounding of b costs < 2^-32
+        rnd = lambda a, d: (2 * a + d) // (2 * d) if d > 0 else (2 * -a + -d) // (2 * -d)   # nearest integer to a / d
+        b1 = rnd(v2[1] << (32 * self.sh), det)
+        b2 = rnd(v1[1] << (32 * self.sh), det)
+        sg = lambda x: -1 if x < 0 else 1
+        self.b1, self.b2 = abs(b1), abs(b2)
+        self.a = [sg(b1) * v1[0], -sg(b2) * v2[0], sg(b1) * v1[1], -sg(b2) * v2[1]]  # a11, a21, a12, a22
+        bound = max(abs(v1[0]) + abs(v2[0]), abs(v1[1]) + abs(v2[1])) + 1
+        self.bits = bound.bit_length()
+        self.hl = (self.bits + 1 + 31) // 32     # + sign bit
+        self.nb = (max(self.b1, self.b2).bit_length() + 31) // 32
+        self.r, self.lam = r, lam
+        assert (r * max(self.b1, self.b2)) >> (32 * self.sh) < 1 << (32 * self.hl)  # m1, m2 fit the half width
+
+    def split(self, s):
+        """(k1, k2) exactly as the device computes them (signed Python ints)."""
+        mod = 1 << (32 * self.hl)
+        m1 = (s * self.b1) >> (32 * self.sh)
+        m2 = (s * self.b2) >> (32 * self.sh)
+        k1 = (s - m1 * self.a[0] - m2 * self.a[1]) % mod
+        k2 = (-m1 * self.a[2] - m2 * self.a[3]) % mod
+        signed = lambda k: k - mod if k >> (32 * self.hl - 1) else k
+        return signed(k1), signed(k2)
+
+    def check(self, samples=2000):
+        import random
+        rng = random.Random(0x676C76)
+        cases = [0, 1, 2, self.r - 1, self.r - 2, self.r // 2, self.r // 3, self.lam, self.lam + 1, self.r - self.lam, (1 << (self.r.bit_length() - 1))]
+        cases += [rng.randrange(self.r) for _ in range(samples)]
+        worst = 0
+        for s in cases:
+            k1, k2 = self.split(s)
+            assert (k1 + k2 * self.lam - s) % self.r == 0
+            worst = max(worst, abs(k1), abs(k2))
+        assert worst < 1 << self.bits, (worst.bit_length(), self.bits)
+        return worst.bit_length()

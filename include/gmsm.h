@@ -176,8 +176,12 @@ int gmsm_multiexp_bases_device(uint64_t handle, const void *d_scalars, size_t n_
 /* ---- two MultiExp calls in flight (the reference's equivalent is several goroutines calling
  *      MultiExp at once, BenchmarkManyMultiExpG1Reference, ecc/bn254/multiexp_test.go:385-415).
  *      submit launches the whole device pipeline for device-resident scalars over registered bases and returns without
- *      waiting; collect waits, folds the windows and writes the Jacobian result. At most two tickets may be outstanding
- *      per device (a third submit returns GMSM_ERR_ARG; so does a submit while all three workspaces are busy); d_scalars must stay valid until its ticket is collected.
+ *      waiting for the device; collect waits, folds the windows and writes the Jacobian result. At most two tickets may be
+ *      outstanding per device: a third submit returns GMSM_ERR_ARG at once. A device has three workspaces; when all of
+ *      them are leased at that moment (blocking callers in other threads, gmsm_trim) submit waits for the first to be
+ *      released, as a blocking entry would - that wait always ends, because tickets never hold more than two of the
+ *      three. A caller still waiting when gmsm_shutdown runs gets GMSM_ERR_DEVICE. d_scalars must stay valid until its
+ *      ticket is collected.
  *      hip_stream: the stream the scalars were produced on (NULL = the default stream); the pipeline is ordered
  *      after the work already queued there. The sort/accumulate of one call overlaps the latency-bound bucket reduction, copy-back and
  *      host fold of the other. ---- */
@@ -283,6 +287,10 @@ size_t gmsm_affine_limbs(int group);   /* uint64 limbs of one affine point */
 size_t gmsm_scalar_limbs(int group);
 /* digits[nwin][n] (uint32 codes: 0 skip, d>0 -> 2d, d<0 -> 2(-d-1)+1) for host scalars; test hook for k_decompose */
 int gmsm_debug_decompose(int group, const uint64_t *scalars, size_t n, unsigned c, uint32_t *out_digits);
+/* test hook for the GLV split of gmsm_glv.h: out = n x 2 x (1 + half_words) uint32 - for scalar i (Montgomery fr limbs, as
+ * everywhere) {sign of k1, |k1| words, sign of k2, |k2| words}, half_words = 4 (BN254), 5 (BLS12-381), 6 (BW6-761);
+ * k1 + k2 lambda = s mod r (lambdaGLV, ecc/bn254/bn254.go:133) */
+int gmsm_debug_glv_split(int group, const uint64_t *scalars, size_t n, uint32_t *out);
 /* element-wise field ops on device: op 0 mul, 1 add, 2 sub, 3 neg, 4 dbl, 5 sqr, 6 from_mont; field 0 = fp, 1 = fr,
  * 2 = the group's coordinate field (Fp2 for G2 where applicable), 3 = the same coordinate field computed by the lazy-limb
  * code the pipeline uses (convert in, operate, convert out).  a,b,out: count x limbs host arrays. */
@@ -327,8 +335,13 @@ enum gmsm_option {
                                  that neither force a window width nor are served by window tables): 0 (default) = on, width
                                  by size; 1 = off (the sorted pipeline for every size); 2..7 = on with this window width */
     GMSM_OPT_SMALL_MAX = 7,   /* largest call the fused small-n kernel takes (0 = the measured default) */
-    GMSM_OPT_SPLIT = 8        /* experiment (default 0 = off): a call's windows in two groups, the fix-up + reduction of the first on a
+    GMSM_OPT_SPLIT = 8,       /* experiment (default 0 = off): a call's windows in two groups, the fix-up + reduction of the first on a
                                  second stream beside the accumulation of the second (measured: profiles/r05_split_groups.log) */
+    GMSM_OPT_GLV = 9,         /* GLV half scalars (ecc/utils.go:62-170; s P = k1 P + k2 phi(P), half the windows and half the host
+                                 fold for the same group element): 0 never, 1 (default) in the fused small-n kernel, 2 in the
+                                 sorted pipeline as well (unregistered bases) */
+    GMSM_OPT_SMALL_QUAD = 10  /* bucket phase of the fused small-n kernel on lane quads: 0 (default) by call size, 1 never,
+                                 2 always (the Fp2 groups and BW6-761 always run it on quads) */
 };
 int gmsm_set_option(int key, unsigned value);
 unsigned gmsm_get_option(int key);

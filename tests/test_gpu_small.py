@@ -29,14 +29,20 @@ def _inputs(o, g, n, seed):
     return pts, sc
 
 
+# the forms of the fused kernel: GLV half scalars on / off (GMSM_OPT_GLV) x bucket phase on lane quads never / always
+# (GMSM_OPT_SMALL_QUAD; the Fp2 groups and BW6-761 are built with the quad form only, whatever the switch says)
+FORMS = [(1, 0), (0, 1), (1, 2), (0, 2), (1, 1)]
+
+
+@pytest.mark.parametrize("glv,quad", FORMS)
 @pytest.mark.parametrize("curve,which", ALL_GROUPS)
-def test_small_kernel_matches_oracle(gm, oracle_mod, curve, which):
-    """Every size through the fused kernel (one and several slices per window), host entry and device entry, against the
-    oracle's MultiExp on the same input."""
+def test_small_kernel_matches_oracle(gm, oracle_mod, curve, which, glv, quad):
+    """Every size through the fused kernel (one and several slices per window, one and several chunks per workgroup of the quad
+    form), host entry and device entry, with and without GLV half scalars, against the oracle's MultiExp on the same input."""
     import torch
     g = (gm.G1Affine if which == "g1" else gm.G2Affine)(curve)
     o = oracle_mod.Oracle(curve, which)
-    with gm.options(small_max=8192):
+    with gm.options(small_max=8192, glv=glv, small_quad=quad):
         for n in SIZES:
             pts, sc = _inputs(o, g, n, 0)
             expected = o.msm_affine(pts, sc, nthreads=8)
@@ -61,11 +67,12 @@ def test_small_kernel_every_width_and_skew(gm, oracle_mod, curve, which):
     pts, sc = _inputs(o, g, n, 1)
     expected = o.msm_affine(pts, sc, nthreads=8)
     for c in range(2, 8):
-        with gm.options(small_bits=c):
-            before = _small_runs(gm)
-            aff, err = g.MultiExp(pts, sc)
-            assert err is None and (aff == expected).all(), c
-            assert _small_runs(gm) == before + 1
+        for glv, quad in ((1, 0), (0, 1), (1, 2)):
+            with gm.options(small_bits=c, glv=glv, small_quad=quad):
+                before = _small_runs(gm)
+                aff, err = g.MultiExp(pts, sc)
+                assert err is None and (aff == expected).all(), (c, glv, quad)
+                assert _small_runs(gm) == before + 1
     equal = np.tile(sc[:1], (n, 1))
     assert (g.MultiExp(pts, equal)[0] == o.msm_affine(pts, equal, nthreads=8)).all()
     same = np.tile(pts[:1], (n, 1))
@@ -147,3 +154,32 @@ def test_small_kernel_over_narrow_window_tables(gm, oracle_mod, curve, which):
             assert table_runs() == tb
     finally:
         rb.release()
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381", "bw6_761"])
+def test_glv_split_on_the_device(gm, curve):
+    """gmsm_glv.h splits every scalar into half scalars k1 + k2 lambda = s mod r (ecc.SplitScalar, ecc/utils.go:141-170, with the
+    lattice of PrecomputeLattice :62-135; lambdaGLV bn254.go:133): the congruence and the bound |k| < 2^GLV_BITS on the
+    device's own output, for random scalars and the edge values, and word for word against the big-int statement of the same
+    formulas (gnark-crypto_amd/curves.py GlvParams.split)."""
+    import importlib
+    curves = importlib.import_module("gnark-crypto_amd.curves")
+    c = curves.CURVES[curve]
+    glv = curves.GlvParams(c)
+    g = gm.G1Jac(curve)
+    rng = rng_for(97, g.gid)
+    vals = [0, 1, 2, c.r - 1, c.r - 2, c.r // 2, c.lambda_glv, c.r - c.lambda_glv, 1 << (c.r.bit_length() - 1)]
+    vals += [int.from_bytes(rng.bytes(64), "little") % c.r for _ in range(500)]
+    sc = scalars_from_ints(c, vals)
+    hl = glv.hl
+    out = np.zeros((len(vals), 2, hl + 1), dtype=np.uint32)
+    rc = gm._lib.load().gmsm_debug_glv_split(g.gid, sc.ctypes.data, len(vals), out.ctypes.data)
+    assert rc == 0, gm._lib.last_error()
+    for s, rec in zip(vals, out):
+        ks = []
+        for h in range(2):
+            mag = sum(int(w) << (32 * i) for i, w in enumerate(rec[h, 1:]))
+            assert mag < 1 << glv.bits
+            ks.append(-mag if rec[h, 0] else mag)
+        assert (ks[0] + ks[1] * c.lambda_glv - s) % c.r == 0, s
+        assert tuple(ks) == glv.split(s), s

@@ -68,7 +68,23 @@ def limbs32(v, n64):
     return [(v >> (32 * i)) & 0xFFFFFFFF for i in range(2 * n64)]
 
 
-def cxx_field(prefix, q, n64, fft=None):
+def glv_block(glv):
+    """Scalar-decomposition constants of the curve (curves.GlvParams), 32-bit words; the A_ij as two's complement mod 2^(32 HL)."""
+    w = lambda v, n: [(v >> (32 * i)) & 0xFFFFFFFF for i in range(n)]
+    arr = lambda name, vals: f"    static constexpr uint32_t {name}[{len(vals)}] = {{" + ", ".join(f"0x{x:08x}u" for x in vals) + "};\n"
+    mod = 1 << (32 * glv.hl)
+    out = "    /* GLV split s = k1 + k2 lambda (ecc/utils.go:62-170; derivation and bounds: gnark-crypto_amd/curves.py GlvParams) */\n"
+    out += f"    static constexpr int GLV_BITS = {glv.bits};  /* |k1|, |k2| < 2^GLV_BITS */\n"
+    out += f"    static constexpr int GLV_HL = {glv.hl};    /* words of a half scalar (two's complement) */\n"
+    out += f"    static constexpr int GLV_SH = {glv.sh};    /* m_i = (s B_i) >> 32 GLV_SH */\n"
+    out += f"    static constexpr int GLV_NB = {glv.nb};\n"
+    out += arr("GLV_B1", w(glv.b1, glv.nb)) + arr("GLV_B2", w(glv.b2, glv.nb))
+    for name, v in zip(("GLV_A11", "GLV_A21", "GLV_A12", "GLV_A22"), glv.a):
+        out += arr(name, w(v % mod, glv.hl))
+    return out
+
+
+def cxx_field(prefix, q, n64, fft=None, glv=None):
     """constexpr 32-bit-limb parameter struct for the HIP kernels (folded into instruction literals).
     fft = (root_of_unity, max_order, mult_gen): the scalar field's FFT constants (fr/generator.go, fr/fft/domain.go)."""
     R = 1 << (64 * n64)
@@ -89,6 +105,8 @@ def cxx_field(prefix, q, n64, fft=None):
         out += arr("ROOT_OF_UNITY", root * R % q)
         out += f"    static constexpr unsigned MAX_ORDER = {max_order};\n"
         out += arr("MULT_GEN", gen * R % q)
+    if glv is not None:
+        out += glv_block(glv)
     out += "};\n"
     return out
 
@@ -175,6 +193,8 @@ def group_consts(c):
         out += f"    static constexpr int RAW_INFINITY_FLAG = {inf_flag};  /* flag value of an uncompressed point at infinity; -1: none */\n"
         out += f"    static constexpr int SUBGROUP_TEST = {kind};   /* which endomorphism identity IsInSubGroup tests (gmsm_subgroup.h) */\n"
         out += f"    static constexpr unsigned long long X_GEN = 0x{c.x_gen:016x}ULL;  /* xGen */\n"
+        gw = words(w1 if gname == "g1" else w1 * w1)  # phi(x, y) = (GLV_W x, y) = [lambda](x, y): w on G1, w^2 on G2 (mulGLV, g1.go:536)
+        out += f"    static constexpr uint32_t GLV_W[{len(gw)}] = {{" + ", ".join(f"0x{x:08x}u" for x in gw) + "};  /* Montgomery */\n"
         if kind in (1, 4):
             w = words(w1 if gname == "g1" else w1 * w1)
             out += f"    static constexpr uint32_t ENDO_W[{len(w)}] = {{" + ", ".join(f"0x{x:08x}u" for x in w) + "};  /* thirdRootOne of this group, Montgomery */\n"
@@ -192,7 +212,9 @@ def render_cxx():
     s += "#pragma once\n#include <stdint.h>\n\nnamespace gmsm {\n\n"
     for c in curves.CURVES.values():
         s += cxx_field(f"{c.name}_fp", c.p, c.fp_limbs)
-        s += cxx_field(f"{c.name}_fr", c.r, c.fr_limbs, (c.fr_root_of_unity, c.fr_max_order, c.fr_mult_gen))
+        glv = curves.GlvParams(c)
+        glv.check()
+        s += cxx_field(f"{c.name}_fr", c.r, c.fr_limbs, (c.fr_root_of_unity, c.fr_max_order, c.fr_mult_gen), glv)
         s += group_consts(c)
         s += "\n"
     s += "}  // namespace gmsm\n"
