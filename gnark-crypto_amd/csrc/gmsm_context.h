@@ -226,6 +226,22 @@ struct Workspace {
         last_stream = nullptr;
         bases_ref.reset();
     }
+    // Streams and events appear with the first lease of the workspace, the two side streams with their first use: creating a
+    // stream costs 10-60 ms on this runtime (tools/hip_floor.hip), and a context used to create nine of them before its
+    // first MultiExp - a small call needs one (profiles/r06_first_call.log: first 2^10 call 83 -> see INTEGRATION.md §4).
+    int ensure_base() {
+        if (stream) return GMSM_OK;
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ev_buckets, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_merged, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_conv, hipEventDisableTiming));
+        return GMSM_OK;
+    }
+    int side_stream(hipStream_t &slot) {  // mstream / cstream on first use
+        if (!slot) HIP_TRY(hipStreamCreateWithFlags(&slot, hipStreamNonBlocking));
+        return GMSM_OK;
+    }
     int ensure_pinned(size_t bytes) {
         if (bytes <= pinned_cap) return GMSM_OK;
         if (pinned) HIP_TRY(hipHostFree(pinned));
@@ -262,15 +278,7 @@ struct Context {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
         num_cus = prop.multiProcessorCount;
-        for (auto &w : ws) {
-            HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
-            HIP_TRY(hipStreamCreateWithFlags(&w.mstream, hipStreamNonBlocking));
-            HIP_TRY(hipStreamCreateWithFlags(&w.cstream, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&w.ev_buckets, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&w.ev_merged, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&w.ev_conv, hipEventDisableTiming));
-        }
+        // (the workspaces' streams and events: Workspace::ensure_base, with the first lease)
         std::lock_guard<std::mutex> lk(mu);
         live = true;
         return GMSM_OK;
@@ -324,6 +332,10 @@ struct Context {
             }
             for (auto &w : ws)
                 if (!w.busy) {
+                    if (w.ensure_base() != GMSM_OK) {  // the caller's device is current; the error text is set
+                        if (why) *why = 4;
+                        return nullptr;
+                    }
                     w.busy = true;
                     w.ticket = for_ticket;
                     return &w;
@@ -396,7 +408,7 @@ struct Lease {
 
 #define GMSM_LEASE_OR_FAIL(name, context)                                                                    \
     Lease name(context);                                                                                     \
-    if (!name.w) return fail(GMSM_ERR_DEVICE, "gmsm_shutdown ran while this call waited for a workspace")
+    if (!name.w) return fail(GMSM_ERR_DEVICE, "no workspace: gmsm_shutdown ran while this call waited, or its stream could not be created")
 
 // Waits for a call's stream. hipStreamSynchronize parks the thread and wakes it when the stream has drained; with
 // GMSM_OPT_SPIN_WAIT_US = t the stream is polled for up to t microseconds first. Measured (profiles/r04_spin_wait.log, same
@@ -432,7 +444,7 @@ static inline int order_after(Workspace &ws, hipStream_t caller) {
 // workspace, end_use publishes the end of this call's work.
 static inline int begin_use(Workspace &ws, hipStream_t stream) {
     if (ws.last_use && ws.last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, ws.last_use, 0));
-    if (ws.conv_pending) {  // a call failed between forking its base rewrite and joining it: the rewrite may still be writing ws.upoints
+    if (ws.conv_pending && ws.cstream) {  // a call failed between forking its base rewrite and joining it: the rewrite may still be writing ws.upoints
         HIP_TRY(hipStreamSynchronize(ws.cstream));
         ws.conv_pending = false;
     }
@@ -584,11 +596,39 @@ static inline constexpr unsigned tune_uint(const char *, unsigned dflt) { return
 static inline unsigned preferred_c(unsigned fr_bits, size_t aff_bytes, size_t n) {
     unsigned lg = 0;
     while (lg < 63 && ((size_t)2 << lg) <= n) ++lg;  // floor(log2 n), n >= 1
-    if (fr_bits > 320) return lg < 17 ? 9u : lg <= 20 ? 14u : 16u;                                    // BW6-761
-    if (fr_bits == 255 && aff_bytes > 96) return lg < 15 ? 8u : lg == 15 ? 10u : lg == 16 ? 12u : lg <= 18 ? 13u : 16u;  // BLS12-381 G2
-    if (fr_bits == 255) return lg < 15 ? 8u : lg == 15 ? 13u : lg < 24 ? 16u : 17u;                 // BLS12-381 G1
-    if (aff_bytes > 64) return lg < 15 ? 8u : lg == 15 ? 13u : lg == 16 ? 15u : lg < 22 ? 16u : 17u; // BN254 G2
-    return lg < 13 ? 8u : lg < 15 ? 13u : lg < 17 ? 15u : lg < 21 ? 16u : 17u;                       // BN254 G1
+    // Round 6: the band 2^13..2^18 re-measured with every width forced (tools/glv_width_sweep.py, profiles/r06_glv_width_sweep.log;
+    // its glv0 columns): BN254 G2 2^16 1.49 -> 1.14 ms (12 instead of 15), 2^17 1.55 -> 1.36 (13), BW6-761 2^16 3.14 -> 2.59 (12),
+    // BLS12-381 G1 2^16 0.96 -> 0.86 (12), 2^18 1.41 -> 1.36 (13), BN254 G1 2^13 0.50 -> 0.41 (12).
+    if (fr_bits > 320) return lg < 13 ? 9u : lg <= 14 ? 10u : lg <= 16 ? 12u : lg <= 20 ? 14u : 16u;   // BW6-761
+    if (fr_bits == 255 && aff_bytes > 96) return lg < 13 ? 8u : lg <= 15 ? 10u : lg == 16 ? 12u : lg <= 18 ? 13u : 16u;  // BLS12-381 G2
+    if (fr_bits == 255) return lg < 13 ? 8u : lg <= 14 ? 12u : lg == 15 ? 13u : lg == 16 ? 12u : lg == 18 ? 13u : lg < 24 ? 16u : 17u;  // BLS12-381 G1
+    if (aff_bytes > 64) return lg < 13 ? 8u : lg <= 14 ? 12u : lg == 15 ? 13u : lg == 16 ? 12u : lg <= 18 ? 13u : lg < 22 ? 16u : 17u;  // BN254 G2
+    return lg < 13 ? 8u : lg < 15 ? 12u : lg < 17 ? 15u : lg < 21 ? 16u : 17u;                       // BN254 G1
+}
+// GLV half scalars in the sorted pipeline (gmsm_glv.h; bases taken anew): the window width of the 2 n-entry call for the sizes
+// where it was measured AHEAD of the best plain width, 0 elsewhere (same sweep, glv2 against glv0 columns, resident ms):
+//   BN254 G1      2^13 0.41 -> 0.33, 2^15 0.49 -> 0.44, 2^16 0.53 -> 0.48, 2^17 0.62 -> 0.54, 2^18 0.78 -> 0.71, 2^19 1.11 -> 1.06,
+//                 2^20 1.776 -> 1.725; 2^21 3.22 -> 3.28 and beyond: slower (2^22 + 8 %, 2^24 + 13 %: the gather works on twice the
+//                 bases, profiles/r06_glv_large.log)
+//   BN254 G2      2^13 0.79 -> 0.62, 2^14 0.85 -> 0.69, 2^16 1.14 -> 0.98, 2^17 1.36 -> 1.18, 2^18 1.92 -> 1.69, 2^19 2.89 -> 2.62,
+//                 2^20 4.77 -> 4.51, 2^21 8.45 -> 8.38
+//   BLS12-381 G1  2^13 0.58 -> 0.52, 2^14 0.64 -> 0.58, 2^16 0.85 -> 0.80, 2^19 2.15 -> 2.07; level or behind elsewhere
+//   BLS12-381 G2  2^13 1.99 -> 1.69, 2^14 2.00 -> 1.76, 2^15 1.94 -> 1.81, 2^16 2.17 -> 1.92, 2^17 2.60 -> 2.29, 2^18 4.02 -> 3.65,
+//                 2^19 6.49 -> 6.29; 2^20 10.56 -> 10.71: behind
+//   BW6-761       2^13 2.20 -> 1.99, 2^14 2.27 -> 2.10, 2^15 2.45 -> 2.24, 2^16 2.59 -> 2.39, 2^17 3.94 -> 3.61, 2^18 6.17 -> 5.82,
+//                 2^19 10.4 -> 9.9, 2^20 18.4 -> 17.4, 2^21 33.6 -> 32.0
+// What it buys is half the bucket sets to reduce and half the host fold; what it costs is a gather over twice as many bases.
+static inline unsigned glv_preferred_c(unsigned fr_bits, size_t aff_bytes, size_t n) {
+    unsigned lg = 0;
+    while (lg < 63 && ((size_t)2 << lg) <= n) ++lg;
+    if (lg < 11 || lg > 21) return 0u;
+    if (fr_bits > 320) return lg <= 14 ? 10u : lg <= 16 ? 12u : lg == 17 ? 13u : lg == 18 ? 14u : 16u;      // BW6-761
+    if (fr_bits == 255 && aff_bytes > 96)                                                                    // BLS12-381 G2
+        return lg <= 14 ? 10u : lg <= 16 ? 12u : lg <= 18 ? 13u : lg == 19 ? 15u : 0u;
+    if (lg < 13) return 0u;  // the narrow types: the fused kernel's sizes
+    if (fr_bits == 255) return lg <= 14 ? 13u : lg == 16 ? 12u : lg == 19 ? 16u : 0u;                       // BLS12-381 G1
+    if (aff_bytes > 64) return lg == 13 ? 12u : lg == 14 ? 13u : lg <= 16 ? 12u : lg == 17 ? 13u : 16u;     // BN254 G2
+    return lg == 13 ? 12u : lg == 14 ? 13u : lg <= 20 ? 16u : 0u;                                            // BN254 G1
 }
 static inline unsigned choose_c(unsigned fr_bits, size_t aff_bytes, size_t n) {
     const unsigned forced = options().window_bits.load(std::memory_order_relaxed);

@@ -1470,7 +1470,7 @@ GMSM_EXPORT int gmsm_set_option(int key, unsigned value) {
         case GMSM_OPT_SMALL_MAX: o.small_max.store(value); return GMSM_OK;
         case GMSM_OPT_SPLIT: o.split.store(value ? 1 : 0); return GMSM_OK;
         case GMSM_OPT_GLV:
-            if (value > 2) return fail(GMSM_ERR_ARG, "GMSM_OPT_GLV: 0 never, 1 the fused small-n kernel, 2 the sorted pipeline too");
+            if (value > 2) return fail(GMSM_ERR_ARG, "GMSM_OPT_GLV: 0 never, 1 where measured ahead, 2 every unregistered call");
             o.glv.store(value);
             return GMSM_OK;
         case GMSM_OPT_SMALL_QUAD:
@@ -1527,9 +1527,9 @@ GMSM_EXPORT int gmsm_trim(size_t keep_bytes, size_t *out_freed) {
             if (!w) continue;  // leased by a running call or a ticket: its scratch is in use
             // an enqueue-only call (gmsm_window_sums_enqueue) may have left work on the caller's stream
             if (w->last_use) (void)hipEventSynchronize(w->last_use);
-            (void)hipStreamSynchronize(w->stream);
-            (void)hipStreamSynchronize(w->mstream);
-            (void)hipStreamSynchronize(w->cstream);
+            if (w->stream) (void)hipStreamSynchronize(w->stream);
+            if (w->mstream) (void)hipStreamSynchronize(w->mstream);
+            if (w->cstream) (void)hipStreamSynchronize(w->cstream);
             w->conv_pending = false;
             std::shared_ptr<ResidentBases> parked;
             parked.swap(w->bases_ref);

@@ -117,8 +117,12 @@ __device__ __forceinline__ FpU<typename U::Params> glv_w() {  // GLV_W of the gr
 }
 
 // ------------------------------------------------------------------ the pipeline's front end with GLV
-// k_convert_points for 2 n entries: upoints[i] = P_i, upoints[n + i] = phi(P_i), both in the lazy Montgomery domain.
-// (0, 0) stays (0, 0) in both halves: the accumulation recognises infinity from the record itself.
+// k_convert_points for 2 n entries: upoints[2 i] = P_i, upoints[2 i + 1] = phi(P_i), both in the lazy Montgomery domain.
+// (0, 0) stays (0, 0) in both: the accumulation recognises infinity from the record itself.
+// The two entries of a point are NEIGHBOURS (one 128-byte line for BN254 G1), not n records apart: with the phi copies in a
+// second half of the array, scalars that are all equal - every first-half entry in one bucket, every second-half entry in
+// another, both walked in index order - made the two walks hit addresses exactly 2^26 bytes apart at the same time, and
+// k_accumulate_seg took 2.7-5.5 ms instead of 1.2 at 2^20 (profiles/r06_glv_all_equal.log).
 template <class U, class C>
 __global__ void __launch_bounds__(256) k_convert_points_glv(const void *__restrict__ points, size_t n, void *__restrict__ upoints) {
     using T = LzTraits<U>;
@@ -129,12 +133,12 @@ __global__ void __launch_bounds__(256) k_convert_points_glv(const void *__restri
     UAffine<U> u;
     T::pack(ux, u.x);
     T::pack(uy, u.y);
-    store_struct(upoints, i, u);
+    store_struct(upoints, 2 * i, u);
     T::pack(glv_mul_w<true>(ux, glv_w<U, C, true>()), u.x);
-    store_struct(upoints, n + i, u);
+    store_struct(upoints, 2 * i + 1, u);
 }
 
-// k_decompose over the half scalars: digits is [nwin_local][2 n], entry i = (P_i, k1), entry n + i = (phi(P_i), k2); the
+// k_decompose over the half scalars: digits is [nwin_local][2 n], entry 2 i = (P_i, k1), entry 2 i + 1 = (phi(P_i), k2); the
 // sign of a half goes into its digit codes. One thread per scalar, the window width a template parameter (as k_decompose_c).
 template <class FrP, class D, int C>
 __global__ void __launch_bounds__(256) k_decompose_glv(const uint32_t *__restrict__ scalars, size_t n, WindowPlan plan,
@@ -156,14 +160,15 @@ __global__ void __launch_bounds__(256) k_decompose_glv(const uint32_t *__restric
     bool neg[2];
     glv_split<FrP>(s.l, k[0], neg[0], k[1], neg[1]);
     constexpr uint32_t mask = (1u << C) - 1u;
-    constexpr int max = (1 << (C - 1)) - 1;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
+        // digits of |k| in [-2^(C-1), 2^(C-1) - 1] as for a full scalar (multiexp.go:779-786) - or, when the half is negative and
+        // every digit is about to change its sign, in [-(2^(C-1) - 1), 2^(C-1)]: the negated digits then lie in the usual range
+        // and their codes fit the same 16 bits (a digit +2^(C-1) would have the code 2^C)
+        const int max = (1 << (C - 1)) - 1 + (neg[h] ? 1 : 0);
         int carry = 0;
 #pragma unroll
         for (uint32_t w = 0; w < NW; ++w) {
-            constexpr uint32_t dummy = 0;
-            (void)dummy;
             const uint32_t bit = w * C, idx = bit >> 5, sh = bit & 31;
             const uint64_t lo = idx < (uint32_t)HL ? k[h][idx < (uint32_t)HL ? idx : 0] : 0u;
             const uint64_t hi = idx + 1 < (uint32_t)HL ? k[h][idx + 1 < (uint32_t)HL ? idx + 1 : 0] : 0u;
@@ -183,7 +188,7 @@ __global__ void __launch_bounds__(256) k_decompose_glv(const uint32_t *__restric
             if (neg[h]) code = code_negate(code);
             if (w >= plan.win_first && (w - plan.win_first) % plan.win_stride == 0) {
                 const uint32_t kk = (w - plan.win_first) / plan.win_stride;
-                if (kk < plan.nwin_local) digits[(size_t)kk * (2 * n) + (size_t)h * n + i] = (D)(zero ? 0u : code);
+                if (kk < plan.nwin_local) digits[(size_t)kk * (2 * n) + 2 * i + (size_t)h] = (D)(zero ? 0u : code);
             }
         }
     }

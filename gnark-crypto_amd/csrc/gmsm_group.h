@@ -153,6 +153,11 @@ struct Group {
     }
     // largest digit code k_decompose can emit for this plan (multiexp.go:779-800): decides uint16 vs uint32 digit arrays
     static uint64_t max_digit_code(const WindowPlan &plan) {
+        if (plan.glv) {  // half scalars below 2^GLV_BITS: the top window holds at most 2^(its bits) (value + carry), code = 2 digit
+            const uint64_t low = ((uint64_t)1 << plan.c) - 1;
+            const unsigned top_bits = GLV_BITS - (plan.nwin_total - 1) * plan.c;
+            return std::max(low, (uint64_t)2 << top_bits);
+        }
         const uint64_t low = ((uint64_t)1 << plan.c) - 1;
         const unsigned top_shift = (plan.nwin_total - 1) * plan.c;
         const uint64_t top = top_shift >= 63 + 32u * FrP::N ? 0 : ((fr_modulus_shifted(top_shift) + 1) << 1);
@@ -294,6 +299,21 @@ struct Group {
     static void launch_decompose(const void *d_scalars, size_t n, const WindowPlan &plan, bool d16, void *digits,
                                  const uint8_t *skip, hipStream_t stream) {
         const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+        if (plan.glv) {  // half scalars: digits[k][2 n] (glv_width_built() lists the widths)
+#define GMSM_DECOMPOSE_GLV(CC)                                                                                                  \
+    case CC:                                                                                                                    \
+        if (d16) hipLaunchKernelGGL((k_decompose_glv<FrP, uint16_t, CC>), grid, block, 0, stream, (const uint32_t *)d_scalars, n, \
+                                    plan, (uint16_t *)digits, skip);                                                             \
+        else hipLaunchKernelGGL((k_decompose_glv<FrP, uint32_t, CC>), grid, block, 0, stream, (const uint32_t *)d_scalars, n,     \
+                                plan, (uint32_t *)digits, skip);                                                                 \
+        return;
+            switch (plan.c) {
+                GMSM_DECOMPOSE_GLV(10) GMSM_DECOMPOSE_GLV(11) GMSM_DECOMPOSE_GLV(12) GMSM_DECOMPOSE_GLV(13) GMSM_DECOMPOSE_GLV(14)
+                GMSM_DECOMPOSE_GLV(15) GMSM_DECOMPOSE_GLV(16) GMSM_DECOMPOSE_GLV(17) GMSM_DECOMPOSE_GLV(18) GMSM_DECOMPOSE_GLV(20)
+                default: return;  // never planned (glv_width_built)
+            }
+#undef GMSM_DECOMPOSE_GLV
+        }
 #define GMSM_DECOMPOSE_C(CC)                                                                                                \
     case CC:                                                                                                                \
         if (d16) hipLaunchKernelGGL((k_decompose_c<FrP, uint16_t, CC>), grid, block, 0, stream, (const uint32_t *)d_scalars, n,  \
@@ -358,6 +378,9 @@ struct Group {
         const size_t n_points = n;  // scalars / bases of this run
         const uint32_t nw = shared ? 1u : nwd;  // bucket sets: what the sort, the accumulation and the reduction see as windows
         if (shared) n *= nwd;                   // ... and their entries
+        const bool glv = plan.glv != 0;         // half scalars: entry 2 i = (P_i, k1_i), entry 2 i + 1 = (phi(P_i), k2_i)
+        if (glv && (shared || resident)) return fail(GMSM_ERR_ARG, "GLV plan over registered bases");
+        if (glv) n *= 2;
         if (n >= ((size_t)1 << 31)) return fail(GMSM_ERR_ARG, "n must be < 2^31");
         const uint32_t NB = plan.nbuckets;
         constexpr size_t REC = sizeof(typename OpsSerial::Mem);  // bucket / partial record (lazy representation on the fast path)
@@ -486,15 +509,20 @@ struct Group {
             // by HBM) and joins before the accumulation. Infinity points are recognised by the accumulation from the
             // rewritten record (uaffine_is_infinity), so the decomposition needs no flags from here. 2^20: 36 us off the
             // critical path, 2^24: 0.44 ms. Small calls keep the single stream (two events cost more than they hide).
-            if ((rc = ws.upoints.ensure(n_points * AFF_BYTES))) return rc;
+            if ((rc = ws.upoints.ensure((glv ? 2 : 1) * n_points * AFF_BYTES))) return rc;
             forked = n_points >= FORK_CONVERT_MIN;
+            if (forked && (rc = ws.side_stream(ws.cstream))) return rc;
             hipStream_t cs = forked ? ws.cstream : stream;
             if (forked) {
                 HIP_TRY(hipEventRecord(ws.ev_fork, stream));
                 HIP_TRY(hipStreamWaitEvent(cs, ws.ev_fork, 0));
             }
-            hipLaunchKernelGGL((k_convert_points<U>), dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0,
-                               cs, d_points, n_points, ws.upoints.ptr, (uint8_t *)nullptr);
+            if (glv)
+                hipLaunchKernelGGL((k_convert_points_glv<U, Consts>), dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0,
+                                   cs, d_points, n_points, ws.upoints.ptr);
+            else
+                hipLaunchKernelGGL((k_convert_points<U>), dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0,
+                                   cs, d_points, n_points, ws.upoints.ptr, (uint8_t *)nullptr);
             if (forked) {
                 ws.conv_pending = true;  // until the join below is enqueued (an error return in between leaves cstream running)
                 HIP_TRY(hipEventRecord(ws.ev_conv, cs));
@@ -602,6 +630,7 @@ struct Group {
             fixup_and_reduce(0, nw, 0, stream, true);
         } else {
             const uint32_t ha = nw / 2;
+            if ((rc = ws.side_stream(ws.mstream))) return rc;
             accumulate(0, ha, stream);
             HIP_TRY(hipEventRecord(ws.ev_buckets, stream));
             HIP_TRY(hipStreamWaitEvent(ws.mstream, ws.ev_buckets, 0));
@@ -962,6 +991,7 @@ struct Group {
     // bucket bits of the coarse pass next to (index, sign) - and the coarse pass takes at most 2^13 partitions.
     static size_t max_run_points(const WindowPlan &plan = WindowPlan{0, 0, 0, 0, 1, 0, 0, 0}) {
         size_t cap = (size_t)1 << 27;
+        if (plan.glv) cap >>= 1;  // two entries per point
         if (plan.shared) {
             uint32_t log2NB = 0;
             while ((1u << log2NB) < plan.nbuckets) ++log2NB;
@@ -998,8 +1028,18 @@ struct Group {
             plan.shared = 1;
             return plan;
         }
+        if (rb == nullptr) {  // bases taken anew: GLV half scalars where they were measured ahead (glv_preferred_c)
+            const unsigned mode = options().glv.load(std::memory_order_relaxed);
+            const unsigned forced = options().window_bits.load(std::memory_order_relaxed);
+            unsigned c = 0;
+            if (mode >= 2) c = choose_c(FR_BITS, AFF_BYTES, 2 * n);           // always (A/B): the width of a 2 n-point call, or the forced one
+            else if (mode == 1 && forced == 0) c = glv_preferred_c(FR_BITS, AFF_BYTES, n);
+            if (c != 0 && glv_width_built(c)) return make_plan_glv(c, 0, 1);
+        }
         return make_plan(choose_c(FR_BITS, AFF_BYTES, n), 0, 1);
     }
+    // widths k_decompose_glv is instantiated for
+    static bool glv_width_built(unsigned c) { return (c >= 10 && c <= 18) || c == 20; }
     // Default table width for n registered points, from sweeps of every group over 2^13..2^21 with the width forced
     // (tools/tables_sweep.py, profiles/r03_tables.log). What moves it away from the plain path's width: the shared set
     // holds nwin * n entries, so (a) a wider window pays twice - fewer slabs to add AND shorter chains of partial sums
@@ -1125,7 +1165,7 @@ struct Group {
     static constexpr size_t small_entry_cap() {
         return SMALL_QUAD_ONLY ? (size_t)SMALL_QUAD_ENTRIES * SMALL_QUAD_MAX_CHUNKS * SMALL_MAX_SLICES : (size_t)SMALL_SL * SMALL_MAX_SLICES;
     }
-    // GLV half scalars in the fused kernel: GMSM_OPT_GLV 0 = never, 1 (default) = the fused kernel, 2 = the sorted pipeline too
+    // GLV half scalars in the fused kernel: unless GMSM_OPT_GLV = 0
     static bool small_glv() { return options().glv.load(std::memory_order_relaxed) >= 1; }
     static WindowPlan small_make_plan(unsigned c, bool glv) { return glv ? make_plan_glv(c, 0, 1) : make_plan(c, 0, 1); }
     static unsigned small_c(size_t n, bool glv) {
@@ -1292,7 +1332,7 @@ struct Group {
         if (nr <= 1) {
             int rc = window_sums(ctx, ws, d_points, d_scalars, n, plan, caller_stream, totals.data(), resident);
             if (rc) return rc;
-            *out = fold(totals.data(), c);
+            *out = fold(totals.data(), c, plan.nwin_total);
             return GMSM_OK;
         }
         // Consecutive point ranges on the workspace's stream: each leaves its bucket sums, k_merge_buckets adds them to the
@@ -1324,7 +1364,7 @@ struct Group {
         if ((rc = enqueue_reduce(ctx, ws, ws.carry.ptr, plan, per, ws.stream))) return rc;
         if ((rc = collect_window_sums(ws, ws.stream, plan.nwin_local, totals.data()))) return rc;
         if (prof) record_stage_times(pms, plaunch);
-        *out = fold(totals.data(), c);
+        *out = fold(totals.data(), c, plan.nwin_total);
         return GMSM_OK;
     }
 
@@ -1431,9 +1471,13 @@ struct Group {
         // (first.carry) on a third stream, and ONE reduction follows the last merge - a range costs its accumulation and
         // one addition per occupied bucket, not another 0.35 ms reduction chain. With one workspace the ranges and the
         // merges simply alternate on its stream.
-        hipStream_t ms = nws == 2 ? first.mstream : first.stream;
         constexpr size_t REC = sizeof(typename OpsSerial::Mem);
         int rc = GMSM_OK;
+        if (nws == 2 && (rc = first.side_stream(first.mstream))) {
+            ctx.release(w[1]);
+            return rc;
+        }
+        hipStream_t ms = nws == 2 ? first.mstream : first.stream;
         if (nr > 1 && (rc = first.carry.ensure((size_t)nsets * plan.nbuckets * REC))) {
             if (w[1]) ctx.release(w[1]);
             return rc;
@@ -1529,7 +1573,7 @@ struct Group {
         std::vector<Ext> totals(plan.nwin_total);
         int rc = window_sums_from_host(ctx, first, points, resident, 0, scalars, n, plan, nr, totals.data());
         if (rc) return rc;
-        *out = fold(totals.data(), c);
+        *out = fold(totals.data(), c, plan.nwin_total);
         return GMSM_OK;
     }
 

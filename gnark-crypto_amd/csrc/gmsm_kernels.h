@@ -36,7 +36,7 @@ struct WindowPlan {
     uint32_t shared;     // 1: window tables (Group::precompute_tables) - the digits of all windows index ONE bucket set,
                          // entry (w, i) gathers 2^(c w) P_i; the launch reports the total as window 0 and infinity above
     uint32_t glv;        // 1: the windows are those of the GLV half scalars (gmsm_glv.h): nwin_total = ceil(GLV_BITS / c), a window
-                         // has 2 n entries - entry i = (P_i, k1_i), entry n + i = (phi(P_i), k2_i)
+                         // has 2 n entries - entry 2 i = (P_i, k1_i), entry 2 i + 1 = (phi(P_i), k2_i) (the fused small-n kernel numbers them i and n + i)
 };
 
 template <class T>
@@ -836,8 +836,22 @@ __global__ void __launch_bounds__(256, AccWaves<U>::value) k_accumulate_seg(cons
             inf = true;
             ++b;
             bend = bend2;
-            while (bend == e) {  // empty buckets (rare: the next bucket's end was prefetched, further ones are not)
+            // empty buckets (rare under uniform scalars: the next bucket's end was prefetched, further ones are not). A few
+            // are stepped over; a long gap is bisected - when two crowded buckets of a window lie far apart (all scalars
+            // equal under GLV: one bucket per half, up to 2^(c-1) apart) the ONE thread whose segment holds the boundary
+            // walked the gap with a dependent load per bucket while the whole launch waited for it: 2.7-5.5 ms instead of
+            // 1.2 at 2^20 (profiles/r06_glv_all_equal.log)
+            for (int step = 0; step < 4 && bend == e; ++step) {
                 ++b;
+                bend = st[b + 1];
+            }
+            if (bend == e) {  // the bucket of entry e: largest b' with st[b'] <= e (st[b + 1] == e holds, st[nbuckets] = total > e)
+                uint32_t glo = b + 1, ghi = nbuckets;
+                while (ghi - glo > 1) {
+                    const uint32_t mid = (glo + ghi) >> 1;
+                    if (st[mid] <= e) glo = mid; else ghi = mid;
+                }
+                b = glo;
                 bend = st[b + 1];
             }
             bend2 = st[b + 2 <= nbuckets ? b + 2 : nbuckets];

@@ -88,7 +88,7 @@ __device__ __forceinline__ uint32_t small_code(const SmallArgs &a, const WindowP
         for (int k = 0; k < NR; ++k) s.l[k] = k < HL ? (half ? k2[k < HL ? k : 0] : k1[k < HL ? k : 0]) : 0u;
     }
     const uint32_t c = plan.c, mask = (1u << c) - 1u;
-    const int max = (1 << (c - 1)) - 1;
+    const int max = (1 << (c - 1)) - 1 + (neg ? 1 : 0);  // a negative half: the mirrored digit range (k_decompose_glv)
     int carry = 0;
     uint32_t code = 0;
     for (uint32_t ww = 0; ww <= w; ++ww) {

@@ -338,8 +338,9 @@ enum gmsm_option {
     GMSM_OPT_SPLIT = 8,       /* experiment (default 0 = off): a call's windows in two groups, the fix-up + reduction of the first on a
                                  second stream beside the accumulation of the second (measured: profiles/r05_split_groups.log) */
     GMSM_OPT_GLV = 9,         /* GLV half scalars (ecc/utils.go:62-170; s P = k1 P + k2 phi(P), half the windows and half the host
-                                 fold for the same group element): 0 never, 1 (default) in the fused small-n kernel, 2 in the
-                                 sorted pipeline as well (unregistered bases) */
+                                 fold for the same group element): 0 never; 1 (default) in the fused small-n kernel and, for
+                                 bases taken anew, in the sorted pipeline at the sizes where it was measured ahead (2^13..2^20
+                                 by group; nothing when a width is forced); 2 in every unregistered call (A/B) */
     GMSM_OPT_SMALL_QUAD = 10  /* bucket phase of the fused small-n kernel on lane quads: 0 (default) by call size, 1 never,
                                  2 always (the Fp2 groups and BW6-761 always run it on quads) */
 };

@@ -23,6 +23,9 @@ def main():
     gm = importlib.import_module("gnark-crypto_amd")
     lib = gm._lib.load()
     assert lib.gmsm_set_device(0) == 0
+    for a in sys.argv[1:]:  # --glv=0|1|2: GMSM_OPT_GLV for the whole run
+        if a.startswith("--glv="):
+            gm.set_option("glv", int(a.split("=", 1)[1]))
     torch.cuda.set_device(0)
     out = bench.distributions_block(gm, lib, torch, *( [tuple(configs)] if configs else []), kinds=kinds, cold=cold)
     for r in out["rows"]:

@@ -1,8 +1,8 @@
 #!/bin/bash
-# rocprofv3 kernel stats of one distribution row: tools/prof_dist.sh <out-dir> <curve> <group> <logn> <kind> [steps]
+# rocprofv3 kernel stats of one distribution row: tools/prof_dist.sh <out-dir> <curve> <group> <logn> <kind> [steps] [--glv=N]
 out=$(realpath -m $1); mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout 240 rocprofv3 --kernel-trace --stats -d $out -o t --output-format csv -- python /root/repo/tools/bench_distributions.py $2 $3 $4 ${6:-3} --kinds=$5 --no-cold > /dev/null 2> $out/run.log
+timeout 240 rocprofv3 --kernel-trace --stats -d $out -o t --output-format csv -- python /root/repo/tools/bench_distributions.py $2 $3 $4 ${6:-3} --kinds=$5 --no-cold ${7:-} > /dev/null 2> $out/run.log
 find $out -name "*kernel_trace.csv" -delete; find $out -name "*agent_info.csv" -delete
 python3 - <<PY
 import csv,glob
