@@ -120,21 +120,31 @@ def roofline_record(g, n, pairs_share, stages, acc_launches, traffic):
             "avg_launch_ms": acc_ms, "launches_per_msm": acc_launches}
 
 
-def int_roofline_record(madds, acc_ms_total):
-    """Integer roofline of the BN254 accumulation: 10 lazy products per mixed add (8M+2S, g1.go:822); one 9x29-bit
-    product = 171 v_mad_u64_u32/v_mul_lo_u32 + 18 v_lshrrev_b64, 4 cycles / wave64 / SIMD each (tools/ubench_valu.hip):
-    issue peak = 1024 SIMDs * 64 lanes * 2.4 GHz / (189 * 4) = 208e9 products/s at the nominal clock; the chip sustains
-    what tools/ubench_fpmul.hip measured (profiles/peaks_r02.json) at its DVFS clock."""
-    mulmods_per_s = madds * 10 / (acc_ms_total * 1e-3) if acc_ms_total > 0 else 0.0
-    int_peak = 1024 * 64 * 2.4e9 / (189 * 4)
-    measured = None
+def product_peak(g):
+    """(measured products/s, key) of the group's coordinate field: the LARGER of the signed (accumulation loops) and unsigned
+    product routines of tools/ubench_peaks.hip (profiles/peaks_r06.json) - the yardstick of int_roofline.frac_of_measured."""
     try:
-        with open(os.path.join(ROOT, "profiles", "peaks_r02.json")) as f:
-            measured = json.load(f)["lazy_mul_9x29_per_s"]
-    except (OSError, KeyError, ValueError):
-        pass
-    return {"achieved_mulmod_per_s": mulmods_per_s, "peak_mulmod_per_s": int_peak, "measured_peak_mulmod_per_s": measured,
-            "frac": mulmods_per_s / int_peak, "frac_of_measured": (mulmods_per_s / measured) if measured else None}
+        with open(os.path.join(ROOT, "profiles", "peaks_r06.json")) as f:
+            pk = json.load(f)
+    except (OSError, ValueError):
+        return None, None
+    field = "fp2" if g.coord_limbs != g.curve.fp_limbs else "fp"
+    keys = [f"{g.curve.name}_{field}_mul", f"{g.curve.name}_{field}_mul_unsigned"]
+    best = max((k for k in keys if k in pk), key=lambda k: pk[k], default=None)
+    return (pk[best], best) if best else (None, None)
+
+
+def int_roofline_record(g, madds, acc_ms_total):
+    """Integer roofline of the accumulation kernel: 10 products of the coordinate field per mixed addition (8M + 2S, g1.go:822;
+    over Fp2 a product is one lz/f2s product = 4 base-field product scans with two reductions) against (a) the sustained rate of
+    the product routine itself on this chip (product_peak) and (b), BN254 G1 only, the nominal-clock issue bound: one 9x29-bit
+    product = 171 v_mad_u64_u32 / v_mul_lo_u32 + 18 v_lshrrev_b64 at 4 cycles / wave64 / SIMD (tools/ubench_valu.hip):
+    1024 SIMDs * 64 lanes * 2.4 GHz / (189 * 4) = 208e9 products/s."""
+    rate = madds * 10 / (acc_ms_total * 1e-3) if acc_ms_total > 0 else 0.0
+    measured, key = product_peak(g)
+    nominal = 1024 * 64 * 2.4e9 / (189 * 4) if (g.curve.name == "bn254" and g.coord_limbs == g.curve.fp_limbs) else None
+    return {"achieved_mulmod_per_s": rate, "peak_mulmod_per_s": nominal, "measured_peak_mulmod_per_s": measured, "measured_peak_routine": key,
+            "frac": (rate / nominal) if nominal else None, "frac_of_measured": (rate / measured) if measured else None}
 
 
 def measured_traffic(curve, group, logn, world, nwin=None):
@@ -145,14 +155,14 @@ def measured_traffic(curve, group, logn, world, nwin=None):
     if world != 1:
         return None
     try:
-        path = os.path.join(ROOT, "profiles", "traffic_r05.json")
-        with open(path if os.path.exists(path) else os.path.join(ROOT, "profiles", "traffic_r04.json")) as f:
+        path = next(p for p in (os.path.join(ROOT, "profiles", f"traffic_r0{r}.json") for r in (6, 5, 4)) if os.path.exists(p))
+        with open(path) as f:
             rec = json.load(f)
         key = f"{curve}_{group}_{logn}"
         if nwin is not None and rec.get("windows", {}).get(key, nwin) != nwin:
             return None  # profiled with another window width: not this workload's traffic
         return rec["k_accumulate_seg"].get(key)
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, StopIteration):
         return None
 
 
@@ -239,8 +249,8 @@ def also_config(gm, lib, torch, curve, group, logn, steps, host_legs, with_cpu=T
     stream = torch.cuda.current_stream().cuda_stream
     g.batch_scalar_mul_device(g.generator, d_a.data_ptr(), n, d_pts.data_ptr(), stream)
     del d_a
-    c = g.default_window_bits(n)
-    nwin = g.num_windows(c)
+    plan = g.default_plan(n)  # width, windows, GLV (2 entries per point) of the call as the library runs it
+    c, nwin = plan["window_bits"], plan["windows"]
     jac = g.multiexp_device(d_pts.data_ptr(), d_b.data_ptr(), n, stream)  # warm-up (allocations, LDS attributes)
     prof = StageProfile(lib, level=2)
     prof.start()
@@ -260,8 +270,9 @@ def also_config(gm, lib, torch, curve, group, logn, steps, host_legs, with_cpu=T
     stages["accumulate"] = acc_only["accumulate"]  # the roofline's kernel duration is the timed region's
     out = {"workload": f"{curve.upper()} {group.upper()} MultiExp 2^{logn} points, bases+scalars resident in HBM",
            "value": steps / dt, "unit": "MSM/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "window_bits": c,
-           "windows": nwin, "stage_ms": stages, "stage_ms_note": STAGE_NOTE,
-           "roofline": roofline_record(g, n, 1.0, stages, acc_launches, measured_traffic(curve, group, logn, 1, nwin))}
+           "windows": nwin, "glv": plan["entries_per_point"] == 2, "stage_ms": stages, "stage_ms_note": STAGE_NOTE,
+           "roofline": roofline_record(g, n, 1.0, stages, acc_launches, measured_traffic(curve, group, logn, 1, nwin)),
+           "int_roofline": int_roofline_record(g, n * nwin * plan["entries_per_point"], stages["accumulate"])}
     pts_host = d_pts.cpu().numpy().view(np.uint64) if (host_legs or with_cpu) else None
     if host_legs:
         cfg = gm.MultiExpConfig()
@@ -901,8 +912,8 @@ def main():
     d_pts = torch.from_numpy(pts.view(np.int64)).cuda()
     d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
     stream = torch.cuda.current_stream().cuda_stream
-    c = g.default_window_bits(n)
-    nwin = g.num_windows(c)
+    plan_info = g.default_plan(n)  # what the single-GPU call runs as: width, windows, GLV half scalars (2 entries per point)
+    c, nwin, epp = plan_info["window_bits"], plan_info["windows"], plan_info["entries_per_point"]
 
     sharding = importlib.import_module("gnark-crypto_amd.sharding")
     sharded = world > 1 or args.force_dist
@@ -911,7 +922,7 @@ def main():
         # One MultiExp over all ranks (strong scaling): point or window decomposition (sharding.py), the totals stay on
         # the device until ONE RCCL all-gather; every rank folds.
         plan = sharding.shard_plan(g, n, rank, world, args.shard)
-        c, nwin = plan["c"], plan["nwin"]
+        c, nwin, epp = plan["c"], plan["nwin"], 1  # the sharded pieces run full scalars (gmsm_window_sums_enqueue)
         exchange = sharding.Exchange(dist, torch.device("cuda", dev_index), plan["rows"], g.xyzz_limbs)
         d_pts_loc, d_sc_loc, n_loc = d_pts[plan["lo"]:plan["hi"]], d_sc[plan["lo"]:plan["hi"]], plan["hi"] - plan["lo"]
 
@@ -1108,7 +1119,7 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = args.steps / dt
         # this rank's share of the (point, window) pairs: all windows of its slice, or its windows of all points
-        my_pairs = (plan["hi"] - plan["lo"]) * len(range(plan["win_first"], nwin, plan["win_stride"])) if sharded else n * nwin
+        my_pairs = (plan["hi"] - plan["lo"]) * len(range(plan["win_first"], nwin, plan["win_stride"])) if sharded else n * nwin * epp
         out = {
             "metric": "G1 MSM/sec (BN254)" if (args.curve, args.group) == ("bn254", "g1") else f"{args.group.upper()} MSM/sec ({args.curve})",
             "value": value, "unit": "MSM/s", "n_gpus": world, "steps": args.steps,
@@ -1116,7 +1127,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"{args.curve.upper()} {args.group.upper()} MultiExp 2^{args.logn} points, bases+scalars resident in HBM",
                        "arithmetic": f"{g.curve.p.bit_length()}-bit Montgomery field on 32-bit words (lazy 28/29-bit limbs, v_mad_u64_u32)",
-                       "points": n, "window_bits": c, "windows": nwin, "resident_bases": resident is not None,
+                       "points": n, "window_bits": c, "windows": nwin, "glv_half_scalars": epp == 2, "resident_bases": resident is not None,
                        "parallelism": "single GPU" if not sharded else
                                       f"{plan['mode']}-sharded x{world} + one {'RCCL' if backend == 'nccl' else backend} all-gather"},
             "value_cold": host_entry["cold_msm_per_s"] if host_entry else None,
@@ -1130,9 +1141,9 @@ def main():
             "tables": tables,
             "c_abi_sharded": c_abi,
             "replica_batch": replica,
-            "roofline": roofline_record(g, n, my_pairs / (n * nwin), stages, acc_launches,
+            "roofline": roofline_record(g, n, my_pairs / (n * nwin * epp), stages, acc_launches,
                                         measured_traffic(args.curve, args.group, args.logn, world, nwin)),
-            "int_roofline": int_roofline_record(my_pairs, stages["accumulate"]),
+            "int_roofline": int_roofline_record(g, my_pairs, stages["accumulate"]),
         }
         tail = {}
         if sharded:
@@ -1165,6 +1176,8 @@ def main():
                     "c_abi_equal_to_reference_result": (c_abi or {}).get("equal_to_reference_result")}
         if world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline(g, pts, sc, jac, args.curve, args.group))
+        if world == 1 and not sharded and not args.no_host_entry:
+            out["first_call"] = first_call_record(args.curve, args.group)
         if world == 1 and not sharded and not args.no_also:
             del d_pts, d_sc, pts
             torch.cuda.empty_cache()
@@ -1229,6 +1242,20 @@ def emit(full, world, full_out, json_out):
     for problem in bench_line.validate(line):
         print(f"[bench] line problem: {problem}", file=sys.stderr)
     print(line, file=json_out, flush=True)
+
+
+def first_call_record(curve, group):
+    """Cold start of the drop-in entry, measured in a FRESH process (tools/first_call.py: dlopen, HIP runtime + device, the first
+    2^10 and 2^20 calls, another group's first call); None when the probe fails."""
+    import subprocess
+    try:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "first_call.py"), curve, group], capture_output=True, text=True,
+                           timeout=300, env=dict(os.environ, GMSM_NO_TORCH="1"))
+        line = next(ln for ln in p.stdout.splitlines() if ln.startswith("{"))
+        return json.loads(line)
+    except (subprocess.SubprocessError, StopIteration, ValueError, OSError) as e:
+        print(f"[bench] first_call probe failed: {e}", file=sys.stderr)
+        return None
 
 
 def effective_cpus():

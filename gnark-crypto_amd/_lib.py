@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "gmsm_bn254_g1_multiexp", "gmsm_bn254_g2_multiexp", "gmsm_bls12_381_g1_multiexp", "gmsm_bls12_381_g2_multiexp",
     "gmsm_bw6_761_g1_multiexp", "gmsm_bw6_761_g2_multiexp", "gmsm_multiexp", "gmsm_multiexp_affine", "gmsm_fold",
     "gmsm_multiexp_device", "gmsm_bases_register", "gmsm_bases_release", "gmsm_multiexp_bases",
-    "gmsm_multiexp_bases_device", "gmsm_multiexp_bases_submit", "gmsm_multiexp_collect", "gmsm_multiexp_bases_batch", "gmsm_default_window_bits", "gmsm_num_windows", "gmsm_window_sums_device",
+    "gmsm_multiexp_bases_device", "gmsm_multiexp_bases_submit", "gmsm_multiexp_collect", "gmsm_multiexp_bases_batch", "gmsm_default_window_bits", "gmsm_default_plan", "gmsm_num_windows", "gmsm_window_sums_device",
     "gmsm_window_sums_enqueue", "gmsm_fold_window_sets", "gmsm_fold_windows", "gmsm_batch_scalar_mul", "gmsm_batch_scalar_mul_device",
     "gmsm_batch_jac_to_affine", "gmsm_jac_to_affine", "gmsm_affine_limbs", "gmsm_scalar_limbs", "gmsm_debug_decompose",
     "gmsm_debug_field_op", "gmsm_debug_group_op", "gmsm_debug_glv_split", "gmsm_generate_points", "gmsm_set_profiling", "gmsm_get_stage_times",
@@ -100,6 +100,8 @@ def load():
     L.gmsm_multiexp_collect.argtypes = [ctypes.c_uint64, u64p]
     L.gmsm_default_window_bits.restype = ctypes.c_uint
     L.gmsm_default_window_bits.argtypes = [ctypes.c_int, sz]
+    L.gmsm_default_plan.restype = ctypes.c_int
+    L.gmsm_default_plan.argtypes = [ctypes.c_int, sz] + [ctypes.POINTER(ctypes.c_uint)] * 4
     L.gmsm_num_windows.restype = ctypes.c_uint
     L.gmsm_num_windows.argtypes = [ctypes.c_int, ctypes.c_uint]
     L.gmsm_window_sums_device.restype = ctypes.c_int

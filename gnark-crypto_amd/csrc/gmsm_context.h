@@ -680,6 +680,7 @@ struct GroupVTable {
                        uint64_t *out_xyzz);
     unsigned (*host_piece_ranges)(size_t n, bool with_points);  // point ranges a host-buffer piece of n points runs as
     int (*debug_glv_split)(const uint64_t *scalars, size_t n, uint32_t *out);  // test hook of gmsm_glv.h
+    void (*plan_info)(size_t n, unsigned *c, unsigned *nwin, unsigned *entries_per_point, unsigned *fused);  // gmsm_default_plan
 };
 
 }  // namespace gmsm

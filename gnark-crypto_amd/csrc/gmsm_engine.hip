@@ -1272,6 +1272,17 @@ GMSM_EXPORT unsigned gmsm_default_window_bits(int group, size_t n) {
     return vt ? choose_c(vt->fr_bits, vt->aff_bytes, n) : 0;
 }
 
+GMSM_EXPORT int gmsm_default_plan(int group, size_t n, unsigned *c, unsigned *nwin, unsigned *entries_per_point, unsigned *fused) {
+    VT_OR_FAIL(group);
+    unsigned a = 0, b = 0, e = 1, f = 0;
+    vt->plan_info(n, &a, &b, &e, &f);
+    if (c) *c = a;
+    if (nwin) *nwin = b;
+    if (entries_per_point) *entries_per_point = e;
+    if (fused) *fused = f;
+    return GMSM_OK;
+}
+
 GMSM_EXPORT unsigned gmsm_num_windows(int group, unsigned c) {
     const GroupVTable *vt = vtable(group);
     return (vt && c) ? num_windows(vt->fr_bits, c) : 0;

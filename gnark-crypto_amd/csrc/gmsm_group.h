@@ -1972,6 +1972,16 @@ struct VTableOf {
         return debug_decompose_impl<G>(scalars, n, c, out_digits);
     }
     static int debug_glv_split(const uint64_t *scalars, size_t n, uint32_t *out) { return debug_glv_split_impl<G>(scalars, n, out); }
+    // what a MultiExp over n bases taken anew runs as (gmsm_default_plan)
+    static void plan_info(size_t n, unsigned *c, unsigned *nwin, unsigned *entries_per_point, unsigned *fused) {
+        if (G::small_serves(n, nullptr)) {
+            const typename G::SmallPlan sp = G::small_plan(n, nullptr);
+            *c = sp.plan.c, *nwin = sp.plan.nwin_total, *entries_per_point = sp.glv ? 2u : 1u, *fused = 1u;
+            return;
+        }
+        const WindowPlan p = G::plan_for(nullptr, n);
+        *c = p.c, *nwin = p.nwin_total, *entries_per_point = p.glv ? 2u : 1u, *fused = 0u;
+    }
     static int debug_field_op(int field, int op, const uint64_t *a, const uint64_t *b, size_t count, uint64_t *out) {
         using BaseP = typename G::F::Params;
         if (field == 0) {
@@ -2016,7 +2026,7 @@ struct VTableOf {
         static const GroupVTable vt = {G::FR_BITS,      G::AFF_BYTES,   G::SCALAR_BYTES, sizeof(typename G::J),
                                        sizeof(typename G::Ext), &multiexp_host, &multiexp_device, &window_sums,
                                        &fold,           &jac_to_affine, &debug_decompose, &debug_field_op,
-                                       &debug_group_op, &generate_points, &register_bases, &submit, &collect, &window_sums_enqueue, &fold_sets, &fold_powers, &multiexp_bases_host, &batch_scalar_mul, &batch_jac_to_affine, &decode_raw, &validate_points, &fft_domain_new, &fft_run, &fft_bit_reverse, &precompute_tables, &tables_serve, &shard_piece, &host_piece_ranges, &debug_glv_split};
+                                       &debug_group_op, &generate_points, &register_bases, &submit, &collect, &window_sums_enqueue, &fold_sets, &fold_powers, &multiexp_bases_host, &batch_scalar_mul, &batch_jac_to_affine, &decode_raw, &validate_points, &fft_domain_new, &fft_run, &fft_bit_reverse, &precompute_tables, &tables_serve, &shard_piece, &host_piece_ranges, &debug_glv_split, &plan_info};
         return &vt;
     }
 };

@@ -295,6 +295,14 @@ class _Group:
     def default_window_bits(self, n):
         return int(_lib.load().gmsm_default_window_bits(self.gid, n))
 
+    def default_plan(self, n):
+        """What a MultiExp over n bases taken anew runs as: dict(window_bits, windows, entries_per_point, fused)."""
+        v = [_lib.ctypes.c_uint(0) for _ in range(4)]
+        rc = _lib.load().gmsm_default_plan(self.gid, n, *[_lib.ctypes.byref(x) for x in v])
+        if rc:
+            raise RuntimeError(self._error(rc))
+        return {"window_bits": v[0].value, "windows": v[1].value, "entries_per_point": v[2].value, "fused": bool(v[3].value)}
+
     def num_windows(self, c):
         return int(_lib.load().gmsm_num_windows(self.gid, c))
 

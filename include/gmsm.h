@@ -263,6 +263,10 @@ unsigned gmsm_default_window_bits(int group, size_t n);            /* the engine
                                                                       table per group, 8..17; c = 17 (BN254 G1 from 2^22
                                                                       points) is beyond the reference's uint16 digits */
 unsigned gmsm_num_windows(int group, unsigned c);                  /* computeNbChunks, multiexp.go:681 */
+/* What a MultiExp over n bases taken anew runs as under the current options: window width, number of windows,
+ * entries_per_point (2 = GLV half scalars: 2 n entries per window, gmsm_glv.h; 1 = full scalars) and fused (1 = the fused
+ * small-n kernel, 0 = the sorted pipeline). Cost only - the result does not depend on any of it. NULL pointers are skipped. */
+int gmsm_default_plan(int group, size_t n, unsigned *c, unsigned *nwin, unsigned *entries_per_point, unsigned *fused);
 /* c: 2..20 (the affine result does not depend on it, multiexp_test.go:95-126; the reference stops at 16); one call takes
  * up to 2^27 points for c <= 17 and 2^(44-c) beyond (32-bit sort entries) - larger inputs: split by point range and add
  * the sets with gmsm_fold_window_sets */
