@@ -1194,6 +1194,12 @@ def main():
             out["distributions"]["worst_vs_uniform"] = max(out["distributions"]["worst_vs_uniform"], g2["worst_vs_uniform"])
             out["distributions"]["all_bit_exact"] = out["distributions"]["all_bit_exact"] and g2["all_bit_exact"]
             out["small_n"] = small_n_block(gm, torch)
+            # ... and 2^5 points (the reference's smallest benchmark size) for the other groups: resident ms, checked against the port
+            wide = {}
+            for cv, gp in (("bn254", "g2"), ("bls12_381", "g1"), ("bls12_381", "g2"), ("bw6_761", "g1")):
+                blk = small_n_block(gm, torch, cv, gp, logns=(5,), reps=20, with_cpu=False)
+                wide[f"{cv}_{gp}"] = blk["rows"][0]["resident_ms"] if blk["rows"][0]["bit_exact"] else None
+            out["small_n"]["wide"] = wide
             out["also"] = [also_config(gm, lib, torch, *cfg_) for cfg_ in ALSO
                            if (cfg_[0], cfg_[1], cfg_[2]) != (args.curve, args.group, args.logn)]
             r24 = next((r for r in out["also"] if r["workload"].startswith("BN254 G1 MultiExp 2^24")), None)

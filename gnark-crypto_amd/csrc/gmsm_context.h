@@ -20,6 +20,7 @@
 namespace gmsm {
 
 int fail(int code, const std::string &msg);  // records the thread-local error text, returns code
+void clear_last_error();                     // this thread's text: a failure that was handled inside a successful call
 
 #define HIP_TRY(expr)                                                                                        \
     do {                                                                                                     \

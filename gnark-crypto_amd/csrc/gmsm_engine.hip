@@ -52,6 +52,8 @@ int fail(int code, const std::string &msg) {
     return code;
 }
 
+void clear_last_error() { g_last_error.clear(); }
+
 static std::mutex g_prof_mu;
 static std::atomic<int> g_profiling{0};
 static double g_stage_ms[STAGE_COUNT] = {0};

@@ -423,6 +423,7 @@ struct Group {
         const uint32_t stage_cap = fine_cnt_bytes >= 156 * 1024 ? 0u
                                    : (uint32_t)std::min<size_t>(GMSM_TUNE(STAGE_CAP, part_log2 >= 15 ? 39000 : 24576),
                                                               (156 * 1024 - fine_cnt_bytes) / 4);
+        if (stage_cap > 40u * 1024u) return fail(GMSM_ERR_ARG, "window geometry: staging slots beyond the fine sort's registers");
         if (fine_cnt_bytes + (size_t)stage_cap * 4 > 160 * 1024)  // cannot happen with fb <= 15; a failed launch must not
             return fail(GMSM_ERR_ARG, "window geometry: fine-sort counters exceed the LDS");  // leave garbage for the next kernels
         const bool d16 = max_digit_code(plan) < 65536;
@@ -475,7 +476,8 @@ struct Group {
         if ((rc = ctx.allow_lds((const void *)k_part_scatter<uint32_t, PART_CHUNK>, 152 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_part_scatter<uint16_t, PART_CHUNK_BIG>, 152 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_part_scatter<uint32_t, PART_CHUNK_BIG>, 152 * 1024))) return rc;
-        if ((rc = ctx.allow_lds((const void *)k_fine_sort, 160 * 1024))) return rc;
+        if ((rc = ctx.allow_lds((const void *)k_fine_sort<24>, 160 * 1024))) return rc;
+        if ((rc = ctx.allow_lds((const void *)k_fine_sort<40>, 160 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_heavy_hist, 128 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_heavy_scan, 128 * 1024))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_heavy_place, 128 * 1024))) return rc;
@@ -567,8 +569,13 @@ struct Group {
             else GMSM_SCATTER(uint32_t, PART_CHUNK_BIG);
 #undef GMSM_SCATTER
         }
-        hipLaunchKernelGGL(k_fine_sort, dim3(nparts, nw), dim3(1024), ((size_t)4 << fbits) + (size_t)stage_cap * 4, stream,
-                           parted, n, NB, fbits, lidx, part_base, sorted, starts, stage_cap);
+        // the partition's references stay in registers between the two passes: 24 per thread (stage_cap <= 24576), else 40
+        if (stage_cap <= 24u * 1024u)
+            hipLaunchKernelGGL(k_fine_sort<24>, dim3(nparts, nw), dim3(1024), ((size_t)4 << fbits) + (size_t)stage_cap * 4, stream,
+                               parted, n, NB, fbits, lidx, part_base, sorted, starts, stage_cap);
+        else
+            hipLaunchKernelGGL(k_fine_sort<40>, dim3(nparts, nw), dim3(1024), ((size_t)4 << fbits) + (size_t)stage_cap * 4, stream,
+                               parted, n, NB, fbits, lidx, part_base, sorted, starts, stage_cap);
         // partitions beyond the staging slots (crowded buckets, narrow top windows): sorted by many workgroups each. A run of at
         // most stage_cap entries per window cannot have one: no launches (14 us of a 0.4 ms call)
         if (n > stage_cap) {
@@ -1121,6 +1128,11 @@ struct Group {
                 rb->small_nw = sp.nwin_total;
                 rb->small_m = m;
                 rb->small_c.store(SMALL_TABLE_C, std::memory_order_release);
+            } else {
+                // the narrow tables are an extra: without them small calls over the handle take the plain fused kernel. Their
+                // memory goes back and the failure's text does not linger as this thread's last error (the call succeeded).
+                rb->small_tables.release();
+                clear_last_error();
             }
         }
         (void)ctx;
@@ -1219,6 +1231,14 @@ struct Group {
             const size_t max_slices = sp.shared ? SMALL_SHARED_MAX_SLICES : SMALL_MAX_SLICES;
             size_t chunks = 1;
             while ((entries + chunks * SMALL_QUAD_ENTRIES - 1) / (chunks * SMALL_QUAD_ENTRIES) > max_slices) chunks *= 2;
+            // every workgroup ends with the same 2 (c - 1) + log2(slices) reduction steps whatever it accumulated: once the
+            // launch has more workgroups than the chip holds at a time (one per CU for the wide types: 310 registers, 89 KB of
+            // LDS), longer walks per workgroup beat more workgroups (BW6-761 2^10: 896 workgroups of one chunk 1.61 ms)
+            const size_t nsets = sp.shared ? 1 : sp.plan.nwin_total, resident_wgs = SMALL_QUAD_ONLY ? 256 : 768;
+            while (chunks < SMALL_QUAD_MAX_CHUNKS &&
+                   (entries + chunks * SMALL_QUAD_ENTRIES - 1) / (chunks * SMALL_QUAD_ENTRIES) * nsets > resident_wgs &&
+                   entries > chunks * SMALL_QUAD_ENTRIES)
+                chunks *= 2;
             sp.chunks = (uint32_t)chunks;
             sp.nslices = (uint32_t)((entries + chunks * SMALL_QUAD_ENTRIES - 1) / (chunks * SMALL_QUAD_ENTRIES));
         } else {

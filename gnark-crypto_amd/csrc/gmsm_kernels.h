@@ -429,15 +429,45 @@ __global__ void __launch_bounds__(1024) k_part_scatter(const D *__restrict__ dig
     constexpr int PER = CHUNK / 1024;  // entries per thread, in registers while the cursors are prepared
     uint32_t ent[PER];
     uint32_t pid[PER];
+    // A full chunk whose codes start on a 16-byte boundary is read as vectors of four codes per lane (round 6: three 8- /
+    // 16-byte loads per thread instead of twelve 2- / 4-byte ones; the lanes of a wave still cover one contiguous block);
+    // the last chunk of a window and unaligned windows (n not a multiple of 8) take the code-by-code loads.
+    static_assert(PER % 4 == 0, "whole vectors of four codes per thread");
+    const bool vec = hi - lo == CHUNK && T == 1024 && (reinterpret_cast<uintptr_t>(d + lo) & 15u) == 0;
+    if (vec) {
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const size_t i = lo + (size_t)j * T + t;
-        uint32_t code = i < hi ? d[i] : 0u;
-        pid[j] = 0xFFFFFFFFu;
-        if (code) {
-            const uint32_t b = code_bucket(code);
-            pid[j] = b >> fbits;
-            ent[j] = ((b & fmask) << lidx) | ((uint32_t)i << 1) | (code & 1u);
+        for (int q = 0; q < PER / 4; ++q) {
+            const size_t i0 = lo + ((size_t)q * T + t) * 4;
+            uint32_t c4[4];
+            if constexpr (sizeof(D) == 2) {
+                const uint2 w = *reinterpret_cast<const uint2 *>(d + i0);
+                c4[0] = w.x & 0xffffu, c4[1] = w.x >> 16, c4[2] = w.y & 0xffffu, c4[3] = w.y >> 16;
+            } else {
+                const uint4 w = *reinterpret_cast<const uint4 *>(d + i0);
+                c4[0] = w.x, c4[1] = w.y, c4[2] = w.z, c4[3] = w.w;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = 4 * q + u;
+                pid[j] = 0xFFFFFFFFu;
+                if (c4[u]) {
+                    const uint32_t b = code_bucket(c4[u]);
+                    pid[j] = b >> fbits;
+                    ent[j] = ((b & fmask) << lidx) | ((uint32_t)(i0 + u) << 1) | (c4[u] & 1u);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const size_t i = lo + (size_t)j * T + t;
+            uint32_t code = i < hi ? d[i] : 0u;
+            pid[j] = 0xFFFFFFFFu;
+            if (code) {
+                const uint32_t b = code_bucket(code);
+                pid[j] = b >> fbits;
+                ent[j] = ((b & fmask) << lidx) | ((uint32_t)i << 1) | (code & 1u);
+            }
         }
     }
     __syncthreads();
@@ -468,6 +498,9 @@ __global__ void __launch_bounds__(1024) k_part_scatter(const D *__restrict__ dig
 
 // grid = (nparts, nwin), block = 1024. Counting sort of one partition by fine bucket; also emits starts[] of its buckets.
 // Partitions of more than stage_cap references are the heavy kernels' (below).
+// Round 6: the partition is read ONCE - its references stay in registers (PER per thread, stage_cap <= 1024 PER) between the
+// counting and the placing pass; rounds 3-5 read it from global memory for both (profiles/r06_front_end_ab.log).
+template <int PER>
 static __global__ void __launch_bounds__(1024) k_fine_sort(const uint32_t *__restrict__ parted, size_t n, uint32_t nbuckets,
                                                           uint32_t fbits, uint32_t lidx,
                                                           const uint32_t *__restrict__ part_base,
@@ -484,19 +517,21 @@ static __global__ void __launch_bounds__(1024) k_fine_sort(const uint32_t *__res
     if (p == nparts - 1 && t == 0) st[nbuckets] = hi;
     const uint32_t pop = hi - lo;
     if (pop > stage_cap) return;  // oversized: k_heavy_hist / k_heavy_scan / k_heavy_place
+    uint32_t v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {  // PER loads in flight per thread; the lanes of a wave read 256 contiguous bytes each
+        const uint32_t e = lo + (uint32_t)j * T + t;
+        v[j] = e < hi ? in[e] : 0u;
+    }
     for (uint32_t f = t; f < nf; f += T) lds_f[f] = 0;
     __syncthreads();
-    {   // 4 loads in flight per thread
-        uint32_t e = lo + t;
-        for (; e + 3 * T < hi; e += 4 * T) {
-            const uint32_t v0 = in[e], v1 = in[e + T], v2 = in[e + 2 * T], v3 = in[e + 3 * T];
-            const bool runny = wave_runny(v0 >> lidx, true);
-            lds_count<false>(lds_f, v0 >> lidx, true, runny);
-            lds_count<false>(lds_f, v1 >> lidx, true, runny);
-            lds_count<false>(lds_f, v2 >> lidx, true, runny);
-            lds_count<false>(lds_f, v3 >> lidx, true, runny);
-        }
-        for (; e < hi; e += T) atomicAdd(&lds_f[in[e] >> lidx], 1u);
+#pragma unroll
+    for (int j = 0; j < PER; j += 4) {
+        if (lo + (uint32_t)j * T >= hi) break;  // uniform: nothing left for any thread
+        const bool runny = wave_runny(v[j] >> lidx, lo + (uint32_t)j * T + t < hi);
+#pragma unroll
+        for (int u = 0; u < 4 && j + u < PER; ++u)
+            lds_count<false>(lds_f, v[j + u] >> lidx, lo + (uint32_t)(j + u) * T + t < hi, runny);
     }
     __syncthreads();
     // exclusive scan of the nf counters -> write cursors (in place) and starts[]
@@ -506,23 +541,16 @@ static __global__ void __launch_bounds__(1024) k_fine_sort(const uint32_t *__res
     // place the references inside LDS and write the sorted run out contiguously (scattered 4-byte global stores are
     // limited to well under one lane per cycle per CU; this path has none)
     uint32_t *stage = lds_f + nf;
-    uint32_t e = lo + t;
-    for (; e + 3 * T < hi; e += 4 * T) {
-        const uint32_t v0 = in[e], v1 = in[e + T], v2 = in[e + 2 * T], v3 = in[e + 3 * T];
-        const bool runny = wave_runny(v0 >> lidx, true);
-        const uint32_t p0 = lds_count<true>(lds_f, v0 >> lidx, true, runny);
-        const uint32_t p1 = lds_count<true>(lds_f, v1 >> lidx, true, runny);
-        const uint32_t p2 = lds_count<true>(lds_f, v2 >> lidx, true, runny);
-        const uint32_t p3 = lds_count<true>(lds_f, v3 >> lidx, true, runny);
-        stage[p0 - lo] = v0 & pmask;
-        stage[p1 - lo] = v1 & pmask;
-        stage[p2 - lo] = v2 & pmask;
-        stage[p3 - lo] = v3 & pmask;
-    }
-    for (; e < hi; e += T) {
-        const uint32_t v = in[e];
-        const uint32_t pos = atomicAdd(&lds_f[v >> lidx], 1u);
-        stage[pos - lo] = v & pmask;
+#pragma unroll
+    for (int j = 0; j < PER; j += 4) {
+        if (lo + (uint32_t)j * T >= hi) break;
+        const bool runny = wave_runny(v[j] >> lidx, lo + (uint32_t)j * T + t < hi);
+#pragma unroll
+        for (int u = 0; u < 4 && j + u < PER; ++u) {
+            const bool act = lo + (uint32_t)(j + u) * T + t < hi;
+            const uint32_t pos = lds_count<true>(lds_f, v[j + u] >> lidx, act, runny);
+            if (act) stage[pos - lo] = v[j + u] & pmask;
+        }
     }
     __syncthreads();
     for (uint32_t i = t; i < pop; i += T) out[lo + i] = stage[i];

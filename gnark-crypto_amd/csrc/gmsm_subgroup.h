@@ -110,7 +110,7 @@ __device__ __forceinline__ void sg_psi(SgPoint<Fp2U<P>> &a, const Fp2U<P> &u, co
 
 // The reference's IsInSubGroup for a point that IS on the curve and is not infinity.
 template <class F, class C>
-__device__ bool point_in_subgroup_endo(const Affine<F> &a) {
+__device__ __forceinline__ bool point_in_subgroup_endo(const Affine<F> &a) {  // inlined into the kernel: as a 142 KB FUNCTION it met the long-branch trap (tools/check_long_branch.py)
     using U = typename IngestLazy<F>::type;
     using T = LzTraits<U>;
     constexpr bool INL = sizeof(U) <= 14 * 4;  // wider elements call their products (code size, as in gmsm_fixedbase.h)

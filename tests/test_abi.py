@@ -58,12 +58,12 @@ def test_default_window_table(gm, curve, which):
             top_bits = fr_bits - (nwin - 1) * c
             assert top_bits >= 6 or n < (1 << 17), (n, c, top_bits)  # narrow top windows only where they were measured to win
             assert c == g.default_window_bits(1 << lg), "one width per power-of-two band"
-        if prev is not None and lg >= 17:
-            assert c >= prev or (curve == "bw6_761"), "the width does not shrink as n grows (large n)"
+        if prev is not None and lg >= 20:  # below 2^19 the measured optimum moves both ways (profiles/r06_glv_width_sweep.log)
+            assert c >= prev, "the width does not shrink as n grows (large n)"
         prev = c
     table = {("bn254", "g1"): {20: 16, 21: 17, 24: 17, 26: 17}, ("bn254", "g2"): {20: 16, 22: 17},
              ("bls12_381", "g1"): {22: 16, 24: 17}, ("bls12_381", "g2"): {16: 12, 22: 16},
-             ("bw6_761", "g1"): {13: 9, 20: 14, 22: 16}, ("bw6_761", "g2"): {13: 9, 20: 14, 22: 16}}[(curve, which)]
+             ("bw6_761", "g1"): {12: 9, 13: 10, 20: 14, 22: 16}, ("bw6_761", "g2"): {12: 9, 13: 10, 20: 14, 22: 16}}[(curve, which)]
     for lg, c in table.items():
         assert g.default_window_bits(1 << lg) == c, (lg, c)
     with gm.options(window_bits=11):  # gmsm_set_option(GMSM_OPT_WINDOW_BITS): the switch the tests and sweeps use

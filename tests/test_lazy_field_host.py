@@ -49,3 +49,19 @@ def test_signed_limb_mixed_addition_matches_unsigned_form(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout
     assert r.stdout.count(" 0 mismatches") == 5, r.stdout
+
+
+def test_host_squaring_matches_the_product(tmp_path):
+    """tests/c/host_sqr_check.cpp: the dedicated squaring the host-side window fold uses (gmsm_field.h fp_sqr, host branch:
+    msmReduceChunk's doublings, multiexp.go:302-315) returns the limbs of fp_mul(x, x) for the six fields, on the edges and on
+    random chains."""
+    import pytest
+    cxx = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(cxx):
+        pytest.skip("ROCm clang++ not found")
+    exe = tmp_path / "host_sqr_check"
+    subprocess.check_call([cxx, "-O2", "-std=c++17", "-D__host__=", "-D__device__=", "-D__noinline__=", "-o", str(exe),
+                           os.path.join(ROOT, "tests", "c", "host_sqr_check.cpp")])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout
+    assert r.stdout.count(": 0 mismatches") == 6, r.stdout
