@@ -166,14 +166,32 @@ def measured_traffic(curve, group, logn, world, nwin=None):
         return None
 
 
-def median_ms(fn, reps=5):
-    fn()
+def median_ms(fn, reps=5, warm=1):
+    """median wall-clock ms of `reps` calls of a BLOCKING entry (host buffers in, result out), after `warm` untimed ones"""
+    for _ in range(warm):
+        fn()
     ts = []
     for _ in range(reps):
         t_ = time.perf_counter()
         fn()
         ts.append((time.perf_counter() - t_) * 1e3)
     return sorted(ts)[len(ts) // 2]
+
+
+def loop_ms(fn, reps, sync=None, warm=1):
+    """(mean ms, last result) of `reps` back-to-back calls between two `sync()`s, after `warm` untimed calls - the one timing
+    loop of every row beside the headline's own (main() keeps its loop in the open: barrier, K steps, barrier)"""
+    out = None
+    for _ in range(warm):
+        out = fn()
+    if sync is not None:
+        sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    if sync is not None:
+        sync()
+    return (time.perf_counter() - t0) / reps * 1e3, out
 
 
 def tables_record(gm, g, d_pts, d_sc, sc, n, stream, jac, steps):
@@ -188,13 +206,7 @@ def tables_record(gm, g, d_pts, d_sc, sc, n, stream, jac, steps):
         cfg = gm.MultiExpConfig()
 
         def resident_ms():
-            rb.multiexp_device(d_sc.data_ptr(), n, stream)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                out = rb.multiexp_device(d_sc.data_ptr(), n, stream)
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / steps * 1e3, out
+            return loop_ms(lambda: rb.multiexp_device(d_sc.data_ptr(), n, stream), steps, torch.cuda.synchronize)
 
         def in_flight_ms():
             def run(k):
@@ -206,9 +218,8 @@ def tables_record(gm, g, d_pts, d_sc, sc, n, stream, jac, steps):
                     prev = t
                 return rb.collect(prev)
             run(3)
-            t0 = time.perf_counter()
-            out = run(steps)
-            return (time.perf_counter() - t0) / steps * 1e3, out
+            ms, out = loop_ms(lambda: run(steps), 1, warm=0)
+            return ms / steps, out
 
         runs0 = int(gm._lib.load().gmsm_debug_table_runs())
         dev_ms, j1 = resident_ms()
@@ -352,13 +363,7 @@ def distributions_block(gm, lib, torch, configs=(("bn254", "g1", 20, 10), ("bn25
         for kind in (kinds or DISTRIBUTIONS):
             b = skewed_scalars(kind, base, g, rng)
             d_b = torch.from_numpy(b.view(np.int64)).cuda()
-            jac = g.multiexp_device(d_pts.data_ptr(), d_b.data_ptr(), n, stream)  # warm-up
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                jac = g.multiexp_device(d_pts.data_ptr(), d_b.data_ptr(), n, stream)
-            torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) / steps * 1e3
+            ms, jac = loop_ms(lambda: g.multiexp_device(d_pts.data_ptr(), d_b.data_ptr(), n, stream), steps, torch.cuda.synchronize)
             prof = StageProfile(lib)
             prof.start()
             for _ in range(max(2, steps // 2)):
@@ -406,23 +411,11 @@ def small_n_block(gm, torch, curve="bn254", group="g1", logns=(2, 3, 4, 5, 6, 8,
     rb.precompute(0)
     for logn in logns:
         n = 1 << logn
-        jac = g.multiexp_device(d_pts.data_ptr(), d_sc.data_ptr(), n, stream)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            jac = g.multiexp_device(d_pts.data_ptr(), d_sc.data_ptr(), n, stream)
-        torch.cuda.synchronize()
-        res_ms = (time.perf_counter() - t0) / reps * 1e3
+        res_ms, jac = loop_ms(lambda: g.multiexp_device(d_pts.data_ptr(), d_sc.data_ptr(), n, stream), reps, torch.cuda.synchronize)
         p_, s_ = np.ascontiguousarray(pts[:n]), np.ascontiguousarray(sc[:n])
         cold_ms = median_ms(lambda: g.MultiExp(p_, s_, cfg), reps=9)
         jc, _ = g.MultiExp(p_, s_, cfg)
-        jt = rb.multiexp_device(d_sc.data_ptr(), n, stream)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            jt = rb.multiexp_device(d_sc.data_ptr(), n, stream)
-        torch.cuda.synchronize()
-        tab_ms = (time.perf_counter() - t0) / reps * 1e3
+        tab_ms, jt = loop_ms(lambda: rb.multiexp_device(d_sc.data_ptr(), n, stream), reps, torch.cuda.synchronize)
         row = {"logn": logn, "resident_ms": round(res_ms, 4), "cold_ms": round(cold_ms, 4), "registered_tables_ms": round(tab_ms, 4)}
         expected = o.msm_affine(p_, s_, nthreads=2 * cores)
         row["bit_exact"] = bool((g.jac_to_affine(jac) == expected).all() and (g.jac_to_affine(jc) == expected).all()
@@ -648,12 +641,7 @@ def fft_config(gm, torch, curve="bn254", logn=24, reps=5):
     d.fft_device(t.data_ptr(), gm.fft.DIF, stream=stream)
     d.fft_device(t.data_ptr(), gm.fft.DIT, inverse=True, stream=stream)
     ok = bool((t.cpu().numpy().view(np.uint64) == a).all())
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        d.fft_device(t.data_ptr(), gm.fft.DIF, stream=stream)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / reps * 1e3
+    ms, _ = loop_ms(lambda: d.fft_device(t.data_ptr(), gm.fft.DIF, stream=stream), reps, torch.cuda.synchronize, warm=0)
     d.release()
     passes = 1 + (max(0, logn - 10) + 7) // 8  # gmsm_fft.h: the low 10 bits in one pass, the rest in passes of <= 8
     traffic = passes * 2 * n * 8 * c.fr_limbs
@@ -715,12 +703,7 @@ def next_rows(gm, lib, torch):
         a = uniform_scalars(rng, g, n)
         d_a = torch.from_numpy(a.view(np.int64)).cuda()
         d_p = torch.empty((n, g.aff_limbs), dtype=torch.int64, device="cuda")
-        g.batch_scalar_mul_device(g.generator, d_a.data_ptr(), n, d_p.data_ptr(), stream)
-        reps = 3
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            g.batch_scalar_mul_device(g.generator, d_a.data_ptr(), n, d_p.data_ptr(), stream)  # returns when complete
-        ms = (time.perf_counter() - t0) / reps * 1e3
+        ms, _ = loop_ms(lambda: g.batch_scalar_mul_device(g.generator, d_a.data_ptr(), n, d_p.data_ptr(), stream), 3)  # returns when complete
         c = 8 if logn < 21 else 11  # Group::batch_scalar_mul: table width by batch size
         nwin = (g.curve.fr_bits + c - 1) // c
         prods = n * (nwin * 10 + 9)  # nwin mixed additions (8M + 2S) + the shared-inversion normalisation (~9 products a point)
@@ -743,24 +726,16 @@ def next_rows(gm, lib, torch):
     bad = _ct.c_int64(-1)
     raw_bytes = raw.size
     for level, name in ((0, "decode_only"), (2, "decode_curve_subgroup")):
-        ts = []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            rc = lib.gmsm_points_from_raw(g.gid, raw.ctypes.data, n, level, None, d_out.data_ptr(), _ct.byref(bad))
-            ts.append((time.perf_counter() - t0) * 1e3)
-            assert rc == 0, gm._lib.last_error()
-        ms = sorted(ts)[1]
+        def decode(level=level):
+            assert lib.gmsm_points_from_raw(g.gid, raw.ctypes.data, n, level, None, d_out.data_ptr(), _ct.byref(bad)) == 0, gm._lib.last_error()
+        ms = median_ms(decode, reps=3, warm=0)
         out[f"points_from_raw_2p22_{name}"] = {"ms": ms, "GB_per_s_in": raw_bytes / (ms * 1e-3) / 1e9, "points_per_s": n / (ms * 1e-3),
                                               "source": "pageable host memory (PCIe-inclusive)"}
     same = bool((d_out.cpu().numpy().view(np.uint64) == pts).all())
     out["points_from_raw_2p22_decode_curve_subgroup"]["equal_to_source_points"] = same
-    ts = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        rc = lib.gmsm_points_validate(g.gid, None, keep.data_ptr(), n, 2, _ct.byref(bad))
-        ts.append((time.perf_counter() - t0) * 1e3)
-        assert rc == 0, gm._lib.last_error()
-    ms = sorted(ts)[1]
+    def validate_resident():
+        assert lib.gmsm_points_validate(g.gid, None, keep.data_ptr(), n, 2, _ct.byref(bad)) == 0, gm._lib.last_error()
+    ms = median_ms(validate_resident, reps=3, warm=0)
     # BN254 G1 has cofactor 1: level 2 is the curve equation alone (y^2 = x^3 + 3: three products a point) - a streaming kernel
     out["points_validate_2p22_level2_resident"] = {
         "ms": ms, "points_per_s": n / (ms * 1e-3), "GB_per_s": n * 64 / (ms * 1e-3) / 1e9, "frac_of_hbm": n * 64 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
@@ -773,17 +748,19 @@ def next_rows(gm, lib, torch):
     d_a2 = torch.from_numpy(a2.view(np.int64)).cuda()
     d_p2 = torch.empty((m, g2.aff_limbs), dtype=torch.int64, device="cuda")
     g2.batch_scalar_mul_device(g2.generator, d_a2.data_ptr(), m, d_p2.data_ptr(), stream)
-    ts = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        rc = lib.gmsm_points_validate(g2.gid, None, d_p2.data_ptr(), m, 2, _ct.byref(bad))
-        ts.append((time.perf_counter() - t0) * 1e3)
-        assert rc == 0, gm._lib.last_error()
-    ms = sorted(ts)[1]
-    prods = m * (255 * 9 + 127 * 10 + 3)  # dbl-2008-s-1: 9 products, madd-2008-s: 10, the curve equation 3
+    def validate_cofactor_group():
+        assert lib.gmsm_points_validate(g2.gid, None, d_p2.data_ptr(), m, 2, _ct.byref(bad)) == 0, gm._lib.last_error()
+    ms = median_ms(validate_cofactor_group, reps=3, warm=0)
+    # level 2 = the reference's identity [x]([x] phi(P)) + P = 0 (gmsm_subgroup.h; x of 64 bits, weight 6): 2 x 63 doublings
+    # (dbl-2008-s-1: 9 products), 5 + 1 mixed additions (madd-2008-s: 10), 5 full additions (add-2008-s: 14), phi 1, the curve
+    # equation 3 - against 255 doublings + 127 additions of the definition [r]P = infinity (level 3)
+    prods = m * (126 * 9 + 6 * 10 + 5 * 14 + 1 + 3)
+    peak, _ = product_peak(g2)
     out["points_validate_bls12_381_g1_2p20_level2_resident"] = {
-        "ms": ms, "points_per_s": m / (ms * 1e-3), "mulmod_per_s": prods / (ms * 1e-3),
-        "note": "on the curve and [r]P = infinity by double-and-add on the pipeline's lazy limbs, one lane per point: compute-bound"}
+        "ms": ms, "points_per_s": m / (ms * 1e-3), "mulmod_per_s": prods / (ms * 1e-3), "products_per_point": prods // m,
+        "frac_of_measured_multiplier_rate": (prods / (ms * 1e-3)) / peak if peak else None,
+        "note": "on the curve and in the r-torsion by the reference's endomorphism identity (ecc/bls12-381/g1.go:481-492) on the "
+                "pipeline's lazy limbs, one lane per point: compute-bound"}
     del d_a2, d_p2
     del d_out, raw, reg
     # ---- N4: SRS dump (marker | length | raw []G1Affine memory) of 2^24 points, from the page cache into HBM

@@ -1,6 +1,7 @@
-// One (curve, group) instance of the engine: pipeline driver, host fold, test hooks, and the function table the C ABI
-// dispatches through. Instantiated once per group in gmsm_group_inst.hip (one translation unit per group so the six
-// groups compile in parallel).
+// One (curve, group) instance of the engine: the pipeline driver (struct Group) over the host-side arithmetic of
+// gmsm_group_host.h. The test hooks live in gmsm_group_debug.h, the function table the C ABI dispatches through in
+// gmsm_group_vtable.h (both included at the end). Instantiated once per group in gmsm_group_inst.hip (one translation
+// unit per group so the six groups compile in parallel).
 #pragma once
 #include <algorithm>
 #include <cstdlib>
@@ -10,6 +11,7 @@
 #include <vector>
 
 #include "gmsm_context.h"
+#include "gmsm_group_host.h"
 #include "gmsm_kernels.h"
 #include "gmsm_fixup_q.h"
 #include "gmsm_small.h"
@@ -34,7 +36,15 @@ template <class P> struct LazyOf<Fp<P>> { using type = FpU<P>; };
 template <class P> struct LazyOf<Fp2<P>> { using type = Fp2U<P>; };
 
 template <class F_, class FrP_, class Consts_, bool NEEDS_TORSION_>
-struct Group {
+struct Group : GroupHost<F_, FrP_> {
+    using Host = GroupHost<F_, FrP_>;  // fold, fold_sets, generate_points, build_fixed_base_table, fold_powers
+    using Host::batch_to_affine;
+    using Host::build_fixed_base_table;
+    using Host::fold;
+    using Host::fold_powers;
+    using Host::fold_sets;
+    using Host::generate_points;
+    using Host::scalar_mul;
     using F = F_;
     using FrP = FrP_;
     using Consts = Consts_;                                   // curve coefficient, wire-format flag bits (gmsm_params32.h)
@@ -742,142 +752,7 @@ struct Group {
         return GMSM_OK;
     }
 
-    // Point-sharded MultiExp: `nsets` ranks each hold the nwin window totals of their own slice of the points; window w
-    // of the whole MultiExp is the sum over the ranks (g1JacExtended.add, g1.go:736), then the usual fold.
-    static J fold_sets(const Ext *sets, unsigned nsets, unsigned c) {
-        const unsigned nwin = num_windows(FR_BITS, c);
-        std::vector<Ext> totals(sets, sets + nwin);
-        for (unsigned s = 1; s < nsets; ++s)
-            for (unsigned w = 0; w < nwin; ++w) xyzz_add(totals[w], sets[(size_t)s * nwin + w]);
-        return fold(totals.data(), c);
-    }
-
-    // msmReduceChunk (multiexp.go:302-315): Horner from the top window down. The (nwin - 1) c doublings are a serial chain
-    // on the host after the device has finished - 83 us of a 1.98 ms BN254 G1 call, 0.28 ms of a BN254 G2 call - so they run
-    // in Jacobian coordinates (2M + 5S per doubling against the 6M + 3S of the extended form; over Fp2 a square is two
-    // base products, a product three: 16 against 24) and the running sum changes form around each window's addition.
-    // Windows at infinity (all but the first under window tables) cost nothing.
-    static J fold(const Ext *totals, unsigned c, unsigned nwin = 0 /* 0: the windows of a full scalar */) {
-        if (nwin == 0) nwin = num_windows(FR_BITS, c);
-        J acc = jac_from_xyzz(totals[nwin - 1]);
-        for (int j = (int)nwin - 2; j >= 0; --j) {
-            if (!acc.z.is_zero())
-                for (unsigned l = 0; l < c; ++l) acc = jac_double(acc);
-            if (totals[j].zz.is_zero()) continue;
-            Ext e = acc.z.is_zero() ? Ext::infinity() : xyzz_from_jac(acc);
-            xyzz_add(e, totals[j]);
-            acc = jac_from_xyzz(e);
-        }
-        if (acc.z.is_zero()) acc = J{F::one(), F::one(), F::zero()};
-        return acc;
-    }
-
-    // out[i] = [k0 + i*k1] base for i < n (affine). Host-side, multi-threaded: start point by double-and-add, then
-    // repeated mixed addition of step = [k1]base with block-wise batch normalisation (one inversion per block).
-    // Utility for building SRS-like on-curve bases (cf. BatchScalarMultiplicationG1, ecc/bn254/g1.go:1039, and the
-    // i*G walk of multiexp_test.go:40-46); bench.py uses it for its synthetic inputs.
-    static Ext scalar_mul(const Aff &a, const uint64_t *k, int klimbs) {
-        Ext acc = Ext::infinity();
-        for (int i = klimbs * 64 - 1; i >= 0; --i) {
-            acc = xyzz_double(acc);
-            if ((k[i / 64] >> (i % 64)) & 1) xyzz_add_mixed(acc, a, false);
-        }
-        return acc;
-    }
-    static void batch_to_affine(Aff *out, const Ext *in, size_t count, F *scratch) {
-        F acc = F::one();
-        for (size_t i = 0; i < count; ++i) {
-            scratch[i] = acc;
-            if (!in[i].zzz.is_zero()) acc = fp_mul(acc, in[i].zzz);
-        }
-        F inv = fp_inv(acc);
-        for (size_t i = count; i-- > 0;) {
-            if (in[i].zzz.is_zero()) {
-                out[i] = Aff{F::zero(), F::zero()};
-                continue;
-            }
-            F zi = fp_mul(inv, scratch[i]);  // 1/zzz_i
-            inv = fp_mul(inv, in[i].zzz);
-            F izz = fp_mul(fp_mul(fp_sqr(zi), in[i].zz), in[i].zz);  // zz^2/zzz^2 = 1/zz
-            out[i].x = fp_mul(in[i].x, izz);
-            out[i].y = fp_mul(in[i].y, zi);
-        }
-    }
-    static void generate_points(const uint64_t *base_limbs, const uint64_t *k0, const uint64_t *k1, int klimbs, size_t n,
-                                int nthreads, uint64_t *out_limbs) {
-        Aff base;
-        memcpy(&base, base_limbs, sizeof base);
-        Aff *out = reinterpret_cast<Aff *>(out_limbs);
-        Aff step;
-        {
-            Ext s = scalar_mul(base, k1, klimbs);
-            F scratch;
-            batch_to_affine(&step, &s, 1, &scratch);
-        }
-        if (nthreads < 1) nthreads = 1;
-        const size_t per = (n + (size_t)nthreads - 1) / (size_t)nthreads;
-        std::vector<std::thread> th;
-        for (int t = 0; t < nthreads; ++t) {
-            const size_t s = (size_t)t * per, e = std::min(n, s + per);
-            if (s >= e) break;
-            th.emplace_back([=, &base, &step]() {
-                constexpr size_t BLK = 1024;
-                std::vector<Ext> blk(BLK);
-                std::vector<F> scr(BLK);
-                Ext cur = scalar_mul(base, k0, klimbs);
-                uint64_t s64 = (uint64_t)s;
-                Ext off = scalar_mul(step, &s64, 1);
-                xyzz_add(cur, off);
-                for (size_t i = s; i < e;) {
-                    const size_t cnt = std::min(BLK, e - i);
-                    for (size_t k = 0; k < cnt; ++k) {
-                        blk[k] = cur;
-                        xyzz_add_mixed(cur, step, false);
-                    }
-                    batch_to_affine(out + i, blk.data(), cnt, scr.data());
-                    i += cnt;
-                }
-            });
-        }
-        for (auto &t : th) t.join();
-    }
-
-    // ---- N3: fixed-base batch scalar multiplication / batch normalisation (gmsm_fixedbase.h) ----
-    // table[j][d-1] = d * 2^(c*j) * base for every window j and d = 1..nb (host, threads over windows), Go layout.
-    static void build_fixed_base_table(const Aff &base, const WindowPlan &plan, int nthreads, std::vector<Aff> &table) {
-        const uint32_t nwin = plan.nwin_total, nb = plan.nbuckets;
-        table.resize((size_t)nwin * nb);
-        std::vector<Aff> win_base(nwin);  // 2^(c*j) * base
-        {
-            std::vector<Ext> wb(nwin);
-            Ext cur = Ext::infinity();
-            xyzz_add_mixed(cur, base, false);
-            for (uint32_t j = 0; j < nwin; ++j) {
-                wb[j] = cur;
-                for (uint32_t l = 0; l < plan.c; ++l) cur = xyzz_double(cur);
-            }
-            std::vector<F> scr(nwin);
-            batch_to_affine(win_base.data(), wb.data(), nwin, scr.data());
-        }
-        if (nthreads < 1) nthreads = 1;
-        if ((uint32_t)nthreads > nwin) nthreads = (int)nwin;
-        std::vector<std::thread> th;
-        for (int t = 0; t < nthreads; ++t)
-            th.emplace_back([&, t] {
-                std::vector<Ext> row(nb);
-                std::vector<F> scr(nb);
-                for (uint32_t j = (uint32_t)t; j < nwin; j += (uint32_t)nthreads) {
-                    Ext cur = Ext::infinity();
-                    for (uint32_t d = 0; d < nb; ++d) {
-                        xyzz_add_mixed(cur, win_base[j], false);
-                        row[d] = cur;
-                    }
-                    batch_to_affine(table.data() + (size_t)j * nb, row.data(), nb, scr.data());
-                }
-            });
-        for (auto &x : th) x.join();
-    }
-
+    // ---- N3: fixed-base batch scalar multiplication / batch normalisation (gmsm_fixedbase.h; the table is GroupHost's) ----
     // recs (lazy XYZZ records, n of them, already on the device in ws.buckets) -> d_out affine; K records per thread
     static int normalize_records(Workspace &ws, size_t n, void *d_out) {
         int rc;
@@ -905,7 +780,7 @@ struct Group {
         const unsigned c = forced_c ? forced_c : n < ((size_t)1 << 21) ? 8 : 11;
         const WindowPlan plan = make_plan(c, 0, 1);
         std::vector<Aff> table;
-        build_fixed_base_table(base, plan, (int)std::min<unsigned>(16, usable_cpus()), table);
+        build_fixed_base_table(base, plan.c, plan.nwin_total, plan.nbuckets, (int)std::min<unsigned>(16, usable_cpus()), table);
         int rc;
         const size_t tn = table.size();
         if ((rc = ws.h2d_points.ensure(tn * AFF_BYTES))) return rc;
@@ -1410,18 +1285,6 @@ struct Group {
         return GMSM_OK;
     }
 
-    // (*G1Jac).Fold (multiexp.go:331-340): the scalars 1, g, g^2, ... (Montgomery fr products on the host); the engine then
-    // runs the MultiExp entry over them.
-    static void fold_powers(const uint64_t *coeff, size_t n, uint64_t *out_scalars) {
-        using Fr = Fp<FrP>;
-        Fr *scalars = reinterpret_cast<Fr *>(out_scalars);
-        Fr g, s = Fr::one();
-        memcpy(&g, coeff, sizeof g);
-        for (size_t i = 0; i < n; ++i) {
-            scalars[i] = s;
-            s = fp_mul(s, g);
-        }
-    }
 
     // Number of point ranges a host-buffer MultiExp is cut into so that the H2D copy of range k+1 runs under the
     // pipeline of range k (two workspaces, two streams). Round 2 reduced every range on its own and added the totals on
@@ -1636,419 +1499,7 @@ struct Group {
     }
 };
 
-// ------------------------------------------------------------------ debug / test kernels
-template <class FT>
-__global__ void k_field_op(int op, const FT *a, const FT *b, size_t count, FT *out) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    FT x = a[i], y = b ? b[i] : a[i], z;
-    switch (op) {
-        case 0: z = fp_mul(x, y); break;
-        case 1: z = fp_add(x, y); break;
-        case 2: z = fp_sub(x, y); break;
-        case 3: z = fp_neg(x); break;
-        case 4: z = fp_dbl(x); break;
-        default: z = fp_sqr(x); break;
-    }
-    out[i] = z;
-}
-
-template <class P>
-__global__ void k_from_mont(const Fp<P> *a, size_t count, Fp<P> *out) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) out[i] = fp_from_mont(a[i]);
-}
-
-template <class F>
-__global__ void k_group_op(int op, const XYZZ<F> *acc, const void *other, size_t count, XYZZ<F> *out) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    XYZZ<F> p = acc[i];
-    if (op == 0 || op == 1) {
-        Affine<F> a = reinterpret_cast<const Affine<F> *>(other)[i];
-        xyzz_add_mixed(p, a, op == 1);
-    } else if (op == 2) {
-        XYZZ<F> q = reinterpret_cast<const XYZZ<F> *>(other)[i];
-        xyzz_add(p, q);
-    } else {
-        p = xyzz_double(p);
-    }
-    out[i] = p;
-}
-
-// ---- the same hooks through the lazy-limb code paths (gmsm_fieldu.h / gmsm_field2u.h / gmsm_curveu.h): operands are
-// converted from canonical saturated limbs, the lazy operation runs, the result is converted back. This exercises
-// pack/unpack, the carry passes, the redundant-constant subtractions, the conditional reductions and the flag-based
-// infinity handling on edge values, independently of the MSM pipeline.
-template <class P> __device__ __forceinline__ FpU<P> dbg_add(const FpU<P> &a, const FpU<P> &b) { return fpu_add(a, b); }
-template <class P> __device__ __forceinline__ FpU<P> dbg_sub(const FpU<P> &a, const FpU<P> &b) { return fpu_sub<P, 4>(a, b); }
-template <class P> __device__ __forceinline__ FpU<P> dbg_neg(const FpU<P> &a) { return fpu_neg4<P>(a); }
-template <class P> __device__ __forceinline__ FpU<P> dbg_dbl(const FpU<P> &a) { return fpu_dbl(a); }
-template <class P> __device__ __forceinline__ Fp2U<P> dbg_add(const Fp2U<P> &a, const Fp2U<P> &b) { return lz_add(a, b); }
-template <class P> __device__ __forceinline__ Fp2U<P> dbg_sub(const Fp2U<P> &a, const Fp2U<P> &b) { return lz_sub(a, b); }
-template <class P> __device__ __forceinline__ Fp2U<P> dbg_neg(const Fp2U<P> &a) { return lz_sub(lz_zero((const Fp2U<P> *)nullptr), a); }
-template <class P> __device__ __forceinline__ Fp2U<P> dbg_dbl(const Fp2U<P> &a) { return lz_dbl(a); }
-
-template <class U>
-__global__ void k_lazy_field_op(int op, const typename LzTraits<U>::Sat *a, const typename LzTraits<U>::Sat *b, size_t count,
-                                typename LzTraits<U>::Sat *out) {
-    using T = LzTraits<U>;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const U x = T::template from_sat<true>(a[i]);
-    const U y = T::template from_sat<true>(b ? b[i] : a[i]);
-    U z;
-    switch (op) {
-        case 0: z = lz_mul<true>(x, y); break;
-        case 1: z = dbg_add(x, y); break;
-        case 2: z = dbg_sub(x, y); break;
-        case 3: z = dbg_neg(x); break;
-        case 4: z = dbg_dbl(x); break;
-        default: z = lz_sqr<true>(x); break;
-    }
-    out[i] = T::template to_sat<true>(z);
-}
-
-template <class U>
-__global__ void k_lazy_group_op(int op, const XYZZ<typename LzTraits<U>::Sat> *acc, const void *other, size_t count,
-                                XYZZ<typename LzTraits<U>::Sat> *out) {
-    using T = LzTraits<U>;
-    using S = typename T::Sat;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    auto to_lazy = [](const XYZZ<S> &m) {
-        UnsatElem<U> e;
-        e.inf = m.zz.is_zero();
-        e.v.x = T::template from_sat<true>(m.x);
-        e.v.y = T::template from_sat<true>(m.y);
-        e.v.zz = T::template from_sat<true>(m.zz);
-        e.v.zzz = T::template from_sat<true>(m.zzz);
-        return e;
-    };
-    UnsatElem<U> p = to_lazy(acc[i]);
-    if (op == 0 || op == 1) {
-        const Affine<S> a = reinterpret_cast<const Affine<S> *>(other)[i];
-        if (!a.is_infinity()) {  // the pipeline drops points at infinity before the accumulation (k_decompose skip flags)
-            lz_madd_acc<true>(p.v, p.inf, T::template from_sat<true>(a.x), T::template from_sat<true>(a.y), op == 1);
-            lz_acc_finish(p.v, p.inf);
-        }
-    } else if (op == 2) {
-        const UnsatElem<U> q = to_lazy(reinterpret_cast<const XYZZ<S> *>(other)[i]);
-        lz_padd<true>(p.v, p.inf, q.v, q.inf);
-    } else if (!p.inf) {
-        p.v = lz_pdbl<true>(p.v);
-    }
-    unsat_store_final<U, true>(out, i, p);
-}
-
-template <class FT, class Launch>
-static int run_elementwise(size_t in_bytes_a, const void *a, size_t in_bytes_b, const void *b, size_t out_bytes, void *out,
-                           Launch launch) {
-    Context *ctx;
-    int rc = get_context(&ctx);
-    if (rc) return rc;
-    HIP_TRY(hipSetDevice(ctx->device));
-    GMSM_LEASE_OR_FAIL(lease, *ctx);
-    hipStream_t stream = lease.w->stream;
-    void *da = nullptr, *db = nullptr, *dout = nullptr;
-    HIP_TRY(hipMalloc(&da, in_bytes_a));
-    HIP_TRY(hipMemcpy(da, a, in_bytes_a, hipMemcpyHostToDevice));
-    if (b) {
-        HIP_TRY(hipMalloc(&db, in_bytes_b));
-        HIP_TRY(hipMemcpy(db, b, in_bytes_b, hipMemcpyHostToDevice));
-    }
-    HIP_TRY(hipMalloc(&dout, out_bytes));
-    launch(da, db, dout, stream);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(stream));
-    HIP_TRY(hipMemcpy(out, dout, out_bytes, hipMemcpyDeviceToHost));
-    (void)hipFree(da);
-    if (db) (void)hipFree(db);
-    (void)hipFree(dout);
-    return GMSM_OK;
-}
-
-template <class FT>
-static int debug_field(int op, const uint64_t *a, const uint64_t *b, size_t count, uint64_t *out) {
-    return run_elementwise<FT>(count * sizeof(FT), a, b ? count * sizeof(FT) : 0, b, count * sizeof(FT), out,
-                               [&](void *da, void *db, void *dout, hipStream_t s) {
-                                   hipLaunchKernelGGL((k_field_op<FT>), dim3((unsigned)((count + 127) / 128)), dim3(128), 0,
-                                                      s, op, (const FT *)da, (const FT *)db, count, (FT *)dout);
-                               });
-}
-
-template <class P>
-static int debug_from_mont(const uint64_t *a, size_t count, uint64_t *out) {
-    return run_elementwise<Fp<P>>(count * sizeof(Fp<P>), a, 0, nullptr, count * sizeof(Fp<P>), out,
-                                  [&](void *da, void *, void *dout, hipStream_t s) {
-                                      hipLaunchKernelGGL((k_from_mont<P>), dim3((unsigned)((count + 127) / 128)),
-                                                         dim3(128), 0, s, (const Fp<P> *)da, count, (Fp<P> *)dout);
-                                  });
-}
-
-template <class G>
-static int debug_group(int op, const uint64_t *acc, const uint64_t *other, size_t count, uint64_t *out) {
-    using F = typename G::F;
-    const size_t ob = (op == 0 || op == 1) ? sizeof(Affine<F>) : sizeof(XYZZ<F>);
-    return run_elementwise<F>(count * sizeof(XYZZ<F>), acc, other ? count * ob : 0, other, count * sizeof(XYZZ<F>), out,
-                              [&](void *da, void *db, void *dout, hipStream_t s) {
-                                  hipLaunchKernelGGL((k_group_op<F>), dim3((unsigned)((count + 63) / 64)), dim3(64), 0, s,
-                                                     op, (const XYZZ<F> *)da, (const void *)db, count, (XYZZ<F> *)dout);
-                              });
-}
-
-template <class G>
-static int debug_decompose_impl(const uint64_t *scalars, size_t n, unsigned c, uint32_t *out_digits) {
-    if (c < 2 || c > 24) return fail(GMSM_ERR_ARG, "c out of range");
-    Context *ctx;
-    int rc = get_context(&ctx);
-    if (rc) return rc;
-    HIP_TRY(hipSetDevice(ctx->device));
-    WindowPlan plan = G::make_plan(c, 0, 1);
-    if (n == 0) return GMSM_OK;
-    GMSM_LEASE_OR_FAIL(lease, *ctx);
-    Workspace &ws = *lease.w;
-    if ((rc = ws.h2d_scalars.ensure(n * G::SCALAR_BYTES))) return rc;
-    if ((rc = ws.digits.ensure((size_t)plan.nwin_total * n * 4))) return rc;
-    HIP_TRY(hipMemcpyAsync(ws.h2d_scalars.ptr, scalars, n * G::SCALAR_BYTES, hipMemcpyHostToDevice, ws.stream));
-    G::launch_decompose(ws.h2d_scalars.ptr, n, plan, /*d16=*/false, ws.digits.ptr, nullptr, ws.stream);  // the kernel the pipeline runs for this c
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out_digits, ws.digits.ptr, (size_t)plan.nwin_total * n * 4, hipMemcpyDeviceToHost, ws.stream));
-    HIP_TRY(hipStreamSynchronize(ws.stream));
-    return GMSM_OK;
-}
-
-
-template <class G>
-static int debug_glv_split_impl(const uint64_t *scalars, size_t n, uint32_t *out) {
-    using FrP = typename G::FrP;
-    Context *ctx;
-    int rc = get_context(&ctx);
-    if (rc) return rc;
-    HIP_TRY(hipSetDevice(ctx->device));
-    if (n == 0) return GMSM_OK;
-    GMSM_LEASE_OR_FAIL(lease, *ctx);
-    Workspace &ws = *lease.w;
-    const size_t ob = n * 2 * (FrP::GLV_HL + 1) * 4;
-    if ((rc = ws.h2d_scalars.ensure(n * G::SCALAR_BYTES))) return rc;
-    if ((rc = ws.digits.ensure(ob))) return rc;
-    HIP_TRY(hipMemcpyAsync(ws.h2d_scalars.ptr, scalars, n * G::SCALAR_BYTES, hipMemcpyHostToDevice, ws.stream));
-    hipLaunchKernelGGL((k_glv_split_debug<FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ws.stream,
-                       (const uint32_t *)ws.h2d_scalars.ptr, n, (uint32_t *)ws.digits.ptr);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out, ws.digits.ptr, ob, hipMemcpyDeviceToHost, ws.stream));
-    HIP_TRY(hipStreamSynchronize(ws.stream));
-    return GMSM_OK;
-}
-
-// ------------------------------------------------------------------ function table
-
-template <class G>
-struct VTableOf {
-    static int multiexp_host(const uint64_t *points, size_t n_points, const uint64_t *scalars, size_t n_scalars,
-                             int nb_tasks, uint64_t *out_jac) {
-        typename G::J j;
-        int rc = G::multiexp_host(points, n_points, scalars, n_scalars, nb_tasks, &j);
-        if (rc) return rc;
-        memcpy(out_jac, &j, sizeof j);
-        return GMSM_OK;
-    }
-    static int multiexp_device(Context &ctx, const void *d_points, const void *d_scalars, size_t n, hipStream_t stream,
-                               uint64_t *out_jac, const ResidentBases *resident) {
-        typename G::J j;
-        if (n == 0) j = typename G::J{G::F::one(), G::F::one(), G::F::zero()};
-        else {
-            GMSM_LEASE_OR_FAIL(lease, ctx);
-            int rc = G::multiexp_device(ctx, *lease.w, d_points, d_scalars, n, stream, &j, resident);
-            if (rc) return rc;
-        }
-        memcpy(out_jac, &j, sizeof j);
-        return GMSM_OK;
-    }
-    static int multiexp_bases_host(Context &ctx, const uint64_t *scalars, size_t n, uint64_t *out_jac,
-                                   const ResidentBases *resident) {
-        GMSM_LEASE_OR_FAIL(lease, ctx);
-        typename G::J j;
-        int rc = G::multiexp_from_host(ctx, *lease.w, nullptr, resident, scalars, n, &j);
-        if (rc) return rc;
-        memcpy(out_jac, &j, sizeof j);
-        return GMSM_OK;
-    }
-    static int shard_piece(Context &ctx, const uint64_t *points, const ResidentBases *resident, size_t resident_base,
-                           const uint64_t *scalars, size_t n, unsigned c, unsigned win_first, unsigned win_stride,
-                           uint64_t *out_xyzz) {
-        return G::shard_piece(ctx, points, resident, resident_base, scalars, n, c, win_first, win_stride,
-                              reinterpret_cast<typename G::Ext *>(out_xyzz));
-    }
-    static unsigned host_piece_ranges(size_t n, bool with_points) { return G::host_range_count(n, with_points, G::plan_for(nullptr, n)); }
-    static int precompute_tables(Context &ctx, Workspace &ws, ResidentBases *rb, unsigned c) {
-        return G::precompute_tables(ctx, ws, rb, c);
-    }
-    static bool tables_serve(size_t n_registered, size_t n_call) { return G::tables_serve(n_registered, n_call); }
-    static int window_sums(Context &ctx, const void *d_points, const void *d_scalars, size_t n, unsigned c,
-                           unsigned win_first, unsigned win_stride, hipStream_t stream, uint64_t *out_xyzz,
-                           const ResidentBases *resident) {
-        WindowPlan plan = G::make_plan(c, win_first, win_stride);
-        GMSM_LEASE_OR_FAIL(lease, ctx);
-        return G::window_sums(ctx, *lease.w, d_points, d_scalars, n, plan, stream,
-                              reinterpret_cast<typename G::Ext *>(out_xyzz), resident);
-    }
-    static int register_bases(Context &ctx, const void *d_points, size_t n, hipStream_t stream, ResidentBases *out) {
-        return G::register_bases(ctx, d_points, n, stream, out);
-    }
-    static int window_sums_enqueue(Context &ctx, const void *d_points, const void *d_scalars, size_t n, unsigned c,
-                                   unsigned win_first, unsigned win_stride, hipStream_t stream, void *d_out_xyzz,
-                                   const std::shared_ptr<ResidentBases> &resident) {
-        WindowPlan plan = G::make_plan(c, win_first, win_stride);
-        // leased for the duration of this call only: the work it leaves in flight is protected by stream order
-        // (Workspace::last_use, honoured by whoever leases the workspace next), not by the lease
-        GMSM_LEASE_OR_FAIL(lease, ctx);
-        Workspace *ws = lease.w;
-        int rc = G::enqueue_window_sums(ctx, *ws, d_points, d_scalars, n, plan, stream, resident.get(), d_out_xyzz);
-        ws->bases_ref = resident;             // alive until the next call on this workspace replaces it
-        ws->uncollected = ws->pending_timed;  // nobody waits for this call: its stage events are read by the next one
-        ws->pending_timed = false;
-        return rc;
-    }
-    static void fold_sets(const uint64_t *xyzz_sets, unsigned nsets, unsigned c, uint64_t *out_jac) {
-        typename G::J j = G::fold_sets(reinterpret_cast<const typename G::Ext *>(xyzz_sets), nsets, c);
-        memcpy(out_jac, &j, sizeof j);
-    }
-    static void fold_powers(const uint64_t *coeff, size_t n, uint64_t *out_scalars) { G::fold_powers(coeff, n, out_scalars); }
-    // host or device scalars / results; exactly one of each pair is given
-    static int batch_scalar_mul(Context &ctx, const uint64_t *base, const uint64_t *scalars, const void *d_scalars, size_t n,
-                                hipStream_t caller_stream, uint64_t *out, void *d_out) {
-        GMSM_LEASE_OR_FAIL(lease, ctx);
-        Workspace &ws = *lease.w;
-        int rc = order_after(ws, caller_stream);
-        if (rc) return rc;
-        const void *dsc = d_scalars;
-        if (scalars && n) {
-            if ((rc = ws.h2d_scalars.ensure(n * G::SCALAR_BYTES))) return rc;
-            HIP_TRY(hipMemcpyAsync(ws.h2d_scalars.ptr, scalars, n * G::SCALAR_BYTES, hipMemcpyHostToDevice, ws.stream));
-            dsc = ws.h2d_scalars.ptr;
-        }
-        void *dres = d_out;
-        if (out && n) {
-            if ((rc = ws.parted.ensure(n * G::AFF_BYTES))) return rc;
-            dres = ws.parted.ptr;
-        }
-        if ((rc = G::batch_scalar_mul(ctx, ws, base, dsc, n, dres))) return rc;
-        if (out && n) HIP_TRY(hipMemcpyAsync(out, dres, n * G::AFF_BYTES, hipMemcpyDeviceToHost, ws.stream));
-        HIP_TRY(hipStreamSynchronize(ws.stream));
-        return GMSM_OK;
-    }
-    static int batch_jac_to_affine(Context &ctx, const uint64_t *jac, size_t n, uint64_t *out) {
-        if (n == 0) return GMSM_OK;
-        GMSM_LEASE_OR_FAIL(lease, ctx);
-        Workspace &ws = *lease.w;
-        int rc;
-        if ((rc = ws.h2d_points.ensure(n * sizeof(typename G::J)))) return rc;
-        if ((rc = ws.parted.ensure(n * G::AFF_BYTES))) return rc;
-        HIP_TRY(hipMemcpyAsync(ws.h2d_points.ptr, jac, n * sizeof(typename G::J), hipMemcpyHostToDevice, ws.stream));
-        if ((rc = G::batch_jac_to_affine(ws, ws.h2d_points.ptr, n, ws.parted.ptr))) return rc;
-        HIP_TRY(hipMemcpyAsync(out, ws.parted.ptr, n * G::AFF_BYTES, hipMemcpyDeviceToHost, ws.stream));
-        HIP_TRY(hipStreamSynchronize(ws.stream));
-        return GMSM_OK;
-    }
-    static int submit(Context &ctx, Workspace &ws, const void *d_scalars, size_t n, const ResidentBases *resident) {
-        return G::multiexp_submit(ctx, ws, d_scalars, n, resident);
-    }
-    static int decode_raw(Workspace &ws, const void *d_raw, size_t n, int level, void *d_out, long long *bad_index,
-                          uint32_t *status) {
-        return G::decode_raw(ws, d_raw, n, level, d_out, bad_index, status);
-    }
-    static int fft_domain_new(Context &ctx, hipStream_t stream, unsigned log2n, FftDomain *out) {
-        return FftField<typename G::FrP>::domain_new(ctx, stream, log2n, out);
-    }
-    static int fft_run(hipStream_t stream, FftDomain *d, void *d_a, bool inverse, bool dif, bool coset) {
-        return FftField<typename G::FrP>::run(stream, d, d_a, inverse, dif, coset);
-    }
-    static int fft_bit_reverse(hipStream_t stream, void *d_a, size_t n) {
-        return FftField<typename G::FrP>::bit_reverse(stream, d_a, n);
-    }
-    static int validate_points(Workspace &ws, const void *d_points, size_t n, int level, long long *bad_index,
-                               uint32_t *status) {
-        return G::validate_points(ws, d_points, n, level, bad_index, status);
-    }
-    static int collect(Workspace &ws, uint64_t *out_jac) {
-        typename G::J j;
-        int rc = G::multiexp_collect(ws, &j);
-        if (rc) return rc;
-        memcpy(out_jac, &j, sizeof j);
-        return GMSM_OK;
-    }
-    static void fold(const uint64_t *xyzz_windows, unsigned c, uint64_t *out_jac) {
-        typename G::J j = G::fold(reinterpret_cast<const typename G::Ext *>(xyzz_windows), c);
-        memcpy(out_jac, &j, sizeof j);
-    }
-    static void jac_to_affine(const uint64_t *jac, uint64_t *out_affine) {
-        typename G::J j;
-        memcpy(&j, jac, sizeof j);
-        typename G::Aff a = affine_from_jac(j);
-        memcpy(out_affine, &a, sizeof a);
-    }
-    static int debug_decompose(const uint64_t *scalars, size_t n, unsigned c, uint32_t *out_digits) {
-        return debug_decompose_impl<G>(scalars, n, c, out_digits);
-    }
-    static int debug_glv_split(const uint64_t *scalars, size_t n, uint32_t *out) { return debug_glv_split_impl<G>(scalars, n, out); }
-    // what a MultiExp over n bases taken anew runs as (gmsm_default_plan)
-    static void plan_info(size_t n, unsigned *c, unsigned *nwin, unsigned *entries_per_point, unsigned *fused) {
-        if (G::small_serves(n, nullptr)) {
-            const typename G::SmallPlan sp = G::small_plan(n, nullptr);
-            *c = sp.plan.c, *nwin = sp.plan.nwin_total, *entries_per_point = sp.glv ? 2u : 1u, *fused = 1u;
-            return;
-        }
-        const WindowPlan p = G::plan_for(nullptr, n);
-        *c = p.c, *nwin = p.nwin_total, *entries_per_point = p.glv ? 2u : 1u, *fused = 0u;
-    }
-    static int debug_field_op(int field, int op, const uint64_t *a, const uint64_t *b, size_t count, uint64_t *out) {
-        using BaseP = typename G::F::Params;
-        if (field == 0) {
-            if (op == 6) return debug_from_mont<BaseP>(a, count, out);
-            return debug_field<Fp<BaseP>>(op, a, b, count, out);
-        } else if (field == 1) {
-            if (op == 6) return debug_from_mont<typename G::FrP>(a, count, out);
-            return debug_field<Fp<typename G::FrP>>(op, a, b, count, out);
-        }
-        if (op == 6) return fail(GMSM_ERR_ARG, "from_mont is defined on prime fields only");
-        if (field == 3) {  // coordinate field through the lazy-limb code
-            using U = typename G::U;
-            using S = typename LzTraits<U>::Sat;
-            return run_elementwise<S>(count * sizeof(S), a, b ? count * sizeof(S) : 0, b, count * sizeof(S), out,
-                                      [&](void *da, void *db, void *dout, hipStream_t s) {
-                                          hipLaunchKernelGGL((k_lazy_field_op<U>), dim3((unsigned)((count + 63) / 64)), dim3(64),
-                                                             0, s, op, (const S *)da, (const S *)db, count, (S *)dout);
-                                      });
-        }
-        return debug_field<typename G::F>(op, a, b, count, out);
-    }
-    static int debug_group_op(int op, const uint64_t *acc, const uint64_t *other, size_t count, uint64_t *out) {
-        if (op >= 4) {  // 4..7 = ops 0..3 through the lazy-limb group law
-            using U = typename G::U;
-            using F = typename G::F;
-            const int lop = op - 4;
-            const size_t ob = (lop == 0 || lop == 1) ? sizeof(Affine<F>) : sizeof(XYZZ<F>);
-            return run_elementwise<F>(count * sizeof(XYZZ<F>), acc, other ? count * ob : 0, other, count * sizeof(XYZZ<F>), out,
-                                      [&](void *da, void *db, void *dout, hipStream_t s) {
-                                          hipLaunchKernelGGL((k_lazy_group_op<U>), dim3((unsigned)((count + 63) / 64)), dim3(64),
-                                                             0, s, lop, (const XYZZ<F> *)da, (const void *)db, count,
-                                                             (XYZZ<F> *)dout);
-                                      });
-        }
-        return debug_group<G>(op, acc, other, count, out);
-    }
-    static void generate_points(const uint64_t *base, const uint64_t *k0, const uint64_t *k1, int klimbs, size_t n,
-                                int nthreads, uint64_t *out) {
-        G::generate_points(base, k0, k1, klimbs, n, nthreads, out);
-    }
-    static const GroupVTable *get() {
-        static const GroupVTable vt = {G::FR_BITS,      G::AFF_BYTES,   G::SCALAR_BYTES, sizeof(typename G::J),
-                                       sizeof(typename G::Ext), &multiexp_host, &multiexp_device, &window_sums,
-                                       &fold,           &jac_to_affine, &debug_decompose, &debug_field_op,
-                                       &debug_group_op, &generate_points, &register_bases, &submit, &collect, &window_sums_enqueue, &fold_sets, &fold_powers, &multiexp_bases_host, &batch_scalar_mul, &batch_jac_to_affine, &decode_raw, &validate_points, &fft_domain_new, &fft_run, &fft_bit_reverse, &precompute_tables, &tables_serve, &shard_piece, &host_piece_ranges, &debug_glv_split, &plan_info};
-        return &vt;
-    }
-};
-
 }  // namespace gmsm
+
+#include "gmsm_group_debug.h"
+#include "gmsm_group_vtable.h"

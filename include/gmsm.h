@@ -344,7 +344,14 @@ enum gmsm_option {
     GMSM_OPT_GLV = 9,         /* GLV half scalars (ecc/utils.go:62-170; s P = k1 P + k2 phi(P), half the windows and half the host
                                  fold for the same group element): 0 never; 1 (default) in the fused small-n kernel and, for
                                  bases taken anew, in the sorted pipeline at the sizes where it was measured ahead (2^13..2^20
-                                 by group; nothing when a width is forced); 2 in every unregistered call (A/B) */
+                                 by group; nothing when a width is forced); 2 in every unregistered call (A/B).
+                                 PRECONDITION while it is on - the one the reference's own mulGLV has (ecc/bn254/g1.go:536-600):
+                                 phi(P) = [lambda]P holds on the r-torsion only. A point ON the curve but OUTSIDE the subgroup
+                                 (possible where the cofactor is not 1: every group but BN254 G1; never a point that passed
+                                 IsInSubGroup / the Decoder's default checks / gmsm_points_validate level 2) then contributes
+                                 k1 P + k2 phi(P) instead of s P. The reference's MultiExp never uses the endomorphism and is
+                                 the integer combination on ANY curve point: GMSM_OPT_GLV = 0 is exactly that
+                                 (tests/test_gpu_glv.py::test_glv_off_is_the_integer_combination_outside_the_subgroup) */
     GMSM_OPT_SMALL_QUAD = 10  /* bucket phase of the fused small-n kernel on lane quads: 0 (default) by call size, 1 never,
                                  2 always (the Fp2 groups and BW6-761 always run it on quads) */
 };

@@ -84,3 +84,34 @@ def test_glv_pipeline_skewed_scalars(gm, oracle_mod, kind):
     d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
     with gm.options(glv=2):
         assert (g.jac_to_affine(g.multiexp_device(d_pts.data_ptr(), d_sc.data_ptr(), n)) == expected).all()
+
+
+@pytest.mark.parametrize("curve,which", [("bls12_381", "g1"), ("bn254", "g2"), ("bw6_761", "g1")])
+def test_glv_off_is_the_integer_combination_outside_the_subgroup(gm, oracle_mod, pyref_mod, curve, which):
+    """The precondition include/gmsm.h states for GMSM_OPT_GLV: phi(P) = [lambda]P holds on the r-torsion only (the reference's
+    mulGLV has the same one, ecc/bn254/g1.go:536-600), while the reference's MultiExp - which never uses the endomorphism - is
+    the integer combination sum s_i P_i on ANY point of the curve. With GLV off the engine is exactly that on points with a
+    cofactor component too (fused kernel and sorted pipeline, against the oracle, which is plain bucket arithmetic); with GLV on
+    the call still succeeds, and agrees once every point is in the subgroup (the other tests of this file)."""
+    from subgroup_points import curve_points, times_r
+    g = (gm.G1Affine if which == "g1" else gm.G2Affine)(curve)
+    o = oracle_mod.Oracle(curve, which)
+    pg = pyref_mod.Group(g.curve, which)
+    n = 300
+    pts = o.gen_points(n, 77, 5, nthreads=4)
+    outside = [P for P in curve_points(pyref_mod, pg, 40, start=2) if times_r(pg, P) is not None][:8]
+    assert len(outside) >= 4
+    for k, P in enumerate(outside):
+        pts[7 + 31 * k] = np.array(pg.point_to_limbs(P), dtype=np.uint64)
+    sc = random_scalars(rng_for(47, g.gid, n), g.curve, n)
+    expected = o.msm_affine(pts, sc, nthreads=4)
+    # the oracle's sum really has a component outside the subgroup (otherwise this test shows nothing)
+    assert times_r(pg, pg.point_from_limbs(expected)) is not None
+    with gm.options(glv=0):
+        aff, err = g.MultiExp(pts, sc)                       # the fused small-n kernel
+        assert err is None and (aff == expected).all()
+        with gm.options(small_bits=1):
+            aff, err = g.MultiExp(pts, sc)                   # the sorted pipeline
+            assert err is None and (aff == expected).all()
+    aff, err = g.MultiExp(pts, sc)                           # default (GLV on): defined, but a different combination
+    assert err is None
