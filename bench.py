@@ -733,6 +733,24 @@ def next_rows(gm, lib, torch):
                                               "source": "pageable host memory (PCIe-inclusive)"}
     same = bool((d_out.cpu().numpy().view(np.uint64) == pts).all())
     out["points_from_raw_2p22_decode_curve_subgroup"]["equal_to_source_points"] = same
+    # ---- N4: the Encoder's DEFAULT (compressed) format, 2^22 points: Y = sqrt(X^3 + 3) on the device - one exponentiation of 252
+    # squarings + ~110 products on the lazy limbs per point (gmsm_decompress.h); the bytes are the device's own Bytes() of the points
+    comp = np.zeros(n * 4 * g.aff_limbs, dtype=np.uint8)
+    assert lib.gmsm_points_compress(g.gid, None, keep.data_ptr(), n, comp.ctypes.data) == 0, gm._lib.last_error()
+
+    def decompress():
+        assert lib.gmsm_points_from_compressed(g.gid, comp.ctypes.data, n, 2, None, d_out.data_ptr(), _ct.byref(bad)) == 0, gm._lib.last_error()
+    ms = median_ms(decompress, reps=3, warm=0)
+    exp_bits = g.curve.p.bit_length() - 3  # the exponent q >> 2 after its top bit
+    prods = n * (exp_bits + bin(g.curve.p >> 2).count("1") - 1 + 8)  # + x^3, the check y^2 = rhs, the domain changes
+    peak, _ = product_peak(g)
+    out["points_from_compressed_2p22"] = {
+        "ms": ms, "points_per_s": n / (ms * 1e-3), "GB_per_s_in": comp.size / (ms * 1e-3) / 1e9, "products_per_point": prods // n,
+        "mulmod_per_s": prods / (ms * 1e-3), "frac_of_measured_multiplier_rate": (prods / (ms * 1e-3)) / peak if peak else None,
+        "equal_to_source_points": bool((d_out.cpu().numpy().view(np.uint64) == pts).all()),
+        "source": "pageable host memory (PCIe-inclusive); what Decoder.Decode does per point in unsafeComputeY (marshal.go:951-989)"}
+    del comp
+
     def validate_resident():
         assert lib.gmsm_points_validate(g.gid, None, keep.data_ptr(), n, 2, _ct.byref(bad)) == 0, gm._lib.last_error()
     ms = median_ms(validate_resident, reps=3, warm=0)

@@ -29,6 +29,7 @@ ABI_SYMBOLS = [
     "gmsm_batch_jac_to_affine", "gmsm_jac_to_affine", "gmsm_affine_limbs", "gmsm_scalar_limbs", "gmsm_debug_decompose",
     "gmsm_debug_field_op", "gmsm_debug_group_op", "gmsm_debug_glv_split", "gmsm_generate_points", "gmsm_set_profiling", "gmsm_get_stage_times",
     "gmsm_get_stage_launches", "gmsm_points_from_raw", "gmsm_points_validate", "gmsm_bases_register_raw",
+    "gmsm_points_from_compressed", "gmsm_points_compress", "gmsm_bases_register_compressed",
     "gmsm_bases_register_dump", "gmsm_fft_domain_new", "gmsm_fft_domain_release", "gmsm_fft_domain_info", "gmsm_fft",
     "gmsm_fft_bit_reverse",
     "gmsm_bases_precompute", "gmsm_bases_table_bits", "gmsm_debug_table_runs", "gmsm_debug_small_runs", "gmsm_multiexp_sharded", "gmsm_bases_register_sharded", "gmsm_multiexp_bases_sharded", "gmsm_set_devices",
@@ -144,6 +145,12 @@ def load():
     L.gmsm_points_validate.argtypes = [ctypes.c_int, u64p, vp, sz, ctypes.c_int, i64p]
     L.gmsm_bases_register_raw.restype = ctypes.c_int
     L.gmsm_bases_register_raw.argtypes = [ctypes.c_int, vp, sz, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), i64p]
+    L.gmsm_points_from_compressed.restype = ctypes.c_int
+    L.gmsm_points_from_compressed.argtypes = [ctypes.c_int, vp, sz, ctypes.c_int, u64p, vp, i64p]
+    L.gmsm_points_compress.restype = ctypes.c_int
+    L.gmsm_points_compress.argtypes = [ctypes.c_int, u64p, vp, sz, vp]
+    L.gmsm_bases_register_compressed.restype = ctypes.c_int
+    L.gmsm_bases_register_compressed.argtypes = [ctypes.c_int, vp, sz, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), i64p]
     L.gmsm_bases_register_dump.restype = ctypes.c_int
     L.gmsm_bases_register_dump.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, sz, ctypes.c_int,
                                            ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(sz), i64p]

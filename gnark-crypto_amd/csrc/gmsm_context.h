@@ -523,7 +523,8 @@ enum PointStatus : uint32_t {
     PT_BAD_INFINITY = 2,    // infinity flag with non-zero payload (ErrInvalidInfinityEncoding, marshal.go:36)
     PT_NOT_CANONICAL = 3,   // a coordinate >= q (SetBytesCanonical, fp/element.go)
     PT_NOT_ON_CURVE = 4,
-    PT_NOT_IN_SUBGROUP = 5
+    PT_NOT_IN_SUBGROUP = 5,
+    PT_NO_SQRT = 6          // compressed X with no Y on the curve (marshal.go:921-923)
 };
 
 static inline const char *point_status_text(uint32_t s) {
@@ -533,6 +534,7 @@ static inline const char *point_status_text(uint32_t s) {
         case PT_NOT_CANONICAL: return "invalid fp.Element encoding (coordinate not below the modulus)";
         case PT_NOT_ON_CURVE: return "invalid point: not on the curve";
         case PT_NOT_IN_SUBGROUP: return "invalid point: subgroup check failed";
+        case PT_NO_SQRT: return "invalid compressed coordinate: square root doesn't exist";
         default: return "ok";
     }
 }
@@ -669,6 +671,10 @@ struct GroupVTable {
     int (*decode_raw)(Workspace &ws, const void *d_raw, size_t n, int level, void *d_out, long long *bad_index,
                       uint32_t *status);
     int (*validate_points)(Workspace &ws, const void *d_points, size_t n, int level, long long *bad_index, uint32_t *status);
+    // the Encoder's default (compressed) format: gmsm_decompress.h
+    int (*decode_compressed)(Workspace &ws, const void *d_comp, size_t n, int level, void *d_out, long long *bad_index,
+                             uint32_t *status);
+    int (*encode_compressed)(Workspace &ws, const void *d_points, size_t n, void *d_comp);
     // fr/fft over the group's scalar field (gmsm_fft.h)
     int (*fft_domain_new)(Context &ctx, hipStream_t stream, unsigned log2n, FftDomain *out);
     int (*fft_run)(hipStream_t stream, FftDomain *d, void *d_a, bool inverse, bool dif, bool coset);

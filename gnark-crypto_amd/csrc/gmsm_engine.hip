@@ -658,6 +658,97 @@ GMSM_EXPORT int gmsm_bases_register_raw(int group, const uint8_t *raw, size_t n,
     return register_device_points(vt, ctx, ws, group, ws.h2d_points.ptr, n, out_handle);
 }
 
+// The Encoder's default (compressed) format: X and the flag of Y's half (gmsm_decompress.h). Same shape as the raw entries.
+GMSM_EXPORT int gmsm_points_from_compressed(int group, const uint8_t *comp, size_t n, int check, uint64_t *out_affine,
+                                            void *d_out_affine, int64_t *bad_index) {
+    VT_OR_FAIL(group);
+    if (!bad_index) return fail(GMSM_ERR_ARG, "gmsm_points_from_compressed: bad_index is null");
+    *bad_index = -1;
+    if (n && (!comp || (!out_affine && !d_out_affine))) return fail(GMSM_ERR_ARG, "gmsm_points_from_compressed: null argument");
+    if (n == 0) return GMSM_OK;
+    Context *ctx;
+    int rc = get_context_of_pointer(d_out_affine, &ctx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    GMSM_LEASE_OR_FAIL(lease, *ctx);
+    Workspace &ws = *lease.w;
+    const size_t bytes = n * vt->aff_bytes, cbytes = bytes / 2;
+    if ((rc = ws.raw_bytes.ensure(cbytes))) return rc;
+    void *d_out = d_out_affine;
+    if (!d_out) {
+        if ((rc = ws.h2d_points.ensure(bytes))) return rc;
+        d_out = ws.h2d_points.ptr;
+    }
+    HIP_TRY(hipMemcpyAsync(ws.raw_bytes.ptr, comp, cbytes, hipMemcpyHostToDevice, ws.stream));
+    long long bad = -1;
+    uint32_t status = 0;
+    if ((rc = vt->decode_compressed(ws, ws.raw_bytes.ptr, n, check, d_out, &bad, &status))) return rc;
+    if (out_affine) {
+        HIP_TRY(hipMemcpyAsync(out_affine, d_out, bytes, hipMemcpyDeviceToHost, ws.stream));
+        HIP_TRY(hipStreamSynchronize(ws.stream));
+    }
+    if (bad >= 0) {
+        *bad_index = bad;
+        return point_error("gmsm_points_from_compressed", bad, status);
+    }
+    return GMSM_OK;
+}
+
+GMSM_EXPORT int gmsm_points_compress(int group, const uint64_t *points, const void *d_points, size_t n, uint8_t *out_comp) {
+    VT_OR_FAIL(group);
+    if (n && ((points == nullptr) == (d_points == nullptr) || !out_comp))
+        return fail(GMSM_ERR_ARG, "gmsm_points_compress: give exactly one of points (host) / d_points (device), and out_comp");
+    if (n == 0) return GMSM_OK;
+    Context *ctx;
+    int rc = get_context_of_pointer(d_points, &ctx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    GMSM_LEASE_OR_FAIL(lease, *ctx);
+    Workspace &ws = *lease.w;
+    const size_t bytes = n * vt->aff_bytes, cbytes = bytes / 2;
+    if ((rc = ws.raw_bytes.ensure(cbytes))) return rc;
+    const void *src = d_points;
+    if (points) {
+        if ((rc = ws.h2d_points.ensure(bytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(ws.h2d_points.ptr, points, bytes, hipMemcpyHostToDevice, ws.stream));
+        src = ws.h2d_points.ptr;
+    } else {
+        HIP_TRY(hipDeviceSynchronize());  // d_points may still be being written on a stream we do not know
+    }
+    if ((rc = vt->encode_compressed(ws, src, n, ws.raw_bytes.ptr))) return rc;
+    HIP_TRY(hipMemcpyAsync(out_comp, ws.raw_bytes.ptr, cbytes, hipMemcpyDeviceToHost, ws.stream));
+    HIP_TRY(hipStreamSynchronize(ws.stream));
+    return GMSM_OK;
+}
+
+GMSM_EXPORT int gmsm_bases_register_compressed(int group, const uint8_t *comp, size_t n, int check, uint64_t *out_handle,
+                                               int64_t *bad_index) {
+    VT_OR_FAIL(group);
+    if (!out_handle || !bad_index) return fail(GMSM_ERR_ARG, "gmsm_bases_register_compressed: null argument");
+    *bad_index = -1;
+    if (n && !comp) return fail(GMSM_ERR_ARG, "gmsm_bases_register_compressed: comp is null");
+    Context *ctx;
+    int rc = get_context(&ctx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    GMSM_LEASE_OR_FAIL(lease, *ctx);
+    Workspace &ws = *lease.w;
+    const size_t bytes = n * vt->aff_bytes;
+    if (n) {
+        if ((rc = ws.raw_bytes.ensure(bytes / 2))) return rc;
+        if ((rc = ws.h2d_points.ensure(bytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(ws.raw_bytes.ptr, comp, bytes / 2, hipMemcpyHostToDevice, ws.stream));
+        long long bad = -1;
+        uint32_t status = 0;
+        if ((rc = vt->decode_compressed(ws, ws.raw_bytes.ptr, n, check, ws.h2d_points.ptr, &bad, &status))) return rc;
+        if (bad >= 0) {
+            *bad_index = bad;
+            return point_error("gmsm_bases_register_compressed", bad, status);
+        }
+    }
+    return register_device_points(vt, ctx, ws, group, ws.h2d_points.ptr, n, out_handle);
+}
+
 GMSM_EXPORT int gmsm_bases_register_dump(int group, const char *path, uint64_t offset, int expect_marker, size_t max_points,
                                          int check, uint64_t *out_handle, size_t *out_n, int64_t *bad_index) {
     VT_OR_FAIL(group);

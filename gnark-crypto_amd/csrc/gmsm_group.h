@@ -17,6 +17,7 @@
 #include "gmsm_small.h"
 #include "gmsm_fixedbase.h"
 #include "gmsm_ingest.h"
+#include "gmsm_decompress.h"
 #include "gmsm_fft.h"
 
 namespace gmsm {
@@ -853,6 +854,33 @@ struct Group : GroupHost<F_, FrP_> {
                                ws.stream, (const uint8_t *)d_raw, n, level, (Aff *)d_out, (unsigned long long *)ws.flagword.ptr);
         HIP_TRY(hipGetLastError());
         return read_first_bad(ws, bad_index, status);
+    }
+    // d_comp: n compressed points (Bytes(), sizeof(F) bytes each) -> d_out: n Go-layout affine points; level >= 2 adds the
+    // subgroup check of the decoded points (the Decoder's default, marshal.go:300-330): a second launch, and the smaller
+    // index of the two kinds of offender is the one reported (the reference stops at the first error of either kind).
+    static int decode_compressed(Workspace &ws, const void *d_comp, size_t n, int level, void *d_out, long long *bad_index,
+                                 uint32_t *status) {
+        int rc;
+        if ((rc = ws.flagword.ensure(8))) return rc;
+        HIP_TRY(hipMemsetAsync(ws.flagword.ptr, 0xff, 8, ws.stream));
+        if (n) {
+            hipLaunchKernelGGL((k_decompress<F, Consts>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ws.stream,
+                               (const uint8_t *)d_comp, n, (Aff *)d_out, (unsigned long long *)ws.flagword.ptr);
+            // offenders were written as infinity, which passes: the word keeps the decoder's verdict for them
+            if (level >= 2 && NEEDS_TORSION)
+                hipLaunchKernelGGL((k_validate_points<F, FrP, Consts, NEEDS_TORSION>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0,
+                                   ws.stream, (const Aff *)d_out, n, level, (unsigned long long *)ws.flagword.ptr);
+        }
+        HIP_TRY(hipGetLastError());
+        return read_first_bad(ws, bad_index, status);
+    }
+    // (*G1Affine).Bytes over a vector: d_points -> d_comp (n * sizeof(F) bytes)
+    static int encode_compressed(Workspace &ws, const void *d_points, size_t n, void *d_comp) {
+        if (n)
+            hipLaunchKernelGGL((k_compress<F, Consts>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ws.stream,
+                               (const Aff *)d_points, n, (uint8_t *)d_comp);
+        HIP_TRY(hipGetLastError());
+        return GMSM_OK;
     }
     static int validate_points(Workspace &ws, const void *d_points, size_t n, int level, long long *bad_index,
                                uint32_t *status) {

@@ -73,6 +73,9 @@ __global__ void k_lazy_field_op(int op, const typename LzTraits<U>::Sat *a, cons
         case 2: z = dbg_sub(x, y); break;
         case 3: z = dbg_neg(x); break;
         case 4: z = dbg_dbl(x); break;
+        case 7:  // a square root (gmsm_decompress.h), zero when there is none (the tests give non-zero operands)
+            if (!lz_sqrt(x, z)) z = lz_zero((const U *)nullptr);
+            break;
         default: z = lz_sqr<true>(x); break;
     }
     out[i] = T::template to_sat<true>(z);

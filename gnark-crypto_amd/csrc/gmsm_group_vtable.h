@@ -123,6 +123,13 @@ struct VTableOf {
                           uint32_t *status) {
         return G::decode_raw(ws, d_raw, n, level, d_out, bad_index, status);
     }
+    static int decode_compressed(Workspace &ws, const void *d_comp, size_t n, int level, void *d_out, long long *bad_index,
+                                 uint32_t *status) {
+        return G::decode_compressed(ws, d_comp, n, level, d_out, bad_index, status);
+    }
+    static int encode_compressed(Workspace &ws, const void *d_points, size_t n, void *d_comp) {
+        return G::encode_compressed(ws, d_points, n, d_comp);
+    }
     static int fft_domain_new(Context &ctx, hipStream_t stream, unsigned log2n, FftDomain *out) {
         return FftField<typename G::FrP>::domain_new(ctx, stream, log2n, out);
     }
@@ -211,7 +218,7 @@ struct VTableOf {
         static const GroupVTable vt = {G::FR_BITS,      G::AFF_BYTES,   G::SCALAR_BYTES, sizeof(typename G::J),
                                        sizeof(typename G::Ext), &multiexp_host, &multiexp_device, &window_sums,
                                        &fold,           &jac_to_affine, &debug_decompose, &debug_field_op,
-                                       &debug_group_op, &generate_points, &register_bases, &submit, &collect, &window_sums_enqueue, &fold_sets, &fold_powers, &multiexp_bases_host, &batch_scalar_mul, &batch_jac_to_affine, &decode_raw, &validate_points, &fft_domain_new, &fft_run, &fft_bit_reverse, &precompute_tables, &tables_serve, &shard_piece, &host_piece_ranges, &debug_glv_split, &plan_info};
+                                       &debug_group_op, &generate_points, &register_bases, &submit, &collect, &window_sums_enqueue, &fold_sets, &fold_powers, &multiexp_bases_host, &batch_scalar_mul, &batch_jac_to_affine, &decode_raw, &validate_points, &decode_compressed, &encode_compressed, &fft_domain_new, &fft_run, &fft_bit_reverse, &precompute_tables, &tables_serve, &shard_piece, &host_piece_ranges, &debug_glv_split, &plan_info};
         return &vt;
     }
 };

@@ -11,7 +11,8 @@
 //   G1: X | Y;   G2 over Fp2: X.A1 | X.A0 | Y.A1 | Y.A0.   Metadata sits in the top RAW_FLAG_BITS of the first byte.
 //   BN254: 2 bits, 00 = uncompressed; the point at infinity is 64 (128) zero bytes under that same flag.
 //   BLS12-381, BW6-761: 3 bits, 000 = uncompressed, 010 = uncompressed infinity (every other bit must be zero).
-//   Compressed encodings (Bytes()) are refused here: this is the RawBytes / RawEncoding() ingest path.
+//   Compressed encodings (Bytes()) are refused here: this is the RawBytes / RawEncoding() ingest path; gmsm_decompress.h
+//   takes those.
 //
 // Subgroup membership (check level 2) is decided by the reference's endomorphism identities (gmsm_subgroup.h: [x^2] phi(P) + P
 // etc., 2-6 x fewer group operations than the definition); level 3 decides it as the definition says - [r]P = infinity -,

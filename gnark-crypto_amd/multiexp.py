@@ -243,6 +243,53 @@ class _Group:
         rc = L.gmsm_points_from_raw(self.gid, _ptr(raw), n, check, _ptr(out), None, _lib.ctypes.byref(bad))
         return (out, None) if rc == 0 else (None, self._error(rc))
 
+    @property
+    def compressed_point_bytes(self):
+        """SizeOfG1AffineCompressed / SizeOfG2AffineCompressed (marshal.go): one coordinate."""
+        return 4 * self.aff_limbs
+
+    def DecodeCompressed(self, buf, subgroup_check=True, d_out=None):
+        """n compressed points (the bytes of Bytes(), the Encoder's default: ecc/bn254/marshal.go:801-823) -> ((n, aff_limbs)
+        Montgomery limbs, None) or (None, error text): setBytes' compressed branch (marshal.go:907-948) with Y = sqrt(X^3 + b)
+        computed on the device.  d_out: leave the points in HBM instead (returns (n, None))."""
+        L = _lib.load()
+        comp = np.frombuffer(bytes(buf), dtype=np.uint8) if not isinstance(buf, np.ndarray) else np.ascontiguousarray(buf, dtype=np.uint8)
+        if comp.size % self.compressed_point_bytes:
+            return None, "short buffer"  # io.ErrShortBuffer
+        n = comp.size // self.compressed_point_bytes
+        bad = _lib.ctypes.c_int64(-1)
+        check = 2 if subgroup_check else 0
+        if d_out is not None:
+            rc = L.gmsm_points_from_compressed(self.gid, _ptr(comp), n, check, None, d_out, _lib.ctypes.byref(bad))
+            return (n, None) if rc == 0 else (None, self._error(rc))
+        out = np.zeros((n, self.aff_limbs), dtype=np.uint64)
+        rc = L.gmsm_points_from_compressed(self.gid, _ptr(comp), n, check, _ptr(out), None, _lib.ctypes.byref(bad))
+        return (out, None) if rc == 0 else (None, self._error(rc))
+
+    def Compress(self, points=None, d_points=None, n=None):
+        """Bytes() of every point of a vector (host limbs or device pointer): (n * compressed_point_bytes uint8 array, None)
+        or (None, error text)."""
+        L = _lib.load()
+        if points is not None:
+            points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, self.aff_limbs)
+            n = points.shape[0]
+        out = np.zeros(n * self.compressed_point_bytes, dtype=np.uint8)
+        rc = L.gmsm_points_compress(self.gid, _ptr(points) if points is not None else None, d_points, n, _ptr(out))
+        return (out, None) if rc == 0 else (None, self._error(rc))
+
+    def register_bases_compressed(self, buf, subgroup_check=True):
+        """Decode (compressed) + validate + register in one call: returns (ResidentBases, None) or (None, error text)."""
+        L = _lib.load()
+        comp = np.frombuffer(bytes(buf), dtype=np.uint8) if not isinstance(buf, np.ndarray) else np.ascontiguousarray(buf, dtype=np.uint8)
+        if comp.size % self.compressed_point_bytes:
+            return None, "short buffer"
+        n = comp.size // self.compressed_point_bytes
+        handle = _lib.ctypes.c_uint64(0)
+        bad = _lib.ctypes.c_int64(-1)
+        rc = L.gmsm_bases_register_compressed(self.gid, _ptr(comp), n, 2 if subgroup_check else 0, _lib.ctypes.byref(handle),
+                                              _lib.ctypes.byref(bad))
+        return (ResidentBases(self, handle.value, n), None) if rc == 0 else (None, self._error(rc))
+
     def DecodeSlice(self, buf, subgroup_check=True):
         """What Decoder.Decode(&[]G1Affine) reads (marshal.go:220-280): uint32 big-endian length, then the points - here
         all in the raw (uncompressed) encoding an Encoder with RawEncoding() writes (marshal.go:418, :586-640)."""

@@ -220,7 +220,7 @@ int gmsm_batch_jac_to_affine(int group, const uint64_t *jac, size_t n, uint64_t 
  *      gmsm_points_from_raw: raw = n points in the uncompressed wire format of (*G1Affine).RawBytes() /
  *      Encoder(RawEncoding()) (marshal.go:826, G2 :1078; bls12-381/marshal.go:855): big-endian, regular (non-Montgomery)
  *      form, X | Y (Fp2: A1 | A0), metadata in the top bits of the first byte, n * gmsm_affine_limbs(group) * 8 bytes in
- *      total.  Compressed encodings are refused.  Decoded points go to out_affine (host) and/or d_out_affine (device);
+ *      total.  Compressed encodings are refused here (gmsm_points_from_compressed below).  Decoded points go to out_affine (host) and/or d_out_affine (device);
  *      give at least one.
  *      gmsm_points_validate: the same checks over points that are already Go-layout limbs (host or device).
  *      gmsm_bases_register_raw: decode + check + register in one call (the SRS never exists on the host in limb form).
@@ -234,6 +234,20 @@ int gmsm_points_from_raw(int group, const uint8_t *raw, size_t n, int check, uin
                          int64_t *bad_index);
 int gmsm_points_validate(int group, const uint64_t *points, const void *d_points, size_t n, int check, int64_t *bad_index);
 int gmsm_bases_register_raw(int group, const uint8_t *raw, size_t n, int check, uint64_t *out_handle, int64_t *bad_index);
+/* The Encoder's DEFAULT format - compressed points, what (*G1Affine).Bytes() writes and kzg.SRS.WriteTo / ReadFrom move
+ * (ecc/bn254/marshal.go:801-823, :907-948; G2 :1051-1075, :1168-1215; bls12-381/marshal.go:25-35 for the 3-bit flags): X only,
+ * gmsm_affine_limbs(group) * 4 bytes a point (Fp2: X.A1 | X.A0), the flag bits say which root Y is (LexicographicallyLargest).
+ *   gmsm_points_from_compressed: decode (Y = sqrt(X^3 + b) on the device: the compute-heavy half of Decoder.Decode,
+ *      unsafeComputeY, marshal.go:951-989) + the checks of `check` (the curve equation holds by construction; 2 / 3 add the
+ *      subgroup test).  Errors as the reference words them: "invalid compressed coordinate: square root doesn't exist",
+ *      "invalid infinity point encoding", "invalid fp.Element encoding", "invalid point: subgroup check failed"; uncompressed
+ *      or undefined flags are refused (gmsm_points_from_raw takes those).
+ *   gmsm_points_compress: the encoder, points (host) or d_points (device) -> out_comp (host).
+ *   gmsm_bases_register_compressed: decode + check + register in one call. */
+int gmsm_points_from_compressed(int group, const uint8_t *comp, size_t n, int check, uint64_t *out_affine, void *d_out_affine,
+                                int64_t *bad_index);
+int gmsm_points_compress(int group, const uint64_t *points, const void *d_points, size_t n, uint8_t *out_comp);
+int gmsm_bases_register_compressed(int group, const uint8_t *comp, size_t n, int check, uint64_t *out_handle, int64_t *bad_index);
 int gmsm_bases_register_dump(int group, const char *path, uint64_t offset, int expect_marker, size_t max_points, int check,
                              uint64_t *out_handle, size_t *out_n, int64_t *bad_index);
 

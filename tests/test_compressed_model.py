@@ -1,0 +1,105 @@
+"""CPU checks of the compressed-encoding restatement (tests/compressed_points.py) that the GPU tests compare the device with:
+known answers that follow from the reference's own constants, round trips on every kind of point, and the error cases
+setBytes words (ecc/bn254/marshal.go:862-948)."""
+import importlib
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import compressed_points as cp  # noqa: E402
+from conftest import ALL_GROUPS  # noqa: E402
+from subgroup_points import curve_b, curve_points, sqrt_fp, times_r  # noqa: E402
+
+curves = importlib.import_module("gnark-crypto_amd.curves")
+
+
+def test_bls12_381_generators_compress_to_the_published_encodings(pyref_mod):
+    """The ZCash / IETF serialisation the reference says it follows (bls12-381/marshal.go:20-25): the compressed generators are
+    the x coordinates of ecc/bls12-381/bls12-381.go:98-116 with flag 100 (both Y are the smaller root) - first bytes 0x97 / 0x93."""
+    c = curves.CURVES["bls12_381"]
+    g1 = pyref_mod.Group(c, "g1")
+    enc = cp.encode_compressed(g1, c.g1)
+    assert enc.hex() == ("97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac58"
+                         "6c55e83ff97a1aeffb3af00adb22c6bb")
+    assert cp.decode_compressed(pyref_mod, g1, enc) == c.g1
+    g2 = pyref_mod.Group(c, "g2")
+    (x0, x1), (y0, y1) = c.g2
+    P = (pyref_mod.Fp2(x0, x1, c.p), pyref_mod.Fp2(y0, y1, c.p))
+    enc = cp.encode_compressed(g2, P)
+    assert enc[0] == 0x93 and len(enc) == 96 and enc[1:48] == x1.to_bytes(48, "big")[1:] and enc[48:] == x0.to_bytes(48, "big")
+    assert cp.decode_compressed(pyref_mod, g2, enc) == P
+
+
+@pytest.mark.parametrize("curve,which", ALL_GROUPS)
+def test_round_trip_and_flags(pyref_mod, curve, which):
+    c = curves.CURVES[curve]
+    pg = pyref_mod.Group(c, which)
+    gen = pg.generator() if hasattr(pg, "generator") else None
+    pts = curve_points(pyref_mod, pg, 6, start=5)
+    if gen is not None:
+        pts.append(gen)
+    bits, small, large, inf = cp.flags(curve)
+    for P in pts:
+        x, y = P
+        Q = (x, cp.neg(pg, y))
+        e1, e2 = cp.encode_compressed(pg, P), cp.encode_compressed(pg, Q)
+        assert len(e1) == cp.compressed_size(pg)
+        assert {e1[0] >> (8 - bits), e2[0] >> (8 - bits)} == {small, large}       # P and -P: one flag each
+        assert e1[1:] == e2[1:] and (e1[0] ^ e2[0]) == (small ^ large) << (8 - bits)
+        assert cp.decode_compressed(pyref_mod, pg, e1) == P and cp.decode_compressed(pyref_mod, pg, e2) == Q
+    e = cp.encode_compressed(pg, None)
+    assert e[0] == inf << (8 - bits) and not any(e[1:]) and cp.decode_compressed(pyref_mod, pg, e) is None
+
+
+@pytest.mark.parametrize("curve,which", ALL_GROUPS)
+def test_errors(pyref_mod, curve, which):
+    c = curves.CURVES[curve]
+    pg = pyref_mod.Group(c, which)
+    bits, small, large, inf = cp.flags(curve)
+    nb = 8 * c.fp_limbs
+    good = cp.encode_compressed(pg, curve_points(pyref_mod, pg, 1, start=9)[0])
+    # infinity flag over a non-zero payload
+    bad = bytearray(cp.encode_compressed(pg, None))
+    bad[-1] = 1
+    with pytest.raises(ValueError, match=cp.ERR_INFINITY):
+        cp.decode_compressed(pyref_mod, pg, bytes(bad))
+    # the uncompressed flag
+    bad = bytearray(good)
+    bad[0] &= 0xff >> bits
+    with pytest.raises(ValueError, match=cp.ERR_FLAG):
+        cp.decode_compressed(pyref_mod, pg, bytes(bad))
+    # a coordinate that is not below the modulus (fits the field's bytes for every curve in scope)
+    bad = bytearray(c.p.to_bytes(nb, "big") * pg.ext)
+    assert bad[0] >> (8 - bits) == 0
+    bad[0] |= small << (8 - bits)
+    with pytest.raises(ValueError, match=cp.ERR_ELEMENT):
+        cp.decode_compressed(pyref_mod, pg, bytes(bad))
+    # an X with no Y
+    t = 1
+    while True:
+        if pg.ext == 1:
+            x = t
+            ok = sqrt_fp((x * x * x + curve_b(pyref_mod, pg)) % pg.p, pg.p) is not None
+            enc = bytearray(x.to_bytes(nb, "big"))
+        else:
+            x = pyref_mod.Fp2(t, 1, pg.p)
+            from subgroup_points import sqrt_fp2
+            ok = sqrt_fp2(pyref_mod, x * x * x + curve_b(pyref_mod, pg)) is not None
+            enc = bytearray(x.a1.to_bytes(nb, "big") + x.a0.to_bytes(nb, "big"))
+        if not ok:
+            break
+        t += 1
+    enc[0] |= large << (8 - bits)
+    with pytest.raises(ValueError, match="square root"):
+        cp.decode_compressed(pyref_mod, pg, bytes(enc))
+
+
+def test_points_outside_the_subgroup_decode(pyref_mod):
+    """Decompression knows nothing about the subgroup: a curve point with a cofactor component round-trips (the subgroup check
+    is a separate step of the Decoder, marshal.go:300-330)."""
+    c = curves.CURVES["bls12_381"]
+    pg = pyref_mod.Group(c, "g1")
+    P = next(P for P in curve_points(pyref_mod, pg, 20) if times_r(pg, P) is not None)
+    assert cp.decode_compressed(pyref_mod, pg, cp.encode_compressed(pg, P)) == P

@@ -97,6 +97,9 @@ def cxx_field(prefix, q, n64, fft=None, glv=None):
     out += f"    static constexpr uint32_t QINV = 0x{(-pow(q, -1, 1 << 32)) % (1 << 32):08x}u; /* -q^-1 mod 2^32 */\n"
     out += arr("ONE", R % q)
     out += arr("RSQ", R * R % q)
+    if q % 4 == 3:  # the base fields (sqrt = x^((q+1)/4); point decompression, gmsm_decompress.h)
+        out += arr("INV2", (q + 1) // 2 * R % q)   # 1/2, Montgomery
+        out += arr("LEX_HALF", (q + 1) // 2)       # regular form: z >= (q+1)/2  <=>  LexicographicallyLargest (fp/element.go:282-296)
     out += unsat_block(q, n64)
     if fft:
         root, max_order, gen = fft
@@ -191,6 +194,8 @@ def group_consts(c):
         out += f"    static constexpr uint32_t B[{len(b)}] = {{" + ", ".join(f"0x{x:08x}u" for x in b) + "};  /* curve coefficient, Montgomery */\n"
         out += f"    static constexpr int RAW_FLAG_BITS = {flag_bits};      /* metadata bits on top of the first byte */\n"
         out += f"    static constexpr int RAW_INFINITY_FLAG = {inf_flag};  /* flag value of an uncompressed point at infinity; -1: none */\n"
+        comp = (0b10, 0b11, 0b01) if flag_bits == 2 else (0b100, 0b101, 0b110)   # marshal.go:26-30 / bls12-381/marshal.go:25-35
+        out += f"    static constexpr int COMP_SMALLEST = {comp[0]}, COMP_LARGEST = {comp[1]}, COMP_INFINITY = {comp[2]};  /* compressed encodings: flag values */\n"
         out += f"    static constexpr int SUBGROUP_TEST = {kind};   /* which endomorphism identity IsInSubGroup tests (gmsm_subgroup.h) */\n"
         out += f"    static constexpr unsigned long long X_GEN = 0x{c.x_gen:016x}ULL;  /* xGen */\n"
         gw = words(w1 if gname == "g1" else w1 * w1)  # phi(x, y) = (GLV_W x, y) = [lambda](x, y): w on G1, w^2 on G2 (mulGLV, g1.go:536)
