@@ -291,15 +291,25 @@ class _Group:
         return (ResidentBases(self, handle.value, n), None) if rc == 0 else (None, self._error(rc))
 
     def DecodeSlice(self, buf, subgroup_check=True):
-        """What Decoder.Decode(&[]G1Affine) reads (marshal.go:220-280): uint32 big-endian length, then the points - here
-        all in the raw (uncompressed) encoding an Encoder with RawEncoding() writes (marshal.go:418, :586-640)."""
+        """What Decoder.Decode(&[]G1Affine) reads (marshal.go:220-277): uint32 big-endian length, then the points - all compressed
+        (the Encoder's default, marshal.go:445-585) or all raw (RawEncoding(), :418, :586-640); the first point's flag bits say
+        which (isCompressed, marshal.go:380-383)."""
         b = bytes(buf)
         if len(b) < 4:
             return None, "short buffer"
         n = int.from_bytes(b[:4], "big")
-        if len(b) < 4 + n * self.raw_point_bytes:
+        if n == 0:
+            return np.zeros((0, self.aff_limbs), dtype=np.uint64), None
+        if len(b) < 5:
             return None, "short buffer"
-        return self.DecodeRaw(b[4:4 + n * self.raw_point_bytes], subgroup_check)
+        flag_bits = 2 if self.curve.name == "bn254" else 3
+        flag = b[4] >> (8 - flag_bits)
+        uncompressed = flag == 0 or (flag_bits == 3 and flag == 0b010)
+        size = self.raw_point_bytes if uncompressed else self.compressed_point_bytes
+        if len(b) < 4 + n * size:
+            return None, "short buffer"
+        body = b[4:4 + n * size]
+        return self.DecodeRaw(body, subgroup_check) if uncompressed else self.DecodeCompressed(body, subgroup_check)
 
     def ValidatePoints(self, points=None, d_points=None, n=None, subgroup_check=True, by_definition=False):
         """IsOnCurve / IsInSubGroup over a whole vector of limb-form points (host array or device pointer): returns

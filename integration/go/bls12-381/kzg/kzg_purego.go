@@ -5,6 +5,7 @@
 package kzg
 
 import (
+	"io"
 	"os"
 
 	"github.com/consensys/gnark-crypto/ecc/bls12-381/fr"
@@ -33,6 +34,22 @@ func ReadDumpResident(path string, windowTables bool, maxPkPoints ...int) (*Resi
 		return nil, nil, err
 	}
 	return &ResidentProvingKey{host: srs.Pk}, &srs.Vk, nil
+}
+
+// ReadFromResident is (*ProvingKey).ReadFrom, or UnsafeReadFrom without the subgroup checks (kzg/marshal.go:140-158).
+func ReadFromResident(r io.Reader, windowTables bool, subgroupCheck bool) (*ResidentProvingKey, int64, error) {
+	var pk ProvingKey
+	var n int64
+	var err error
+	if subgroupCheck {
+		n, err = pk.ReadFrom(r)
+	} else {
+		n, err = pk.UnsafeReadFrom(r)
+	}
+	if err != nil {
+		return nil, n, err
+	}
+	return &ResidentProvingKey{host: pk}, n, nil
 }
 
 // Size is the number of points of the key.

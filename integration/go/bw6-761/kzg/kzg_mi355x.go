@@ -14,6 +14,11 @@
 //	ReadDumpResident(path, max...)      SRS.ReadDump's twin (kzg/marshal.go:98-113): Vk through ReadFrom, the []G1Affine memory of
 //	                                    the dump streamed from the file into HBM (gmsm_bases_register_dump) - it never exists as
 //	                                    host limbs
+//	ReadFromResident(r, tables)         (*ProvingKey).ReadFrom's twin (kzg/marshal.go:140-147): the Encoder's default stream - uint32
+//	                                    length, then COMPRESSED points - goes to the device as bytes; Y = sqrt(X^3 + b) and the
+//	                                    subgroup checks of Decoder.Decode's []G1Affine case (ecc/bn254/marshal.go:220-277: unsafeComputeY in parallel) run
+//	                                    there (gmsm_bases_register_compressed); a raw stream (WriteRawTo) takes
+//	                                    gmsm_bases_register_raw. subgroupCheck = false is UnsafeReadFrom (:151-158)
 //	(*ResidentProvingKey).Commit        gmsm_multiexp_bases; below MinDevicePoints the package's Commit when the host copy exists
 //	(*ResidentProvingKey).CommitBatch   k polynomials of equal length in one call, two MSMs in flight (gmsm_multiexp_bases_batch)
 //	(*ResidentProvingKey).Release       gmsm_bases_release (also the finalizer)
@@ -31,6 +36,7 @@ package kzg
 import "C"
 
 import (
+	"encoding/binary"
 	"errors"
 	"io"
 	"os"
@@ -40,6 +46,11 @@ import (
 	"github.com/consensys/gnark-crypto/ecc/bw6-761"
 	"github.com/consensys/gnark-crypto/ecc/bw6-761/fr"
 )
+
+// compressedFlagMask: every compressed flag value has the top bit of the first byte set and no uncompressed one has
+// (marshal.go:26-30: 10 / 11 against 00 / 01 = infinity, which Bytes() writes over a compressed-size buffer - a proving key
+// holds no point at infinity; bls12-381/marshal.go:25-35: 100 / 101 / 110 against 000 / 010).
+const compressedFlagMask = 0x80
 
 // MinDevicePoints is the shortest polynomial that is committed on the device when a host copy of the key exists
 // (same measured crossover as bw6761.MinDevicePoints, INTEGRATION.md section 2c).
@@ -121,6 +132,59 @@ func ReadDumpResident(path string, windowTables bool, maxPkPoints ...int) (*Resi
 	}
 	runtime.SetFinalizer(rk, func(k *ResidentProvingKey) { k.Release() })
 	return rk, &vk, nil
+}
+
+// ReadFromResident reads what (*ProvingKey).WriteTo / WriteRawTo wrote (kzg/marshal.go:16-32): a big-endian uint32 length and
+// the points, compressed (the Encoder's default: X and the flag of Y's half, marshal.go:801-823) or raw. The bytes go to the
+// device as they are; decompression - the square root per point that Decoder.Decode spreads over the cores (ecc/bn254/marshal.go:258-272)
+// - and the subgroup checks run there. subgroupCheck = false is (*ProvingKey).UnsafeReadFrom. A stream that mixes both
+// encodings (no Encoder writes one) is refused.
+func ReadFromResident(r io.Reader, windowTables bool, subgroupCheck bool) (*ResidentProvingKey, int64, error) {
+	var hdr [4]byte
+	if _, err := io.ReadFull(r, hdr[:]); err != nil {
+		return nil, 0, err
+	}
+	n := int(binary.BigEndian.Uint32(hdr[:]))
+	if n == 0 {
+		return nil, 4, ErrMinSRSSize
+	}
+	first := make([]byte, bw6761.SizeOfG1AffineCompressed)
+	if _, err := io.ReadFull(r, first); err != nil {
+		return nil, 4, err
+	}
+	size := bw6761.SizeOfG1AffineCompressed
+	compressed := first[0]&compressedFlagMask != 0
+	if !compressed {
+		size = bw6761.SizeOfG1AffineUncompressed
+	}
+	buf := make([]byte, n*size)
+	copy(buf, first)
+	if _, err := io.ReadFull(r, buf[len(first):]); err != nil {
+		return nil, 4 + int64(len(first)), err
+	}
+	check := C.int(0)
+	if subgroupCheck {
+		check = 2
+	}
+	rk := &ResidentProvingKey{n: n}
+	var bad C.int64_t
+	var rc C.int
+	if compressed {
+		rc = C.gmsm_bases_register_compressed(C.GMSM_BW6_761_G1, (*C.uint8_t)(unsafe.Pointer(&buf[0])), C.size_t(n), check, &rk.handle, &bad)
+	} else {
+		rc = C.gmsm_bases_register_raw(C.GMSM_BW6_761_G1, (*C.uint8_t)(unsafe.Pointer(&buf[0])), C.size_t(n), check, &rk.handle, &bad)
+	}
+	if rc != 0 {
+		return nil, 4 + int64(len(buf)), gmsmErr()
+	}
+	if windowTables {
+		if rc := C.gmsm_bases_precompute(rk.handle, 0); rc != 0 {
+			C.gmsm_bases_release(rk.handle)
+			return nil, 4 + int64(len(buf)), gmsmErr()
+		}
+	}
+	runtime.SetFinalizer(rk, func(k *ResidentProvingKey) { k.Release() })
+	return rk, 4 + int64(len(buf)), nil
 }
 
 // Size is the number of registered points.

@@ -75,6 +75,7 @@ def test_kzg_resident_key_files(gm, curve):
     assert dev.startswith("//go:build mi355x\n") and pure.startswith("//go:build !mi355x\n")
     api = ["func NewResidentProvingKey(pk ProvingKey, windowTables bool) (*ResidentProvingKey, error)",
            "func ReadDumpResident(path string, windowTables bool, maxPkPoints ...int) (*ResidentProvingKey, *VerifyingKey, error)",
+           "func ReadFromResident(r io.Reader, windowTables bool, subgroupCheck bool) (*ResidentProvingKey, int64, error)",
            "func (rk *ResidentProvingKey) Size() int", "func (rk *ResidentProvingKey) Commit(p []fr.Element, nbTasks ...int) (Digest, error)",
            "func (rk *ResidentProvingKey) CommitBatch(ps [][]fr.Element) ([]Digest, error)", "func (rk *ResidentProvingKey) Release()"]
     for text in (dev, pure):
@@ -87,7 +88,7 @@ def test_kzg_resident_key_files(gm, curve):
     header = open(os.path.join(ROOT, "include", "gmsm.h")).read()
     lib = gm._lib.load()
     called = set(re.findall(r"C\.(gmsm_[a-z0-9_]+)\(", dev))
-    assert {"gmsm_bases_register", "gmsm_bases_register_dump", "gmsm_bases_precompute", "gmsm_bases_release", "gmsm_multiexp_bases",
+    assert {"gmsm_bases_register", "gmsm_bases_register_dump", "gmsm_bases_register_compressed", "gmsm_bases_register_raw", "gmsm_bases_precompute", "gmsm_bases_release", "gmsm_multiexp_bases",
             "gmsm_multiexp_bases_batch", "gmsm_last_error"} <= called
     for sym in called:
         assert re.search(rf"\b{sym}\s*\(", header), sym
@@ -128,5 +129,11 @@ def test_kzg_files_cite_the_reference(curve):
     assert any("ErrInvalidPolynomialSize" in ln for ln in kzg[:40]) and any("ErrMinSRSSize" in ln for ln in kzg[:40])
     marshal = open(os.path.join(ref, "marshal.go")).read().splitlines()
     assert marshal[98 - 1].startswith("func (srs *SRS) ReadDump(") and "unsafe.ReadSlice" in "\n".join(marshal[98:113])
+    # ReadFromResident's twins and the stream they read
+    assert marshal[16 - 1].startswith("func (pk *ProvingKey) WriteTo(") and "enc.Encode(pk.G1)" in "\n".join(marshal[16:32])
+    assert marshal[140 - 1].startswith("func (pk *ProvingKey) ReadFrom(") and "dec.Decode(&pk.G1)" in "\n".join(marshal[140:147])
+    assert marshal[151 - 1].startswith("func (pk *ProvingKey) UnsafeReadFrom(") and "NoSubgroupChecks()" in "\n".join(marshal[151:158])
+    dec = open(os.path.join("/root/reference", path, "marshal.go")).read()
+    assert "unsafeComputeY(dec.subGroupCheck)" in dec and "func isCompressed(msb byte) bool" in dec
     g1 = open(os.path.join("/root/reference", path, "g1.go")).read()
     assert "func BatchJacobianToAffineG1(points []G1Jac) []G1Affine" in g1

@@ -47,6 +47,11 @@ def test_decode_and_encode_match_the_model(gm, pyref_mod, curve, which):
     d_out = torch.zeros_like(d_pts)
     m, err = g.DecodeCompressed(model, d_out=d_out.data_ptr())
     assert err is None and m == n and (d_out.cpu().numpy().view(np.uint64) == pts).all()
+    # the slice form of the Decoder: length prefix, encoding told by the first point's flag
+    got, err = g.DecodeSlice(n.to_bytes(4, "big") + model)
+    assert err is None and (got == pts).all()
+    got, err = g.DecodeSlice(n.to_bytes(4, "big") + model[:-1])
+    assert got is None and err == "short buffer"
 
 
 @pytest.mark.parametrize("curve,which", ALL_GROUPS)
