@@ -33,7 +33,7 @@ def main():
     handles[1].precompute(0)
     handles[2].precompute(11)
     t0 = time.time()
-    cases = bad = 0
+    cases = bad = trips = 0
     while time.time() - t0 < budget:
         n = int(rng.choice([rng.integers(1, 64), rng.integers(64, 5000), rng.integers(5000, nmax)]))
         kind = int(rng.integers(0, 11))
@@ -41,6 +41,9 @@ def main():
         gm.set_option("small_bits", int(rng.choice([0, 0, 0, 1, 4, 5, 6, 7])))
         gm.set_option("small_max", int(rng.choice([0, 0, 300, 16384])))
         gm.set_option("split", int(rng.choice([0, 0, 0, 1])))
+        # round 6: GLV half scalars never / by the measured table / always, the fused kernel's bucket phase by size / one lane / quads
+        gm.set_option("glv", int(rng.choice([0, 1, 1, 2])))
+        gm.set_option("small_quad", int(rng.choice([0, 0, 1, 2])))
         if kind == 0:
             sc = random_scalars(rng, g.curve, n)
         elif kind == 1:  # small values
@@ -107,12 +110,22 @@ def main():
         cases += 1
         if not (got == want).all():
             bad += 1
-            print("MISMATCH", dict(n=n, kind=kind, entry=entry), flush=True)
-    for k in ("small_bits", "small_max", "split"):
+            print("MISMATCH", dict(n=n, kind=kind, entry=entry, glv=gm.get_option("glv"), quad=gm.get_option("small_quad")), flush=True)
+        if cases % 16 == 0:  # round 6: the compressed encoding there and back on this case's bases (with the MSM result among them)
+            both = np.concatenate([pts, got[None, :]])
+            comp, err = g.Compress(points=both)
+            assert err is None
+            back, err = g.DecodeCompressed(comp)
+            trips += 1
+            if err is not None or not (back == both).all():
+                bad += 1
+                print("COMPRESSED ROUND TRIP MISMATCH", dict(n=n, err=err), flush=True)
+    for k in ("small_bits", "small_max", "split", "small_quad"):
         gm.set_option(k, 0)
+    gm.set_option("glv", 1)
     for h in handles:
         h.release()
-    print(f"{curve} {which}: {cases} cases, {bad} mismatches", flush=True)
+    print(f"{curve} {which}: {cases} cases ({trips} compressed round trips), {bad} mismatches", flush=True)
     sys.exit(1 if bad else 0)
 
 
