@@ -627,6 +627,22 @@ def sharded_also(gm, lib, torch, dist, sharding, rank, world, dev_index, mode, r
     return out
 
 
+def sqrt_chain_products(q):
+    """squarings + products of gmsm_decompress.h's x^(q >> 2): sliding window of three bits over x, x^3, x^5, x^7"""
+    bit = lambda j: (q >> (j + 2)) & 1
+    j, ops, started = q.bit_length() - 3, 4, False  # x^2 and the three odd powers
+    while j >= 0:
+        if not bit(j):
+            ops, j = ops + 1, j - 1
+            continue
+        lo = max(j - 2, 0)
+        while not bit(lo):
+            lo += 1
+        ops += (j - lo + 2) if started else 0  # the window's squarings and its product
+        started, j = True, lo - 1
+    return ops
+
+
 def fft_config(gm, torch, curve="bn254", logn=24, reps=5):
     """fr/fft next to the MSM: (*Domain).FFT DIF on 2^logn resident coefficients, and the round trip
     FFTInverse(DIT) o FFT(DIF) == identity as the size-independent check (fft_test.go:160-180)."""
@@ -733,16 +749,15 @@ def next_rows(gm, lib, torch):
                                               "source": "pageable host memory (PCIe-inclusive)"}
     same = bool((d_out.cpu().numpy().view(np.uint64) == pts).all())
     out["points_from_raw_2p22_decode_curve_subgroup"]["equal_to_source_points"] = same
-    # ---- N4: the Encoder's DEFAULT (compressed) format, 2^22 points: Y = sqrt(X^3 + 3) on the device - one exponentiation of 252
-    # squarings + ~110 products on the lazy limbs per point (gmsm_decompress.h); the bytes are the device's own Bytes() of the points
+    # ---- N4: the Encoder's DEFAULT (compressed) format, 2^22 points: Y = sqrt(X^3 + 3) on the device - one exponentiation of 251
+    # squarings + 58 products on the lazy limbs per point (gmsm_decompress.h); the bytes are the device's own Bytes() of the points
     comp = np.zeros(n * 4 * g.aff_limbs, dtype=np.uint8)
     assert lib.gmsm_points_compress(g.gid, None, keep.data_ptr(), n, comp.ctypes.data) == 0, gm._lib.last_error()
 
     def decompress():
         assert lib.gmsm_points_from_compressed(g.gid, comp.ctypes.data, n, 2, None, d_out.data_ptr(), _ct.byref(bad)) == 0, gm._lib.last_error()
     ms = median_ms(decompress, reps=3, warm=0)
-    exp_bits = g.curve.p.bit_length() - 3  # the exponent q >> 2 after its top bit
-    prods = n * (exp_bits + bin(g.curve.p >> 2).count("1") - 1 + 8)  # + x^3, the check y^2 = rhs, the domain changes
+    prods = n * (sqrt_chain_products(g.curve.p) + 8)  # + x^3, the check y^2 = rhs, the domain changes
     peak, _ = product_peak(g)
     out["points_from_compressed_2p22"] = {
         "ms": ms, "points_per_s": n / (ms * 1e-3), "GB_per_s_in": comp.size / (ms * 1e-3) / 1e9, "products_per_point": prods // n,

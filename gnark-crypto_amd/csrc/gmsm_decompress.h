@@ -23,17 +23,42 @@
 
 namespace gmsm {
 
-// x^((q-3)/4) for q = 3 mod 4: the exponent is q >> 2, its bit j is bit j + 2 of q. Operands in the product routine's input
-// range; result < 2q.
+// x^((q-3)/4) for q = 3 mod 4: the exponent is q >> 2, its bit j is bit j + 2 of q. Left-to-right with a sliding window of
+// three bits over the odd powers x, x^3, x^5, x^7: every squaring of the binary method and about a quarter as many products
+// as the exponent has bits (BN254: 251 squarings + 58 products instead of + 108, BLS12-381 378 + 108 instead of + 227, BW6-761
+// 759 + 179 instead of + 343). The exponent is a constant, so the
+// control flow is the same in every lane; the one squaring and the one product of the loop are inlined (two bodies).
+// Operands in the product routine's input range; result < 2q.
 template <class P>
 __device__ __noinline__ FpU<P> fpu_pow_q4(const FpU<P> &x) {
     static_assert((P::Q[0] & 3u) == 3u, "sqrt by one exponentiation needs q = 3 mod 4");
-    FpU<P> r = x;  // the top bit of q >> 2 (bit BITS - 1 of q)
+    auto bit = [](int j) -> uint32_t { return (P::Q[(j + 2) >> 5] >> ((j + 2) & 31)) & 1u; };  // of the exponent q >> 2
+    const FpU<P> x2 = fsqr<false>(x);  // the four odd powers: one-off products, out of line
+    const FpU<P> p3 = fmul<false>(x, x2), p5 = fmul<false>(p3, x2), p7 = fmul<false>(p5, x2);
+    FpU<P> r = x;
+    bool started = false;
+    int mulpos = -1;  // where the window that is being squared through ends (its lowest bit, which is set)
+    uint32_t val = 0;
 #pragma nounroll
-    for (int j = P::BITS - 4; j >= 0; --j) {
-        const int b = j + 2;
-        r = fsqr<false>(r);
-        if ((P::Q[b >> 5] >> (b & 31)) & 1u) r = fmul<false>(r, x);
+    for (int j = P::BITS - 3; j >= 0; --j) {  // from the exponent's top bit down: ONE squaring site, ONE product site
+        if (mulpos < 0 && bit(j)) {           // a window of at most three bits opens at a set bit and ends in one
+            mulpos = j >= 2 ? j - 2 : 0;
+            while (!bit(mulpos)) ++mulpos;
+            val = 0;
+            for (int k = j; k >= mulpos; --k) val = (val << 1) | bit(k);
+        }
+        if (started) r = fsqr<true>(r);
+        if (j == mulpos) {
+            FpU<P> m;
+#pragma unroll
+            for (int i = 0; i < P::UL; ++i) {  // the odd power `val`, selected limb by limb (the condition is uniform)
+                const uint32_t a01 = (val & 2u) ? p3.l[i] : x.l[i], a23 = (val & 2u) ? p7.l[i] : p5.l[i];
+                m.l[i] = (val & 4u) ? a23 : a01;
+            }
+            r = started ? fmul<true>(r, m) : m;
+            started = true;
+            mulpos = -1;
+        }
     }
     return r;
 }
