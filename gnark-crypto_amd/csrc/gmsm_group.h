@@ -80,6 +80,10 @@ struct Group : GroupHost<F_, FrP_> {
 #define GMSM_SERIAL_QUAD_WORDS 14
 #endif
     static constexpr bool SERIAL_QUAD = sizeof(U) >= GMSM_SERIAL_QUAD_WORDS * 4;
+#ifndef GMSM_SERIAL_Q_QUADS
+#define GMSM_SERIAL_Q_QUADS 64
+#endif
+    static constexpr int SERIAL_Q_QUADS = GMSM_SERIAL_Q_QUADS;  // quads per workgroup of k_reduce_serial_q (A/B: tools/build_ab.sh)
     // The work-efficient combine (k_combine_we: half the issue work, one step more) where the combine is throughput-bound:
     // the 9-limb field with at least two workgroups per CU. Measured k_combine_q / k_combine_we reduce times, BN254 G1:
     // 2^16 0.293 / 0.277 ms, 2^18 0.337 / 0.308, 2^20 0.344 / 0.312, 2^24 0.465 / 0.433 - but 2^12 (a handful of
@@ -499,7 +503,7 @@ struct Group : GroupHost<F_, FrP_> {
         if constexpr (COMBINE_WE)
             if ((rc = ctx.allow_lds((const void *)k_combine_we<U, true>, (int)((2 * COMBINE_N + 1) * sizeof(QRec<U>))))) return rc;
         if constexpr (SERIAL_QUAD)
-            if ((rc = ctx.allow_lds((const void *)k_reduce_serial_q<U>, (int)(192 * sizeof(QRec<U>))))) return rc;
+            if ((rc = ctx.allow_lds((const void *)k_reduce_serial_q<U, SERIAL_Q_QUADS>, (int)(3 * SERIAL_Q_QUADS * sizeof(QRec<U>))))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_reduce2_q<U, true>, (int)(2 * RED2_TPB * sizeof(QRec<U>))))) return rc;
 
         // Stage times cover single-run calls: the ranges of a multi-range call (buckets_only) reuse a workspace's events
@@ -687,8 +691,8 @@ struct Group : GroupHost<F_, FrP_> {
         // log2span times while the trees run): level 2 then has no serial doubling tail
         const uint32_t prescale = q.log2span;
         if constexpr (SERIAL_QUAD)
-            hipLaunchKernelGGL((k_reduce_serial_q<U>), dim3((T + 63) / 64, nw), dim3(256), 192 * sizeof(QRec<U>), stream, buckets,
-                               NB, q.log2L, T, starts, red_pre);
+            hipLaunchKernelGGL((k_reduce_serial_q<U, SERIAL_Q_QUADS>), dim3((T + SERIAL_Q_QUADS - 1) / SERIAL_Q_QUADS, nw), dim3(4 * SERIAL_Q_QUADS),
+                               3 * SERIAL_Q_QUADS * sizeof(QRec<U>), stream, buckets, NB, q.log2L, T, starts, red_pre);
         else
             hipLaunchKernelGGL((k_reduce_serial<OpsSerial>), dim3((T + 255) / 256, nw), dim3(256), 0, stream, buckets, NB,
                                q.log2L, T, starts, red_pre);
@@ -743,7 +747,7 @@ struct Group : GroupHost<F_, FrP_> {
         if constexpr (COMBINE_WE)
             if ((rc = ctx.allow_lds((const void *)k_combine_we<U, true>, (int)((2 * COMBINE_N + 1) * sizeof(QRec<U>))))) return rc;
         if constexpr (SERIAL_QUAD)
-            if ((rc = ctx.allow_lds((const void *)k_reduce_serial_q<U>, (int)(192 * sizeof(QRec<U>))))) return rc;
+            if ((rc = ctx.allow_lds((const void *)k_reduce_serial_q<U, SERIAL_Q_QUADS>, (int)(3 * SERIAL_Q_QUADS * sizeof(QRec<U>))))) return rc;
         if ((rc = ctx.allow_lds((const void *)k_reduce2_q<U, true>, (int)(2 * RED2_TPB * sizeof(QRec<U>))))) return rc;
         enqueue_reduce_kernels(ctx, ws, q, T, buckets, nullptr, nw, NB, stream);
         if (nwd > nw)

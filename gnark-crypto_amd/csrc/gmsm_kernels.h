@@ -1138,15 +1138,18 @@ __global__ void __launch_bounds__(256, 1) k_reduce_serial(const void *__restrict
 // time, so with the same number of lanes busy the chain is 4/3.3 as long per bucket - but a window of 2^13 buckets now
 // occupies four times as many lanes, and the number of (S, W) pairs left for the combine is a quarter.
 // Every record belongs to one quad: no workgroup barriers, only the ordering of a wave's own LDS accesses.
-// grid = (ceil(T / 64), nwin), block = 256, dynamic LDS = 192 * sizeof(QRec<U>); output as k_reduce_serial.
-template <class U>
-__global__ void __launch_bounds__(256) k_reduce_serial_q(const void *__restrict__ buckets, uint32_t nbuckets, uint32_t log2L,
-                                                         uint32_t T, const uint32_t *__restrict__ starts,
-                                                         void *__restrict__ pre) {
+// grid = (ceil(T / QPB), nwin), block = 4 QPB, dynamic LDS = 3 QPB * sizeof(QRec<U>); output as k_reduce_serial.
+#ifndef GMSM_SERIAL_Q_WAVES
+#define GMSM_SERIAL_Q_WAVES 1  // waves per SIMD the register allocation leaves room for (A/B: tools/build_ab.sh)
+#endif
+template <class U, int QPB /* quads per workgroup: 3 QPB records of LDS, 4 QPB threads */>
+__global__ void __launch_bounds__(4 * QPB, GMSM_SERIAL_Q_WAVES) k_reduce_serial_q(const void *__restrict__ buckets, uint32_t nbuckets, uint32_t log2L,
+                                                             uint32_t T, const uint32_t *__restrict__ starts,
+                                                             void *__restrict__ pre) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    QRec<U> *run = reinterpret_cast<QRec<U> *>(lds_raw), *tot = run + 64, *stage = run + 128;
+    QRec<U> *run = reinterpret_cast<QRec<U> *>(lds_raw), *tot = run + QPB, *stage = run + 2 * QPB;
     const uint32_t tid = threadIdx.x, j = tid >> 2, lane = tid & 63u, k = blockIdx.y;
-    const uint32_t g = blockIdx.x * 64 + j;
+    const uint32_t g = blockIdx.x * QPB + j;
     const uint32_t L = 1u << log2L, lo = g * L;
     const uint32_t *st = starts ? starts + (size_t)k * (nbuckets + 1) : nullptr;  // null: every record is stored
     if ((tid & 3u) == 0) {
