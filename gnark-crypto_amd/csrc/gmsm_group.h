@@ -854,8 +854,15 @@ struct Group : GroupHost<F_, FrP_> {
         if ((rc = ws.flagword.ensure(8))) return rc;
         HIP_TRY(hipMemsetAsync(ws.flagword.ptr, 0xff, 8, ws.stream));
         if (n)
-            hipLaunchKernelGGL((k_decode_raw<F, FrP, Consts, NEEDS_TORSION>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0,
-                               ws.stream, (const uint8_t *)d_raw, n, level, (Aff *)d_out, (unsigned long long *)ws.flagword.ptr);
+        {
+            const dim3 grid((unsigned)((n + 127) / 128));
+            if (level >= 3 && NEEDS_TORSION)
+                hipLaunchKernelGGL((k_decode_raw<F, FrP, Consts, NEEDS_TORSION, NEEDS_TORSION>), grid, dim3(128), 0, ws.stream,
+                                   (const uint8_t *)d_raw, n, level, (Aff *)d_out, (unsigned long long *)ws.flagword.ptr);
+            else
+                hipLaunchKernelGGL((k_decode_raw<F, FrP, Consts, NEEDS_TORSION, false>), grid, dim3(128), 0, ws.stream,
+                                   (const uint8_t *)d_raw, n, level, (Aff *)d_out, (unsigned long long *)ws.flagword.ptr);
+        }
         HIP_TRY(hipGetLastError());
         return read_first_bad(ws, bad_index, status);
     }
@@ -871,9 +878,7 @@ struct Group : GroupHost<F_, FrP_> {
             hipLaunchKernelGGL((k_decompress<F, Consts>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ws.stream,
                                (const uint8_t *)d_comp, n, (Aff *)d_out, (unsigned long long *)ws.flagword.ptr);
             // offenders were written as infinity, which passes: the word keeps the decoder's verdict for them
-            if (level >= 2 && NEEDS_TORSION)
-                hipLaunchKernelGGL((k_validate_points<F, FrP, Consts, NEEDS_TORSION>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0,
-                                   ws.stream, (const Aff *)d_out, n, level, (unsigned long long *)ws.flagword.ptr);
+            if (level >= 2 && NEEDS_TORSION) launch_validate(ws, d_out, n, level);
         }
         HIP_TRY(hipGetLastError());
         return read_first_bad(ws, bad_index, status);
@@ -886,14 +891,21 @@ struct Group : GroupHost<F_, FrP_> {
         HIP_TRY(hipGetLastError());
         return GMSM_OK;
     }
+    static void launch_validate(Workspace &ws, const void *d_points, size_t n, int level) {
+        const dim3 grid((unsigned)((n + 127) / 128));
+        if (level >= 3 && NEEDS_TORSION)  // the definition [r]P = infinity: its own kernel (gmsm_ingest.h, BY_DEF)
+            hipLaunchKernelGGL((k_validate_points<F, FrP, Consts, NEEDS_TORSION, NEEDS_TORSION>), grid, dim3(128), 0, ws.stream,
+                               (const Aff *)d_points, n, level, (unsigned long long *)ws.flagword.ptr);
+        else
+            hipLaunchKernelGGL((k_validate_points<F, FrP, Consts, NEEDS_TORSION, false>), grid, dim3(128), 0, ws.stream,
+                               (const Aff *)d_points, n, level, (unsigned long long *)ws.flagword.ptr);
+    }
     static int validate_points(Workspace &ws, const void *d_points, size_t n, int level, long long *bad_index,
                                uint32_t *status) {
         int rc;
         if ((rc = ws.flagword.ensure(8))) return rc;
         HIP_TRY(hipMemsetAsync(ws.flagword.ptr, 0xff, 8, ws.stream));
-        if (n && level > 0)
-            hipLaunchKernelGGL((k_validate_points<F, FrP, Consts, NEEDS_TORSION>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0,
-                               ws.stream, (const Aff *)d_points, n, level, (unsigned long long *)ws.flagword.ptr);
+        if (n && level > 0) launch_validate(ws, d_points, n, level);
         HIP_TRY(hipGetLastError());
         return read_first_bad(ws, bad_index, status);
     }

@@ -91,15 +91,19 @@ __device__ bool point_in_r_torsion(const Affine<F> &a) {
 }
 
 // level 0: nothing, 1: on the curve, 2: on the curve and in the r-torsion by the reference's endomorphism identity, 3: the
-// same decided by [r]P = infinity (NEEDS_TORSION false: prime-order curve, the curve check is the subgroup check - BN254 G1,
+// same decided by [r]P = infinity (BY_DEF) (NEEDS_TORSION false: prime-order curve, the curve check is the subgroup check - BN254 G1,
 // g1.go:475-482)
-template <class F, class FrP, class C, bool NEEDS_TORSION>
+// BY_DEF picks the subgroup test at COMPILE time (level 3 launches the BY_DEF kernels): one kernel holding both loops is sized - registers
+// and call frames - for the larger of the two, which is the 255/377-bit walk of the definition (round 6).
+template <class F, class FrP, class C, bool NEEDS_TORSION, bool BY_DEF>
 __device__ uint32_t validate_point(const Affine<F> &a, int level) {
     if (level <= 0) return PT_OK;
     if (!point_on_curve<F, C>(a)) return PT_NOT_ON_CURVE;
     if constexpr (NEEDS_TORSION) {
         if (level >= 2 && !a.is_infinity()) {
-            const bool in = (level == 2) ? point_in_subgroup_endo<F, C>(a) : point_in_r_torsion<F, FrP>(a);
+            bool in;
+            if constexpr (BY_DEF) in = point_in_r_torsion<F, FrP>(a);
+            else in = point_in_subgroup_endo<F, C>(a);
             if (!in) return PT_NOT_IN_SUBGROUP;
         }
     }
@@ -158,7 +162,7 @@ __device__ bool coord_from_be(const uint8_t *src, uint8_t first_byte_mask, Fp2<P
 
 // One thread per point. raw: n * sizeof(Affine<F>) bytes (the uncompressed size equals the in-memory size for every
 // group in scope); out: Go-layout affine points. Offending points are written as infinity and reported.
-template <class F, class FrP, class C, bool NEEDS_TORSION>
+template <class F, class FrP, class C, bool NEEDS_TORSION, bool BY_DEF>
 __global__ void __launch_bounds__(128) k_decode_raw(const uint8_t *__restrict__ raw, size_t n, int level,
                                                     Affine<F> *__restrict__ out, unsigned long long *first_bad) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -184,7 +188,7 @@ __global__ void __launch_bounds__(128) k_decode_raw(const uint8_t *__restrict__ 
             status = PT_NOT_CANONICAL;
             a = Affine<F>{F::zero(), F::zero()};
         } else {
-            status = validate_point<F, FrP, C, NEEDS_TORSION>(a, level);
+            status = validate_point<F, FrP, C, NEEDS_TORSION, BY_DEF>(a, level);
         }
     }
     if (status != PT_OK) {
@@ -196,12 +200,12 @@ __global__ void __launch_bounds__(128) k_decode_raw(const uint8_t *__restrict__ 
 
 // The same checks over points that are already Montgomery limbs (an SRS dump is raw memory, utils/unsafe/dump_slice.go;
 // ReadDump itself validates nothing, this is the optional check after it).
-template <class F, class FrP, class C, bool NEEDS_TORSION>
+template <class F, class FrP, class C, bool NEEDS_TORSION, bool BY_DEF>
 __global__ void __launch_bounds__(128) k_validate_points(const Affine<F> *__restrict__ pts, size_t n, int level,
                                                          unsigned long long *first_bad) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t status = validate_point<F, FrP, C, NEEDS_TORSION>(pts[i], level);
+    const uint32_t status = validate_point<F, FrP, C, NEEDS_TORSION, BY_DEF>(pts[i], level);
     if (status != PT_OK) report_bad(first_bad, i, status);
 }
 

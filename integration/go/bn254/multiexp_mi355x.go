@@ -9,6 +9,15 @@
 //  2. multiexp_purego.go (//go:build !mi355x) keeps the exported methods as one-line wrappers around multiExpCPU;
 //  3. this file (//go:build mi355x) provides them on the device and hands calls below MinDevicePoints to multiExpCPU.
 //
+// One precondition beyond the reference's (round 6): the device splits every scalar with the curve's endomorphism (the package's
+// own mulGLV does the same for single multiplications), which is the integer combination only on points of the r-torsion -
+// every point that passed IsInSubGroup / a Decoder with its default checks, and every curve point at all where the cofactor is 1
+// (BN254 G1). A caller that feeds MultiExp curve points OUTSIDE the subgroup and relies on the plain combination adds
+//
+//	func init() { C.gmsm_set_option(C.GMSM_OPT_GLV, 0) }
+//
+// to this file (INTEGRATION.md section 1).
+//
 // NOT compiled in the build environment of this repository (no Go toolchain there); the behaviour of the C entry
 // points it calls is covered by tests/ through the same C ABI.  See INTEGRATION.md.
 package bn254

@@ -73,3 +73,32 @@ def decode_compressed(pyref, pg, buf):
     if lex_largest(pg, y) != (flag == large):
         y = neg(pg, y)
     return (x, y)
+
+
+def pow_q4_schedule(x, q):
+    """The device's x^(q >> 2) (gmsm_decompress.h::fpu_pow_q4) step for step: left to right, a sliding window of three bits over
+    x, x^3, x^5, x^7, one squaring per exponent bit below the first window. Returns (value, squarings, products)."""
+    bit = lambda j: (q >> (j + 2)) & 1
+    x2 = x * x % q
+    odd = {1: x, 3: x * x2 % q}
+    odd[5] = odd[3] * x2 % q
+    odd[7] = odd[5] * x2 % q
+    sq, mu = 1, 3
+    r, started, mulpos, val = x, False, -1, 0
+    for j in range(q.bit_length() - 3, -1, -1):
+        if mulpos < 0 and bit(j):
+            mulpos = j - 2 if j >= 2 else 0
+            while not bit(mulpos):
+                mulpos += 1
+            val = 0
+            for k in range(j, mulpos - 1, -1):
+                val = (val << 1) | bit(k)
+        if started:
+            r, sq = r * r % q, sq + 1
+        if j == mulpos:
+            if started:
+                r, mu = r * odd[val] % q, mu + 1
+            else:
+                r = odd[val]
+            started, mulpos = True, -1
+    return r, sq, mu

@@ -103,3 +103,25 @@ def test_points_outside_the_subgroup_decode(pyref_mod):
     pg = pyref_mod.Group(c, "g1")
     P = next(P for P in curve_points(pyref_mod, pg, 20) if times_r(pg, P) is not None)
     assert cp.decode_compressed(pyref_mod, pg, cp.encode_compressed(pg, P)) == P
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381", "bw6_761"])
+def test_square_root_exponentiation_schedule(curve):
+    """gmsm_decompress.h computes w = a^((q-3)/4) with a sliding window; sqrt(a) = w a and 1/sqrt(a) = w for a residue. The
+    schedule restated step for step gives the plain power, and its operation count is what bench.py prices the kernel with."""
+    import random
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    q = curves.CURVES[curve].p
+    assert q % 4 == 3
+    rnd = random.Random(5)
+    for a in [1, 2, q - 1, 3] + [rnd.randrange(1, q) for _ in range(20)]:
+        w, sq, mu = cp.pow_q4_schedule(a, q)
+        assert w == pow(a, q >> 2, q)
+        y = w * a % q
+        if y * y % q == a:                      # a residue: y is a root and w its inverse
+            assert w * y % q == 1
+        else:
+            assert pow(a, (q - 1) // 2, q) == q - 1
+    assert sq + mu == bench.sqrt_chain_products(q)
+    assert (sq, mu) == {"bn254": (251, 58), "bls12_381": (378, 108), "bw6_761": (759, 179)}[curve]
