@@ -3,7 +3,7 @@
 out=/root/repo/gpurun_out/${1:-prof}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-Q="--no-cpu-baseline --no-host-entry --no-pipeline --no-also --no-next-rows"
+Q="--no-cpu-baseline --no-host-entry --no-pipeline --no-also --no-next-rows --full-out /tmp/bench_full_profile.json"  # the profiled commands must not overwrite the round's bench_full_n1.json
 run() {  # label, bench args...
   label=$1; shift
   timeout 300 rocprofv3 --kernel-trace --stats -d $out/$label/trace -o t --output-format csv -- python /root/repo/bench.py $Q "$@" > $out/$label/bench.json 2> $out/$label/trace.log
