@@ -4,9 +4,11 @@
  *   abi_client <group 0..5> <in.bin> <out.bin>
  *   in.bin  : u64 n | u64 aff_limbs | u64 fr_limbs | n*aff_limbs u64 points | n*fr_limbs u64 scalars   (little endian,
  *             the layout of utils/unsafe.WriteSlice payloads, utils/unsafe/dump_slice.go:16-32)
- *   out.bin : 3 blocks of aff_limbs u64: MultiExp via the per-curve drop-in symbol (Jacobian -> affine with
- *             gmsm_jac_to_affine), via gmsm_multiexp_affine, via registered bases; then u64 rc of the length-mismatch
- *             call and u64 rc of the NbTasks > 1024 call.
+ *   out.bin : 4 blocks of aff_limbs u64: MultiExp via the per-curve drop-in symbol (Jacobian -> affine with
+ *             gmsm_jac_to_affine), via gmsm_multiexp_affine, via registered bases, and via bases that went through the
+ *             Encoder's default wire format (gmsm_points_compress -> gmsm_bases_register_compressed with the Decoder's
+ *             default checks: what kzg's ReadFromResident does, integration/go); then u64 rc of the length-mismatch call
+ *             and u64 rc of the NbTasks > 1024 call.
  * Exit code 0 when every call returned what the contract says. */
 #include <stdint.h>
 #include <stdio.h>
@@ -33,7 +35,7 @@ int main(int argc, char **argv) {
     if (fread(pts, 8, n * al, f) != n * al || fread(sc, 8, n * fl, f) != n * fl) return 65;
     fclose(f);
 
-    uint64_t jac[3 * 24], aff[3][2 * 24];
+    uint64_t jac[3 * 24], aff[4][2 * 24];
     memset(aff, 0, sizeof aff);
     int rc = dropin[group](pts, n, sc, n, 0, jac);
     if (rc != GMSM_OK) { fprintf(stderr, "drop-in: %d %s\n", rc, gmsm_last_error()); return 1; }
@@ -44,12 +46,22 @@ int main(int argc, char **argv) {
     if (gmsm_multiexp_bases(h, sc, n, 0, jac) != GMSM_OK) return 5;
     if (gmsm_jac_to_affine(group, jac, aff[2]) != GMSM_OK) return 6;
     if (gmsm_bases_release(h) != GMSM_OK) return 7;
+    {   /* the same bases as compressed bytes: X and the flag of Y's half, al * 4 bytes a point */
+        uint8_t *comp = malloc(n * al * 4 + 1);
+        int64_t bad = -1;
+        if (gmsm_points_compress(group, pts, NULL, n, comp) != GMSM_OK) { fprintf(stderr, "compress: %s\n", gmsm_last_error()); return 9; }
+        if (gmsm_bases_register_compressed(group, comp, n, 2, &h, &bad) != GMSM_OK) { fprintf(stderr, "register_compressed: point %lld: %s\n", (long long)bad, gmsm_last_error()); return 10; }
+        if (gmsm_multiexp_bases(h, sc, n, 0, jac) != GMSM_OK) return 11;
+        if (gmsm_jac_to_affine(group, jac, aff[3]) != GMSM_OK) return 12;
+        if (gmsm_bases_release(h) != GMSM_OK) return 13;
+        free(comp);
+    }
     const uint64_t rc_len = (uint64_t)dropin[group](pts, n, sc, n ? n - 1 : 1, 0, jac);
     const uint64_t rc_cfg = (uint64_t)dropin[group](pts, n, sc, n, 1025, jac);
 
     f = fopen(argv[3], "wb");
     if (!f) return 65;
-    for (int i = 0; i < 3; ++i) fwrite(aff[i], 8, al, f);
+    for (int i = 0; i < 4; ++i) fwrite(aff[i], 8, al, f);
     fwrite(&rc_len, 8, 1, f);
     fwrite(&rc_cfg, 8, 1, f);
     fclose(f);

@@ -23,6 +23,7 @@
 
 static size_t N = 20000, ITER = 6;
 static uint64_t *pts, *sc, *fft_in, *fft_ref;
+static uint8_t *comp; /* the bases in the Encoder's default (compressed) wire format */
 static uint64_t ref_aff[AL], ref_small_aff[AL], shared_handle, fft_domain;
 static const size_t N_SMALL = 700; /* a call the fused small-n kernel takes (three slices per window) */
 static const size_t FFT_N = 1 << 12;
@@ -65,7 +66,9 @@ static void *worker(void *arg) {
                 break;
             case 2: {  /* a handle of its own, released while its own call has just finished and others keep going */
                 uint64_t h = 0;
-                int rc = gmsm_bases_register(G, pts, NULL, N, &h);
+                int64_t bad_index = -1;
+                /* every other time from the compressed bytes: decode (a square root per point) + subgroup step + register */
+                int rc = (it & 1) ? gmsm_bases_register_compressed(G, comp, N, 2, &h, &bad_index) : gmsm_bases_register(G, pts, NULL, N, &h);
                 if (rc) { bad("register", rc); break; }
                 check_jac("own bases", gmsm_multiexp_bases(h, sc, N, 0, jac), jac);
                 if ((rc = gmsm_bases_release(h))) bad("release", rc);
@@ -117,6 +120,8 @@ int main(int argc, char **argv) {
     sc = malloc(N * FL * 8);
     const uint64_t k0[4] = {12345, 0, 0, 0}, k1[4] = {0x9e3779b97f4a7c15ull, 77, 0, 0};
     if ((rc = gmsm_generate_points(G, gen, k0, k1, 4, N, 8, pts))) return 2;
+    comp = malloc(N * AL * 4);
+    if ((rc = gmsm_points_compress(G, pts, NULL, N, comp))) { fprintf(stderr, "compress: %s\n", gmsm_last_error()); return 2; }
     uint64_t x = 0x243f6a8885a308d3ull;
     for (size_t i = 0; i < N * FL; ++i) {  /* xorshift scalars below 2^252 (canonical limbs) */
         x ^= x << 13; x ^= x >> 7; x ^= x << 17;

@@ -867,8 +867,8 @@ def test_batch_jacobian_to_affine(gm, oracle_mod, curve, which):
 @pytest.mark.parametrize("curve,which", [("bn254", "g1"), ("bls12_381", "g2"), ("bw6_761", "g1")])
 def test_c_client_through_the_abi(gm, oracle_mod, curve, which, tmp_path):
     """tests/c/abi_client.c is compiled with gcc against include/gmsm.h and linked to libgmsm.so only - no Python, no torch
-    in the process: the per-curve drop-in symbol, gmsm_multiexp_affine and the registered-bases entry must all return the
-    oracle's affine point; the two argument errors must come back as the documented codes."""
+    in the process: the per-curve drop-in symbol, gmsm_multiexp_affine, the registered-bases entry and bases registered from their
+    compressed encoding must all return the oracle's affine point; the two argument errors must come back as the documented codes."""
     import os
     import subprocess
     g = _group(gm, curve, which)
@@ -894,9 +894,9 @@ def test_c_client_through_the_abi(gm, oracle_mod, curve, which, tmp_path):
     assert r.returncode == 0, (r.returncode, r.stderr)
     out = np.fromfile(fout, dtype=np.uint64)
     expected = o.msm_affine(pts, sc, nthreads=4)
-    for i in range(3):
+    for i in range(4):  # drop-in symbol, affine entry, registered bases, bases through the compressed wire format
         assert (out[i * g.aff_limbs:(i + 1) * g.aff_limbs] == expected).all(), i
-    assert out[3 * g.aff_limbs] == gm._lib.GMSM_ERR_LEN and out[3 * g.aff_limbs + 1] == gm._lib.GMSM_ERR_CONFIG
+    assert out[4 * g.aff_limbs] == gm._lib.GMSM_ERR_LEN and out[4 * g.aff_limbs + 1] == gm._lib.GMSM_ERR_CONFIG
 
 
 @pytest.mark.parametrize("curve,which,budget", [("bn254", "g1", 12.0), ("bls12_381", "g1", 8.0), ("bn254", "g2", 8.0)])
