@@ -519,7 +519,7 @@ int get_context_of_pointer(const void *p, Context **out);
 // ------------------------------------------------------------------ point ingest status (gmsm_ingest.h)
 enum PointStatus : uint32_t {
     PT_OK = 0,
-    PT_BAD_FLAG = 1,        // compressed or undefined metadata bits
+    PT_BAD_FLAG = 1,        // metadata bits of the other encoding, or undefined ones
     PT_BAD_INFINITY = 2,    // infinity flag with non-zero payload (ErrInvalidInfinityEncoding, marshal.go:36)
     PT_NOT_CANONICAL = 3,   // a coordinate >= q (SetBytesCanonical, fp/element.go)
     PT_NOT_ON_CURVE = 4,
@@ -529,7 +529,7 @@ enum PointStatus : uint32_t {
 
 static inline const char *point_status_text(uint32_t s) {
     switch (s) {
-        case PT_BAD_FLAG: return "invalid point encoding (compressed or undefined flag bits; the raw ingest takes RawBytes output)";
+        case PT_BAD_FLAG: return "invalid point encoding (flag bits this entry does not take: the raw entries read RawBytes() output, the compressed ones Bytes() output)";
         case PT_BAD_INFINITY: return "invalid infinity point encoding";
         case PT_NOT_CANONICAL: return "invalid fp.Element encoding (coordinate not below the modulus)";
         case PT_NOT_ON_CURVE: return "invalid point: not on the curve";

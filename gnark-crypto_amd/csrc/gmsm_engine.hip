@@ -1710,6 +1710,6 @@ GMSM_EXPORT const char *gmsm_last_error(void) {
     }
     return g_last_error.c_str();
 }
-GMSM_EXPORT const char *gmsm_version(void) { return "gmsm 0.4 (gfx950)"; }
+GMSM_EXPORT const char *gmsm_version(void) { return "gmsm 0.6 (gfx950)"; }
 
 }  // extern "C"
