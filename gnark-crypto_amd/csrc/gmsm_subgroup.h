@@ -113,7 +113,14 @@ template <class F, class C>
 __device__ __forceinline__ bool point_in_subgroup_endo(const Affine<F> &a) {  // inlined into the kernel: as a 142 KB FUNCTION it met the long-branch trap (tools/check_long_branch.py)
     using U = typename IngestLazy<F>::type;
     using T = LzTraits<U>;
-    constexpr bool INL = sizeof(U) <= 14 * 4;  // wider elements call their products (code size, as in gmsm_fixedbase.h)
+    // Every group inlines its group operations here (round 6, same-box A/B profiles/r06_subgroup_inline_ab.log: BN254 G2 2^20 41.4 ->
+    // 22.1 ms, BLS12-381 G2 2^18 12.9 -> 9.7, BW6-761 2^18 57.0 -> 47.2 against the out-of-line operations the level-3 walk and the
+    // fixed-base kernels keep for code size): a few hundred KB of straight-line code per kernel, as in the accumulation.
+    // -DGMSM_SUBGROUP_INL_BYTES=56 gives the out-of-line form back for the types wider than 14 words (tools/build_ab.sh).
+#ifndef GMSM_SUBGROUP_INL_BYTES
+#define GMSM_SUBGROUP_INL_BYTES (28 * 4)
+#endif
+    constexpr bool INL = sizeof(U) <= GMSM_SUBGROUP_INL_BYTES;
     constexpr unsigned long long X = C::X_GEN;
     static_assert(C::SUBGROUP_TEST >= 1 && C::SUBGROUP_TEST <= 4, "no endomorphism test for this group");
     const U px = T::template from_sat<INL>(a.x), py = T::template from_sat<INL>(a.y);
