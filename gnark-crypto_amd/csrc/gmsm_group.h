@@ -62,7 +62,13 @@ struct Group : GroupHost<F_, FrP_> {
     // Group operations are inlined where a kernel has ONE call site of the addition (k_accumulate_seg, k_fixup_seg,
     // k_reduce_serial: a single inlined Fp2 or BW6-761 addition is 60-350 KB of code); everything that combines few
     // elements (long chains, the reduction's combine and level 2) runs on lane quads with the operands in LDS (gmsm_quad.h).
-    static constexpr bool INLINE_OPS = sizeof(U) <= 14 * 4;  // fixed-base / normalisation kernels: inline their products
+    // fixed-base / normalisation / table-doubling kernels: every type inlines its group operations since the end of round 6 (the wide
+    // types called theirs out of line through rounds 2-6 for code size: same-box A/B profiles/r06_fixed_base_inline_ab.log - BN254 G2
+    // 2^20 17.7 -> 8.7 ms, BLS12-381 G2 34.4 -> 18.2, BW6-761 53.6 -> 36.1). -DGMSM_INLINE_OPS_BYTES=56 gives the old form back.
+#ifndef GMSM_INLINE_OPS_BYTES
+#define GMSM_INLINE_OPS_BYTES (28 * 4)
+#endif
+    static constexpr bool INLINE_OPS = sizeof(U) <= GMSM_INLINE_OPS_BYTES;
     using OpsSerial = UnsatOps<U>;
     using OpsElem = typename OpsSerial::Elem;
     // Level 1 of the bucket reduction = k_reduce_serial (one thread per L buckets, no LDS) + k_combine_q (COMBINE_N
