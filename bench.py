@@ -795,6 +795,22 @@ def next_rows(gm, lib, torch):
         "note": "on the curve and in the r-torsion by the reference's endomorphism identity (ecc/bls12-381/g1.go:481-492) on the "
                 "pipeline's lazy limbs, one lane per point: compute-bound"}
     del d_a2, d_p2
+    # ... and the Fp2 groups, whose group operations these kernels inline since the end of round 6: the fixed-base batch of BLS12-381 G2
+    # (2^20 scalars x the G2 generator, resident) and the subgroup identity of BN254 G2 (g2.go:483-497) over its 2^20 results
+    for cv, key_b, key_v in (("bls12_381", "batch_scalar_mul_bls12_381_g2_2p20", None), ("bn254", None, "points_validate_bn254_g2_2p20_level2")):
+        g3 = gm.G2Jac(cv)
+        a3 = uniform_scalars(rng, g3, m)
+        d_a3 = torch.from_numpy(a3.view(np.int64)).cuda()
+        d_p3 = torch.empty((m, g3.aff_limbs), dtype=torch.int64, device="cuda")
+        ms, _ = loop_ms(lambda: g3.batch_scalar_mul_device(g3.generator, d_a3.data_ptr(), m, d_p3.data_ptr(), stream), 2)
+        if key_b:
+            out[key_b] = {"ms": ms, "points_per_s": m / (ms * 1e-3), "window_bits": 8, "mixed_adds_per_point": (g3.curve.fr_bits + 7) // 8}
+        if key_v:
+            def validate_g2():
+                assert lib.gmsm_points_validate(g3.gid, None, d_p3.data_ptr(), m, 2, _ct.byref(bad)) == 0, gm._lib.last_error()
+            ms = median_ms(validate_g2, reps=3, warm=0)
+            out[key_v] = {"ms": ms, "points_per_s": m / (ms * 1e-3)}
+        del d_a3, d_p3
     del d_out, raw, reg
     # ---- N4: SRS dump (marker | length | raw []G1Affine memory) of 2^24 points, from the page cache into HBM
     import tempfile
